@@ -1,0 +1,309 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (build container only).
+
+Run here, never on the GPU box:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_goldens.py
+
+The reference (/root/reference, read-only) is imported with ``sys.modules`` stubs for
+its absent non-arithmetic dependencies; every failure that made
+the stubs necessary was an ordinary ModuleNotFoundError, no permission was denied.
+What is real reference code in these goldens:
+  * VolSeg2dPredictor._predict_single_axis / _predict_3_ways_max_probs /
+    _predict_12_ways_max_probs / _merge_vols_in_mem / *_one_hot
+    (volume_segmantics/model/operations/vol_seg_2d_predictor.py:31-136)
+  * VolSeg2dPredictionDataset + get_2d_prediction_dataloader (data/datasets.py:89-181,
+    data/dataloaders.py:60-71), get_padded_dimension (data/augmentations.py:30-43)
+  * crop_tensor_to_array / rotate_array_to_axis / one_hot_encode_array /
+    prepare_training_batch (utilities/base_data_utils.py:125-158)
+  * DiceLoss(normalization="none"), MeanIoU (data/pytorch3dunet_{losses,metrics}.py)
+  * VolSeg2dTrainer._train_one_batch / _freeze_model / _find_lr_from_graph /
+    _lr_exp_stepper (model/operations/vol_seg_2d_trainer.py)
+What is restated (third-party code that is not installed; [3p-memory] in SURVEY.md):
+  * the network itself (oracle/unet_resnet34_torch.py, injected as predictor.model the
+    way _get_model_from_trainer does, vol_seg_2d_predictor.py:28-29)
+  * albumentations.PadIfNeeded (centre, BORDER_REFLECT_101) and ToTensorV2,
+    torchvision.transforms.functional.center_crop - pure data movement.
+Nothing of the reference (source or bytecode) is written into this repository: the
+outputs are data only (inputs + expected outputs).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+OUT = REPO / "tests" / "golden"
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REPO))
+
+
+# ------------------------------------------------------------------------------------------
+# stubs for absent third-party modules
+# ------------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class Compose:
+        def __init__(self, transforms, p=1.0):
+            self.transforms = transforms
+
+        def __call__(self, **data):
+            for t in self.transforms:
+                data = t(**data)
+            return data
+
+    class PadIfNeeded:
+        """albumentations ^1.1 PadIfNeeded, position=center, border_mode=BORDER_REFLECT_101."""
+
+        def __init__(self, min_height, min_width, p=1.0):
+            self.min_height, self.min_width = min_height, min_width
+
+        def __call__(self, **data):
+            img = data["image"]
+            rows, cols = img.shape[:2]
+            if rows < self.min_height:
+                top = int((self.min_height - rows) / 2.0)
+                bottom = self.min_height - rows - top
+            else:
+                top = bottom = 0
+            if cols < self.min_width:
+                left = int((self.min_width - cols) / 2.0)
+                right = self.min_width - cols - left
+            else:
+                left = right = 0
+            if top or bottom or left or right:
+                img = np.pad(img, ((top, bottom), (left, right)), mode="reflect")
+            out = dict(data)
+            out["image"] = img
+            return out
+
+    class ToTensorV2:
+        def __call__(self, **data):
+            out = dict(data)
+            img = data["image"]
+            if img.ndim == 2:
+                img = np.expand_dims(img, 2)
+            out["image"] = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+            if "mask" in data and data["mask"] is not None:
+                out["mask"] = torch.from_numpy(data["mask"])
+            return out
+
+    class _Unused:
+        def __init__(self, *a, **k):
+            raise RuntimeError("stub: not available in the build container")
+
+    comp = _mod("albumentations.core.composition", Compose=Compose)
+    core = _mod("albumentations.core", composition=comp)
+    A = _mod("albumentations", Compose=Compose, PadIfNeeded=PadIfNeeded, core=core)
+    for n in ("LongestMaxSize", "RandomSizedCrop", "VerticalFlip", "RandomRotate90", "Transpose", "OneOf",
+              "ElasticTransform", "GridDistortion", "OpticalDistortion", "CLAHE", "RandomBrightnessContrast",
+              "RandomGamma"):
+        setattr(A, n, _Unused)
+    tr = _mod("albumentations.pytorch.transforms", ToTensorV2=ToTensorV2)
+    _mod("albumentations.pytorch", transforms=tr, ToTensorV2=ToTensorV2)
+    _mod("cv2", IMREAD_GRAYSCALE=0, BORDER_REFLECT_101=4)
+    _mod("h5py")
+    _mod("imageio")
+    _mod("termplotlib")
+    _mod("segmentation_models_pytorch")
+    sk = _mod("skimage", img_as_ubyte=None)
+    sk.io = _mod("skimage.io")
+    sk.measure = _mod("skimage.measure", block_reduce=None)
+    sk.metrics = _mod("skimage.metrics", peak_signal_noise_ratio=None, mean_squared_error=None)
+    sk.exposure = _mod("skimage.exposure")
+
+    def center_crop(img, output_size):
+        """torchvision.transforms.functional.center_crop for tensors, no-padding case."""
+        ch, cw = int(output_size[0]), int(output_size[1])
+        h, w = img.shape[-2:]
+        top = int(round((h - ch) / 2.0))
+        left = int(round((w - cw) / 2.0))
+        return img[..., top:top + ch, left:left + cw]
+
+    fn = _mod("torchvision.transforms.functional", center_crop=center_crop)
+    tf = _mod("torchvision.transforms", functional=fn)
+    _mod("torchvision", transforms=tf)
+
+
+def weight_fingerprint(net) -> np.ndarray:
+    sd = net.state_dict()
+    tot = sum(float(v.double().sum()) for k, v in sd.items() if v.dtype.is_floating_point)
+    sq = sum(float((v.double() ** 2).sum()) for k, v in sd.items() if v.dtype.is_floating_point)
+    return np.array([tot, sq, float(sd["segmentation_head.0.weight"].flatten()[3]),
+                     float(sd["encoder.layer3.2.conv1.weight"].flatten()[1234])], dtype=np.float64)
+
+
+def synth_volume(shape, seed):
+    """Smooth-ish uint8 test volume (cheap separable box blur of gaussian noise)."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(shape).astype(np.float32)
+    for ax in range(3):
+        v = (np.roll(v, 1, ax) + v + np.roll(v, -1, ax)) / 3.0
+    v = (v - v.mean()) / v.std()
+    return np.clip(128 + 40 * v, 0, 255).astype(np.uint8)
+
+
+def main():
+    os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+    install_stubs()
+    sys.path.insert(0, str(REF))
+    torch.set_num_threads(8)
+
+    import volume_segmantics.utilities.base_data_utils as utils
+    from volume_segmantics.data.augmentations import get_padded_dimension
+    from volume_segmantics.data.pytorch3dunet_losses import DiceLoss
+    from volume_segmantics.data.pytorch3dunet_metrics import MeanIoU
+    from volume_segmantics.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    from volume_segmantics.model.operations.vol_seg_2d_trainer import VolSeg2dTrainer
+    from volume_segmantics.utilities.base_data_utils import Axis
+
+    from oracle.unet_resnet34_torch import seeded_oracle
+
+    OUT.mkdir(parents=True, exist_ok=True)
+    utils.get_batch_size = lambda settings, prediction=False: 4 if prediction else 12  # needs CUDA in the reference
+
+    # ---- G7: pad / crop tables --------------------------------------------------------------
+    dims = np.arange(0, 200)
+    padded = np.array([get_padded_dimension(int(d)) for d in dims])
+    np.savez_compressed(OUT / "g7_padded_dimension.npz", dims=dims, padded=padded)
+
+    # ---- G3/G4/G5: prediction through the reference's predictor --------------------------------
+    classes = 4
+    net = seeded_oracle(classes=classes, seed=0)
+    pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
+    pred.model = net
+    pred.settings = SimpleNamespace(cuda_device=0)
+    pred.model_device_num = "cpu"
+    pred.num_labels = classes
+    pred.label_codes = {}
+    vol = synth_volume((29, 64, 40), seed=1234)  # Z=29 -> padded 32, d=3: exercises the pad/crop quirk
+    g = {"vol": vol, "classes": np.array(classes), "seed": np.array(0), "fingerprint": weight_fingerprint(net)}
+    for name, ax in (("z", Axis.Z), ("y", Axis.Y), ("x", Axis.X)):
+        l, p = pred._predict_single_axis(vol, output_probs=True, axis=ax)
+        g[f"single_{name}_labels"], g[f"single_{name}_probs"] = l.copy(), p.copy()
+        assert l.dtype == np.uint8 and p.dtype == np.float16 and l.shape == vol.shape
+    l, p = pred._predict_3_ways_max_probs(vol)
+    g["three_labels"], g["three_probs"] = l.copy(), p.copy()
+    l, p = pred._predict_12_ways_max_probs(vol)
+    g["twelve_labels"], g["twelve_probs"] = l.copy(), p.copy()
+    g["onehot_z"] = pred._predict_single_axis_to_one_hot(vol, axis=Axis.Z)
+    g["onehot_three"] = pred._predict_3_ways_one_hot(vol)
+    g["onehot_twelve"] = pred._predict_12_ways_one_hot(vol)
+    np.savez_compressed(OUT / "g3_predict_29x64x40_c4.npz", **g)
+    print("prediction goldens done; label histogram:", np.bincount(g["twelve_labels"].ravel(), minlength=classes))
+
+    # ---- merge alone: tie-heavy synthetic containers ------------------------------------------
+    rng = np.random.default_rng(7)
+    shape = (6, 10, 12)
+    ndir = 12
+    probs_choices = np.array([0.25, 0.5, 0.999, 1.0, 0.9995, 0.33325, 6e-5, 0.0], dtype=np.float16)
+    dprobs = probs_choices[rng.integers(0, len(probs_choices), size=(ndir, *shape))]
+    dlabels = rng.integers(0, 5, size=(ndir, *shape)).astype(np.uint8)
+    lab = np.empty((2, *shape), np.uint8)
+    prb = np.empty((2, *shape), np.float16)
+    lab[0], prb[0] = dlabels[0], dprobs[0]
+    chain_l, chain_p = [], []
+    for d in range(1, ndir):
+        lab[1], prb[1] = dlabels[d], dprobs[d]
+        pred._merge_vols_in_mem(prb, lab)
+        chain_l.append(lab[0].copy())
+        chain_p.append(prb[0].copy())
+    np.savez_compressed(OUT / "g4_merge_ties.npz", dlabels=dlabels, dprobs=dprobs,
+                        chain_labels=np.stack(chain_l), chain_probs=np.stack(chain_p))
+
+    # direction order / index maps of the 12-way scheme: a fake single-axis predictor that
+    # returns the voxel's own flat index as the label lets the goldens record which voxel
+    # each (direction, slice, pixel) touches (labels mod 251 to stay uint8-safe is not
+    # needed - we record via probabilities instead)
+    idxvol = np.arange(5 * 6 * 7, dtype=np.int64).reshape(5, 6, 7)
+    calls = []
+
+    def fake_single_axis(data_vol, output_probs=True, axis=Axis.Z):
+        v = utils.rotate_array_to_axis(data_vol, axis)
+        calls.append(np.ascontiguousarray(v))
+        lab_ = utils.rotate_array_to_axis((np.ascontiguousarray(v) % 251).astype(np.uint8), axis)
+        prob_ = utils.rotate_array_to_axis(np.full(v.shape, 0.5, np.float16), axis)
+        return lab_, prob_
+
+    pred._predict_single_axis = fake_single_axis
+    l, _ = pred._predict_12_ways_max_probs(idxvol)
+    assert np.array_equal(l, (idxvol % 251).astype(np.uint8))  # every direction maps back onto the voxel it read
+    np.savez_compressed(OUT / "g4_direction_order.npz", idxvol=idxvol,
+                        **{f"dir{d:02d}": c for d, c in enumerate(calls)})
+    del pred._predict_single_axis
+
+    # ---- G6: loss / metric / LR-finder / batch-prep KATs -----------------------------------
+    tg = torch.Generator().manual_seed(11)
+    logits = torch.randn(3, 4, 16, 24, generator=tg, requires_grad=True)
+    mask = torch.randint(0, 4, (3, 16, 24), generator=tg, dtype=torch.uint8)
+    img = torch.randn(3, 1, 16, 24, generator=tg)
+    inputs, targets = utils.prepare_training_batch([img, mask], "cpu", 4)
+    loss = DiceLoss(normalization="none")(logits, targets.float())
+    loss.backward()
+    probs = torch.softmax(logits.detach(), dim=1)
+    miou = MeanIoU()(torch.unsqueeze(probs, 2), torch.unsqueeze(targets, 2))
+    perfect = MeanIoU()(torch.unsqueeze(targets.float(), 2), torch.unsqueeze(targets, 2))
+    lr_cases = {}
+    for i, curve in enumerate((np.array([1.0, 0.9, 0.7, 0.2, 0.25, 0.9, 3.0]),
+                               np.array([0.5, 0.6, 0.7, 0.9]),
+                               np.linspace(1, 0, 9) ** 2)):
+        lrs = list(np.geomspace(1e-6, 50, len(curve)))
+        lr_cases[f"lr_curve{i}"] = curve
+        lr_cases[f"lr_lrs{i}"] = np.array(lrs)
+        lr_cases[f"lr_out{i}"] = np.array(
+            VolSeg2dTrainer._find_lr_from_graph([torch.tensor(c) for c in curve], lrs))
+    np.savez_compressed(OUT / "g6_loss_metric_lr.npz", logits=logits.detach().numpy(), mask=mask.numpy(),
+                        targets=targets.numpy(), dice_loss=loss.detach().numpy(),
+                        dice_grad=logits.grad.numpy(), mean_iou=miou.numpy(), mean_iou_perfect=perfect.numpy(),
+                        **lr_cases)
+
+    # ---- G2: three training steps through the reference's _train_one_batch ---------------------
+    net2 = seeded_oracle(classes=2, seed=3, perturb_bn=False)
+    tr = VolSeg2dTrainer.__new__(VolSeg2dTrainer)
+    tr.model = net2
+    tr.model_device_num = "cpu"
+    tr.label_no = 2
+    tr.settings = SimpleNamespace(loss_criterion="DiceLoss", pct_lr_inc=0.3)
+    tr.loss_criterion = DiceLoss(normalization="none")
+    tr.training_loader = [None] * 4  # len() only: steps_per_epoch
+    tr._freeze_model()
+    frozen = [n for n, p_ in net2.named_parameters() if not p_.requires_grad]
+    tr._unfreeze_model()
+    assert all(p_.requires_grad for p_ in net2.parameters())
+    tr.optimizer = tr._create_optimizer(1e-3)
+    sched = tr._create_oc_lr_scheduler(num_epochs=1, lr_to_use=2e-3)
+    tg = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 1, 64, 64, generator=tg)
+    m = (torch.rand(4, 64, 64, generator=tg) > 0.65).to(torch.uint8)
+    losses, lrs, betas = [], [], []
+    net2.train()
+    for step in range(3):
+        lrs.append(tr.optimizer.param_groups[0]["lr"])
+        betas.append(tr.optimizer.param_groups[0]["betas"][0])
+        losses.append(float(tr._train_one_batch(sched, [x, m])))
+    sd = net2.state_dict()
+    keep = ["segmentation_head.0.weight", "segmentation_head.0.bias", "decoder.blocks.4.conv2.0.weight",
+            "decoder.blocks.4.conv2.1.weight", "decoder.blocks.4.conv2.1.running_mean",
+            "decoder.blocks.4.conv2.1.running_var", "encoder.conv1.weight", "encoder.bn1.running_mean",
+            "encoder.bn1.running_var", "encoder.layer4.2.bn2.weight", "encoder.layer2.0.downsample.0.weight"]
+    np.savez_compressed(OUT / "g2_train3_b4_64.npz", x=x.numpy(), mask=m.numpy(), losses=np.array(losses),
+                        lrs=np.array(lrs), beta1=np.array(betas), n_frozen=np.array(len(frozen)),
+                        frozen_names=np.array(frozen), fingerprint0=weight_fingerprint(seeded_oracle(2, 3, False)),
+                        **{"after__" + k: sd[k].numpy() for k in keep})
+    print("train goldens done; losses", losses, "lrs", lrs, "beta1", betas, "frozen", len(frozen))
+
+
+if __name__ == "__main__":
+    main()

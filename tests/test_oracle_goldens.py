@@ -1,0 +1,128 @@
+"""Pin the CPU oracle (oracle/*.py) to goldens produced by the reference's own code
+(oracle/gen_goldens.py, run in the build container with /root/reference importable)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fingerprint
+from oracle import predictor_numpy as P
+from oracle.unet_resnet34_torch import seeded_oracle
+
+
+def test_padded_dimension_table(golden):
+    g = golden("g7_padded_dimension.npz")
+    assert [P.get_padded_dimension(int(d)) for d in g["dims"]] == list(g["padded"])
+    # reference KATs: tests/test_augmentations.py:6-10
+    assert [P.get_padded_dimension(d) for d in (32, 33, 13, 0)] == [32, 64, 32, 0]
+
+
+def test_pad_crop_quirk_row_p():
+    # d = 3 (mod 4): pad top floor(d/2), crop round-half-even(d/2) -> one pixel apart
+    assert P.pad_offsets(29) == (1, 2) and P.crop_offset(32, 29) == 2
+    assert P.pad_offsets(25) == (3, 4) and P.crop_offset(32, 25) == 4
+    assert P.pad_offsets(30) == (1, 1) and P.crop_offset(32, 30) == 1
+
+
+@pytest.fixture(scope="module")
+def pred_golden(golden):
+    g = golden("g3_predict_29x64x40_c4.npz")
+    net = seeded_oracle(classes=int(g["classes"]), seed=int(g["seed"]))
+    if not np.array_equal(fingerprint(net), g["fingerprint"]):
+        pytest.skip("torch RNG stream differs from the build container: seeded weights not reproducible")
+    return g, net
+
+
+def test_single_axis_bit_exact(pred_golden):
+    g, net = pred_golden
+    for ax, name in enumerate("zyx"):
+        l, p = P.predict_single_axis(net, g["vol"], ax)
+        assert l.dtype == np.uint8 and p.dtype == np.float16
+        assert np.array_equal(l, g[f"single_{name}_labels"])
+        assert np.array_equal(p.view(np.uint16), g[f"single_{name}_probs"].view(np.uint16))
+
+
+def test_three_and_twelve_way_bit_exact(pred_golden):
+    g, net = pred_golden
+    l, p = P.predict_3_ways_max_probs(net, g["vol"])
+    assert np.array_equal(l, g["three_labels"]) and np.array_equal(p, g["three_probs"])
+    l, p = P.predict_12_ways_max_probs(net, g["vol"])
+    assert np.array_equal(l, g["twelve_labels"]) and np.array_equal(p, g["twelve_probs"])
+
+
+def test_one_hot_votes_bit_exact(pred_golden):
+    g, net = pred_golden
+    k = int(g["classes"])
+    assert np.array_equal(P.one_hot_encode_array(P.predict_single_axis(net, g["vol"], 0)[0], k), g["onehot_z"])
+    assert np.array_equal(P.predict_3_ways_one_hot(net, g["vol"], k), g["onehot_three"])
+    oh = P.predict_12_ways_one_hot(net, g["vol"], k)
+    assert np.array_equal(oh, g["onehot_twelve"]) and oh.sum(0).min() == 12 == oh.sum(0).max()
+
+
+def test_packed_key_max_equals_reference_merge_chain(golden):
+    g = golden("g4_merge_ties.npz")
+    dl, dp = g["dlabels"], g["dprobs"]
+    lab = np.empty((2, *dl.shape[1:]), np.uint8)
+    prb = np.empty((2, *dl.shape[1:]), np.float16)
+    lab[0], prb[0] = dl[0], dp[0]
+    key = P.pack_key(dp[0], dl[0], 0)
+    for d in range(1, dl.shape[0]):
+        lab[1], prb[1] = dl[d], dp[d]
+        P.merge_vols_in_mem(prb, lab)
+        assert np.array_equal(lab[0], g["chain_labels"][d - 1])
+        assert np.array_equal(prb[0].view(np.uint16), g["chain_probs"][d - 1].view(np.uint16))
+        key = np.maximum(key, P.pack_key(dp[d], dl[d], d))
+        kl, kp = P.unpack_key(key)
+        assert np.array_equal(kl, lab[0]) and np.array_equal(kp.view(np.uint16), prb[0].view(np.uint16))
+    assert int(key.max()) < 2 ** 31  # int32 max all-reduce is order-equivalent
+
+
+def test_direction_views_follow_reference_call_order(golden):
+    g = golden("g4_direction_order.npz")
+    views = P.direction_views(g["idxvol"], 12)
+    assert len(views) == 12
+    for d, v in enumerate(views):
+        assert np.array_equal(np.ascontiguousarray(v), g[f"dir{d:02d}"])
+    assert [v.shape for v in P.direction_views(g["idxvol"], 3)] == [(5, 6, 7), (6, 5, 7), (7, 6, 5)]
+
+
+def test_dice_meaniou_lr_finder(golden):
+    g = golden("g6_loss_metric_lr.npz")
+    logits = torch.tensor(g["logits"], requires_grad=True)
+    _, targets = P.prepare_training_batch(None, torch.tensor(g["mask"]), 4)
+    assert np.array_equal(targets.numpy(), g["targets"])
+    loss = P.dice_loss_none(logits, targets.float())
+    loss.backward()
+    assert np.allclose(loss.item(), g["dice_loss"], rtol=0, atol=1e-7)
+    assert np.allclose(logits.grad.numpy(), g["dice_grad"], rtol=1e-6, atol=1e-9)
+    probs = torch.softmax(logits.detach(), 1)
+    assert np.allclose(P.mean_iou(probs, targets).item(), g["mean_iou"], atol=1e-7)
+    assert P.mean_iou(targets.float(), targets).item() == 1.0 == float(g["mean_iou_perfect"])
+    for i in range(3):
+        got = P.find_lr_from_graph(g[f"lr_curve{i}"], list(g[f"lr_lrs{i}"]))
+        assert np.isclose(got, float(g[f"lr_out{i}"]), rtol=1e-12)
+
+
+def test_three_training_steps_match_reference_loop(golden):
+    g = golden("g2_train3_b4_64.npz")
+    net = seeded_oracle(2, 3, perturb_bn=False)
+    if not np.array_equal(fingerprint(net), g["fingerprint0"]):
+        pytest.skip("torch RNG stream differs from the build container")
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, steps_per_epoch=4, epochs=1, pct_start=0.3)
+    x, m = torch.tensor(g["x"]), torch.tensor(g["mask"])
+    net.train()
+    for step in range(3):
+        assert np.isclose(opt.param_groups[0]["lr"], g["lrs"][step], rtol=1e-12)
+        assert np.isclose(opt.param_groups[0]["betas"][0], g["beta1"][step], rtol=1e-12)
+        _, t = P.prepare_training_batch(x, m, 2)
+        opt.zero_grad()
+        loss = P.dice_loss_none(net(x), t.float())
+        loss.backward()
+        opt.step()
+        sched.step()
+        assert np.isclose(loss.item(), g["losses"][step], rtol=0, atol=2e-6)
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith("after__"):
+            assert np.allclose(sd[k[7:]].numpy(), g[k], rtol=1e-4, atol=1e-6), k
+    assert int(g["n_frozen"]) == 33

@@ -1,0 +1,45 @@
+"""Structural known answers for the restated smp U-Net/ResNet-34."""
+import torch
+
+from oracle.unet_resnet34_torch import OracleUnetResnet34, conv_macs_per_slice
+
+
+def test_param_count_matches_published_smp_figure():
+    # smp.Unet("resnet34") (3-channel input, 1 class) is published as 24,436,369 parameters
+    assert sum(p.numel() for p in OracleUnetResnet34(3, 1).parameters()) == 24_436_369
+    # 1-channel stem drops 2*64*49 weights
+    assert sum(p.numel() for p in OracleUnetResnet34(1, 1).parameters()) == 24_436_369 - 2 * 64 * 49
+
+
+def test_state_dict_keys_and_shapes():
+    sd = OracleUnetResnet34(1, 4).state_dict()
+    assert sd["encoder.conv1.weight"].shape == (64, 1, 7, 7)
+    assert sd["encoder.layer2.0.downsample.0.weight"].shape == (128, 64, 1, 1)
+    assert sd["encoder.layer4.2.conv2.weight"].shape == (512, 512, 3, 3)
+    assert sd["decoder.blocks.0.conv1.0.weight"].shape == (256, 768, 3, 3)
+    assert sd["decoder.blocks.3.conv1.0.weight"].shape == (32, 128, 3, 3)
+    assert sd["decoder.blocks.4.conv1.0.weight"].shape == (16, 32, 3, 3)
+    assert sd["decoder.blocks.4.conv2.1.num_batches_tracked"].shape == ()
+    assert sd["segmentation_head.0.weight"].shape == (4, 16, 3, 3)
+    assert sd["segmentation_head.0.bias"].shape == (4,)
+    assert len(sd) == 278
+    assert not any("downsample" in k for k in sd if k.startswith("encoder.layer1"))
+
+
+def test_freeze_predicate_counts():
+    # reference predicate: "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108;
+    # KAT from tests/test_vol_seg_2d_trainer.py:37-44): stem + 2 convs per BasicBlock, not the 1x1 shortcuts
+    names = [n for n, _ in OracleUnetResnet34(1, 2).named_parameters() if "encoder" in n and "conv" in n]
+    assert len(names) == 1 + 2 * (3 + 4 + 6 + 3)
+    assert not any("downsample" in n for n in names)
+
+
+def test_macs_match_survey():
+    assert abs(conv_macs_per_slice(256, 256, 2) / 1e9 - 7.721) < 1e-3
+    assert abs(conv_macs_per_slice(512, 512, 4) / 1e9 - 30.958) < 1e-3
+
+
+def test_forward_shape_multiple_of_32():
+    net = OracleUnetResnet34(1, 3).eval()
+    with torch.no_grad():
+        assert net(torch.zeros(1, 1, 96, 64)).shape == (1, 3, 96, 64)
