@@ -1,0 +1,170 @@
+/* libvolseg_hip.so - C ABI of the MI355X-native (gfx950) 2D-slice segmentation engine.
+ *
+ * Drop-in boundary: the reference constructs the object behind ``self.model`` only in
+ * ``create_model_on_device`` (volume_segmantics/model/model_2d.py:10-39) and uses it as
+ * ``model(x)`` / ``loss.backward()`` (vol_seg_2d_trainer.py:424-430) and
+ * ``model(batch)`` + softmax/argmax/gather/crop (vol_seg_2d_predictor.py:44-58), followed
+ * by the max-probability merges (vol_seg_2d_predictor.py:90-98).  Every entry point below
+ * cites the reference lines it replaces.  All pointers are DEVICE pointers unless named
+ * ``host_*``; all activations are NHWC; nothing here allocates device memory or copies
+ * host<->device; all work is enqueued on the caller's HIP stream (``void* stream`` is a
+ * hipStream_t).  Functions return VS_OK (0) or a negative error code; the message is
+ * available from vs_last_error() (thread local).
+ */
+#ifndef VOLSEG_HIP_H
+#define VOLSEG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VS_OK = 0, VS_ERR_INVALID = -1, VS_ERR_HIP = -2, VS_ERR_UNSUPPORTED = -3 };
+enum { VS_F32 = 0, VS_BF16 = 1 }; /* compute/storage dtype of activations and conv weights */
+
+const char* vs_last_error(void);
+int vs_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Single operators (unit-testable pieces of the network; torch equivalents in comments)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Convolution geometry.  The input is the *virtual* tensor cat(upsample_nearest(src0, 2^up0),
+ * src1) along channels - smp's DecoderBlock (F.interpolate(scale_factor=2, "nearest") +
+ * torch.cat) is never materialised. */
+typedef struct vs_conv_desc {
+    int32_t dtype;             /* VS_F32 | VS_BF16 */
+    int32_t n, hin, win;       /* virtual input dims (after upsampling src0) */
+    int32_t c0, c1, up0;       /* channels of src0 / src1 (0 = absent), log2 upsample of src0 */
+    int32_t cout, kh, kw, stride, pad;
+    int32_t relu;              /* apply ReLU in the epilogue */
+    int32_t out_f32;           /* store fp32 output regardless of dtype */
+    int32_t split_c;           /* >0: output channels >= split_c go to y1 (dgrad through a concat) */
+} vs_conv_desc;
+
+/* y = relu?( conv(x, w) * scale[c] + shift[c] + residual ).  w: [cout][kh*kw][c0+c1] in dtype.
+ * Replaces F.conv2d (+ eval-mode F.batch_norm folded into scale/shift, + residual add, + ReLU)
+ * inside smp.Unet.forward (reference call sites vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44).
+ * Also used as dgrad (conv of dy with the flipped/transposed weights from vs_weights_prepare). */
+int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void* src1, const void* w,
+                  const float* scale, const float* shift, const void* residual,
+                  void* y, void* y1, void* stream);
+
+/* dw[cout][kh*kw][cin] (fp32) = sum_pixels dy (x) x.  torch: conv weight gradient of loss.backward()
+ * (vol_seg_2d_trainer.py:429).  workspace >= vs_conv2d_wgrad_workspace(d). */
+size_t vs_conv2d_wgrad_workspace(const vs_conv_desc* d);
+int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const void* src1, const void* dy,
+                    float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stem: 7x7 stride-2 pad-3 conv with one input channel (encoder.conv1 after smp's
+ * patch_first_conv).  x: [n][h][w] fp32 (the caller's (B,1,H,W) tensor); w: [64][49] fp32;
+ * y: [n][h/2][w/2][64] in dtype; dy likewise. */
+int vs_stem_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, int relu,
+                void* y, int n, int h, int w_, void* stream);
+int vs_stem_wgrad(int dtype, const float* x, const void* dy, float* dw, float* workspace, size_t workspace_bytes,
+                  int n, int h, int w_, void* stream);
+size_t vs_stem_wgrad_workspace(int n, int h, int w_);
+
+/* Train-mode BatchNorm2d (eps 1e-5, momentum 0.1, biased batch var, unbiased running var) on
+ * x: [rows][c].  stats: mean[c], invstd[c]; running stats updated in place when not null. */
+int vs_bn_stats(int dtype, const void* x, int64_t rows, int c, float eps, float momentum,
+                float* mean, float* invstd, float* running_mean, float* running_var,
+                float* workspace, size_t workspace_bytes, void* stream);
+size_t vs_bn_workspace(int64_t rows, int c);
+/* y = relu?( (x-mean)*invstd*gamma + beta + residual ) */
+int vs_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma,
+                const float* beta, const void* residual, int relu, void* y, int64_t rows, int c, void* stream);
+/* backward of the above: dz = dy * (y > 0 if relu); dgamma, dbeta; dx; optionally dres = dz. */
+int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+              const float* gamma, int relu, void* dx, void* dres, float* dgamma, float* dbeta,
+              int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream);
+/* eval-mode folding: scale = gamma / sqrt(var + eps), shift = beta - mean * scale */
+int vs_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               float eps, float* scale, float* shift, int c, void* stream);
+
+/* MaxPool2d(3, stride 2, pad 1) on NHWC; idx: uint8 [n][h/2][w/2][c] window position of the first max. */
+int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, void* stream);
+int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int accumulate,
+                   int n, int h, int w, int c, void* stream);
+/* backward of nearest x2 upsampling: dx[n][h][w][c] = sum of the 2x2 block of dy[n][2h][2w][c] */
+int vs_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, void* stream);
+/* zero-stuffing for stride-2 dgrad: y[n][2h][2w][c] = x at even positions, 0 elsewhere */
+int vs_zero_stuff2x(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole network: smp.Unet(resnet34, in_channels=1, classes=K)   (model_2d.py:15-16)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vs_unet vs_unet_t;
+
+/* Parameter table (same for every instance with the same class count): tensors in smp's
+ * state_dict order.  kind: 0 = conv weight (stored [cout][kh][kw][cin] = torch channels_last),
+ * 1 = BN gamma, 2 = BN beta, 3 = conv bias, 4 = BN running_mean, 5 = BN running_var.
+ * Kinds 0-3 live in the flat fp32 ``params`` buffer, kinds 4-5 in the flat ``bnstate`` buffer;
+ * offset is in elements. */
+int vs_unet_num_tensors(int classes);
+int vs_unet_tensor_info(int classes, int index, char* name, int name_len, int64_t shape[4], int* ndim,
+                        int* kind, int64_t* offset);
+int64_t vs_unet_param_elems(int classes);
+int64_t vs_unet_bnstate_elems(int classes);
+
+int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w);
+void vs_unet_destroy(vs_unet_t* net);
+size_t vs_unet_workspace_bytes(const vs_unet_t* net, int training);
+/* (re)derive low-precision / transposed weight copies and folded BN constants from the fp32
+ * master parameters; call after every optimizer step or load_state_dict. */
+int vs_unet_prepare(vs_unet_t* net, const float* params, const float* bnstate, int training, void* workspace,
+                    void* stream);
+/* logits (n, K, h, w) fp32 NCHW = model(x), x: (n, 1, h, w) fp32.  training != 0: batch-stat BN,
+ * running stats in ``bnstate`` updated, activations kept in ``workspace`` for vs_unet_backward.
+ * Replaces self.model(inputs) (vol_seg_2d_trainer.py:232,424; vol_seg_2d_predictor.py:44). */
+int vs_unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
+                    float* logits, void* workspace, void* stream);
+/* grads (flat fp32, same layout as params, overwritten) = d loss / d params given dlogits
+ * (n, K, h, w) fp32 NCHW.  need_encoder_wgrad = 0 skips the weight gradients of the tensors
+ * the reference freezes (vol_seg_2d_trainer.py:102-108).  Replaces loss.backward() (:429). */
+int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                     int need_encoder_wgrad, float* grads, void* workspace, void* stream);
+
+/* AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, vol_seg_2d_trainer.py:395-396,430);
+ * ``mask`` (uint8 per element, may be null) = 0 freezes an element (requires_grad False). */
+int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prediction path (vol_seg_2d_predictor.py:31-136)
+ * ---------------------------------------------------------------------------------------- */
+/* Index map of one prediction direction: voxel address of slice s, row h, column w of the
+ * rotated/swapped stack = base + s*ss + h*sh + w*sw (elements).  np.rot90 / swapaxes
+ * (vol_seg_2d_predictor.py:34,108; base_data_utils.py:132-138) are pure index maps. */
+typedef struct vs_dirmap {
+    int64_t base, ss, sh, sw;
+    int32_t depth, h, w;      /* stack dims (un-padded) */
+    int32_t hp, wp;           /* padded to multiples of 32 (augmentations.py:30-65) */
+    int32_t pad_top, pad_left;   /* PadIfNeeded centre offsets */
+    int32_t crop_top, crop_left; /* torchvision center_crop offsets (base_data_utils.py:125-129) */
+} vs_dirmap;
+
+/* x[b][hp][wp] fp32 = normalised, reflect-101 padded slices s0..s0+nb-1 of the uint8 volume
+ * (data/datasets.py:120-142: /255, -0.449, /0.226). */
+int vs_slices_gather(const uint8_t* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream);
+
+/* softmax -> argmax (first max) -> max prob (fp32 -> fp16 RNE) on logits (nb, K, hp, wp) NCHW,
+ * centre-cropped and scattered to voxel addresses (vol_seg_2d_predictor.py:45-64).
+ * mode 0: labels[u8] and probs[f16] volumes (either may be null);
+ * mode 1: keys[addr] = max(keys[addr], prob_bits<<16 | (15-dir)<<8 | label)  (packed-key merge);
+ * mode 2: votes[label][addr] += 1 (one-hot variants, :118-136). */
+int vs_logits_to_volume(const float* logits, int classes, const vs_dirmap* m, int s0, int nb, int mode,
+                        int direction, uint8_t* labels, uint16_t* probs, uint32_t* keys, uint8_t* votes,
+                        int64_t nvox, void* stream);
+
+/* The reference's pairwise merge (_merge_vols_in_mem, :90-98): where prob1 > prob0 take slot 1. */
+int vs_merge_maxprob(uint8_t* label0, uint16_t* prob0, const uint8_t* label1, const uint16_t* prob1,
+                     int64_t n, void* stream);
+int vs_keys_unpack(const uint32_t* keys, uint8_t* labels, uint16_t* probs, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLSEG_HIP_H */

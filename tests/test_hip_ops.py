@@ -1,0 +1,330 @@
+"""-m gpu: every HIP operator, called through the C ABI, against torch CPU fp32 (primitives of the
+oracle).  fp32 path: tight tolerance (exact-fp32 MFMA, different summation
+order); bf16 path: inputs pre-rounded to bf16 on the CPU side, tolerance = bf16 output rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_helpers import (DEV, conv_desc, from_nhwc, lib, rounded, sync, tdtype, to_nhwc, tol, w_krsc)
+
+pytestmark = pytest.mark.gpu
+CODES = [0, 1]
+
+
+def _conv_case(code, n, h, w, cin, cout, k, stride, pad, seed=0, relu=0, affine=False, residual=False):
+    L = lib()
+    g = torch.Generator().manual_seed(seed)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code)
+    wt = rounded(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, code)
+    ref = F.conv2d(x, wt, stride=stride, padding=pad)
+    scale = shift = res = None
+    if affine:
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if residual:
+        res = rounded(torch.randn(ref.shape, generator=g), code)
+        ref = ref + res
+    if relu:
+        ref = ref.relu()
+    d = conv_desc(L, code, n, h, w, cin, cout, k, stride, pad, relu=relu)
+    xd, wd = to_nhwc(x, code), w_krsc(wt, code)
+    y = torch.full((n, ref.shape[2], ref.shape[3], cout), float("nan"), device=DEV, dtype=tdtype(code))
+    sc = scale.to(DEV) if affine else None
+    sh = shift.to(DEV) if affine else None
+    rd = to_nhwc(res, code) if residual else None
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wd), L.ptr(sc), L.ptr(sh), L.ptr(rd), L.ptr(y), None, None))
+    sync()
+    got = from_nhwc(y)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, ref, **tol(code, ref.abs().max().item())), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [
+    (2, 16, 16, 64, 64, 3, 1, 1),     # layer1-like
+    (2, 16, 16, 64, 128, 3, 2, 1),    # stride-2 3x3
+    (2, 16, 16, 64, 128, 1, 2, 0),    # 1x1 stride-2 shortcut
+    (1, 32, 32, 32, 16, 3, 1, 1),     # small cout (decoder tail)
+    (2, 32, 48, 16, 16, 3, 1, 1),     # cin 16 (half-empty bf16 chunk), non-square
+    (3, 8, 8, 128, 128, 3, 1, 1),     # 8-wide tile path
+    (2, 2, 2, 256, 64, 3, 1, 1),      # tiny spatial
+    (1, 4, 4, 128, 256, 3, 2, 1),     # stride 2 onto 2x2
+    (1, 24, 40, 96, 32, 3, 1, 1),     # ragged tiles (24x40 not multiples of the 8x16 tile)
+])
+def test_conv_fwd_matches_torch(code, shape):
+    _conv_case(code, *shape)
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_conv_epilogue_affine_residual_relu(code):
+    _conv_case(code, 2, 16, 16, 64, 64, 3, 1, 1, seed=3, relu=1, affine=True, residual=True)
+    _conv_case(code, 1, 8, 8, 32, 32, 3, 1, 1, seed=4, relu=0, affine=True, residual=False)
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_conv_upsample_concat_never_materialised(code):
+    """Decoder block input: cat(F.interpolate(x, 2, 'nearest'), skip) folded into the patch loader."""
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    n, h, w, c0, c1, cout = 2, 16, 16, 64, 32, 32
+    x0 = rounded(torch.randn(n, c0, h // 2, w // 2, generator=g), code)
+    x1 = rounded(torch.randn(n, c1, h, w, generator=g), code)
+    wt = rounded(torch.randn(cout, c0 + c1, 3, 3, generator=g) / 30, code)
+    ref = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), wt, padding=1)
+    d = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, c1=c1, up0=1)
+    y = torch.empty((n, h, w, cout), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x0, code)), L.ptr(to_nhwc(x1, code)), L.ptr(w_krsc(wt, code)),
+                                None, None, None, L.ptr(y), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
+    # no skip (last decoder block)
+    ref2 = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), wt[:, :c0], padding=1)
+    d2 = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, up0=1)
+    L.check(L.lib.vs_conv2d_fwd(d2, L.ptr(to_nhwc(x0, code)), None, L.ptr(w_krsc(wt[:, :c0].contiguous(), code)),
+                                None, None, None, L.ptr(y), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(y), ref2, **tol(code, ref2.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("classes", [1, 2, 3, 4, 7])
+def test_head_conv_bias_fp32_nchw(code, classes):
+    L = lib()
+    g = torch.Generator().manual_seed(6)
+    n, h, w = 2, 32, 32
+    x = rounded(torch.randn(n, 16, h, w, generator=g), code)
+    wt = rounded(torch.randn(classes, 16, 3, 3, generator=g) / 12, code)
+    b = torch.randn(classes, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    d = conv_desc(L, code, n, h, w, 16, classes, 3, 1, 1, out_f32=3)
+    y = torch.full((n, classes, h, w), float("nan"), device=DEV)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x, code)), None, L.ptr(w_krsc(wt, code)), None, L.ptr(b.to(DEV)), None,
+                                L.ptr(y), None, None))
+    sync()
+    assert torch.allclose(y.cpu(), ref, rtol=1e-4, atol=1e-4 if code == 0 else 2e-2)
+
+
+def _prep_weights(L, code, w_oihw):
+    cout, cin, k, _ = w_oihw.shape
+    wf = w_oihw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wc = torch.empty(wf.shape, device=DEV, dtype=tdtype(code))
+    wt = torch.empty((cin, k, k, cout), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_weights_prepare(code, L.ptr(wf), L.ptr(wc), L.ptr(wt), cout, k * k, cin, None))
+    return wc, wt
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_weights_prepare_layout(code):
+    L = lib()
+    w = rounded(torch.randn(40, 24, 3, 3), code)
+    wc, wt = _prep_weights(L, code, w)
+    sync()
+    assert torch.equal(wc.float().cpu(), w.permute(0, 2, 3, 1))
+    assert torch.equal(wt.float().cpu(), torch.flip(w, dims=(2, 3)).permute(1, 2, 3, 0))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 32, 128, 3, 2, 1),
+                                   (2, 16, 16, 64, 128, 1, 2, 0), (1, 32, 32, 16, 16, 3, 1, 1)])
+def test_dgrad_and_wgrad_match_autograd(code, shape):
+    L = lib()
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(7)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, code).requires_grad_()
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    ho, wo = y.shape[2:]
+    # ---- wgrad ----
+    d = conv_desc(L, code, n, h, w, cin, cout, k, stride, pad)
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((cout, k, k, cin), float("nan"), device=DEV)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(to_nhwc(x.detach(), code)), None, L.ptr(to_nhwc(dy, code)), L.ptr(dw),
+                                  L.ptr(ws), ws_bytes, None))
+    sync()
+    ref_dw = wt.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    # ---- dgrad = stride-1 conv of the (zero-stuffed) dy with flipped/transposed weights ----
+    _, wtr = _prep_weights(L, code, wt.detach())
+    dyd = to_nhwc(dy, code)
+    if stride == 2:
+        zs = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+        L.check(L.lib.vs_zero_stuff2x(code, L.ptr(dyd), L.ptr(zs), n, ho, wo, cout, None))
+        dyd = zs
+    dd = conv_desc(L, code, n, h, w, cout, cin, k, 1, pad)
+    dx = torch.full((n, h, w, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_wgrad_through_upsample_concat_and_split_dgrad(code):
+    L = lib()
+    g = torch.Generator().manual_seed(8)
+    n, h, w, c0, c1, cout = 2, 16, 16, 64, 64, 32
+    x0 = rounded(torch.randn(n, c0, h // 2, w // 2, generator=g), code).requires_grad_()
+    x1 = rounded(torch.randn(n, c1, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(cout, c0 + c1, 3, 3, generator=g) / 30, code).requires_grad_()
+    y = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), wt, padding=1)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    d = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, c1=c1, up0=1)
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    dw = torch.empty((cout, 3, 3, c0 + c1), device=DEV)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(to_nhwc(x0.detach(), code)), L.ptr(to_nhwc(x1.detach(), code)),
+                                  L.ptr(to_nhwc(dy, code)), L.ptr(dw), L.ptr(ws), ws_bytes, None))
+    sync()
+    ref_dw = wt.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    # dgrad split across the concat: channels < c0 -> full-res "dup" (then 2x2 summed), >= c0 -> dskip
+    _, wtr = _prep_weights(L, code, wt.detach())
+    dd = conv_desc(L, code, n, h, w, cout, c0 + c1, 3, 1, 1, split_c=c0)
+    dup = torch.empty((n, h, w, c0), device=DEV, dtype=tdtype(code))
+    dskip = torch.empty((n, h, w, c1), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(to_nhwc(dy, code)), None, L.ptr(wtr), None, None, None, L.ptr(dup), L.ptr(dskip), None))
+    dx0 = torch.empty((n, h // 2, w // 2, c0), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_upsample2x_bwd(code, L.ptr(dup), L.ptr(dx0), n, h // 2, w // 2, c0, None))
+    sync()
+    assert torch.allclose(from_nhwc(dskip), x1.grad, **tol(code, x1.grad.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx0), x0.grad, **tol(code, 2 * x0.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_stem_fwd_and_wgrad(code):
+    L = lib()
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 2, 64, 96
+    x = torch.randn(n, 1, h, w, generator=g).requires_grad_(False)
+    wt = (torch.randn(64, 1, 7, 7, generator=g) / 7).requires_grad_()
+    y = F.conv2d(x, wt, stride=2, padding=3)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    out = torch.empty((n, h // 2, w // 2, 64), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_stem_fwd(code, L.ptr(x.to(DEV)), L.ptr(wt.detach().reshape(64, 49).to(DEV)), None, None, 0, L.ptr(out), n, h, w, None))
+    sync()
+    assert torch.allclose(from_nhwc(out), y.detach(), **tol(code, y.abs().max().item()))
+    sc, sh = torch.rand(64) + 0.5, torch.randn(64)
+    L.check(L.lib.vs_stem_fwd(code, L.ptr(x.to(DEV)), L.ptr(wt.detach().reshape(64, 49).to(DEV)), L.ptr(sc.to(DEV)),
+                              L.ptr(sh.to(DEV)), 1, L.ptr(out), n, h, w, None))
+    sync()
+    ref = (y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).relu()
+    assert torch.allclose(from_nhwc(out), ref, **tol(code, ref.abs().max().item()))
+    wsb = L.lib.vs_stem_wgrad_workspace(n, h, w)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 49), float("nan"), device=DEV)
+    L.check(L.lib.vs_stem_wgrad(code, L.ptr(x.to(DEV)), L.ptr(to_nhwc(dy, code)), L.ptr(dw), L.ptr(ws), wsb, n, h, w, None))
+    sync()
+    ref_dw = wt.grad.reshape(64, 49)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("c,rows_shape", [(64, (2, 16, 16)), (16, (2, 32, 32)), (512, (3, 2, 2)), (128, (1, 8, 8))])
+def test_batchnorm_train_fwd_bwd(code, c, rows_shape):
+    L = lib()
+    g = torch.Generator().manual_seed(10)
+    n, h, w = rows_shape
+    x = rounded(torch.randn(n, c, h, w, generator=g) * 2 + 0.5, code).requires_grad_()
+    res = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_()
+    beta = torch.randn(c, generator=g).requires_grad_()
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = (F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5) + res).relu()
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    rows = n * h * w
+    xd, resd = to_nhwc(x.detach(), code), to_nhwc(res.detach(), code)
+    wsb = L.lib.vs_bn_workspace(rows, c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    L.check(L.lib.vs_bn_stats(code, L.ptr(xd), rows, c, 1e-5, 0.1, L.ptr(mean), L.ptr(invstd), L.ptr(rmd), L.ptr(rvd), L.ptr(ws), wsb, None))
+    yd = torch.empty_like(xd)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    L.check(L.lib.vs_bn_apply(code, L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), L.ptr(bd), L.ptr(resd), 1, L.ptr(yd), rows, c, None))
+    sync()
+    xr = x.detach()
+    assert torch.allclose(mean.cpu(), xr.mean((0, 2, 3)), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(invstd.cpu(), 1 / torch.sqrt(xr.var((0, 2, 3), unbiased=False) + 1e-5), rtol=1e-4)
+    assert torch.allclose(rmd.cpu(), rm_ref, atol=1e-5, rtol=1e-5) and torch.allclose(rvd.cpu(), rv_ref, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    dx, dres = torch.empty_like(xd), torch.empty_like(xd)
+    dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    yin = to_nhwc(y.detach(), code)
+    L.check(L.lib.vs_bn_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(yin), L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), 1,
+                            L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, c, L.ptr(ws), wsb, None))
+    sync()
+    t = tol(code, x.grad.abs().max().item())
+    assert torch.allclose(from_nhwc(dres), res.grad, **tol(code, res.grad.abs().max().item()))
+    assert torch.allclose(dbeta.cpu(), beta.grad, rtol=1e-3, atol=1e-3 * beta.grad.abs().max().item())
+    assert torch.allclose(dgamma.cpu(), gamma.grad, rtol=2e-3, atol=2e-3 * gamma.grad.abs().max().item() + (0 if code == 0 else 0.05))
+    assert torch.allclose(from_nhwc(dx), x.grad, **t)
+
+
+def test_bn_fold_matches_eval_batchnorm():
+    L = lib()
+    c = 96
+    gamma, beta, rm, rv = torch.rand(c) + 0.5, torch.randn(c), torch.randn(c), torch.rand(c) + 0.1
+    sc, sh = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    L.check(L.lib.vs_bn_fold(L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)), L.ptr(rm.to(DEV)), L.ptr(rv.to(DEV)), 1e-5, L.ptr(sc), L.ptr(sh), c, None))
+    sync()
+    x = torch.randn(2, c, 4, 4)
+    ref = F.batch_norm(x, rm, rv, gamma, beta, training=False, eps=1e-5)
+    assert torch.allclose(x * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_maxpool_fwd_bwd_and_helpers(code):
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 2, 64, 16, 24
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).relu().requires_grad_()  # ReLU output: many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), code)
+    yd = torch.empty((n, h // 2, w // 2, c), device=DEV, dtype=tdtype(code))
+    idx = torch.empty((n, h // 2, w // 2, c), device=DEV, dtype=torch.uint8)
+    L.check(L.lib.vs_maxpool_fwd(code, L.ptr(xd), L.ptr(yd), L.ptr(idx), n, h, w, c, None))
+    base = rounded(torch.randn(n, c, h, w, generator=g), code)
+    dx = to_nhwc(base, code)
+    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(idx), L.ptr(dx), 1, n, h, w, c, None))
+    dx0 = torch.empty_like(dx)
+    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(idx), L.ptr(dx0), 0, n, h, w, c, None))
+    sync()
+    assert torch.equal(from_nhwc(yd), y.detach())
+    # gradient routed to the first maximum of each window, exactly like torch
+    assert torch.allclose(from_nhwc(dx0), x.grad, **tol(code, 4.0))
+    assert torch.allclose(from_nhwc(dx), rounded(x.grad + base, code), **tol(code, 4.0))
+
+
+def test_adamw_matches_torch():
+    L = lib()
+    g = torch.Generator().manual_seed(12)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([p_ref], lr=1e-3)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    mask = (torch.rand(n, generator=g) > 0.3).to(torch.uint8)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        lr, b1 = 1e-3 * step, 0.95 - 0.03 * step
+        opt.param_groups[0]["lr"], opt.param_groups[0]["betas"] = lr, (b1, 0.999)
+        p_ref.grad = grad.clone()
+        opt.step()
+        L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(grad.to(DEV)), L.ptr(m), L.ptr(v), None, n, lr, b1, 0.999, 1e-8, 0.01, step, None))
+        sync()
+        assert torch.allclose(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
+    # masked elements stay frozen
+    before = p.clone()
+    L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(torch.ones(n, device=DEV)), L.ptr(m), L.ptr(v), L.ptr(mask.to(DEV)), n, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, None))
+    sync()
+    frozen = mask == 0
+    assert torch.equal(p.cpu()[frozen], before.cpu()[frozen]) and not torch.equal(p.cpu()[~frozen], before.cpu()[~frozen])

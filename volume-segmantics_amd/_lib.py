@@ -1,0 +1,122 @@
+"""ctypes binding of libvolseg_hip.so (declared in include/volseg_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing this module raises at
+import, and every wrapper raises RuntimeError(vs_last_error()) on a non-zero status."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("VOLSEG_HIP_LIB", _HERE / "lib" / "libvolseg_hip.so"))
+
+VS_F32, VS_BF16 = 0, 1
+
+
+class VolsegHipMissing(ImportError):
+    pass
+
+
+if not LIB_PATH.exists():
+    raise VolsegHipMissing(
+        f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        f"(or `make -C {_HERE / 'csrc'}`); there is no CPU fallback for the HIP path")
+
+lib = C.CDLL(str(LIB_PATH))
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c")]
+
+
+class DirMap(C.Structure):
+    _fields_ = [("base", C.c_int64), ("ss", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)] + [
+        (n, C.c_int32) for n in ("depth", "h", "w", "hp", "wp", "pad_top", "pad_left", "crop_top", "crop_left")]
+
+
+P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_SIGS = {
+    "vs_last_error": (C.c_char_p, []),
+    "vs_version": (I, []),
+    "vs_conv2d_fwd": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
+    "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
+    "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
+    "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),
+    "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
+    "vs_stem_wgrad": (I, [I, P, P, P, P, SZ, I, I, I, P]),
+    "vs_stem_wgrad_workspace": (SZ, [I, I, I]),
+    "vs_bn_stats": (I, [I, P, I64, I, F, F, P, P, P, P, P, SZ, P]),
+    "vs_bn_workspace": (SZ, [I64, I]),
+    "vs_bn_apply": (I, [I, P, P, P, P, P, P, I, P, I64, I, P]),
+    "vs_bn_bwd": (I, [I, P, P, P, P, P, P, I, P, P, P, P, I64, I, P, SZ, P]),
+    "vs_bn_fold": (I, [P, P, P, P, F, P, P, I, P]),
+    "vs_maxpool_fwd": (I, [I, P, P, P, I, I, I, I, P]),
+    "vs_maxpool_bwd": (I, [I, P, P, P, I, I, I, I, I, P]),
+    "vs_upsample2x_bwd": (I, [I, P, P, I, I, I, I, P]),
+    "vs_zero_stuff2x": (I, [I, P, P, I, I, I, I, P]),
+    "vs_unet_num_tensors": (I, [I]),
+    "vs_unet_tensor_info": (I, [I, I, C.c_char_p, I, C.POINTER(I64), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
+    "vs_unet_param_elems": (I64, [I]),
+    "vs_unet_bnstate_elems": (I64, [I]),
+    "vs_unet_create": (I, [C.POINTER(P), I, I, I, I, I]),
+    "vs_unet_destroy": (None, [P]),
+    "vs_unet_workspace_bytes": (SZ, [P, I]),
+    "vs_unet_prepare": (I, [P, P, P, I, P, P]),
+    "vs_unet_forward": (I, [P, P, P, P, I, I, P, P, P]),
+    "vs_unet_backward": (I, [P, P, P, P, I, I, P, P, P]),
+    "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
+    "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
+    "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
+    "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),
+    "vs_keys_unpack": (I, [P, P, P, I64, P]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def last_error() -> str:
+    return lib.vs_last_error().decode()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libvolseg_hip error {rc}: {last_error()}")
+
+
+def ptr(t) -> int | None:
+    """Device/host address of a torch tensor (None passes a null pointer)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+
+    if torch_dtype == torch.float32:
+        return VS_F32
+    if torch_dtype == torch.bfloat16:
+        return VS_BF16
+    raise ValueError(f"unsupported compute dtype {torch_dtype}")
+
+
+def unet_tensor_table(classes: int):
+    """[(name, shape, kind, offset)] in smp state_dict order (see vs_unet_tensor_info)."""
+    n = lib.vs_unet_num_tensors(classes)
+    if n < 0:
+        raise RuntimeError(last_error())
+    out = []
+    name = C.create_string_buffer(128)
+    shape = (I64 * 4)()
+    ndim, kind, off = I(), I(), I64()
+    for i in range(n):
+        check(lib.vs_unet_tensor_info(classes, i, name, 128, shape, C.byref(ndim), C.byref(kind), C.byref(off)))
+        out.append((name.value.decode(), tuple(shape[: ndim.value]), kind.value, off.value))
+    return out

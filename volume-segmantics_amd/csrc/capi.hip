@@ -1,0 +1,77 @@
+// C-ABI glue: error reporting and the single-operator entry points declared in include/volseg_hip.h.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void vs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* vs_last_error(void) { return g_err; }
+extern "C" int vs_version(void) { return 100; }
+
+static int desc_to_params(const vs_conv_desc* d, ConvParams& p) {
+    VS_REQUIRE(d, "conv: null descriptor");
+    p = ConvParams{};
+    p.C0 = d->c0; p.C1 = d->c1; p.up0 = d->up0;
+    p.N = d->n; p.Hin = d->hin; p.Win = d->win;
+    p.stride = d->stride; p.pad = d->pad; p.KH = d->kh; p.KW = d->kw;
+    VS_REQUIRE(d->stride >= 1 && d->kh >= 1 && d->kw >= 1, "conv: bad geometry");
+    p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
+    p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
+    p.Cout = d->cout; p.relu = d->relu; p.out_f32 = d->out_f32; p.split_c = d->split_c;
+    return VS_OK;
+}
+
+extern "C" int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void* src1, const void* w,
+                             const float* scale, const float* shift, const void* residual, void* y, void* y1,
+                             void* stream) {
+    ConvParams p;
+    int rc = desc_to_params(d, p);
+    if (rc) return rc;
+    VS_REQUIRE((d->c1 == 0) == (src1 == nullptr), "conv: src1 / c1 mismatch");
+    VS_REQUIRE((d->split_c > 0) == (y1 != nullptr), "conv: y1 / split_c mismatch");
+    p.src0 = src0; p.src1 = src1; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.out = y; p.out1 = y1;
+    return launch_conv_igemm(d->dtype, p, (hipStream_t)stream);
+}
+
+static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
+    VS_REQUIRE(d, "conv: null descriptor");
+    p = WgradParams{};
+    p.C0 = d->c0; p.C1 = d->c1; p.up0 = d->up0; p.N = d->n; p.Hin = d->hin; p.Win = d->win;
+    p.stride = d->stride; p.pad = d->pad; p.KH = d->kh; p.KW = d->kw;
+    p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
+    p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
+    p.Cout = d->cout;
+    return VS_OK;
+}
+
+extern "C" size_t vs_conv2d_wgrad_workspace(const vs_conv_desc* d) {
+    WgradParams p;
+    if (desc_to_wgrad(d, p)) return 0;
+    return wgrad_workspace_bytes(d->dtype, p);
+}
+
+extern "C" int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const void* src1, const void* dy, float* dw,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    WgradParams p;
+    int rc = desc_to_wgrad(d, p);
+    if (rc) return rc;
+    VS_REQUIRE(src0 && dy && dw, "conv_wgrad: null pointer");
+    p.src0 = src0; p.src1 = src1; p.dy = dy; p.dw = dw;
+    p.partials = (float*)workspace; p.partial_bytes = workspace_bytes;
+    return launch_conv_wgrad(d->dtype, p, (hipStream_t)stream);
+}
+
+int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
+/* fp32 [cout][taps][cin] -> dtype copy (wc, may be null) and flipped/transposed dgrad copy [cin][taps][cout] (wt) */
+extern "C" int vs_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, void* stream) {
+    VS_REQUIRE(w && (wc || wt), "weights_prepare: null pointer");
+    return launch_weight_prepare(dtype, w, wc, wt, cout, taps, cin, cout, (hipStream_t)stream);
+}

@@ -1,0 +1,130 @@
+// Shared device/host helpers for libvolseg_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/volseg_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+
+typedef uint16_t bf16_t;  // storage type for bf16 tensors
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void vs_set_error(const char* fmt, ...);
+#define VS_CHECK_HIP(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            vs_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return VS_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+#define VS_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            vs_set_error(__VA_ARGS__);        \
+            return VS_ERR_INVALID;            \
+        }                                     \
+    } while (0)
+#define VS_LAUNCH_CHECK() VS_CHECK_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 --------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kDtype = VS_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kDtype = VS_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4 consecutive elements <-> float4
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+// 8 consecutive elements
+__device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+    float4 a = ld4(p), b = ld4(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+    uint4 u;
+    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+    st4(p, make_float4(v[0], v[1], v[2], v[3]));
+    st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline size_t dtype_size(int dt) { return dt == VS_BF16 ? 2 : 4; }
+
+// ---- internal op launchers (one per .hip file) ------------------------------------------------------
+struct ConvParams {
+    const void* src0; const void* src1;  // virtual input = cat(upsample(src0, 2^up0), src1) along C
+    int C0, C1, up0;
+    int N, Hin, Win;                     // virtual input spatial dims
+    int Hout, Wout, stride, pad, KH, KW;
+    const void* w;                       // [Cout][KH*KW][C0+C1]
+    int Cout;
+    void* out;                           // [N][Hout][Wout][Cout or split_c]
+    void* out1; int split_c;             // optional: couts >= split_c go to out1 ([..][Cout-split_c])
+    const float* scale; const float* shift;  // per-cout affine applied to the accumulator (may be null)
+    const void* residual;                // same shape as out, added after the affine (may be null)
+    int relu;
+    int out_f32;                         // store fp32 regardless of the compute dtype
+};
+int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
+
+struct WgradParams {
+    const void* src0; const void* src1; int C0, C1, up0;  // the forward conv's virtual input
+    int N, Hin, Win, Hout, Wout, stride, pad, KH, KW;
+    const void* dy; int Cout;             // [N][Hout][Wout][Cout]
+    float* dw;                            // [Cout][KH*KW][Cin] fp32 (overwritten)
+    float* partials; size_t partial_bytes;  // workspace
+};
+size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
+int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);

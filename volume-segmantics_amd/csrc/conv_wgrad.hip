@@ -1,0 +1,253 @@
+// Convolution weight gradient on MFMA (gfx950): dw[co][tap][ci] = sum_pixels dy[p][co] * x[p (+) tap][ci].
+//
+// GEMM view per tap: D[cout][cin] with K = output pixels.  NHWC keeps channels contiguous, so both
+// operands need "8 consecutive pixels of one channel" per lane - the transposed fragment.  bf16 gets it
+// for free from ds_read_b64_tr_b16 on the naturally laid out [pixel][channel] LDS tiles; f32 uses
+// v_mfma_f32_16x16x4_f32 whose fragments are one scalar per lane (plain ds_read_b32).
+// The staged input patch is the same virtual tensor cat(upsample(src0), src1) the forward conv read.
+// Split-K over pixel tiles: every (workgroup, K-wave) writes an fp32 partial slab, a second kernel
+// sums the slabs in a fixed order (bitwise reproducible, no float atomics).
+//
+// Replaces the conv weight gradients of loss.backward() (vol_seg_2d_trainer.py:429).
+#include "common.h"
+
+namespace {
+
+constexpr int kXS = 80;  // LDS bytes per staged input pixel (64 data + 16 pad)
+
+template <typename T> struct WT;
+template <> struct WT<bf16_t> { static constexpr int CK = 32, EPS = 8, NCI = 2, KSTEP = 32; };
+template <> struct WT<float> { static constexpr int CK = 16, EPS = 4, NCI = 1, KSTEP = 4; };
+
+struct WGeom {
+    int tw_shift, TH, tiles_h, tiles_w, PH, PW;
+    int ctiles, cchunks, nsplit, total_tiles, dys;  // dys: LDS bytes per dy pixel row
+};
+
+__device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
+    short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <typename T, int WO, int NTAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g) {
+    constexpr int CK = WT<T>::CK, EPS = WT<T>::EPS, NCI = WT<T>::NCI, KSTEP = WT<T>::KSTEP;
+    constexpr int WK = 4 / WO, BNO = 16 * WO;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int wo = wave % WO, wk = wave / WO;
+    const int TW = 1 << g.tw_shift, BM = g.TH * TW;
+    const int Cin = p.C0 + p.C1;
+    const int P = g.PH * g.PW;
+    char* patch = smem;
+    char* dyl = smem + P * kXS;
+
+    const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x % g.cchunks;
+    const int co0 = ct * BNO, c0 = cc * CK;
+    const int split = blockIdx.y;
+    const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
+    const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
+    const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    const bool from0 = c0 < p.C0;
+    const T* src = from0 ? (const T*)p.src0 : (const T*)p.src1;
+    const int cs = from0 ? p.C0 : p.C1;
+    const int cb = from0 ? c0 : c0 - p.C0;
+    const int sh = from0 ? p.up0 : 0;
+    const int Hs = from0 ? H0 : p.Hin, Ws = from0 ? W0 : p.Win;
+
+    f32x4 acc[NTAPS][NCI];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = t0; tile < t1; ++tile) {
+        int b = tile;
+        const int tx = b % g.tiles_w; b /= g.tiles_w;
+        const int ty = b % g.tiles_h;
+        const int n = b / g.tiles_h;
+        const int h0 = ty * g.TH, w0 = tx * TW;
+        const int hbase = h0 * p.stride - p.pad, wbase = w0 * p.stride - p.pad;
+        __syncthreads();
+        for (int item = tid; item < P * 4; item += 256) {
+            const int pp = item >> 2, seg = item & 3;
+            const int ph = pp / g.PW, pw = pp - ph * g.PW;
+            const int hi = hbase + ph, wi = wbase + pw;
+            const int c = cb + seg * EPS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win && c < cs)
+                v = *reinterpret_cast<const uint4*>(src + (((size_t)n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs + c);
+            *reinterpret_cast<uint4*>(patch + pp * kXS + seg * 16) = v;
+        }
+        constexpr int SEGS = BNO / EPS;  // 16-byte segments per dy pixel row
+        for (int item = tid; item < BM * SEGS; item += 256) {
+            const int pl = item / SEGS, seg = item % SEGS;
+            const int ho = h0 + (pl >> g.tw_shift), wo_ = w0 + (pl & (TW - 1));
+            const int co = co0 + seg * EPS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ho < p.Hout && wo_ < p.Wout && co < p.Cout) {
+                const T* s = (const T*)p.dy + (((size_t)n * p.Hout + ho) * p.Wout + wo_) * p.Cout + co;
+                if (co + EPS <= p.Cout) v = *reinterpret_cast<const uint4*>(s);
+                else {  // ragged channel tail (segmentation head: Cout = classes)
+                    T tmp[EPS];
+                    for (int e = 0; e < EPS; ++e) tmp[e] = (co + e < p.Cout) ? s[e] : (T)0;
+                    v = *reinterpret_cast<const uint4*>(tmp);
+                }
+            }
+            *reinterpret_cast<uint4*>(dyl + pl * g.dys + seg * 16) = v;
+        }
+        __syncthreads();
+
+        for (int ks = wk; ks < BM / KSTEP; ks += WK) {
+            if constexpr (sizeof(T) == 2) {
+                // pixel rows this lane addresses for the two transposed reads: 8*lq + (lr>>2) (+4)
+                const int pa = ks * 32 + 8 * lq + (lr >> 2), pb = pa + 4;
+                const int coff = (lr & 3) * 8;  // 4 channels * 2 B
+                uint4 af;
+                {
+                    const uint2 lo = ds_read_tr16(dyl + pa * g.dys + wo * 32 + coff);
+                    const uint2 hi = ds_read_tr16(dyl + pb * g.dys + wo * 32 + coff);
+                    af = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+                const int xa = (((pa >> g.tw_shift) * p.stride) * g.PW + (pa & (TW - 1)) * p.stride) * kXS + coff;
+                const int xb = (((pb >> g.tw_shift) * p.stride) * g.PW + (pb & (TW - 1)) * p.stride) * kXS + coff;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int kh = t / p.KW, kw = t - kh * p.KW;
+                    const int toff = (kh * g.PW + kw) * kXS;
+#pragma unroll
+                    for (int c = 0; c < NCI; ++c) {
+                        const uint2 lo = ds_read_tr16(patch + xa + toff + c * 32);
+                        const uint2 hi = ds_read_tr16(patch + xb + toff + c * 32);
+                        const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t][c], 0, 0, 0);
+                    }
+                }
+            } else {
+                const int pk = ks * 4 + lq;
+                const float a = *reinterpret_cast<const float*>(dyl + pk * g.dys + (wo * 16 + lr) * 4);
+                const int xo = (((pk >> g.tw_shift) * p.stride) * g.PW + (pk & (TW - 1)) * p.stride) * kXS + lr * 4;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int kh = t / p.KW, kw = t - kh * p.KW;
+                    const float bv = *reinterpret_cast<const float*>(patch + xo + (kh * g.PW + kw) * kXS);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t][0], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial slab of this (split, K-wave): [Cout][NTAPS][Cin] fp32
+    float* out = p.partials + (size_t)(split * WK + wk) * p.Cout * NTAPS * Cin;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) {
+            const int ci = c0 + c * 16 + lr;
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wo * 16 + lq * 4 + r;
+                if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cin + ci] = acc[t][c][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, size_t n, int nparts) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nparts; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)k * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dw + i) = s;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < nparts; ++k) s += partials[(size_t)k * n + j];
+            dw[j] = s;
+        }
+    }
+}
+
+template <typename T>
+int geom(const WgradParams& p, WGeom& g, int& WO) {
+    constexpr int CK = WT<T>::CK, EPS = WT<T>::EPS;
+    const int Cin = p.C0 + p.C1;
+    VS_REQUIRE(Cin % EPS == 0 && p.C0 % EPS == 0, "conv_wgrad: channel counts must be multiples of %d", EPS);
+    VS_REQUIRE(p.C1 == 0 || p.C0 % CK == 0, "conv_wgrad: concat boundary must be a multiple of %d", CK);
+    VS_REQUIRE((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1), "conv_wgrad: only 3x3 and 1x1 kernels");
+    g.tw_shift = p.Wout >= 16 ? 4 : 3;
+    const int TW = 1 << g.tw_shift;
+    const int PT = (p.stride == 1 && p.Hout * p.Wout >= 128) ? 2 : 1;
+    g.TH = 64 * PT / TW;
+    g.tiles_h = cdiv(p.Hout, g.TH);
+    g.tiles_w = cdiv(p.Wout, TW);
+    g.PH = (g.TH - 1) * p.stride + p.KH;
+    g.PW = (TW - 1) * p.stride + p.KW;
+    WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);
+    g.ctiles = cdiv(p.Cout, 16 * WO);
+    g.cchunks = cdiv(Cin, CK);
+    g.total_tiles = p.N * g.tiles_h * g.tiles_w;
+    int want = 1024 / (g.ctiles * g.cchunks);
+    if (want < 1) want = 1;
+    g.nsplit = want < g.total_tiles ? want : g.total_tiles;
+    const int per = cdiv(g.total_tiles, g.nsplit);
+    g.nsplit = cdiv(g.total_tiles, per);  // no empty splits
+    g.dys = 16 * WO * (int)sizeof(T) + 16;
+    return VS_OK;
+}
+
+template <typename T, int WO, int NTAPS>
+int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = conv_wgrad_kernel<T, WO, NTAPS>;
+    const int BM = g.TH << g.tw_shift;
+    const size_t lds = (size_t)g.PH * g.PW * kXS + (size_t)BM * g.dys;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, p, g);
+    VS_LAUNCH_CHECK();
+    const size_t n = (size_t)p.Cout * NTAPS * (p.C0 + p.C1);
+    const int nparts = g.nsplit * (4 / WO);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)cdiv((int)n, 4), 256)), dim3(256), 0, s,
+                       p.partials, p.dw, n, nparts);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+template <typename T>
+int dispatch(const WgradParams& p, hipStream_t s) {
+    WGeom g; int WO;
+    int rc = geom<T>(p, g, WO);
+    if (rc) return rc;
+    const size_t need = (size_t)g.nsplit * (4 / WO) * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+    VS_REQUIRE(p.partials && p.partial_bytes >= need, "conv_wgrad: workspace %zu < %zu", p.partial_bytes, need);
+    const int nt = p.KH * p.KW;
+#define VS_WG_CASE(wo, t) if (WO == wo && nt == t) return launch_one<T, wo, t>(p, g, s)
+    VS_WG_CASE(4, 9); VS_WG_CASE(2, 9); VS_WG_CASE(1, 9); VS_WG_CASE(4, 1); VS_WG_CASE(2, 1); VS_WG_CASE(1, 1);
+#undef VS_WG_CASE
+    return VS_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {
+    WGeom g; int WO;
+    if (dtype == VS_BF16) { if (geom<bf16_t>(p, g, WO)) return 0; }
+    else { if (geom<float>(p, g, WO)) return 0; }
+    return (size_t)g.nsplit * (4 / WO) * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+}
+
+int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s) {
+    if (dtype == VS_BF16) return dispatch<bf16_t>(p, s);
+    if (dtype == VS_F32) return dispatch<float>(p, s);
+    vs_set_error("conv_wgrad: bad dtype %d", dtype);
+    return VS_ERR_INVALID;
+}

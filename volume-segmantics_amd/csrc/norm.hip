@@ -1,0 +1,314 @@
+// BatchNorm2d on NHWC activations viewed as [rows = N*H*W][C] (gfx950).  HBM-bound streaming kernels:
+// 16-byte loads per lane, per-channel reductions kept in registers across a row loop, combined
+// through LDS, written as per-block partials and finalised in fp64 in a fixed order (bitwise
+// reproducible - no float atomics).
+//
+// Semantics = torch.nn.BatchNorm2d defaults used by smp/torchvision: eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased variance for the running estimate.
+#include "common.h"
+
+namespace {
+
+constexpr int kVec = 8;  // channels per thread (C is always a multiple of 8 in this network)
+constexpr int kMaxBlocks = 1024;
+
+struct RowMap {
+    int cv;       // channel vectors per row = C / 8
+    int rpb;      // rows processed per block iteration = 256 / cv
+    int nblocks;  // grid size
+    int64_t rows_per_block;
+};
+
+RowMap make_rowmap(int64_t rows, int c) {
+    RowMap m;
+    m.cv = c / kVec;
+    if (m.cv > 256) m.cv = 256;  // C <= 2048
+    m.rpb = 256 / m.cv;
+    int64_t iters = (rows + m.rpb - 1) / m.rpb;
+    int64_t nb = (iters + 3) / 4;  // >= 4 iterations per block when possible
+    if (nb > kMaxBlocks) nb = kMaxBlocks;
+    if (nb < 1) nb = 1;
+    m.nblocks = (int)nb;
+    int64_t ipb = (iters + nb - 1) / nb;
+    m.rows_per_block = ipb * m.rpb;
+    return m;
+}
+
+// ---- forward statistics ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, int64_t rows, int c, RowMap m,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[2][256][kVec + 1];
+    const int tid = threadIdx.x;
+    const int cvi = tid % m.cv, rl = tid / m.cv;
+    float s[kVec], q[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) s[k] = q[k] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
+    const int64_t r1 = min(rows, r0 + m.rows_per_block);
+    if (rl < m.rpb) {
+        for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
+            float v[kVec];
+            ld8(x + r * c + cvi * kVec, v);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) { s[k] += v[k]; q[k] += v[k] * v[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) { red[0][tid][k] = s[k]; red[1][tid][k] = q[k]; }
+    __syncthreads();
+    // thread t < C (per 8-channel group: first cv*8 threads) sums over row lanes
+    for (int ch = tid; ch < m.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < m.rpb; ++j) { a += red[0][j * m.cv + g][k]; b += red[1][j * m.cv + g][k]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * c + ch] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * c + ch] = b;
+    }
+}
+
+__global__ void bn_stats_finalize(const float* __restrict__ partial, int nblocks, int c, int64_t rows, float eps,
+                                  float momentum, float* mean, float* invstd, float* running_mean,
+                                  float* running_var) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
+        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    const double mu = s / (double)rows;
+    double var = q / (double)rows - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[ch] = (float)mu;
+    invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+        running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+    }
+}
+
+// ---- forward apply -----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const T* __restrict__ res, int relu,
+                                                     T* __restrict__ y, int64_t rows, int c, RowMap m) {
+    const int tid = threadIdx.x;
+    const int cvi = tid % m.cv, rl = tid / m.cv;
+    if (rl >= m.rpb) return;
+    float a[kVec], b[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = cvi * kVec + k;
+        a[k] = invstd[ch] * gamma[ch];
+        b[k] = beta[ch] - mean[ch] * a[k];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
+    const int64_t r1 = min(rows, r0 + m.rows_per_block);
+    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
+        const size_t o = (size_t)r * c + cvi * kVec;
+        float v[kVec];
+        ld8(x + o, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = v[k] * a[k] + b[k];
+        if (res) {
+            float rv[kVec];
+            ld8(res + o, rv);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] += rv[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        st8(y + o, v);
+    }
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, const T* __restrict__ y,
+                                                    const T* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, int relu, int64_t rows, int c,
+                                                    RowMap m, float* __restrict__ partial) {
+    __shared__ float red[2][256][kVec + 1];
+    const int tid = threadIdx.x;
+    const int cvi = tid % m.cv, rl = tid / m.cv;
+    float s[kVec], q[kVec], mu[kVec], is[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        s[k] = q[k] = 0.f;
+        mu[k] = mean[(cvi * kVec + k) % c];
+        is[k] = invstd[(cvi * kVec + k) % c];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
+    const int64_t r1 = min(rows, r0 + m.rows_per_block);
+    if (rl < m.rpb) {
+        for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
+            const size_t o = (size_t)r * c + cvi * kVec;
+            float g[kVec], xv[kVec];
+            ld8(dy + o, g);
+            ld8(x + o, xv);
+            if (relu) {
+                float yv[kVec];
+                ld8(y + o, yv);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) { s[k] += g[k]; q[k] += g[k] * (xv[k] - mu[k]) * is[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) { red[0][tid][k] = s[k]; red[1][tid][k] = q[k]; }
+    __syncthreads();
+    for (int ch = tid; ch < m.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < m.rpb; ++j) { a += red[0][j * m.cv + g][k]; b += red[1][j * m.cv + g][k]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * c + ch] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * c + ch] = b;
+    }
+}
+
+__global__ void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int c, float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
+        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    dbeta[ch] = (float)s;
+    dgamma[ch] = (float)q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y,
+                                                  const T* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                  int relu, T* __restrict__ dx, T* __restrict__ dres, int64_t rows,
+                                                  int c, RowMap m) {
+    const int tid = threadIdx.x;
+    const int cvi = tid % m.cv, rl = tid / m.cv;
+    if (rl >= m.rpb) return;
+    const float inv_m = 1.0f / (float)rows;
+    float mu[kVec], is[kVec], gi[kVec], db[kVec], dg[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = cvi * kVec + k;
+        mu[k] = mean[ch]; is[k] = invstd[ch]; gi[k] = gamma[ch] * invstd[ch];
+        db[k] = dbeta[ch] * inv_m; dg[k] = dgamma[ch] * inv_m;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
+    const int64_t r1 = min(rows, r0 + m.rows_per_block);
+    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
+        const size_t o = (size_t)r * c + cvi * kVec;
+        float g[kVec], xv[kVec];
+        ld8(dy + o, g);
+        ld8(x + o, xv);
+        if (relu) {
+            float yv[kVec];
+            ld8(y + o, yv);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+        if (dres) st8(dres + o, g);
+        float o8[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) o8[k] = gi[k] * (g[k] - db[k] - (xv[k] - mu[k]) * is[k] * dg[k]);
+        st8(dx + o, o8);
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = gamma[i] / sqrtf(rv[i] + eps);
+    scale[i] = s;
+    shift[i] = beta[i] - rm[i] * s;
+}
+
+template <typename T>
+int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd, float* rm,
+            float* rv, float* ws, hipStream_t s) {
+    RowMap m = make_rowmap(rows, c);
+    hipLaunchKernelGGL(bn_stats_partial<T>, dim3(m.nblocks), dim3(256), 0, s, (const T*)x, rows, c, m, ws);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, m.nblocks, c, rows, eps, momentum, mean,
+                       invstd, rm, rv);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vs_bn_workspace(int64_t rows, int c) {
+    (void)rows;
+    return (size_t)kMaxBlocks * 2 * c * sizeof(float);
+}
+
+extern "C" int vs_bn_stats(int dtype, const void* x, int64_t rows, int c, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, float* workspace,
+                           size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec > 256 ? 256 : c / kVec) == 0,
+               "bn_stats: unsupported channel count %d", c);
+    VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_stats: workspace too small");
+    if (dtype == VS_BF16)
+        return stats_t<bf16_t>(x, rows, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, (hipStream_t)stream);
+    return stats_t<float>(x, rows, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, (hipStream_t)stream);
+}
+
+extern "C" int vs_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const void* residual, int relu, void* y, int64_t rows, int c,
+                           void* stream) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_apply: unsupported channel count %d", c);
+    RowMap m = make_rowmap(rows, c);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)x, mean, invstd, gamma,
+                           beta, (const bf16_t*)residual, relu, (bf16_t*)y, rows, c, m);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)x, mean, invstd, gamma,
+                           beta, (const float*)residual, relu, (float*)y, rows, c, m);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x, const float* mean,
+                         const float* invstd, const float* gamma, int relu, void* dx, void* dres, float* dgamma,
+                         float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_bwd: unsupported channel count %d", c);
+    VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_bwd: workspace too small");
+    RowMap m = make_rowmap(rows, c);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(bn_bwd_partial<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y,
+                           (const bf16_t*)x, mean, invstd, relu, rows, c, m, workspace);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)dy, (const float*)y,
+                           (const float*)x, mean, invstd, relu, rows, c, m, workspace);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(c, 64)), dim3(64), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
+    VS_LAUNCH_CHECK();
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y,
+                           (const bf16_t*)x, mean, invstd, gamma, dgamma, dbeta, relu, (bf16_t*)dx, (bf16_t*)dres, rows, c, m);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)dy, (const float*)y,
+                           (const float*)x, mean, invstd, gamma, dgamma, dbeta, relu, (float*)dx, (float*)dres, rows, c, m);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* scale, float* shift, int c, void* stream) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

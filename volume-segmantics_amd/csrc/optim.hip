@@ -1,0 +1,139 @@
+// Parameter-side kernels (gfx950): fused AdamW over the flat fp32 parameter buffer, derivation of
+// the low-precision / flipped-transposed weight copies the conv kernels read, and the small layout
+// transforms around the segmentation head's gradient.
+#include "common.h"
+
+namespace {
+
+// torch.optim.AdamW (single tensor path): p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, const uint8_t* __restrict__ mask, int64_t n, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask && !mask[i]) continue;
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+
+// w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps flipped][cout_pad], optional)
+template <typename T>
+__global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout,
+                                      int taps, int cin, int cout_pad) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < cout && ci < cin) {
+            v = w[((size_t)co * taps + tap) * cin + ci];
+            if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int ci = ci0 + r, co = co0 + tx;
+            if (ci < cin && co < cout_pad)
+                Elem<T>::st(wt + ((size_t)ci * taps + (taps - 1 - tap)) * cout_pad + co, tile[tx][r]);
+        }
+    }
+}
+
+// dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels) + per-class sums (bias gradient)
+template <typename T>
+__global__ void dlogits_to_nhwc16_kernel(const float* __restrict__ d, T* __restrict__ o, int n, int k, int64_t hw) {
+    const int64_t total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / hw, px = i % hw;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = c < k ? d[((size_t)b * k + c) * hw + px] : 0.f;
+        st8(o + (size_t)i * 16, v);
+        st8(o + (size_t)i * 16 + 8, v + 8);
+    }
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ d, float* __restrict__ db, int n, int k, int64_t hw) {
+    // one block per class; fixed-order tree reduction (reproducible)
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)n * hw; i += 256) {
+        const int64_t b = i / hw, px = i % hw;
+        s += d[((size_t)b * k + c) * hw + px];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = red[0];
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ a, T* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(b + i, a[i]);
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                             void* stream) {
+    VS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adamw_step: bad arguments");
+    if (n == 0) return VS_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad,
+                          hipStream_t s) {
+    dim3 grid(cdiv(cin, 32), cdiv(cout_pad > cout ? cout_pad : cout, 32), taps);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cout, taps,
+                           cin, cout_pad);
+    else
+        hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cin,
+                           cout_pad);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s) {
+    VS_REQUIRE(k >= 1 && k <= 16, "segmentation head: classes must be <= 16 (got %d)", k);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<bf16_t>, dim3(grid_for((int64_t)n * hw)), dim3(256), 0, s, d, (bf16_t*)o, n, k, hw);
+    else
+        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<float>, dim3(grid_for((int64_t)n * hw)), dim3(256), 0, s, d, (float*)o, n, k, hw);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_bias_grad(const float* d, float* db, int n, int k, int64_t hw, hipStream_t s) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(k), dim3(256), 0, s, d, db, n, k, hw);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

@@ -1,0 +1,204 @@
+// Spatial data-movement kernels on NHWC tensors (gfx950, HBM-bound, 16-byte accesses per lane):
+//  * MaxPool2d(3, stride 2, pad 1) forward (+ uint8 argmax-in-window) and gather-form backward
+//    (torchvision ResNet stem, inside smp's encoder);
+//  * backward of the decoder's nearest x2 upsampling (2x2 sum);
+//  * zero stuffing used to express the dgrad of the stride-2 convolutions as a stride-1 convolution.
+#include "common.h"
+
+namespace {
+
+constexpr int kVec = 8;
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int n,
+                                   int h, int w, int c) {
+    const int ho_n = h / 2, wo_n = w / 2, cv = c / kVec;
+    const int64_t total = (int64_t)n * ho_n * wo_n * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int wo = t % wo_n; t /= wo_n;
+        const int ho = t % ho_n;
+        const int b = t / ho_n;
+        float best[kVec];
+        int bi[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        // first max in (kh, kw) scan order wins (torch CPU max_pool2d: `val > maxval`)
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = 2 * ho - 1 + kh;
+            if (hi < 0 || hi >= h) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = 2 * wo - 1 + kw;
+                if (wi < 0 || wi >= w) continue;
+                float v[kVec];
+                ld8(x + (((size_t)b * h + hi) * w + wi) * c + cg * kVec, v);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k)
+                    if (v[k] > best[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
+            }
+        }
+        const size_t o = (((size_t)b * ho_n + ho) * wo_n + wo) * c + cg * kVec;
+        st8(y + o, best);
+        if (idx) {
+            uint2 pk;
+            pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+            pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+            *reinterpret_cast<uint2*>(idx + o) = pk;
+        }
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
+                                   int accumulate, int n, int h, int w, int c) {
+    const int ho_n = h / 2, wo_n = w / 2, cv = c / kVec;
+    const int64_t total = (int64_t)n * h * w * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int wi = t % w; t /= w;
+        const int hi = t % h;
+        const int b = t / h;
+        float g[kVec];
+        const size_t xo = (((size_t)b * h + hi) * w + wi) * c + cg * kVec;
+        if (accumulate) ld8(dx + xo, g);
+        else {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) g[k] = 0.f;
+        }
+        // windows containing (hi, wi): ho in {(hi+1)/2 (kh = hi - 2ho + 1)} and, for odd hi, also (hi-1)/2
+        for (int a = 0; a < 2; ++a) {
+            const int ho = (hi + 1) / 2 - a;
+            const int kh = hi - 2 * ho + 1;
+            if (ho < 0 || ho >= ho_n || kh < 0 || kh > 2) continue;
+            for (int bb = 0; bb < 2; ++bb) {
+                const int wo = (wi + 1) / 2 - bb;
+                const int kw = wi - 2 * wo + 1;
+                if (wo < 0 || wo >= wo_n || kw < 0 || kw > 2) continue;
+                const size_t o = (((size_t)b * ho_n + ho) * wo_n + wo) * c + cg * kVec;
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+                float d[kVec];
+                ld8(dy + o, d);
+                const int code = kh * 3 + kw;
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) {
+                    const int id = ((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff;
+                    if (id == code) g[k] += d[k];
+                }
+            }
+        }
+        st8(dx + xo, g);
+    }
+}
+
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int h, int w, int c) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * h * w * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int wi = t % w; t /= w;
+        const int hi = t % h;
+        const int b = t / h;
+        float s[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) s[k] = 0.f;
+        for (int a = 0; a < 2; ++a)
+            for (int bb = 0; bb < 2; ++bb) {
+                float v[kVec];
+                ld8(dy + (((size_t)b * 2 * h + 2 * hi + a) * 2 * w + 2 * wi + bb) * c + cg * kVec, v);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) s[k] += v[k];
+            }
+        st8(dx + (((size_t)b * h + hi) * w + wi) * c + cg * kVec, s);
+    }
+}
+
+template <typename T>
+__global__ void zero_stuff2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * 2 * h * 2 * w * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int wo = t % (2 * w); t /= (2 * w);
+        const int ho = t % (2 * h);
+        const int b = t / (2 * h);
+        float v[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = 0.f;
+        if (!(ho & 1) && !(wo & 1)) ld8(x + (((size_t)b * h + ho / 2) * w + wo / 2) * c + cg * kVec, v);
+        st8(y + (((size_t)b * 2 * h + ho) * 2 * w + wo) * c + cg * kVec, v);
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define VS_DISPATCH_T(kern, total, ...)                                                                      \
+    do {                                                                                                     \
+        if (dtype == VS_BF16)                                                                                \
+            hipLaunchKernelGGL(kern<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else                                                                                                 \
+            hipLaunchKernelGGL(kern<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+        VS_LAUNCH_CHECK();                                                                                   \
+    } while (0)
+
+extern "C" int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, void* stream) {
+    VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0, "maxpool_fwd: bad shape");
+    const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, idx, n, h, w, c);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, idx, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int accumulate, int n, int h,
+                              int w, int c, void* stream) {
+    VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0 && idx, "maxpool_bwd: bad arguments");
+    const int64_t total = (int64_t)n * h * w * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dy, idx, (bf16_t*)dx, accumulate, n, h, w, c);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dy, idx, (float*)dx, accumulate, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, void* stream) {
+    VS_REQUIRE(c % kVec == 0, "upsample2x_bwd: channels must be a multiple of 8");
+    const int64_t total = (int64_t)n * h * w * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dy, (bf16_t*)dx, n, h, w, c);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dy, (float*)dx, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_zero_stuff2x(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream) {
+    VS_REQUIRE(c % kVec == 0, "zero_stuff2x: channels must be a multiple of 8");
+    const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(zero_stuff2x_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, n, h, w, c);
+    else
+        hipLaunchKernelGGL(zero_stuff2x_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

@@ -1,0 +1,165 @@
+// Prediction-side kernels (gfx950, HBM-bound byte/integer work):
+//  * slice gather + reflect-101 pad + ImageNet normalisation straight from the resident uint8 volume
+//    (VolSeg2dPredictionDataset.__getitem__, data/datasets.py:120-142; augmentations.py:46-65);
+//  * softmax -> first-argmax -> max-prob(fp16 RNE) -> centre-crop -> scatter to the voxel address of the
+//    (axis, rotation) direction (vol_seg_2d_predictor.py:45-64 and base_data_utils.py:125-138);
+//  * the max-probability merge, both in the reference's pairwise form (_merge_vols_in_mem, :90-98) and as
+//    the packed (prob, direction, label) key maximum that is order-independent and all-reducible.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    const int m = 2 * (len - 1);
+    p %= m;
+    if (p < 0) p += m;
+    return p >= len ? m - p : p;
+}
+
+__global__ void slices_gather_kernel(const uint8_t* __restrict__ vol, vs_dirmap m, int s0, int nb, float* __restrict__ x) {
+    const int64_t total = (int64_t)nb * m.hp * m.wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int j = t % m.wp; t /= m.wp;
+        const int r = t % m.hp;
+        const int b = t / m.hp;
+        const int hh = reflect101(r - m.pad_top, m.h), ww = reflect101(j - m.pad_left, m.w);
+        const float u = (float)vol[m.base + (int64_t)(s0 + b) * m.ss + (int64_t)hh * m.sh + (int64_t)ww * m.sw];
+        // numpy order of operations in fp32: (u / 255 - 0.449) / 0.226
+        x[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.449f), 0.226f);
+    }
+}
+
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    const __half hv = __float2half_rn(f);
+    return __builtin_bit_cast(uint16_t, hv);
+}
+
+template <int MODE>
+__global__ void logits_to_volume_kernel(const float* __restrict__ logits, int classes, vs_dirmap m, int s0, int nb,
+                                        int direction, uint8_t* __restrict__ labels, uint16_t* __restrict__ probs,
+                                        uint32_t* __restrict__ keys, uint8_t* __restrict__ votes, int64_t nvox) {
+    const int64_t total = (int64_t)nb * m.h * m.w;
+    const size_t plane = (size_t)m.hp * m.wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int j = t % m.w; t /= m.w;
+        const int r = t % m.h;
+        const int b = t / m.h;
+        const float* lp = logits + (size_t)b * classes * plane + (size_t)(r + m.crop_top) * m.wp + (j + m.crop_left);
+        float mx = lp[0];
+        for (int k = 1; k < classes; ++k) mx = fmaxf(mx, lp[k * plane]);
+        float sum = 0.f;
+        for (int k = 0; k < classes; ++k) sum += expf(lp[k * plane] - mx);
+        // argmax over the *probabilities* (first max wins), as torch.argmax(softmax(x)) does
+        float best = -1.f;
+        int lab = 0;
+        for (int k = 0; k < classes; ++k) {
+            const float pk = __fdiv_rn(expf(lp[k * plane] - mx), sum);
+            if (pk > best) { best = pk; lab = k; }
+        }
+        const int64_t addr = m.base + (int64_t)(s0 + b) * m.ss + (int64_t)r * m.sh + (int64_t)j * m.sw;
+        if (MODE == 0) {
+            if (labels) labels[addr] = (uint8_t)lab;
+            if (probs) probs[addr] = f32_to_f16_bits(best);
+        } else if (MODE == 1) {
+            const uint32_t key = ((uint32_t)f32_to_f16_bits(best) << 16) | ((uint32_t)(15 - direction) << 8) | (uint32_t)lab;
+            const uint32_t old = keys[addr];
+            if (key > old) keys[addr] = key;
+        } else {
+            votes[(int64_t)lab * nvox + addr] += 1;
+        }
+    }
+}
+
+__global__ void merge_maxprob_kernel(uint8_t* __restrict__ l0, uint16_t* __restrict__ p0, const uint8_t* __restrict__ l1,
+                                     const uint16_t* __restrict__ p1, int64_t n) {
+    // np.argmax over the 2 slots: slot 1 wins only when strictly greater (ties keep slot 0)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = __half2float(__builtin_bit_cast(__half, p0[i]));
+        const float b = __half2float(__builtin_bit_cast(__half, p1[i]));
+        if (b > a) { p0[i] = p1[i]; l0[i] = l1[i]; }
+    }
+}
+
+__global__ void keys_unpack_kernel(const uint32_t* __restrict__ keys, uint8_t* __restrict__ labels,
+                                   uint16_t* __restrict__ probs, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i];
+        if (labels) labels[i] = (uint8_t)(k & 0xff);
+        if (probs) probs[i] = (uint16_t)(k >> 16);
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+int check_map(const vs_dirmap* m, int s0, int nb) {
+    VS_REQUIRE(m && m->depth > 0 && m->h > 0 && m->w > 0 && m->hp >= m->h && m->wp >= m->w, "dirmap: bad dims");
+    VS_REQUIRE(s0 >= 0 && nb > 0 && s0 + nb <= m->depth, "dirmap: slice range [%d,%d) outside depth %d", s0, s0 + nb, m->depth);
+    VS_REQUIRE(m->crop_top >= 0 && m->crop_top + m->h <= m->hp && m->crop_left >= 0 && m->crop_left + m->w <= m->wp,
+               "dirmap: crop window outside the padded slice");
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" int vs_slices_gather(const uint8_t* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream) {
+    int rc = check_map(m, s0, nb);
+    if (rc) return rc;
+    VS_REQUIRE(vol && x, "slices_gather: null pointer");
+    const int64_t total = (int64_t)nb * m->hp * m->wp;
+    hipLaunchKernelGGL(slices_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, vol, *m, s0, nb, x);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_logits_to_volume(const float* logits, int classes, const vs_dirmap* m, int s0, int nb, int mode,
+                                   int direction, uint8_t* labels, uint16_t* probs, uint32_t* keys, uint8_t* votes,
+                                   int64_t nvox, void* stream) {
+    int rc = check_map(m, s0, nb);
+    if (rc) return rc;
+    VS_REQUIRE(logits && classes >= 1 && classes <= 255, "logits_to_volume: bad arguments");
+    VS_REQUIRE(direction >= 0 && direction < 16, "logits_to_volume: direction %d out of range", direction);
+    const int64_t total = (int64_t)nb * m->h * m->w;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        hipLaunchKernelGGL(logits_to_volume_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, logits, classes, *m, s0, nb,
+                           direction, labels, probs, keys, votes, nvox);
+    } else if (mode == 1) {
+        VS_REQUIRE(keys, "logits_to_volume: mode 1 needs a key volume");
+        hipLaunchKernelGGL(logits_to_volume_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, logits, classes, *m, s0, nb,
+                           direction, labels, probs, keys, votes, nvox);
+    } else if (mode == 2) {
+        VS_REQUIRE(votes && nvox > 0, "logits_to_volume: mode 2 needs a vote volume");
+        hipLaunchKernelGGL(logits_to_volume_kernel<2>, dim3(grid_for(total)), dim3(256), 0, s, logits, classes, *m, s0, nb,
+                           direction, labels, probs, keys, votes, nvox);
+    } else {
+        vs_set_error("logits_to_volume: bad mode %d", mode);
+        return VS_ERR_INVALID;
+    }
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_merge_maxprob(uint8_t* label0, uint16_t* prob0, const uint8_t* label1, const uint16_t* prob1,
+                                int64_t n, void* stream) {
+    VS_REQUIRE(label0 && prob0 && label1 && prob1 && n >= 0, "merge_maxprob: bad arguments");
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(merge_maxprob_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, label0, prob0, label1, prob1, n);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_keys_unpack(const uint32_t* keys, uint8_t* labels, uint16_t* probs, int64_t n, void* stream) {
+    VS_REQUIRE(keys && n >= 0, "keys_unpack: bad arguments");
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(keys_unpack_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, keys, labels, probs, n);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

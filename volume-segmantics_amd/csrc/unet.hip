@@ -1,0 +1,503 @@
+// Whole-network plan for smp.Unet(encoder_name="resnet34", in_channels=1, classes=K)
+// (reference construction: volume_segmantics/model/model_2d.py:15-16; topology: SURVEY.md section 8a).
+//
+// The plan is a flat list of units (stem, maxpool, conv+BN(+residual)(+ReLU), head) with all activation,
+// gradient and scratch buffers laid out once in a caller-owned workspace.  vs_unet_forward /
+// vs_unet_backward enqueue every kernel of a step from C++ on the caller's stream - Python makes one
+// call per pass.  Forward in training mode keeps the pre-BN (z) and post-activation (a) tensors;
+// backward walks the units in reverse with a statically known first-write / accumulate discipline for
+// the gradients of tensors with two consumers (ResNet identities, U-Net skips).
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
+int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s);
+int launch_bias_grad(const float* d, float* db, int n, int k, int64_t hw, hipStream_t s);
+
+namespace {
+
+struct TensorInfo {
+    std::string name;
+    int64_t shape[4];
+    int ndim, kind;
+    int64_t offset;
+};
+
+enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD };
+
+struct Act {  // one activation tensor (per-sample element count = c*h*w)
+    int c, h, w;
+    bool has_z;
+    size_t off_a = 0, off_z = 0, off_da = 0, off_dz = 0;
+};
+
+struct Unit {
+    UnitKind kind;
+    int src0 = -1, src1 = -1, up0 = 0;  // input activation ids
+    int cin0 = 0, cin1 = 0, cout = 0, k = 3, stride = 1, pad = 1;
+    int hin = 0, win = 0, hout = 0, wout = 0;  // virtual input / output spatial dims
+    int w_idx = -1, bn_idx = -1, bias_idx = -1;  // indices into the tensor table (bn_idx -> gamma)
+    int out = -1;   // output activation id
+    int res = -1;   // residual activation id
+    int relu = 1;
+    bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
+    size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
+};
+
+struct Layout {
+    std::vector<TensorInfo> tensors;
+    int64_t n_params = 0, n_bnstate = 0;
+};
+
+void add_tensor(Layout& L, const std::string& name, std::initializer_list<int64_t> shape, int kind) {
+    TensorInfo t;
+    t.name = name;
+    t.ndim = (int)shape.size();
+    int64_t numel = 1;
+    int i = 0;
+    for (auto s : shape) { t.shape[i++] = s; numel *= s; }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    t.kind = kind;
+    if (kind <= 3) { t.offset = L.n_params; L.n_params += numel; }
+    else { t.offset = L.n_bnstate; L.n_bnstate += numel; }
+    L.tensors.push_back(t);
+}
+
+// returns index of gamma
+int add_bn(Layout& L, const std::string& prefix, int c) {
+    const int idx = (int)L.tensors.size();
+    add_tensor(L, prefix + ".weight", {c}, 1);
+    add_tensor(L, prefix + ".bias", {c}, 2);
+    add_tensor(L, prefix + ".running_mean", {c}, 4);
+    add_tensor(L, prefix + ".running_var", {c}, 5);
+    return idx;
+}
+
+}  // namespace
+
+struct vs_unet {
+    int dtype, classes, max_batch, h, w;
+    Layout layout;
+    std::vector<Act> acts;
+    std::vector<Unit> units;
+    size_t esz;
+    // workspace regions (bytes)
+    size_t off_bnws = 0, bnws_bytes = 0, off_wgws = 0, wgws_bytes = 0, off_headdw = 0, off_dyh = 0, off_dup = 0,
+           off_zs = 0, off_idx = 0;
+    size_t ws_eval = 0, ws_train = 0;
+    int last_n = 0;
+};
+
+namespace {
+
+int build(vs_unet* net) {
+    Layout& L = net->layout;
+    auto& A = net->acts;
+    auto& U = net->units;
+    const int H = net->h, W = net->w;
+    auto new_act = [&](int c, int h, int w, bool has_z) {
+        Act a; a.c = c; a.h = h; a.w = w; a.has_z = has_z;
+        A.push_back(a);
+        return (int)A.size() - 1;
+    };
+    // ---- encoder ----
+    add_tensor(L, "encoder.conv1.weight", {64, 1, 7, 7}, 0);
+    Unit stem; stem.kind = U_STEM; stem.cout = 64; stem.k = 7; stem.stride = 2; stem.pad = 3;
+    stem.hin = H; stem.win = W; stem.hout = H / 2; stem.wout = W / 2;
+    stem.w_idx = 0; stem.bn_idx = add_bn(L, "encoder.bn1", 64);
+    stem.out = new_act(64, H / 2, W / 2, true); stem.frozen_candidate = true;
+    U.push_back(stem);
+    int feat[6]; feat[1] = stem.out;
+    Unit pool; pool.kind = U_POOL; pool.src0 = stem.out; pool.cout = 64; pool.hin = H / 2; pool.win = W / 2;
+    pool.hout = H / 4; pool.wout = W / 4; pool.out = new_act(64, H / 4, W / 4, false);
+    U.push_back(pool);
+    int cur = pool.out, inpl = 64, ch = H / 4, cw = W / 4;
+    const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < blocks[l]; ++b) {
+            const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(b);
+            const int stride = (b == 0 && l > 0) ? 2 : 1;
+            const int oh = ch / stride, ow = cw / stride, pl = planes[l];
+            Unit u1; u1.kind = U_CONV; u1.src0 = cur; u1.cin0 = inpl; u1.cout = pl; u1.stride = stride;
+            u1.hin = ch; u1.win = cw; u1.hout = oh; u1.wout = ow; u1.frozen_candidate = true;
+            u1.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv1.weight", {pl, inpl, 3, 3}, 0);
+            u1.bn_idx = add_bn(L, pre + ".bn1", pl);
+            u1.out = new_act(pl, oh, ow, true);
+            Unit u2; u2.kind = U_CONV; u2.src0 = u1.out; u2.cin0 = pl; u2.cout = pl;
+            u2.hin = oh; u2.win = ow; u2.hout = oh; u2.wout = ow; u2.frozen_candidate = true;
+            u2.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.weight", {pl, pl, 3, 3}, 0);
+            u2.bn_idx = add_bn(L, pre + ".bn2", pl);
+            u2.out = new_act(pl, oh, ow, true);
+            U.push_back(u1);
+            if (stride != 1 || inpl != pl) {
+                Unit ud; ud.kind = U_CONV; ud.src0 = cur; ud.cin0 = inpl; ud.cout = pl; ud.k = 1; ud.pad = 0;
+                ud.stride = stride; ud.hin = ch; ud.win = cw; ud.hout = oh; ud.wout = ow; ud.relu = 0;
+                ud.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".downsample.0.weight", {pl, inpl, 1, 1}, 0);
+                ud.bn_idx = add_bn(L, pre + ".downsample.1", pl);
+                ud.out = new_act(pl, oh, ow, true);
+                U.push_back(ud);
+                u2.res = ud.out;
+            } else {
+                u2.res = cur;
+            }
+            U.push_back(u2);
+            cur = u2.out; inpl = pl; ch = oh; cw = ow;
+        }
+        feat[l + 2] = cur;
+    }
+    // ---- decoder ----
+    const int dec[5] = {256, 128, 64, 32, 16};
+    const int skipc[5] = {256, 128, 64, 64, 0};
+    int xin = feat[5], xc = 512;
+    for (int i = 0; i < 5; ++i) {
+        const std::string pre = "decoder.blocks." + std::to_string(i);
+        const int oh = ch * 2, ow = cw * 2;
+        Unit u1; u1.kind = U_CONV; u1.src0 = xin; u1.up0 = 1; u1.cin0 = xc; u1.cin1 = skipc[i];
+        u1.src1 = skipc[i] ? feat[4 - i] : -1; u1.cout = dec[i];
+        u1.hin = oh; u1.win = ow; u1.hout = oh; u1.wout = ow;
+        u1.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv1.0.weight", {dec[i], xc + skipc[i], 3, 3}, 0);
+        u1.bn_idx = add_bn(L, pre + ".conv1.1", dec[i]);
+        u1.out = new_act(dec[i], oh, ow, true);
+        Unit u2; u2.kind = U_CONV; u2.src0 = u1.out; u2.cin0 = dec[i]; u2.cout = dec[i];
+        u2.hin = oh; u2.win = ow; u2.hout = oh; u2.wout = ow;
+        u2.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.0.weight", {dec[i], dec[i], 3, 3}, 0);
+        u2.bn_idx = add_bn(L, pre + ".conv2.1", dec[i]);
+        u2.out = new_act(dec[i], oh, ow, true);
+        U.push_back(u1); U.push_back(u2);
+        xin = u2.out; xc = dec[i]; ch = oh; cw = ow;
+    }
+    Unit head; head.kind = U_HEAD; head.src0 = xin; head.cin0 = 16; head.cout = net->classes; head.relu = 0;
+    head.hin = H; head.win = W; head.hout = H; head.wout = W;
+    head.w_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.weight", {net->classes, 16, 3, 3}, 0);
+    head.bias_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.bias", {net->classes}, 3);
+    U.push_back(head);
+    return VS_OK;
+}
+
+size_t plan_workspace(vs_unet* net) {
+    const size_t N = (size_t)net->max_batch, esz = net->esz;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // weight copies + BN constants
+    for (auto& u : net->units) {
+        if (u.kind == U_CONV || u.kind == U_HEAD) {
+            const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
+            const size_t cout_pad = u.kind == U_HEAD ? 16 : (size_t)u.cout;
+            u.off_wc = take((size_t)u.cout * taps * cin * esz);
+            u.off_wt = take(cin * taps * cout_pad * esz);
+        }
+        if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
+    }
+    net->bnws_bytes = vs_bn_workspace(0, 512);
+    net->off_bnws = take(net->bnws_bytes);
+    // activations (a for all, z for conv/stem outputs)
+    for (auto& a : net->acts) {
+        const size_t bytes = N * a.c * a.h * a.w * esz;
+        a.off_a = take(bytes);
+    }
+    net->ws_eval = off;
+    for (auto& a : net->acts) {
+        const size_t bytes = N * a.c * a.h * a.w * esz;
+        if (a.has_z) { a.off_z = take(bytes); a.off_dz = take(bytes); }
+        a.off_da = take(bytes);
+    }
+    // wgrad split-K slabs: worst case over layers
+    size_t wg = vs_stem_wgrad_workspace((int)N, net->h, net->w);
+    for (auto& u : net->units) {
+        if (u.kind != U_CONV && u.kind != U_HEAD) continue;
+        WgradParams p{};
+        p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = (int)N; p.Hin = u.hin; p.Win = u.win;
+        p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+        p.Cout = u.kind == U_HEAD ? 16 : u.cout;
+        const size_t b = wgrad_workspace_bytes(net->dtype, p);
+        if (b > wg) wg = b;
+    }
+    net->wgws_bytes = wg;
+    net->off_wgws = take(wg);
+    net->off_headdw = take(16 * 9 * 16 * sizeof(float));
+    net->off_dyh = take(N * net->h * net->w * 16 * esz);
+    size_t dup = 0, zs = 0;
+    for (auto& u : net->units) {
+        if (u.kind != U_CONV) continue;
+        if (u.up0) dup = std::max(dup, N * u.hin * u.win * u.cin0 * esz);
+        if (u.stride == 2) zs = std::max(zs, N * u.hin * u.win * u.cout * esz);
+    }
+    net->off_dup = take(dup);
+    net->off_zs = take(zs);
+    net->off_idx = take(N * (net->h / 4) * (net->w / 4) * 64);
+    net->ws_train = off;
+    return off;
+}
+
+struct Ctx {
+    vs_unet* net;
+    char* ws;
+    const float* params;
+    float* bnstate;
+    hipStream_t s;
+    int n;
+    void* a(int id) const { return ws + net->acts[id].off_a; }
+    void* z(int id) const { return ws + net->acts[id].off_z; }
+    void* da(int id) const { return ws + net->acts[id].off_da; }
+    void* dz(int id) const { return ws + net->acts[id].off_dz; }
+    const TensorInfo& t(int idx) const { return net->layout.tensors[idx]; }
+    const float* P(int idx) const { return params + t(idx).offset; }
+    const void* wfwd(const Unit& u) const {  // weights in the compute dtype
+        return net->dtype == VS_F32 ? (const void*)P(u.w_idx) : (const void*)(ws + u.off_wc);
+    }
+    float* bnc(const Unit& u, int which) const { return reinterpret_cast<float*>(ws + u.off_bn) + (size_t)which * u.cout; }
+    int64_t rows(const Unit& u) const { return (int64_t)n * u.hout * u.wout; }
+};
+
+ConvParams conv_params(const Ctx& c, const Unit& u) {
+    ConvParams p{};
+    p.src0 = c.a(u.src0);
+    p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
+    p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0;
+    p.N = c.n; p.Hin = u.hin; p.Win = u.win; p.Hout = u.hout; p.Wout = u.wout;
+    p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+    p.w = c.wfwd(u); p.Cout = u.cout;
+    return p;
+}
+
+}  // namespace
+
+// ---- parameter table -------------------------------------------------------------------------------
+static int with_layout(int classes, Layout& out) {
+    vs_unet tmp{};
+    tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4;
+    VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
+    build(&tmp);
+    out = tmp.layout;
+    return VS_OK;
+}
+
+extern "C" int vs_unet_num_tensors(int classes) {
+    Layout L;
+    if (with_layout(classes, L)) return VS_ERR_INVALID;
+    return (int)L.tensors.size();
+}
+
+extern "C" int vs_unet_tensor_info(int classes, int index, char* name, int name_len, int64_t shape[4], int* ndim,
+                                   int* kind, int64_t* offset) {
+    Layout L;
+    if (with_layout(classes, L)) return VS_ERR_INVALID;
+    VS_REQUIRE(index >= 0 && index < (int)L.tensors.size(), "tensor index %d out of range", index);
+    const TensorInfo& t = L.tensors[index];
+    if (name && name_len > 0) { strncpy(name, t.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+    *ndim = t.ndim; *kind = t.kind; *offset = t.offset;
+    return VS_OK;
+}
+
+extern "C" int64_t vs_unet_param_elems(int classes) {
+    Layout L;
+    if (with_layout(classes, L)) return -1;
+    return L.n_params;
+}
+
+extern "C" int64_t vs_unet_bnstate_elems(int classes) {
+    Layout L;
+    if (with_layout(classes, L)) return -1;
+    return L.n_bnstate;
+}
+
+// ---- lifecycle -------------------------------------------------------------------------------------
+extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w) {
+    VS_REQUIRE(out, "unet_create: null out pointer");
+    VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
+    VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
+    VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
+               "unet_create: batch %d, %dx%d - spatial dims must be positive multiples of 32", max_batch, h, w);
+    vs_unet* net = new vs_unet();
+    net->dtype = dtype; net->classes = classes; net->max_batch = max_batch; net->h = h; net->w = w;
+    net->esz = dtype_size(dtype);
+    build(net);
+    plan_workspace(net);
+    *out = net;
+    return VS_OK;
+}
+
+extern "C" void vs_unet_destroy(vs_unet_t* net) { delete net; }
+
+extern "C" size_t vs_unet_workspace_bytes(const vs_unet_t* net, int training) {
+    return training ? net->ws_train : net->ws_eval;
+}
+
+extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float* bnstate, int training, void* workspace,
+                               void* stream) {
+    VS_REQUIRE(net && params && bnstate && workspace, "unet_prepare: null pointer");
+    Ctx c{net, (char*)workspace, params, const_cast<float*>(bnstate), (hipStream_t)stream, 0};
+    for (auto& u : net->units) {
+        if (u.kind == U_CONV || u.kind == U_HEAD) {
+            const int taps = u.k * u.k, cin = u.cin0 + u.cin1;
+            void* wc = net->dtype == VS_BF16 ? (void*)(c.ws + u.off_wc) : nullptr;
+            void* wt = training ? (void*)(c.ws + u.off_wt) : nullptr;
+            if (wc || wt) {
+                int rc = launch_weight_prepare(net->dtype, c.P(u.w_idx), wc, wt, u.cout, taps, cin,
+                                               u.kind == U_HEAD ? 16 : u.cout, c.s);
+                if (rc) return rc;
+            }
+        }
+        if (u.bn_idx >= 0 && !training) {  // eval-mode folding from the running statistics
+            const float* rm = bnstate + c.t(u.bn_idx + 2).offset;
+            const float* rv = bnstate + c.t(u.bn_idx + 3).offset;
+            int rc = vs_bn_fold(c.P(u.bn_idx), c.P(u.bn_idx + 1), rm, rv, 1e-5f, c.bnc(u, 0), c.bnc(u, 1), u.cout, stream);
+            if (rc) return rc;
+        }
+    }
+    return VS_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------
+extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
+                               float* logits, void* workspace, void* stream) {
+    VS_REQUIRE(net && params && bnstate && x && logits && workspace, "unet_forward: null pointer");
+    VS_REQUIRE(n >= 1 && n <= net->max_batch, "unet_forward: batch %d exceeds the plan's max_batch %d", n, net->max_batch);
+    Ctx c{net, (char*)workspace, params, bnstate, (hipStream_t)stream, n};
+    const int dt = net->dtype;
+    int rc;
+    net->last_n = n;
+    for (auto& u : net->units) {
+        float* rm = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 2).offset : nullptr;
+        float* rv = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 3).offset : nullptr;
+        switch (u.kind) {
+        case U_STEM:
+            if (training) {
+                if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), nullptr, nullptr, 0, c.z(u.out), n, net->h, net->w, stream))) return rc;
+            } else {
+                if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), c.bnc(u, 0), c.bnc(u, 1), 1, c.a(u.out), n, net->h, net->w, stream))) return rc;
+            }
+            break;
+        case U_POOL:
+            if ((rc = vs_maxpool_fwd(dt, c.a(u.src0), c.a(u.out), training ? (uint8_t*)(c.ws + net->off_idx) : nullptr, n,
+                                     u.hin, u.win, u.cout, stream))) return rc;
+            continue;
+        case U_CONV: {
+            ConvParams p = conv_params(c, u);
+            if (training) {
+                p.out = c.z(u.out);
+            } else {
+                p.out = c.a(u.out);
+                p.scale = c.bnc(u, 0); p.shift = c.bnc(u, 1);
+                p.residual = u.res >= 0 ? c.a(u.res) : nullptr;
+                p.relu = u.relu;
+            }
+            if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            break;
+        }
+        case U_HEAD: {
+            ConvParams p = conv_params(c, u);
+            p.out = logits; p.shift = c.P(u.bias_idx); p.out_f32 = 3;  // fp32, NCHW
+            if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            continue;
+        }
+        }
+        if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
+            if ((rc = vs_bn_stats(dt, c.z(u.out), c.rows(u), u.cout, 1e-5f, 0.1f, c.bnc(u, 2), c.bnc(u, 3), rm, rv,
+                                  (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            if ((rc = vs_bn_apply(dt, c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1),
+                                  u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, stream))) return rc;
+        }
+    }
+    return VS_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------------------
+extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                                int need_encoder_wgrad, float* grads, void* workspace, void* stream) {
+    VS_REQUIRE(net && params && x && dlogits && grads && workspace, "unet_backward: null pointer");
+    VS_REQUIRE(n == net->last_n, "unet_backward: batch %d does not match the last training forward (%d)", n, net->last_n);
+    Ctx c{net, (char*)workspace, params, nullptr, (hipStream_t)stream, n};
+    const int dt = net->dtype;
+    int rc;
+    std::vector<char> written(net->acts.size(), 0);
+    float* wgws = (float*)(c.ws + net->off_wgws);
+    for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
+        const Unit& u = net->units[ui];
+        if (u.kind == U_POOL) {
+            VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
+            if ((rc = vs_maxpool_bwd(dt, c.da(u.out), (const uint8_t*)(c.ws + net->off_idx), c.da(u.src0), written[u.src0], n,
+                                     u.hin, u.win, u.cout, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        const void* dzp;  // gradient w.r.t. the conv output of this unit
+        int dz_c;
+        if (u.kind == U_HEAD) {
+            void* dyh = c.ws + net->off_dyh;
+            if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
+            if ((rc = launch_bias_grad(dlogits, grads + c.t(u.bias_idx).offset, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
+            dzp = dyh; dz_c = 16;
+        } else {
+            VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
+            void* dres = nullptr;
+            if (u.res >= 0) {
+                VS_REQUIRE(!written[u.res], "backward: residual gradient written twice (unit %d)", ui);
+                dres = c.da(u.res);
+                written[u.res] = 1;
+            }
+            if ((rc = vs_bn_bwd(dt, c.da(u.out), c.a(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), u.relu,
+                                c.dz(u.out), dres, grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u),
+                                u.cout, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            dzp = c.dz(u.out); dz_c = u.cout;
+        }
+        const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
+        if (u.kind == U_STEM) {  // no data gradient: the input image needs none
+            if (want_w) {
+                if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, stream))) return rc;
+            } else {
+                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), c.s));
+            }
+            continue;
+        }
+        // ---- weight gradient ----
+        if (want_w) {
+            WgradParams p{};
+            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
+            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
+            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+            p.dy = dzp; p.Cout = dz_c;
+            p.partials = wgws; p.partial_bytes = net->wgws_bytes;
+            if (u.kind == U_HEAD) {
+                p.dw = (float*)(c.ws + net->off_headdw);
+                if ((rc = launch_conv_wgrad(dt, p, c.s))) return rc;
+                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
+                                            hipMemcpyDeviceToDevice, c.s));
+            } else {
+                p.dw = grads + c.t(u.w_idx).offset;
+                if ((rc = launch_conv_wgrad(dt, p, c.s))) return rc;
+            }
+        } else {
+            VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
+                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), c.s));
+        }
+        // ---- data gradient ----
+        ConvParams p{};
+        const void* dsrc = dzp;
+        if (u.stride == 2) {
+            void* zs = c.ws + net->off_zs;
+            if ((rc = vs_zero_stuff2x(dt, dzp, zs, n, u.hout, u.wout, dz_c, stream))) return rc;
+            dsrc = zs;
+        }
+        p.src0 = dsrc; p.C0 = dz_c; p.N = n; p.Hin = u.hin; p.Win = u.win; p.Hout = u.hin; p.Wout = u.win;
+        p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
+        p.w = c.ws + u.off_wt; p.Cout = u.cin0 + u.cin1;
+        if (u.up0) {
+            VS_REQUIRE(!written[u.src0] && (u.src1 < 0 || !written[u.src1]), "backward: decoder input gradient written twice");
+            p.out = c.ws + net->off_dup;
+            if (u.src1 >= 0) { p.out1 = c.da(u.src1); p.split_c = u.cin0; written[u.src1] = 1; }
+            if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            if ((rc = vs_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, stream))) return rc;
+            written[u.src0] = 1;
+        } else {
+            p.out = c.da(u.src0);
+            p.residual = written[u.src0] ? c.da(u.src0) : nullptr;
+            if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            written[u.src0] = 1;
+        }
+    }
+    return VS_OK;
+}

@@ -1,0 +1,372 @@
+"""VolSegUnet: the object ``create_model_on_device`` returns for U_NET + resnet34.
+
+It looks like the ``smp.Unet`` the reference builds (volume_segmantics/model/model_2d.py:15-16):
+``__call__((B,1,H,W) fp32) -> (B,K,H,W) fp32 logits``, ``train()/eval()``, ``named_parameters()``
+with smp's names (so the reference's freeze predicate works, vol_seg_2d_trainer.py:102-116),
+``state_dict()/load_state_dict()`` with smp's keys and OIHW shapes, autograd-compatible output so
+``loss.backward()`` populates ``.grad`` (vol_seg_2d_trainer.py:429-430).
+
+Underneath there is no torch arithmetic: all parameters are views of ONE flat fp32 buffer (conv
+weights stored [cout][kh][kw][cin] = torch channels_last), and forward / backward are single calls
+into libvolseg_hip.so (vs_unet_forward / vs_unet_backward) on the current HIP stream.  PyTorch
+tensors are only the memory container.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+KIND_CONV, KIND_GAMMA, KIND_BETA, KIND_BIAS, KIND_RMEAN, KIND_RVAR = range(6)
+
+
+def default_precision() -> str:
+    return os.environ.get("VOLSEG_PRECISION", "fp32")
+
+
+class _Node(nn.Module):
+    """Name-space container so that parameter names come out as smp's dotted keys."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor, is_param: bool):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    if is_param:
+        node.register_parameter(parts[-1], tensor)
+    else:
+        node.register_buffer(parts[-1], tensor)
+
+
+class _UnetFn(torch.autograd.Function):
+    """One autograd node for the whole network.  Weight gradients are written by the library
+    into the model's flat gradient buffer and attached to ``param.grad`` directly (views, no
+    per-tensor copies); the returned gradients for the parameter inputs are therefore None."""
+
+    @staticmethod
+    def forward(ctx, x, model, anchor):
+        ctx.model = model
+        ctx.x = x
+        ctx.token = model._train_forward_token + 1
+        return model._forward_impl(x, training=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if ctx.token != model._train_forward_token:
+            raise RuntimeError("VolSegUnet: backward() must follow the training forward that produced this output "
+                               "(activations live in a single workspace; only the latest forward can be differentiated)")
+        model._backward_impl(ctx.x, dlogits)
+        return None, None, None
+
+
+class VolSegUnet(nn.Module):
+    def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None):
+        super().__init__()
+        precision = precision or default_precision()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.classes = int(classes)
+        self.precision = precision
+        self._dtype_code = _lib.VS_F32 if precision == "fp32" else _lib.VS_BF16
+        self._table = _lib.unet_tensor_table(self.classes)
+        dev = torch.device(device if device is not None else "cpu")
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        n_params = lib.vs_unet_param_elems(self.classes)
+        n_bn = lib.vs_unet_bnstate_elems(self.classes)
+        self._flat = torch.zeros(n_params, dtype=torch.float32, device=dev)
+        self._flat_grad = None
+        self._bnstate = torch.zeros(n_bn, dtype=torch.float32, device=dev)
+        n_bns = sum(1 for t in self._table if t[2] == KIND_RMEAN)
+        self._nbt = torch.zeros(n_bns, dtype=torch.int64, device=dev)
+        self._views: dict[str, torch.Tensor] = {}
+        self._build_views()
+        self._plans: dict = {}
+        self._prep_key = None
+        self._train_forward_token = 0
+        self._anchor = None
+        self.dp_group = None  # torch.distributed process group for data-parallel gradient all-reduce
+        self.dp_grad_dtype = torch.float32
+        self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
+        self._bnver = 0  # bumped when a training forward moves the running statistics
+        if init == "smp":
+            self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _view_of(self, flat, shape, kind, off):
+        numel = math.prod(shape)
+        v = flat[off:off + numel]
+        if kind == KIND_CONV:
+            o, i, kh, kw = shape
+            return v.view(o, kh, kw, i).permute(0, 3, 1, 2)  # OIHW shape, KRSC memory
+        return v.view(shape)
+
+    def _build_views(self):
+        for name in list(self._modules):
+            del self._modules[name]
+        bn_i = 0
+        for name, shape, kind, off in self._table:
+            if kind <= KIND_BIAS:
+                p = nn.Parameter(self._view_of(self._flat, shape, kind, off), requires_grad=True)
+                _attach(self, name, p, True)
+                self._views[name] = p
+            else:
+                b = self._view_of(self._bnstate, shape, kind, off)
+                _attach(self, name, b, False)
+                self._views[name] = b
+                if kind == KIND_RVAR:
+                    _attach(self, name.rsplit(".", 1)[0] + ".num_batches_tracked", self._nbt[bn_i], False)
+                    bn_i += 1
+        self._param_cache = None
+
+    def reset_parameters(self, seed: int | None = None):
+        """smp / torchvision initialisation: encoder convs kaiming_normal(fan_out, relu),
+        decoder convs kaiming_uniform(fan_in, relu), head xavier_uniform, biases 0, BN weight 1 / bias 0,
+        running_mean 0 / running_var 1."""
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for name, shape, kind, off in self._table:
+                v = self._views[name]
+                if kind == KIND_CONV:
+                    w = torch.empty(shape, dtype=torch.float32)
+                    if name.startswith("encoder."):
+                        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu", generator=gen)
+                    elif name.startswith("decoder."):
+                        nn.init.kaiming_uniform_(w, mode="fan_in", nonlinearity="relu", generator=gen)
+                    else:
+                        nn.init.xavier_uniform_(w, generator=gen)
+                    v.copy_(w)
+                elif kind in (KIND_GAMMA, KIND_RVAR):
+                    v.fill_(1.0)
+                else:
+                    v.zero_()
+            self._nbt.zero_()
+
+    def _apply(self, fn, recurse=True):
+        """.to(device) / .cuda() / .float(): move the flat buffers and rebuild the views."""
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("VolSegUnet keeps fp32 master parameters; choose the compute precision with precision=")
+        moved = new_flat.device != self._flat.device
+        if moved or new_flat is not self._flat:
+            req = {n: p.requires_grad for n, p in self.named_parameters()}
+            self._flat = new_flat.contiguous()
+            self._bnstate = fn(self._bnstate).contiguous()
+            self._nbt = fn(self._nbt).contiguous()
+            self._flat_grad = None
+            self._build_views()
+            for n, p in self.named_parameters():
+                p.requires_grad = req[n]
+            self._plans.clear()
+            self._prep_key = None
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        out = OrderedDict()
+        for k, v in sd.items():  # plain contiguous OIHW tensors: interchangeable with smp checkpoints
+            out[k] = v.detach().clone(memory_format=torch.contiguous_format)
+        if hasattr(sd, "_metadata"):
+            out._metadata = sd._metadata
+        return out
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    # ------------------------------------------------------------------ plans / workspace
+    def _plan(self, n: int, h: int, w: int, training: bool):
+        if self.device.type != "cuda":
+            raise RuntimeError("VolSegUnet: the HIP engine needs a GPU device; there is no CPU fallback "
+                               "(the CPU oracle lives under oracle/ and is test infrastructure only)")
+        if h % 32 or w % 32:
+            raise ValueError(f"VolSegUnet: input height/width must be multiples of 32, got {h}x{w}")
+        key = (h, w)
+        plan = self._plans.get(key)
+        if plan is None or plan["max_batch"] < n or (training and not plan["training"]):
+            if plan is not None:
+                lib.vs_unet_destroy(plan["handle"])
+            handle = _lib.C.c_void_p()
+            max_batch = max(n, plan["max_batch"] if plan else 0)
+            check(lib.vs_unet_create(_lib.C.byref(handle), self._dtype_code, self.classes, max_batch, h, w))
+            train_ws = training or (plan is not None and plan["training"])
+            nbytes = lib.vs_unet_workspace_bytes(handle, 1 if train_ws else 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            plan = {"handle": handle, "max_batch": max_batch, "training": train_ws, "ws": ws, "prep": None}
+            self._plans[key] = plan
+        return plan
+
+    def __del__(self):
+        try:
+            for plan in self._plans.values():
+                lib.vs_unet_destroy(plan["handle"])
+        except Exception:
+            pass
+
+    def _prepare(self, plan, training: bool):
+        key = (self._flat._version, self._wver, training,
+               None if training else (self._bnstate._version, self._bnver))
+        if plan["prep"] != key:
+            check(lib.vs_unet_prepare(plan["handle"], ptr(self._flat), ptr(self._bnstate), 1 if training else 0,
+                                      ptr(plan["ws"]), _lib.stream_ptr()))
+            plan["prep"] = key
+
+    # ------------------------------------------------------------------ forward / backward
+    def _check_input(self, x):
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"VolSegUnet expects (B,1,H,W) input, got {tuple(x.shape)}")
+        if x.device != self.device:
+            raise RuntimeError(f"input on {x.device}, model on {self.device}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        return x.contiguous()
+
+    def _forward_impl(self, x, training: bool):
+        n, _, h, w = x.shape
+        plan = self._plan(n, h, w, training)
+        self._prepare(plan, training)
+        logits = torch.empty((n, self.classes, h, w), dtype=torch.float32, device=self.device)
+        check(lib.vs_unet_forward(plan["handle"], ptr(self._flat), ptr(self._bnstate), ptr(x), n, 1 if training else 0,
+                                  ptr(logits), ptr(plan["ws"]), _lib.stream_ptr()))
+        if training:
+            self._nbt += 1
+            self._train_forward_token += 1
+            self._bnver += 1
+        return logits
+
+    def _backward_impl(self, x, dlogits):
+        n, _, h, w = x.shape
+        plan = self._plans[(h, w)]
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        if self._param_cache is None:
+            named = dict(self.named_parameters())
+            self._param_cache = [(named[t[0]], t[1], t[2], t[3], "encoder" in t[0] and "conv" in t[0])
+                                 for t in self._table if t[2] <= KIND_BIAS]
+        need_enc = any(p.requires_grad for p, _, _, _, enc in self._param_cache if enc)
+        dlogits = dlogits.contiguous()
+        if dlogits.dtype != torch.float32:
+            dlogits = dlogits.float()
+        check(lib.vs_unet_backward(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
+                                   ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr()))
+        if self.dp_group is not None:
+            self._allreduce_grads()
+        for p, shape, kind, off, _ in self._param_cache:
+            if not p.requires_grad:
+                continue
+            g = self._view_of(self._flat_grad, shape, kind, off)
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)
+            # else: .grad already aliases the flat buffer, which now holds this step's gradient
+
+    def _allreduce_grads(self):
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.dp_group)
+        if world == 1:
+            return
+        if self.dp_grad_dtype == torch.float32:
+            dist.all_reduce(self._flat_grad, group=self.dp_group)
+            self._flat_grad.div_(world)
+        else:
+            g = self._flat_grad.to(self.dp_grad_dtype)
+            dist.all_reduce(g, group=self.dp_group)
+            self._flat_grad.copy_(g)
+            self._flat_grad.div_(world)
+
+    def forward(self, x):
+        x = self._check_input(x)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self._anchor is None or self._anchor.device != self.device:
+                self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+            return _UnetFn.apply(x, self, self._anchor)
+        return self._forward_impl(x, training=self.training)
+
+    # ------------------------------------------------------------------ optimizer
+    def fused_adamw(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        return FusedAdamW(self, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (the reference's optimiser, vol_seg_2d_trainer.py:395-396) as ONE HIP
+    kernel over the model's flat parameter buffer.  Exposes a normal ``param_groups[0]`` with ``lr`` and
+    ``betas`` so LambdaLR / OneCycleLR (which cycles beta1, :401-408) drive it unchanged."""
+
+    def __init__(self, model: VolSegUnet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(list(model.parameters()), defaults)
+        self.model = model
+        self.exp_avg = torch.zeros_like(model._flat)
+        self.exp_avg_sq = torch.zeros_like(model._flat)
+        self.step_count = 0
+        self._mask = None
+        self._mask_key = None
+
+    def _grad_mask(self):
+        params = list(self.model.parameters())
+        key = tuple(p.requires_grad and p.grad is not None for p in params)
+        if key != self._mask_key:
+            if all(key):
+                self._mask = None
+            else:
+                m = torch.zeros(self.model._flat.numel(), dtype=torch.uint8)
+                for (name, shape, kind, off), on in zip([t for t in self.model._table if t[2] <= KIND_BIAS], key):
+                    if on:
+                        m[off:off + math.prod(shape)] = 1
+                self._mask = m.to(self.model.device)
+            self._mask_key = key
+        return self._mask
+
+    def zero_grad(self, set_to_none: bool = True):
+        # gradients live in the model's flat buffer and are overwritten by every backward: keep the
+        # aliases (no per-tensor work); set_to_none=False zeroes the flat buffer in one kernel
+        if not set_to_none and self.model._flat_grad is not None:
+            self.model._flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self.model
+        if m._flat_grad is None:
+            return loss
+        g = self.param_groups[0]
+        self.step_count += 1
+        mask = self._grad_mask()
+        check(lib.vs_adamw_step(ptr(m._flat), ptr(m._flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(mask),
+                                m._flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                float(g["eps"]), float(g["weight_decay"]), self.step_count, _lib.stream_ptr()))
+        m._wver += 1  # weight copies are re-derived before the next forward
+        return loss
+
+    def state_dict(self):
+        return {"state": {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq},
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["state"]["step"])
+        self.exp_avg.copy_(sd["state"]["exp_avg"])
+        self.exp_avg_sq.copy_(sd["state"]["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+def load_oracle_state(model: VolSegUnet, state_dict) -> None:
+    """Strict load of an smp-keyed state dict (e.g. from the CPU oracle or a reference checkpoint)."""
+    missing, unexpected = model.load_state_dict(state_dict, strict=True)
+    assert not missing and not unexpected
+    logging.debug("loaded %d tensors", len(state_dict))
