@@ -126,6 +126,12 @@ int vs_unet_forward(vs_unet_t* net, const float* params, float* bnstate, const f
 int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                      int need_encoder_wgrad, float* grads, void* workspace, void* stream);
 
+/* Diagnostics: where a unit's activation (a), pre-BN output (z) and their gradients (da, dz) live
+ * inside the workspace (byte offsets; NHWC, dtype of the plan).  Tests only. */
+int vs_unet_num_units(const vs_unet_t* net);
+int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* weight_name, int name_len, int* c, int* h, int* w,
+                       size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz);
+
 /* AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, vol_seg_2d_trainer.py:395-396,430);
  * ``mask`` (uint8 per element, may be null) = 0 freezes an element (requires_grad False). */
 int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,

@@ -74,15 +74,15 @@ def test_conv_upsample_concat_never_materialised(code):
     ref = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), wt, padding=1)
     d = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, c1=c1, up0=1)
     y = torch.empty((n, h, w, cout), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x0, code)), L.ptr(to_nhwc(x1, code)), L.ptr(w_krsc(wt, code)),
-                                None, None, None, L.ptr(y), None, None))
+    x0d, x1d, wd = to_nhwc(x0, code), to_nhwc(x1, code), w_krsc(wt, code)  # keep alive until the kernel ran
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(x0d), L.ptr(x1d), L.ptr(wd), None, None, None, L.ptr(y), None, None))
     sync()
     assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
     # no skip (last decoder block)
     ref2 = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), wt[:, :c0], padding=1)
     d2 = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, up0=1)
-    L.check(L.lib.vs_conv2d_fwd(d2, L.ptr(to_nhwc(x0, code)), None, L.ptr(w_krsc(wt[:, :c0].contiguous(), code)),
-                                None, None, None, L.ptr(y), None, None))
+    wd2 = w_krsc(wt[:, :c0].contiguous(), code)
+    L.check(L.lib.vs_conv2d_fwd(d2, L.ptr(x0d), None, L.ptr(wd2), None, None, None, L.ptr(y), None, None))
     sync()
     assert torch.allclose(from_nhwc(y), ref2, **tol(code, ref2.abs().max().item()))
 
@@ -99,8 +99,8 @@ def test_head_conv_bias_fp32_nchw(code, classes):
     ref = F.conv2d(x, wt, b, padding=1)
     d = conv_desc(L, code, n, h, w, 16, classes, 3, 1, 1, out_f32=3)
     y = torch.full((n, classes, h, w), float("nan"), device=DEV)
-    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x, code)), None, L.ptr(w_krsc(wt, code)), None, L.ptr(b.to(DEV)), None,
-                                L.ptr(y), None, None))
+    xd, wd, bd = to_nhwc(x, code), w_krsc(wt, code), b.to(DEV)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wd), None, L.ptr(bd), None, L.ptr(y), None, None))
     sync()
     assert torch.allclose(y.cpu(), ref, rtol=1e-4, atol=1e-4 if code == 0 else 2e-2)
 
@@ -142,8 +142,8 @@ def test_dgrad_and_wgrad_match_autograd(code, shape):
     ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((cout, k, k, cin), float("nan"), device=DEV)
-    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(to_nhwc(x.detach(), code)), None, L.ptr(to_nhwc(dy, code)), L.ptr(dw),
-                                  L.ptr(ws), ws_bytes, None))
+    xd, dyd0 = to_nhwc(x.detach(), code), to_nhwc(dy, code)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(xd), None, L.ptr(dyd0), L.ptr(dw), L.ptr(ws), ws_bytes, None))
     sync()
     ref_dw = wt.grad.permute(0, 2, 3, 1)
     assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
@@ -176,8 +176,8 @@ def test_wgrad_through_upsample_concat_and_split_dgrad(code):
     ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
     dw = torch.empty((cout, 3, 3, c0 + c1), device=DEV)
-    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(to_nhwc(x0.detach(), code)), L.ptr(to_nhwc(x1.detach(), code)),
-                                  L.ptr(to_nhwc(dy, code)), L.ptr(dw), L.ptr(ws), ws_bytes, None))
+    x0d, x1d, dyd = to_nhwc(x0.detach(), code), to_nhwc(x1.detach(), code), to_nhwc(dy, code)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(x0d), L.ptr(x1d), L.ptr(dyd), L.ptr(dw), L.ptr(ws), ws_bytes, None))
     sync()
     ref_dw = wt.grad.permute(0, 2, 3, 1)
     assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
@@ -186,7 +186,7 @@ def test_wgrad_through_upsample_concat_and_split_dgrad(code):
     dd = conv_desc(L, code, n, h, w, cout, c0 + c1, 3, 1, 1, split_c=c0)
     dup = torch.empty((n, h, w, c0), device=DEV, dtype=tdtype(code))
     dskip = torch.empty((n, h, w, c1), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(to_nhwc(dy, code)), None, L.ptr(wtr), None, None, None, L.ptr(dup), L.ptr(dskip), None))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dup), L.ptr(dskip), None))
     dx0 = torch.empty((n, h // 2, w // 2, c0), device=DEV, dtype=tdtype(code))
     L.check(L.lib.vs_upsample2x_bwd(code, L.ptr(dup), L.ptr(dx0), n, h // 2, w // 2, c0, None))
     sync()
@@ -205,19 +205,20 @@ def test_stem_fwd_and_wgrad(code):
     dy = rounded(torch.randn(y.shape, generator=g), code)
     y.backward(dy)
     out = torch.empty((n, h // 2, w // 2, 64), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_stem_fwd(code, L.ptr(x.to(DEV)), L.ptr(wt.detach().reshape(64, 49).to(DEV)), None, None, 0, L.ptr(out), n, h, w, None))
+    xd, wd, dyd = x.to(DEV), wt.detach().reshape(64, 49).to(DEV), to_nhwc(dy, code)
+    L.check(L.lib.vs_stem_fwd(code, L.ptr(xd), L.ptr(wd), None, None, 0, L.ptr(out), n, h, w, None))
     sync()
     assert torch.allclose(from_nhwc(out), y.detach(), **tol(code, y.abs().max().item()))
     sc, sh = torch.rand(64) + 0.5, torch.randn(64)
-    L.check(L.lib.vs_stem_fwd(code, L.ptr(x.to(DEV)), L.ptr(wt.detach().reshape(64, 49).to(DEV)), L.ptr(sc.to(DEV)),
-                              L.ptr(sh.to(DEV)), 1, L.ptr(out), n, h, w, None))
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    L.check(L.lib.vs_stem_fwd(code, L.ptr(xd), L.ptr(wd), L.ptr(scd), L.ptr(shd), 1, L.ptr(out), n, h, w, None))
     sync()
     ref = (y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).relu()
     assert torch.allclose(from_nhwc(out), ref, **tol(code, ref.abs().max().item()))
     wsb = L.lib.vs_stem_wgrad_workspace(n, h, w)
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, 49), float("nan"), device=DEV)
-    L.check(L.lib.vs_stem_wgrad(code, L.ptr(x.to(DEV)), L.ptr(to_nhwc(dy, code)), L.ptr(dw), L.ptr(ws), wsb, n, h, w, None))
+    L.check(L.lib.vs_stem_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(ws), wsb, n, h, w, None))
     sync()
     ref_dw = wt.grad.reshape(64, 49)
     assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
@@ -257,7 +258,8 @@ def test_batchnorm_train_fwd_bwd(code, c, rows_shape):
     dx, dres = torch.empty_like(xd), torch.empty_like(xd)
     dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
     yin = to_nhwc(y.detach(), code)
-    L.check(L.lib.vs_bn_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(yin), L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), 1,
+    dyd = to_nhwc(dy, code)
+    L.check(L.lib.vs_bn_bwd(code, L.ptr(dyd), L.ptr(yin), L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), 1,
                             L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, c, L.ptr(ws), wsb, None))
     sync()
     t = tol(code, x.grad.abs().max().item())
@@ -272,7 +274,8 @@ def test_bn_fold_matches_eval_batchnorm():
     c = 96
     gamma, beta, rm, rv = torch.rand(c) + 0.5, torch.randn(c), torch.randn(c), torch.rand(c) + 0.1
     sc, sh = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-    L.check(L.lib.vs_bn_fold(L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)), L.ptr(rm.to(DEV)), L.ptr(rv.to(DEV)), 1e-5, L.ptr(sc), L.ptr(sh), c, None))
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    L.check(L.lib.vs_bn_fold(L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 1e-5, L.ptr(sc), L.ptr(sh), c, None))
     sync()
     x = torch.randn(2, c, 4, 4)
     ref = F.batch_norm(x, rm, rv, gamma, beta, training=False, eps=1e-5)
@@ -293,10 +296,10 @@ def test_maxpool_fwd_bwd_and_helpers(code):
     idx = torch.empty((n, h // 2, w // 2, c), device=DEV, dtype=torch.uint8)
     L.check(L.lib.vs_maxpool_fwd(code, L.ptr(xd), L.ptr(yd), L.ptr(idx), n, h, w, c, None))
     base = rounded(torch.randn(n, c, h, w, generator=g), code)
-    dx = to_nhwc(base, code)
-    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(idx), L.ptr(dx), 1, n, h, w, c, None))
+    dx, dyd = to_nhwc(base, code), to_nhwc(dy, code)
+    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(dyd), L.ptr(idx), L.ptr(dx), 1, n, h, w, c, None))
     dx0 = torch.empty_like(dx)
-    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(to_nhwc(dy, code)), L.ptr(idx), L.ptr(dx0), 0, n, h, w, c, None))
+    L.check(L.lib.vs_maxpool_bwd(code, L.ptr(dyd), L.ptr(idx), L.ptr(dx0), 0, n, h, w, c, None))
     sync()
     assert torch.equal(from_nhwc(yd), y.detach())
     # gradient routed to the first maximum of each window, exactly like torch
@@ -319,12 +322,14 @@ def test_adamw_matches_torch():
         opt.param_groups[0]["lr"], opt.param_groups[0]["betas"] = lr, (b1, 0.999)
         p_ref.grad = grad.clone()
         opt.step()
-        L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(grad.to(DEV)), L.ptr(m), L.ptr(v), None, n, lr, b1, 0.999, 1e-8, 0.01, step, None))
+        gd = grad.to(DEV)
+        L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), None, n, lr, b1, 0.999, 1e-8, 0.01, step, None))
         sync()
         assert torch.allclose(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
     # masked elements stay frozen
     before = p.clone()
-    L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(torch.ones(n, device=DEV)), L.ptr(m), L.ptr(v), L.ptr(mask.to(DEV)), n, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, None))
+    ones, maskd = torch.ones(n, device=DEV), mask.to(DEV)
+    L.check(L.lib.vs_adamw_step(L.ptr(p), L.ptr(ones), L.ptr(m), L.ptr(v), L.ptr(maskd), n, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, None))
     sync()
     frozen = mask == 0
     assert torch.equal(p.cpu()[frozen], before.cpu()[frozen]) and not torch.equal(p.cpu()[~frozen], before.cpu()[~frozen])

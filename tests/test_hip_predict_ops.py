@@ -31,7 +31,8 @@ def test_reflect101_when_padding_exceeds_size():
     vol = np.random.default_rng(0).integers(0, 256, size=(3, 10, 13), dtype=np.uint8)  # pads 11 / 9 > size-1? (10->32)
     m = dirmap_from_view(L, vol, vol)
     x = torch.empty((3, m.hp, m.wp), device=DEV)
-    L.check(L.lib.vs_slices_gather(L.ptr(torch.from_numpy(vol).to(DEV)), m, 0, 3, L.ptr(x), None))
+    vd = torch.from_numpy(vol).to(DEV)
+    L.check(L.lib.vs_slices_gather(L.ptr(vd), m, 0, 3, L.ptr(x), None))
     sync()
     ref = np.stack([P.preprocess_slice(vol[i]) for i in range(3)])
     assert np.array_equal(x.cpu().numpy(), ref)

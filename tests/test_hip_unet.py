@@ -45,12 +45,11 @@ def test_eval_logits_bf16_close_and_labels_agree():
     assert agree > 0.9, agree
 
 
-@pytest.mark.parametrize("precision,rtol", [("fp32", 2e-3), ("bf16", 0.12)])
-def test_train_forward_backward_matches_autograd(precision, rtol):
-    oracle, model = _pair(2, 3, precision, perturb_bn=False)
+def _train_pair(precision, B=4, hw=64, seed=3):
+    oracle, model = _pair(2, seed, precision, perturb_bn=False)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(4, 1, 64, 64, generator=g)
-    mask = (torch.rand(4, 64, 64, generator=g) > 0.65).to(torch.uint8)
+    x = torch.randn(B, 1, hw, hw, generator=g)
+    mask = (torch.rand(B, hw, hw, generator=g) > 0.65).to(torch.uint8)
     _, t = P.prepare_training_batch(x, mask, 2)
     oracle.train(); model.train()
     ref_out = oracle(x)
@@ -60,23 +59,146 @@ def test_train_forward_backward_matches_autograd(precision, rtol):
     loss = P.dice_loss_none(out, t.to(DEV).float())
     loss.backward()
     sync()
-    assert abs(loss.item() - ref_loss.item()) < (1e-4 if precision == "fp32" else 2e-2)
-    assert (out.detach().cpu() - ref_out.detach()).abs().max() < (2e-3 if precision == "fp32" else 0.35)
-    ref_grads = dict(oracle.named_parameters())
-    worst = 0.0
+    return oracle, model, x, ref_out.detach(), ref_loss.item(), out.detach().cpu(), loss.item()
+
+
+def _cos(a, b):
+    return (torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-300)).item()
+
+
+def test_train_forward_fp32_tight_and_backward_vs_autograd():
+    """Forward (train-mode BN) is compared tightly.  Gradients are compared with a ReLU-flip tolerant
+    criterion: two correct fp32 implementations disagree on the sign of a handful of pre-activations that
+    are ~1e-6 from zero, and every such flip changes a gradient element by its full value (one flip among
+    the 8192 elements of a layer4 tensor is already a 1e-2 relative L2 change).  Exactness of the backward
+    kernels themselves is pinned by test_backward_self_consistency_in_network below."""
+    oracle, model, x, ref_out, ref_loss, out, loss = _train_pair("fp32")
+    assert abs(loss - ref_loss) < 1e-5
+    assert ((out - ref_out).norm() / ref_out.norm()).item() < 1e-4
+    ref = dict(oracle.named_parameters())
     for name, p in model.named_parameters():
-        assert p.grad is not None, name
-        r = ref_grads[name].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        r = ref[name].grad
         err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
-        worst = max(worst, err)
-        assert err < rtol, (name, err)
-    # running statistics moved exactly like torch's
+        assert _cos(p.grad.cpu(), r) > 0.99 and err < 0.15, (name, err)
+        if name.startswith(("segmentation_head", "decoder.blocks.4.conv2")):
+            assert err < 1e-3, (name, err)   # upstream of every ReLU but one: no flips to speak of
     osd, msd = oracle.state_dict(), model.state_dict()
-    for k in osd:
+    for k in osd:   # running statistics moved exactly like torch's
         if "running" in k:
-            assert torch.allclose(msd[k].cpu(), osd[k], rtol=1e-3 if precision == "fp32" else 5e-2, atol=1e-4 if precision == "fp32" else 2e-2), k
+            assert torch.allclose(msd[k].cpu(), osd[k], rtol=1e-3, atol=1e-5), k
         if "num_batches" in k:
             assert int(msd[k]) == int(osd[k]) == 1
+
+
+def test_train_forward_backward_bf16_sane():
+    oracle, model, x, ref_out, ref_loss, out, loss = _train_pair("bf16")
+    assert abs(loss - ref_loss) < 2e-2
+    assert ((out - ref_out).norm() / ref_out.norm()).item() < 0.15
+    ref = dict(oracle.named_parameters())
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        if name.startswith(("segmentation_head", "decoder.blocks.4")):
+            assert _cos(p.grad.cpu(), ref[name].grad) > 0.9, name
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_backward_self_consistency_in_network(precision):
+    """Every backward kernel, in the network, at the network's own shapes: recompute BN-backward, one dgrad
+    per block and EVERY weight gradient in fp64 on the CPU from the engine's own saved tensors (so ReLU masks
+    are identical by construction) and compare.  fp32: exact to rounding; bf16: to bf16 storage rounding."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from volume_segmantics_amd import _lib as L
+    B, hw = 4, 64
+    oracle, model, x, *_ = _train_pair(precision, B, hw)
+    tight = precision == "fp32"
+    plan = model._plans[(hw, hw)]
+    ws = plan["ws"]
+    dt, esz = (torch.float32, 4) if tight else (torch.bfloat16, 2)
+    nu = L.lib.vs_unet_num_units(plan["handle"])
+    name = C.create_string_buffer(128)
+    c, h, w = C.c_int(), C.c_int(), C.c_int()
+    offs = [C.c_size_t() for _ in range(4)]
+    units = {}
+    order = []
+    for u in range(nu):
+        L.check(L.lib.vs_unet_debug_unit(plan["handle"], u, name, 128, C.byref(c), C.byref(h), C.byref(w), *[C.byref(o) for o in offs]))
+        n_el = B * c.value * h.value * w.value
+        def get(off, n_el=n_el, c=c.value, h=h.value, w=w.value):
+            return ws[off:off + n_el * esz].view(dt).view(B, h, w, c).cpu().double().permute(0, 3, 1, 2).contiguous()
+        wn = name.value.decode()
+        units[wn] = dict(a=get(offs[0].value), z=get(offs[1].value), da=get(offs[2].value), dz=get(offs[3].value)) if wn != "segmentation_head.0.weight" else {}
+        order.append(wn)
+    sd = {k: v.double().cpu() for k, v in model.state_dict().items()}
+    grads = {n: p.grad.double().cpu() for n, p in model.named_parameters()}
+    tol_op = 2e-5 if tight else 2e-2
+    feats = {"f1": "encoder.conv1.weight", "f2": "encoder.layer1.2.conv2.weight", "f3": "encoder.layer2.3.conv2.weight",
+             "f4": "encoder.layer3.5.conv2.weight", "f5": "encoder.layer4.2.conv2.weight"}
+
+    def rel(a, b):
+        return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+    def conv_input(wn):
+        """the (virtual) input tensor the forward conv of this unit read, from the engine's own activations"""
+        if wn.startswith("decoder.blocks."):
+            i = int(wn.split(".")[2])
+            if ".conv2." in wn:
+                return units[wn.replace("conv2.0", "conv1.0")]["a"]
+            prev = units[feats["f5"]]["a"] if i == 0 else units[f"decoder.blocks.{i - 1}.conv2.0.weight"]["a"]
+            up = F.interpolate(prev, scale_factor=2, mode="nearest")
+            return up if i == 4 else torch.cat([up, units[feats[f"f{4 - i}"]]["a"]], 1)
+        if wn == "segmentation_head.0.weight":
+            return units["decoder.blocks.4.conv2.0.weight"]["a"]
+        parts = wn.split(".")   # encoder.layerL.B.{conv1|conv2|downsample.0}.weight
+        l, b = int(parts[1][5:]), int(parts[2])
+        if parts[3] == "conv2":
+            return units[wn.replace("conv2", "conv1")]["a"]
+        if b > 0:
+            return units[f"encoder.layer{l}.{b - 1}.conv2.weight"]["a"]
+        return units["maxpool"]["a"] if l == 1 else units[feats[f"f{l}"]]["a"]
+
+    checked = dict(bn=0, wgrad=0, dgrad=0)
+    for wn in order:
+        if wn == "maxpool":
+            continue
+        W = sd[wn]
+        stride = 2 if (W.shape[0] != W.shape[1] and wn.startswith("encoder.layer") and "conv2" not in wn) else 1
+        pad = W.shape[2] // 2
+        if wn == "encoder.conv1.weight":
+            xin, stride, pad = x.double(), 2, 3
+        else:
+            xin = conv_input(wn)
+        if wn == "segmentation_head.0.weight":
+            continue  # head gradients are compared against the oracle directly (no ReLU in between)
+        t = units[wn]
+        bn = wn.replace("conv1.0.weight", "conv1.1").replace("conv2.0.weight", "conv2.1").replace("downsample.0.weight", "downsample.1")
+        if bn == wn:
+            bn = wn.replace("conv1.weight", "bn1").replace("conv2.weight", "bn2")
+        relu = "downsample" not in wn
+        dzm = t["da"] * (t["a"] > 0) if relu else t["da"]
+        z = t["z"]
+        mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+        invstd = 1 / torch.sqrt(var + 1e-5)
+        xh = (z - mean) * invstd
+        M = z.numel() / z.shape[1]
+        db, dg = dzm.sum((0, 2, 3)), (dzm * xh).sum((0, 2, 3))
+        ref_dz = sd[bn + ".weight"].view(1, -1, 1, 1) * invstd * (dzm - db.view(1, -1, 1, 1) / M - xh * dg.view(1, -1, 1, 1) / M)
+        assert rel(t["dz"], ref_dz) < tol_op, ("bn_bwd", wn, rel(t["dz"], ref_dz))
+        assert rel(grads[bn + ".bias"], db) < tol_op and rel(grads[bn + ".weight"], dg) < tol_op, ("bn grads", wn)
+        checked["bn"] += 1
+        # weight gradient of this conv from its (virtual) input and dz
+        Wr = W.clone().requires_grad_()
+        (gw,) = torch.autograd.grad(F.conv2d(xin, Wr, stride=stride, padding=pad), Wr, t["dz"])
+        assert rel(grads[wn], gw) < (5e-5 if tight else 2e-2), ("wgrad", wn, rel(grads[wn], gw))
+        checked["wgrad"] += 1
+        # data gradient where the input has this conv as its only consumer (conv2 of every block)
+        if "conv2" in wn:
+            src = units[wn.replace("conv2.0", "conv1.0").replace("conv2.weight", "conv1.weight")]
+            ref_da = F.conv_transpose2d(t["dz"], W, padding=1)
+            assert rel(src["da"], ref_da) < tol_op, ("dgrad", wn, rel(src["da"], ref_da))
+            checked["dgrad"] += 1
+    assert checked == dict(bn=46, wgrad=46, dgrad=21), checked
 
 
 def test_three_reference_training_steps_fp32(golden):
@@ -99,11 +221,16 @@ def test_three_reference_training_steps_fp32(golden):
         loss.backward()
         opt.step()
         sched.step()
-        assert abs(loss.item() - g["losses"][step]) < 5e-4, (step, loss.item(), g["losses"][step])
-    sd = model.state_dict()
-    for k in g.files:
-        if k.startswith("after__"):
-            assert torch.allclose(sd[k[7:]].cpu(), torch.tensor(g[k]), rtol=2e-2, atol=2e-3), k
+        # step 0 is a pure forward comparison; later steps sit behind AdamW updates driven by flip-sensitive gradients
+        assert abs(loss.item() - g["losses"][step]) < (2e-5 if step == 0 else 5e-3), (step, loss.item(), g["losses"][step])
+    sd, sd0 = model.state_dict(), seeded_oracle(2, 3, False).state_dict()
+    for k in g.files:   # AdamW normalises gradients: elements with ~zero gradient move by +-lr on rounding noise,
+        if k.startswith("after__"):   # so compare the update as a whole (direction and size), not element by element
+            ours, ref, w0 = sd[k[7:]].cpu().double(), torch.tensor(g[k]).double(), sd0[k[7:]].double()
+            assert ((ours - ref).norm() / (ref.norm() + 1e-12)).item() < 2e-2, k
+            if "running" not in k and (ref - w0).norm() > 0:
+                cos = torch.dot((ours - w0).flatten(), (ref - w0).flatten()) / ((ours - w0).norm() * (ref - w0).norm())
+                assert cos.item() > (0.9 if k[7:].startswith(("segmentation_head", "decoder")) else 0.5), (k, cos.item())
 
 
 def test_frozen_encoder_matches_reference_predicate():
@@ -124,4 +251,4 @@ def test_frozen_encoder_matches_reference_predicate():
             assert p.grad is None
         else:
             r = ref[name].grad
-            assert ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)) < 2e-3, name
+            assert _cos(p.grad.cpu(), r) > 0.99, name   # ReLU-flip tolerant (see the fp32 test above)

@@ -66,6 +66,9 @@ _SIGS = {
     "vs_unet_prepare": (I, [P, P, P, I, P, P]),
     "vs_unet_forward": (I, [P, P, P, P, I, I, P, P, P]),
     "vs_unet_backward": (I, [P, P, P, P, I, I, P, P, P]),
+    "vs_unet_num_units": (I, [P]),
+    "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),
+                               C.POINTER(SZ), C.POINTER(SZ)]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),

@@ -41,9 +41,12 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     __shared__ float red[2][256][kVec + 1];
     const int tid = threadIdx.x;
     const int cvi = tid % m.cv, rl = tid / m.cv;
-    float s[kVec], q[kVec];
+    float s[kVec], q[kVec], sh[kVec];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) s[k] = q[k] = 0.f;
+    // shifted sums: K = first row of the tensor (same for every block) keeps E[(x-K)^2] - E[x-K]^2 free of
+    // catastrophic cancellation when |mean| >> std (few samples per channel in the deep layers)
+    ld8(x + cvi * kVec, sh);
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
     if (rl < m.rpb) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
             float v[kVec];
             ld8(x + r * c + cvi * kVec, v);
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) { s[k] += v[k]; q[k] += v[k] * v[k]; }
+            for (int k = 0; k < kVec; ++k) { const float d = v[k] - sh[k]; s[k] += d; q[k] += d * d; }
         }
     }
 #pragma unroll
@@ -67,9 +70,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     }
 }
 
-__global__ void bn_stats_finalize(const float* __restrict__ partial, int nblocks, int c, int64_t rows, float eps,
-                                  float momentum, float* mean, float* invstd, float* running_mean,
-                                  float* running_var) {
+template <typename T>
+__global__ void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x, int nblocks, int c,
+                                  int64_t rows, float eps, float momentum, float* mean, float* invstd,
+                                  float* running_mean, float* running_var) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     double s = 0.0, q = 0.0;
@@ -77,9 +81,10 @@ __global__ void bn_stats_finalize(const float* __restrict__ partial, int nblocks
         s += (double)partial[((size_t)b * 2 + 0) * c + ch];
         q += (double)partial[((size_t)b * 2 + 1) * c + ch];
     }
-    const double mu = s / (double)rows;
-    double var = q / (double)rows - mu * mu;
+    const double dm = s / (double)rows;  // mean of (x - K)
+    double var = q / (double)rows - dm * dm;
     if (var < 0.0) var = 0.0;
+    const double mu = dm + (double)Elem<T>::ld(x + ch);
     mean[ch] = (float)mu;
     invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
@@ -98,12 +103,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const int tid = threadIdx.x;
     const int cvi = tid % m.cv, rl = tid / m.cv;
     if (rl >= m.rpb) return;
-    float a[kVec], b[kVec];
+    float a[kVec], b[kVec], mu[kVec];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
         const int ch = cvi * kVec + k;
         a[k] = invstd[ch] * gamma[ch];
-        b[k] = beta[ch] - mean[ch] * a[k];
+        b[k] = beta[ch];
+        mu[k] = mean[ch];
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         float v[kVec];
         ld8(x + o, v);
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) v[k] = v[k] * a[k] + b[k];
+        for (int k = 0; k < kVec; ++k) v[k] = (v[k] - mu[k]) * a[k] + b[k];
         if (res) {
             float rv[kVec];
             ld8(res + o, rv);
@@ -239,8 +245,8 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
     RowMap m = make_rowmap(rows, c);
     hipLaunchKernelGGL(bn_stats_partial<T>, dim3(m.nblocks), dim3(256), 0, s, (const T*)x, rows, c, m, ws);
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, m.nblocks, c, rows, eps, momentum, mean,
-                       invstd, rm, rv);
+    hipLaunchKernelGGL(bn_stats_finalize<T>, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, (const T*)x, m.nblocks, c, rows, eps,
+                       momentum, mean, invstd, rm, rv);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

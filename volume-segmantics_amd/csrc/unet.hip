@@ -501,3 +501,17 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
     }
     return VS_OK;
 }
+
+// ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------
+extern "C" int vs_unet_num_units(const vs_unet_t* net) { return (int)net->units.size(); }
+extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, int name_len, int* c, int* h, int* w,
+                                  size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
+    VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
+    const Unit& u = net->units[unit];
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : "maxpool";
+    strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
+    if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
+    const Act& a = net->acts[u.out];
+    *c = a.c; *h = a.h; *w = a.w; *off_a = a.off_a; *off_z = a.off_z; *off_da = a.off_da; *off_dz = a.off_dz;
+    return VS_OK;
+}
