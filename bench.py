@@ -1,0 +1,194 @@
+"""bench.py - headline benchmark of the hot path (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one training step of U-Net/ResNet-34 (2 classes) on a batch of 32 synthetic 256x256 slices that
+are already resident in HBM: weight-copy refresh, forward (train-mode BN), DiceLoss(normalization="none"),
+backward (all weights trainable), gradient all-reduce over RCCL when N > 1, fused AdamW, OneCycleLR step -
+i.e. VolSeg2dTrainer._train_one_batch (reference vol_seg_2d_trainer.py:419-432) with bf16 activations and
+fp32 master weights.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+
+FLOP_PER_SLICE_FWD_BWD_256 = 46.22e9   # 3 * 7.721 GMAC - stem dgrad, x2
+MFMA_PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch(batch: int, size: int, classes: int, seed: int):
+    """Slices of a seeded blurred-noise uint8 volume + labels by thresholding the same field."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((batch, size, size)).astype(np.float32)
+    for ax in (1, 2):
+        for _ in range(3):
+            v = (np.roll(v, 1, ax) + v + np.roll(v, -1, ax)) / 3.0
+    v = (v - v.mean()) / v.std()
+    u8 = np.clip(128 + 40 * v, 0, 255).astype(np.uint8)
+    qs = np.quantile(v, [0.65] if classes == 2 else list(np.linspace(0, 1, classes + 1)[1:-1]))
+    lab = np.digitize(v, qs).astype(np.int64)
+    x = ((u8.astype(np.float32) / 255) - 0.449) / 0.226   # data/datasets.py:63-69
+    return torch.from_numpy(x).unsqueeze(1), torch.from_numpy(lab)
+
+
+def dice_loss(output, target, eps=1e-6):
+    """DiceLoss(normalization='none') of the reference (data/pytorch3dunet_losses.py:15-41,89-135)."""
+    inter = (output * target).sum((0, 2, 3))
+    denom = (output * output).sum((0, 2, 3)) + (target * target).sum((0, 2, 3))
+    return 1.0 - torch.mean(2 * (inter / denom.clamp(min=eps)))
+
+
+def cpu_baseline(batch: int, steps: int):
+    """The oracle (pure-torch CPU fp32 restatement of the reference path) timed on this host: reported
+    baseline, not the target.  Bounded sample: `steps` training steps at the reference's default batch 12."""
+    from oracle.unet_resnet34_torch import seeded_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = seeded_oracle(2, 0, perturb_bn=False)
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    x, lab = synth_batch(batch, 256, 2, seed=99)
+    t = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).float()
+    def step():
+        opt.zero_grad()
+        loss = dice_loss(net(x), t)
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} fwd+bwd+AdamW steps, batch {batch} (reference default), 256x256, fp32, torch CPU "
+                      f"({torch.get_num_threads()} threads) after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from volume_segmantics_amd import _lib
+    from volume_segmantics_amd.engine import VolSegUnet
+
+    model = VolSegUnet(2, device=dev, precision=args.precision, seed=0)
+    if world > 1:
+        dist.broadcast(model._flat, 0)
+        dist.broadcast(model._bnstate, 0)
+        model.dp_group = dist.group.WORLD
+    x, lab = synth_batch(args.batch, 256, 2, seed=1234 + rank)   # every rank: its own shard of the global batch
+    x = x.to(dev)
+    target = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8).float()
+    opt = model.fused_adamw(lr=1e-4)
+    total = args.warmup + args.steps + 8
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total + 1, pct_start=0.3)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        out = model(x)
+        loss = dice_loss(out, target)
+        loss.backward()
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    final_loss = float(loss)
+
+    # ---- roofline block: per-kernel-class HIP-event timing of the same step (separate, instrumented steps) ----
+    prof_steps = 3
+    _lib.check(_lib.lib.vs_profile_enable(1))
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.check(_lib.lib.vs_profile_enable(0))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        slices_per_s = args.batch * world * args.steps / elapsed
+        mfma_kinds = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+        dom = max(mfma_kinds, key=lambda k: prof[k]["ms"])
+        ach = prof[dom]["flops"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else 0.0
+        conv_ms = sum(prof[k]["ms"] for k in mfma_kinds) / prof_steps
+        conv_fl = sum(prof[k]["flops"] for k in mfma_kinds) / prof_steps
+        breakdown = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["calls"] // prof_steps,
+                         **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] and v["ms"] else {}),
+                         **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] and v["ms"] else {})}
+                     for k, v in prof.items()}
+        out = {
+            "metric": "slices/sec fwd+bwd U-Net/ResNet-34 256x256 bf16 batch 32 (training step incl. loss, AdamW)",
+            "value": round(slices_per_s, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 256^3-style 1-ch slices, 2-class, U-Net/ResNet-34, batch 32 per GPU, "
+                                   "train step (fwd + DiceLoss + bwd + AdamW + OneCycleLR)",
+                       "global_batch": args.batch * world, "slice": "256x256", "parallelism": f"dp{world}",
+                       "master_weights": "fp32", "final_loss": round(final_loss, 5)},
+            "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": prof[dom]["calls"] // prof_steps,
+                         "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["calls"]), 5),
+                         "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else 0.0,
+                         "note": "algorithmic conv FLOPs of the class / HIP-event time of its launches, instrumented steps"},
+            "kernel_classes": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(12, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,14 @@ int vs_unet_num_units(const vs_unet_t* net);
 int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* weight_name, int name_len, int* c, int* h, int* w,
                        size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline block).
+ * vs_profile_enable(1) clears and starts collecting; vs_profile_read sums, per kind, the elapsed ms, the
+ * algorithmic flops / bytes and the number of launches recorded since then (arrays of vs_profile_num_kinds()). */
+int vs_profile_enable(int on);
+int vs_profile_num_kinds(void);
+const char* vs_profile_kind_name(int kind);
+int vs_profile_read(double* ms, double* flops, double* bytes, int64_t* calls);
+
 /* AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, vol_seg_2d_trainer.py:395-396,430);
  * ``mask`` (uint8 per element, may be null) = 0 freezes an element (requires_grad False). */
 int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,

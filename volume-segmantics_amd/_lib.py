@@ -69,6 +69,10 @@ _SIGS = {
     "vs_unet_num_units": (I, [P]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),
                                C.POINTER(SZ), C.POINTER(SZ)]),
+    "vs_profile_enable": (I, [I]),
+    "vs_profile_num_kinds": (I, []),
+    "vs_profile_kind_name": (C.c_char_p, [I]),
+    "vs_profile_read": (I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(I64)]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
@@ -123,3 +127,12 @@ def unet_tensor_table(classes: int):
         check(lib.vs_unet_tensor_info(classes, i, name, 128, shape, C.byref(ndim), C.byref(kind), C.byref(off)))
         out.append((name.value.decode(), tuple(shape[: ndim.value]), kind.value, off.value))
     return out
+
+
+def profile_read():
+    """{kind: dict(ms, flops, bytes, calls)} accumulated since vs_profile_enable(1)."""
+    n = lib.vs_profile_num_kinds()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    calls = (I64 * n)()
+    check(lib.vs_profile_read(ms, fl, by, calls))
+    return {lib.vs_profile_kind_name(k).decode(): dict(ms=ms[k], flops=fl[k], bytes=by[k], calls=calls[k]) for k in range(n)}

@@ -1,0 +1,31 @@
+// In-library kernel timing with HIP events on the launch stream (used by bench.py for the roofline block).
+// Disabled by default: when off, a scope costs one branch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum ProfKind {
+    PK_CONV_FWD = 0,   // conv_igemm_kernel, forward convolutions
+    PK_CONV_DGRAD,     // conv_igemm_kernel fed with flipped/transposed weights (data gradient)
+    PK_CONV_WGRAD,     // conv_wgrad_kernel + its slab reduction
+    PK_STEM,           // stem forward / weight gradient
+    PK_BN_STATS, PK_BN_APPLY, PK_BN_BWD,
+    PK_POOL_MISC,      // maxpool, upsample-backward, zero stuffing, layout transforms
+    PK_PREPARE,        // weight copies / BN folding
+    PK_HEAD,           // segmentation head conv (fwd), bias gradient
+    PK_COUNT
+};
+
+bool prof_on();
+void prof_begin(int kind, double flops, double bytes, hipStream_t s);
+void prof_end(hipStream_t s);
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(int kind, double flops, double bytes, hipStream_t st) : s(st), on(prof_on()) {
+        if (on) prof_begin(kind, flops, bytes, s);
+    }
+    ~ProfScope() {
+        if (on) prof_end(s);
+    }
+};

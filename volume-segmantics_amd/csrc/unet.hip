@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "prof.h"
 
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s);
@@ -251,6 +252,13 @@ struct Ctx {
     int64_t rows(const Unit& u) const { return (int64_t)n * u.hout * u.wout; }
 };
 
+double conv_flops(const Ctx& c, const Unit& u) {  // algorithmic: 2 * MACs of the (un-padded, un-stuffed) convolution
+    return 2.0 * c.n * u.hout * u.wout * (double)u.cout * u.k * u.k * (u.cin0 + u.cin1);
+}
+double act_bytes(const Ctx& c, const Unit& u, int passes) {  // `passes` full sweeps over the unit's output tensor
+    return (double)passes * c.n * u.hout * u.wout * u.cout * c.net->esz;
+}
+
 ConvParams conv_params(const Ctx& c, const Unit& u) {
     ConvParams p{};
     p.src0 = c.a(u.src0);
@@ -330,6 +338,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
                                void* stream) {
     VS_REQUIRE(net && params && bnstate && workspace, "unet_prepare: null pointer");
     Ctx c{net, (char*)workspace, params, const_cast<float*>(bnstate), (hipStream_t)stream, 0};
+    ProfScope prof(PK_PREPARE, 0, (double)net->layout.n_params * (4 + net->esz * (training ? 2 : 1)), c.s);
     for (auto& u : net->units) {
         if (u.kind == U_CONV || u.kind == U_HEAD) {
             const int taps = u.k * u.k, cin = u.cin0 + u.cin1;
@@ -364,19 +373,24 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
         float* rm = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 2).offset : nullptr;
         float* rv = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 3).offset : nullptr;
         switch (u.kind) {
-        case U_STEM:
+        case U_STEM: {
+            ProfScope prof(PK_STEM, 2.0 * n * u.hout * u.wout * 64 * 49, 4.0 * n * net->h * net->w + act_bytes(c, u, 1), c.s);
             if (training) {
                 if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), nullptr, nullptr, 0, c.z(u.out), n, net->h, net->w, stream))) return rc;
             } else {
                 if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), c.bnc(u, 0), c.bnc(u, 1), 1, c.a(u.out), n, net->h, net->w, stream))) return rc;
             }
             break;
-        case U_POOL:
+        }
+        case U_POOL: {
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * 64 * net->esz * 1.25, c.s);
             if ((rc = vs_maxpool_fwd(dt, c.a(u.src0), c.a(u.out), training ? (uint8_t*)(c.ws + net->off_idx) : nullptr, n,
                                      u.hin, u.win, u.cout, stream))) return rc;
             continue;
+        }
         case U_CONV: {
             ConvParams p = conv_params(c, u);
+            ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
             if (training) {
                 p.out = c.z(u.out);
             } else {
@@ -391,13 +405,18 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
         case U_HEAD: {
             ConvParams p = conv_params(c, u);
             p.out = logits; p.shift = c.P(u.bias_idx); p.out_f32 = 3;  // fp32, NCHW
+            ProfScope prof(PK_HEAD, conv_flops(c, u), 0, c.s);
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             continue;
         }
         }
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
-            if ((rc = vs_bn_stats(dt, c.z(u.out), c.rows(u), u.cout, 1e-5f, 0.1f, c.bnc(u, 2), c.bnc(u, 3), rm, rv,
-                                  (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            {
+                ProfScope prof(PK_BN_STATS, 0, act_bytes(c, u, 1), c.s);
+                if ((rc = vs_bn_stats(dt, c.z(u.out), c.rows(u), u.cout, 1e-5f, 0.1f, c.bnc(u, 2), c.bnc(u, 3), rm, rv,
+                                      (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            }
+            ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
             if ((rc = vs_bn_apply(dt, c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1),
                                   u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, stream))) return rc;
         }
@@ -419,6 +438,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         const Unit& u = net->units[ui];
         if (u.kind == U_POOL) {
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * 64 * net->esz * 1.5, c.s);
             if ((rc = vs_maxpool_bwd(dt, c.da(u.out), (const uint8_t*)(c.ws + net->off_idx), c.da(u.src0), written[u.src0], n,
                                      u.hin, u.win, u.cout, stream))) return rc;
             written[u.src0] = 1;
@@ -428,6 +448,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         int dz_c;
         if (u.kind == U_HEAD) {
             void* dyh = c.ws + net->off_dyh;
+            ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
             if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
             if ((rc = launch_bias_grad(dlogits, grads + c.t(u.bias_idx).offset, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
             dzp = dyh; dz_c = 16;
@@ -439,6 +460,8 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
                 dres = c.da(u.res);
                 written[u.res] = 1;
             }
+            // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
+            ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, (u.relu ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
             if ((rc = vs_bn_bwd(dt, c.da(u.out), c.a(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), u.relu,
                                 c.dz(u.out), dres, grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u),
                                 u.cout, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
@@ -446,6 +469,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         }
         const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
         if (u.kind == U_STEM) {  // no data gradient: the input image needs none
+            ProfScope prof(PK_STEM, want_w ? 2.0 * n * u.hout * u.wout * 64 * 49 : 0, 0, c.s);
             if (want_w) {
                 if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, stream))) return rc;
             } else {
@@ -455,6 +479,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         }
         // ---- weight gradient ----
         if (want_w) {
+            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, c.s);
             WgradParams p{};
             p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
             p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
@@ -479,6 +504,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         const void* dsrc = dzp;
         if (u.stride == 2) {
             void* zs = c.ws + net->off_zs;
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * dz_c * net->esz * 1.25, c.s);
             if ((rc = vs_zero_stuff2x(dt, dzp, zs, n, u.hout, u.wout, dz_c, stream))) return rc;
             dsrc = zs;
         }
@@ -489,12 +515,17 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
             VS_REQUIRE(!written[u.src0] && (u.src1 < 0 || !written[u.src1]), "backward: decoder input gradient written twice");
             p.out = c.ws + net->off_dup;
             if (u.src1 >= 0) { p.out1 = c.da(u.src1); p.split_c = u.cin0; written[u.src1] = 1; }
-            if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            {
+                ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            }
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cin0 * net->esz * 1.25, c.s);
             if ((rc = vs_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, stream))) return rc;
             written[u.src0] = 1;
         } else {
             p.out = c.da(u.src0);
             p.residual = written[u.src0] ? c.da(u.src0) : nullptr;
+            ProfScope prof(PK_CONV_DGRAD, u.kind == U_HEAD ? 2.0 * n * u.hout * u.wout * net->classes * 9 * 16 : conv_flops(c, u), 0, c.s);
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             written[u.src0] = 1;
         }
