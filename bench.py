@@ -51,12 +51,29 @@ def dice_loss(output, target, eps=1e-6):
     return 1.0 - torch.mean(2 * (inter / denom.clamp(min=eps)))
 
 
+def usable_cpus() -> int:
+    """CPU share of this container: affinity mask, cgroup quota, and the 16-core share of a 1-GPU box."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(batch: int, steps: int):
     """The oracle (pure-torch CPU fp32 restatement of the reference path) timed on this host: reported
     baseline, not the target.  Bounded sample: `steps` training steps at the reference's default batch 12."""
     from oracle.unet_resnet34_torch import seeded_oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     net = seeded_oracle(2, 0, perturb_bn=False)
     net.train()
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
@@ -68,9 +85,11 @@ def cpu_baseline(batch: int, steps: int):
         loss.backward()
         opt.step()
     step()
+    log("cpu baseline warm-up step done")
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+        log(f"cpu baseline step done at {time.perf_counter() - t0:.1f}s")
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
             "sample": f"{steps} fwd+bwd+AdamW steps, batch {batch} (reference default), 256x256, fp32, torch CPU "
@@ -86,6 +105,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--per-unit", default="", help="write a per-layer kernel-time table (instrumented steps) to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,9 +144,11 @@ def main():
         sched.step()
         return loss
 
+    log(f"model ready on {dev}, warming up")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    log("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -142,7 +164,8 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    log(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step")
 
     # ---- roofline block: per-kernel-class HIP-event timing of the same step (separate, instrumented steps) ----
     prof_steps = 3
@@ -151,7 +174,21 @@ def main():
         step()
     torch.cuda.synchronize()
     prof = _lib.profile_read()
+    raw = _lib.profile_read_raw()
     _lib.check(_lib.lib.vs_profile_enable(0))
+    if rank == 0 and args.per_unit:
+        names = _lib.unit_names(model._plans[(256, 256)]["handle"])
+        agg = {}
+        for kind, tag, ms, fl, by in raw:
+            a = agg.setdefault((kind, tag), [0.0, 0.0, 0.0])
+            a[0] += ms / prof_steps; a[1] += fl / prof_steps; a[2] += by / prof_steps
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        with open(args.per_unit, "w") as f:
+            f.write("ms_per_step\tkind\tunit\tTFLOP/s\tGB/s\n")
+            for (kind, tag), (ms, fl, by) in rows:
+                f.write(f"{ms:.4f}\t{kind}\t{names[tag] if 0 <= tag < len(names) else tag}\t"
+                        f"{fl / (ms * 1e-3) / 1e12 if ms else 0:.1f}\t{by / (ms * 1e-3) / 1e9 if ms else 0:.0f}\n")
+    log("instrumented steps done")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

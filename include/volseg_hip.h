@@ -139,6 +139,8 @@ int vs_profile_enable(int on);
 int vs_profile_num_kinds(void);
 const char* vs_profile_kind_name(int kind);
 int vs_profile_read(double* ms, double* flops, double* bytes, int64_t* calls);
+/* raw records in launch order (tag = unit index inside the network plan); returns the count or -1 */
+int vs_profile_read_raw(int max_n, int* kind, int* tag, double* ms, double* flops, double* bytes);
 
 /* AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, vol_seg_2d_trainer.py:395-396,430);
  * ``mask`` (uint8 per element, may be null) = 0 freezes an element (requires_grad False). */

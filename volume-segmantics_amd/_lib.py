@@ -73,6 +73,7 @@ _SIGS = {
     "vs_profile_num_kinds": (I, []),
     "vs_profile_kind_name": (C.c_char_p, [I]),
     "vs_profile_read": (I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(I64)]),
+    "vs_profile_read_raw": (I, [I, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
@@ -136,3 +137,25 @@ def profile_read():
     calls = (I64 * n)()
     check(lib.vs_profile_read(ms, fl, by, calls))
     return {lib.vs_profile_kind_name(k).decode(): dict(ms=ms[k], flops=fl[k], bytes=by[k], calls=calls[k]) for k in range(n)}
+
+
+def profile_read_raw(max_n: int = 1 << 16):
+    """[(kind_name, unit_index, ms, flops, bytes)] in launch order."""
+    kind, tag = (I * max_n)(), (I * max_n)()
+    ms, fl, by = (C.c_double * max_n)(), (C.c_double * max_n)(), (C.c_double * max_n)()
+    n = lib.vs_profile_read_raw(max_n, kind, tag, ms, fl, by)
+    if n < 0:
+        raise RuntimeError("vs_profile_read_raw failed")
+    return [(lib.vs_profile_kind_name(kind[i]).decode(), tag[i], ms[i], fl[i], by[i]) for i in range(n)]
+
+
+def unit_names(handle) -> list[str]:
+    """weight-tensor name of every unit of a network plan (index = profiler tag)."""
+    out = []
+    name = C.create_string_buffer(128)
+    c, h, w = I(), I(), I()
+    o = [SZ() for _ in range(4)]
+    for u in range(lib.vs_unet_num_units(handle)):
+        check(lib.vs_unet_debug_unit(handle, u, name, 128, C.byref(c), C.byref(h), C.byref(w), *[C.byref(x) for x in o]))
+        out.append(f"{name.value.decode()} [{c.value}x{h.value}x{w.value}]")
+    return out

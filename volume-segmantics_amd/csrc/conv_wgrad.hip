@@ -9,6 +9,8 @@
 // sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 //
 // Replaces the conv weight gradients of loss.backward() (vol_seg_2d_trainer.py:429).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -139,8 +141,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
         }
     }
 
-    // partial slab of this (split, K-wave): [Cout][NTAPS][Cin] fp32
-    float* out = p.partials + (size_t)(split * WK + wk) * p.Cout * NTAPS * Cin;
+    // combine the WK K-wave partial accumulators through LDS (wave wk=0 of every cout tile owns the result)
+    if constexpr (WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // NTAPS*NCI*256 floats per cout-wave, reused per round
+        for (int round = 1; round < WK; ++round) {
+            __syncthreads();
+            if (wk == round) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCI; ++c)
+                        *reinterpret_cast<f32x4*>(red + (((wo * NTAPS + t) * NCI + c) * 64 + lane) * 4) = acc[t][c];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCI; ++c)
+                        acc[t][c] += *reinterpret_cast<const f32x4*>(red + (((wo * NTAPS + t) * NCI + c) * 64 + lane) * 4);
+            }
+        }
+        if (wk != 0) return;
+    }
+    // partial slab of this split: [Cout][NTAPS][Cin] fp32
+    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cin;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
@@ -155,23 +180,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
         }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, size_t n, int nparts) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nparts; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)k * n + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// dw[i] = sum over slabs, fixed order: thread (j, g) sums slabs g, g+4, ... of output 64*block + j; 4 groups meet in LDS
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
+                                                         size_t n, int nparts) {
+    __shared__ float red[4][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + j;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int k = g;
+        for (; k + 4 < nparts; k += 8) {
+            s0 += partials[(size_t)k * n + i];
+            s1 += partials[(size_t)(k + 4) * n + i];
         }
-        *reinterpret_cast<float4*>(dw + i) = s;
-    } else {
-        for (size_t j = i; j < n; ++j) {
-            float s = 0.f;
-            for (int k = 0; k < nparts; ++k) s += partials[(size_t)k * n + j];
-            dw[j] = s;
-        }
+        if (k < nparts) s0 += partials[(size_t)k * n + i];
     }
+    red[g][j] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && i < n) dw[i] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
 template <typename T>
@@ -207,7 +233,8 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     static bool attr_set = false;
     auto kern = conv_wgrad_kernel<T, WO, NTAPS>;
     const int BM = g.TH << g.tw_shift;
-    const size_t lds = (size_t)g.PH * g.PW * kXS + (size_t)BM * g.dys;
+    size_t lds = (size_t)g.PH * g.PW * kXS + (size_t)BM * g.dys;
+    if (WO < 4) lds = std::max(lds, (size_t)WO * NTAPS * WT<T>::NCI * 256 * sizeof(float));  // K-wave combine buffer
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -215,9 +242,8 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, p, g);
     VS_LAUNCH_CHECK();
     const size_t n = (size_t)p.Cout * NTAPS * (p.C0 + p.C1);
-    const int nparts = g.nsplit * (4 / WO);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)cdiv((int)n, 4), 256)), dim3(256), 0, s,
-                       p.partials, p.dw, n, nparts);
+    const int nparts = g.nsplit;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, p.partials, p.dw, n, nparts);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -227,7 +253,7 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     WGeom g; int WO;
     int rc = geom<T>(p, g, WO);
     if (rc) return rc;
-    const size_t need = (size_t)g.nsplit * (4 / WO) * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+    const size_t need = (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
     VS_REQUIRE(p.partials && p.partial_bytes >= need, "conv_wgrad: workspace %zu < %zu", p.partial_bytes, need);
     const int nt = p.KH * p.KW;
 #define VS_WG_CASE(wo, t) if (WO == wo && nt == t) return launch_one<T, wo, t>(p, g, s)
@@ -242,7 +268,7 @@ size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {
     WGeom g; int WO;
     if (dtype == VS_BF16) { if (geom<bf16_t>(p, g, WO)) return 0; }
     else { if (geom<float>(p, g, WO)) return 0; }
-    return (size_t)g.nsplit * (4 / WO) * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+    return (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
 }
 
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s) {

@@ -70,17 +70,27 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     }
 }
 
+// one wave per channel: lanes stride over the per-block partials, fp64 butterfly reduction (fixed order)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 template <typename T>
-__global__ void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x, int nblocks, int c,
-                                  int64_t rows, float eps, float momentum, float* mean, float* invstd,
-                                  float* running_mean, float* running_var) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ __launch_bounds__(64) void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x,
+                                                        int nblocks, int c, int64_t rows, float eps, float momentum,
+                                                        float* mean, float* invstd, float* running_mean,
+                                                        float* running_var) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         s += (double)partial[((size_t)b * 2 + 0) * c + ch];
         q += (double)partial[((size_t)b * 2 + 1) * c + ch];
     }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane != 0) return;
     const double dm = s / (double)rows;  // mean of (x - K)
     double var = q / (double)rows - dm * dm;
     if (var < 0.0) var = 0.0;
@@ -179,16 +189,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, 
     }
 }
 
-__global__ void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int c, float* dgamma, float* dbeta) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int c,
+                                                      float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         s += (double)partial[((size_t)b * 2 + 0) * c + ch];
         q += (double)partial[((size_t)b * 2 + 1) * c + ch];
     }
-    dbeta[ch] = (float)s;
-    dgamma[ch] = (float)q;
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
 }
 
 template <typename T>
@@ -245,7 +256,7 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
     RowMap m = make_rowmap(rows, c);
     hipLaunchKernelGGL(bn_stats_partial<T>, dim3(m.nblocks), dim3(256), 0, s, (const T*)x, rows, c, m, ws);
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize<T>, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, (const T*)x, m.nblocks, c, rows, eps,
+    hipLaunchKernelGGL(bn_stats_finalize<T>, dim3(c), dim3(64), 0, s, ws, (const T*)x, m.nblocks, c, rows, eps,
                        momentum, mean, invstd, rm, rv);
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -299,7 +310,7 @@ extern "C" int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x
         hipLaunchKernelGGL(bn_bwd_partial<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)dy, (const float*)y,
                            (const float*)x, mean, invstd, relu, rows, c, m, workspace);
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(c, 64)), dim3(64), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(64), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
     if (dtype == VS_BF16)
         hipLaunchKernelGGL(bn_bwd_apply<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y,

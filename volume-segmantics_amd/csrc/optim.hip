@@ -65,22 +65,30 @@ __global__ void dlogits_to_nhwc16_kernel(const float* __restrict__ d, T* __restr
     }
 }
 
-__global__ void bias_grad_kernel(const float* __restrict__ d, float* __restrict__ db, int n, int k, int64_t hw) {
-    // one block per class; fixed-order tree reduction (reproducible)
-    __shared__ float red[256];
-    const int c = blockIdx.x;
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < (int64_t)n * hw; i += 256) {
-        const int64_t b = i / hw, px = i % hw;
-        s += d[((size_t)b * k + c) * hw + px];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+// per-class sum of dlogits (n, K, hw): stage 1 = 256 blocks x K partials, stage 2 = one wave per class (fixed order)
+__global__ __launch_bounds__(256) void bias_grad_partial(const float* __restrict__ d, float* __restrict__ partial, int n,
+                                                       int k, int64_t hw) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < k; ++c) {
+        float s = 0.f;
+        for (int b = 0; b < n; ++b) {
+            const float* base = d + ((size_t)b * k + c) * hw;
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) s += base[i];
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * k + c] = red[0] + red[1] + red[2] + red[3];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[c] = red[0];
+}
+__global__ __launch_bounds__(64) void bias_grad_final(const float* __restrict__ partial, float* __restrict__ db, int nblk, int k) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * k + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) db[c] = s;
 }
 
 template <typename T>
@@ -132,8 +140,11 @@ int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, i
     return VS_OK;
 }
 
-int launch_bias_grad(const float* d, float* db, int n, int k, int64_t hw, hipStream_t s) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(k), dim3(256), 0, s, d, db, n, k, hw);
+int launch_bias_grad(const float* d, float* db, float* partial, int n, int k, int64_t hw, hipStream_t s) {
+    constexpr int kBlocks = 256;  // partial must hold kBlocks * k floats
+    hipLaunchKernelGGL(bias_grad_partial, dim3(kBlocks), dim3(256), 0, s, d, partial, n, k, hw);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_grad_final, dim3(k), dim3(64), 0, s, partial, db, kBlocks, k);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

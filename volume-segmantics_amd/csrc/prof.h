@@ -18,6 +18,7 @@ enum ProfKind {
 bool prof_on();
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
+void prof_set_tag(int tag);  // attached to subsequent records (unit index)
 
 struct ProfScope {
     hipStream_t s;

@@ -5,7 +5,8 @@
 #include "common.h"
 
 namespace {
-struct Rec { int kind; double flops, bytes; hipEvent_t e0, e1; };
+struct Rec { int kind, tag; double flops, bytes; hipEvent_t e0, e1; };
+int g_tag = -1;
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -24,11 +25,27 @@ const char* kNames[PK_COUNT] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "stem", 
 
 bool prof_on() { return g_on; }
 void prof_begin(int kind, double flops, double bytes, hipStream_t s) {
-    Rec r{kind, flops, bytes, get_event(), get_event()};
+    Rec r{kind, g_tag, flops, bytes, get_event(), get_event()};
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+
+void prof_set_tag(int tag) { g_tag = tag; }
+
+// raw records (kind, tag = unit index, ms, flops, bytes) in launch order; returns the number written
+extern "C" int vs_profile_read_raw(int max_n, int* kind, int* tag, double* ms, double* flops, double* bytes) {
+    int n = 0;
+    for (auto& r : g_recs) {
+        if (n >= max_n) break;
+        if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
+        kind[n] = r.kind; tag[n] = r.tag; ms[n] = t; flops[n] = r.flops; bytes[n] = r.bytes;
+        ++n;
+    }
+    return n;
+}
 
 // enable/disable; enabling clears previously collected records
 extern "C" int vs_profile_enable(int on) {

@@ -15,7 +15,7 @@
 
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s);
-int launch_bias_grad(const float* d, float* db, int n, int k, int64_t hw, hipStream_t s);
+int launch_bias_grad(const float* d, float* db, float* partial, int n, int k, int64_t hw, hipStream_t s);
 
 namespace {
 
@@ -369,7 +369,9 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
     const int dt = net->dtype;
     int rc;
     net->last_n = n;
+    int unit_index = -1;
     for (auto& u : net->units) {
+        prof_set_tag(++unit_index);
         float* rm = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 2).offset : nullptr;
         float* rv = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 3).offset : nullptr;
         switch (u.kind) {
@@ -436,6 +438,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
     float* wgws = (float*)(c.ws + net->off_wgws);
     for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
         const Unit& u = net->units[ui];
+        prof_set_tag(ui);
         if (u.kind == U_POOL) {
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * 64 * net->esz * 1.5, c.s);
@@ -450,7 +453,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
             void* dyh = c.ws + net->off_dyh;
             ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
             if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
-            if ((rc = launch_bias_grad(dlogits, grads + c.t(u.bias_idx).offset, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
+            if ((rc = launch_bias_grad(dlogits, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
             dzp = dyh; dz_c = 16;
         } else {
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
