@@ -17,6 +17,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than a few seconds")
 
 
+@pytest.fixture(autouse=True)
+def _oracle_threads():
+    """The CPU oracle's last float bits depend on the intra-op thread count; the goldens were generated with 8."""
+    import torch
+    torch.set_num_threads(8)
+    yield
+    torch.set_num_threads(8)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -1,0 +1,87 @@
+"""world_size-2 gloo tests (CPU) of the N>1 paths: sharded 12-direction prediction meeting in ONE max all-reduce of
+the packed keys, one-hot vote sums, and the data-parallel gradient all-reduce of the flat gradient buffer."""
+import os
+import socket
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from cpu_backend import OracleBackend
+    from oracle.unet_resnet34_torch import seeded_oracle
+    from volume_segmantics_amd import dist as vdist
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    assert vdist.init_from_env("gloo")[:2] == (rank, world)
+    g = np.load(REPO / "tests" / "golden" / "g3_predict_29x64x40_c4.npz")
+    net = seeded_oracle(4, 0).eval()
+    pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
+    pred.model, pred.num_labels, pred.settings = net, 4, SimpleNamespace(prediction_batch_size=1, cuda_device=0)
+    backends = []
+    def factory(*a):
+        b = OracleBackend(*a); backends.append(b); return b
+    pred.backend_factory = factory
+    vol = g["vol"][:, :32, :]   # keep the CPU cost small: (29, 32, 40)
+    l12, p12 = pred._predict_12_ways_max_probs(vol)
+    oh3 = pred._predict_3_ways_one_hot(vol)
+    l1, p1 = pred._predict_single_axis(vol)
+    # every rank touched only its own contiguous share of every direction
+    calls = backends[0].calls
+    per_dir = {}
+    for d, s0, nb in calls:
+        per_dir.setdefault(d, []).append((s0, s0 + nb))
+    shares = {d: (min(a for a, _ in v), max(b for _, b in v)) for d, v in per_dir.items()}
+    # data-parallel gradient averaging on the flat buffer
+    m = VolSegUnet(2)
+    m.dp_group = dist.group.WORLD
+    m._flat_grad = torch.full_like(m._flat, float(rank + 1))
+    m._allreduce_grads()
+    np.savez(Path(out_dir) / f"r{rank}.npz", l12=l12, p12=p12, oh3=oh3, l1=l1, p1=p1,
+             shares=np.array([shares[d] for d in sorted(shares)]), gmean=m._flat_grad[:5].numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
+    from oracle import predictor_numpy as P
+    from oracle.unet_resnet34_torch import seeded_oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    g = np.load(REPO / "tests" / "golden" / "g3_predict_29x64x40_c4.npz")
+    vol = g["vol"][:, :32, :]
+    net = seeded_oracle(4, 0).eval()
+    # slice-at-a-time with the workers' thread count: the CPU oracle's last float bits depend on batch shape and
+    # threading, the sharding logic under test does not
+    torch.set_num_threads(2)
+    ref_l, ref_p = P.predict_12_ways_max_probs(net, vol, batch_size=1)
+    ref_oh = P.predict_3_ways_one_hot(net, vol, 4, batch_size=1)
+    ref_l1, ref_p1 = P.predict_single_axis(net, vol, 0, batch_size=1)
+    for r in (r0, r1):   # both ranks hold the full merged result, identical to the single-process reference order
+        assert np.array_equal(r["l12"], ref_l) and np.array_equal(r["p12"].view(np.uint16), ref_p.view(np.uint16))
+        assert np.array_equal(r["oh3"], ref_oh)
+        assert np.array_equal(r["l1"], ref_l1) and np.array_equal(r["p1"].view(np.uint16), ref_p1.view(np.uint16))
+        assert np.allclose(r["gmean"], 1.5)
+    # shares are disjoint and cover every direction's stack
+    depths = [29, 32, 40] * 4
+    depths[3:6] = [32, 29, 40]; depths[9:12] = [32, 29, 40]   # rot90 / rot270 volumes have shape (Y, Z, X)
+    for d in range(12):
+        assert r0["shares"][d][0] == 0 and r0["shares"][d][1] == r1["shares"][d][0] and r1["shares"][d][1] == depths[d]

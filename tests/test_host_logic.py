@@ -1,0 +1,172 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute)."""
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import predictor_numpy as P
+from volume_segmantics_amd import dist as vdist
+from volume_segmantics_amd.data.losses import DiceLoss, MeanIoU
+from volume_segmantics_amd.data.settings_data import get_settings_data
+from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor, dirmap_of, direction_views
+from volume_segmantics_amd.model.operations.vol_seg_2d_trainer import VolSeg2dTrainer
+from volume_segmantics_amd.utilities import base_data_utils as utils
+from volume_segmantics_amd.utilities.base_data_utils import Axis, ModelType, Quality
+
+
+def test_settings_yaml_surface():
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent / "volseg-settings"
+    tr = get_settings_data(root / "2d_model_train_settings.yaml")
+    pr = get_settings_data(root / "2d_model_predict_settings.yaml")
+    for k in ("data_im_dirname seg_im_out_dirname model_output_fn clip_data st_dev_factor data_hdf5_path seg_hdf5_path "
+              "training_axes image_size downsample training_set_proportion cuda_device num_cyc_frozen num_cyc_unfrozen "
+              "patience loss_criterion alpha beta eval_metric pct_lr_inc starting_lr end_lr lr_find_epochs "
+              "lr_reduce_factor plot_lr_graph model").split():
+        assert hasattr(tr, k), k
+    assert tr.model == {"type": "U_Net", "encoder_name": "resnet34", "encoder_weights": "imagenet"}
+    assert (tr.image_size, tr.num_cyc_frozen, tr.num_cyc_unfrozen, tr.patience, tr.lr_reduce_factor) == (256, 8, 5, 3, 500)
+    for k in "quality output_probs clip_data st_dev_factor data_hdf5_path cuda_device downsample one_hot prediction_axis".split():
+        assert hasattr(pr, k), k
+    assert pr.quality == "medium" and pr.st_dev_factor == 2.575
+    assert get_settings_data(None) == SimpleNamespace() and get_settings_data({"a": 1}).a == 1
+    with pytest.raises(SystemExit) as e:   # reference: tests/test_settings_data.py:29-34
+        get_settings_data(root / "missing.yaml")
+    assert e.value.code == 1
+
+
+def test_enums_and_bad_names_exit_1():
+    assert [q.value for q in Quality] == [1, 3, 12] and Axis.ALL.value == 4 and ModelType.U_NET.value == 1
+    assert utils.get_prediction_quality(SimpleNamespace(quality="High")) == Quality.HIGH
+    assert utils.get_prediction_axis(SimpleNamespace()) == Axis.Z and utils.get_training_axis(SimpleNamespace()) == Axis.ALL
+    with pytest.raises(SystemExit) as e:
+        utils.get_prediction_quality(SimpleNamespace(quality="ultra"))
+    assert e.value.code == 1
+    # checkpoints name the reference's module path
+    assert b"volume_segmantics.utilities.base_data_utils" in pickle.dumps(ModelType.U_NET)
+
+
+def test_pad_crop_offsets_match_oracle_and_golden(golden):
+    g = golden("g7_padded_dimension.npz")
+    for d, p in zip(g["dims"], g["padded"]):
+        assert utils.get_padded_dimension(int(d)) == int(p)
+        if d > 0:
+            padded, top, crop = utils.pad_crop_offsets(int(d))
+            assert (padded, top, crop) == (int(p), P.pad_offsets(int(d))[0], P.crop_offset(int(p), int(d)))
+
+
+def test_direction_maps_follow_reference_order(golden):
+    g = golden("g4_direction_order.npz")
+    idx = g["idxvol"]
+    views = direction_views(idx, 12)
+    flat = idx.ravel()
+    for d, v in enumerate(views):
+        m = dirmap_of(idx, v)
+        s, h, w = np.meshgrid(np.arange(m.depth), np.arange(m.h), np.arange(m.w), indexing="ij")
+        assert np.array_equal(flat[m.base + s * m.ss + h * m.sh + w * m.sw], g[f"dir{d:02d}"])
+    assert [v.shape for v in direction_views(idx, 3)] == [(5, 6, 7), (6, 5, 7), (7, 6, 5)]
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 512, 513):
+        for world in (1, 2, 3, 8):
+            parts = [vdist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def test_clip_to_uint8_and_one_hot():
+    rng = np.random.default_rng(0)
+    v = rng.normal(100, 20, size=(6, 7, 8))
+    v[0, 0, 0] = np.nan
+    out = utils.clip_to_uint8(v.copy(), np.nanmean(v), 2.575)
+    assert out.dtype == np.uint8 and out.min() == 0 and out.max() == 255
+    lab = rng.integers(0, 3, size=(4, 5, 6))
+    oh = utils.one_hot_encode_array(lab, 3)
+    assert oh.shape == (3, 4, 5, 6) and np.array_equal(oh, P.one_hot_encode_array(lab, 3))
+
+
+def test_losses_and_lr_finder_match_reference_goldens(golden):
+    g = golden("g6_loss_metric_lr.npz")
+    logits = torch.tensor(g["logits"], requires_grad=True)
+    targets = torch.tensor(g["targets"])
+    loss = DiceLoss(normalization="none")(logits, targets.float())
+    loss.backward()
+    assert np.allclose(loss.item(), g["dice_loss"], atol=1e-7) and np.allclose(logits.grad.numpy(), g["dice_grad"], rtol=1e-6, atol=1e-9)
+    probs = torch.softmax(logits.detach(), 1)
+    assert np.isclose(MeanIoU()(probs.unsqueeze(2), targets.unsqueeze(2)).item(), g["mean_iou"], atol=1e-7)
+    assert MeanIoU()(targets.float(), targets).item() == 1.0   # reference KAT tests/test_pytorch3dunet_metrics.py:57-78
+    for i in range(3):
+        got = VolSeg2dTrainer._find_lr_from_graph([torch.tensor(c) for c in g[f"lr_curve{i}"]], list(g[f"lr_lrs{i}"]))
+        assert np.isclose(got, float(g[f"lr_out{i}"]), rtol=1e-12)
+    b = utils.prepare_training_batch([torch.zeros(3, 1, 16, 24), torch.tensor(g["mask"])], "cpu", 4)
+    assert np.array_equal(b[1].numpy(), g["targets"]) and b[1].dtype == torch.uint8
+
+
+def test_trainer_freeze_and_loss_selection():
+    from volume_segmantics_amd.engine import VolSegUnet
+    tr = VolSeg2dTrainer.__new__(VolSeg2dTrainer)
+    tr.model = VolSegUnet(2)
+    tr._freeze_model()
+    frozen = [n for n, p in tr.model.named_parameters() if not p.requires_grad]
+    assert len(frozen) == 33 and not any("downsample" in n or "bn" in n for n in frozen)
+    tr._unfreeze_model()
+    assert tr._count_trainable_parameters() == tr._count_parameters() == 24_430_242
+    base = dict(alpha=0.75, beta=0.25, eval_metric="MeanIoU")
+    for name in ("BCEDiceLoss", "DiceLoss", "BCELoss", "CrossEntropyLoss", "GeneralizedDiceLoss"):
+        tr.settings = SimpleNamespace(loss_criterion=name, **base)
+        assert tr._get_loss_criterion() is not None
+    tr.settings = SimpleNamespace(loss_criterion="Nope", **base)
+    with pytest.raises(SystemExit) as e:   # reference: tests/test_vol_seg_2d_trainer.py:62-70
+        tr._get_loss_criterion()
+    assert e.value.code == 1
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """EarlyStopping writes the reference's dict; create_model_from_file-style loading restores it (CPU part)."""
+    from volume_segmantics_amd.checkpoint_compat import reference_pickle_enum
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.utilities.early_stopping import EarlyStopping
+    m = VolSegUnet(3, seed=4)
+    struct = {"type": reference_pickle_enum(ModelType.U_NET), "encoder_name": "resnet34", "encoder_weights": "imagenet",
+              "in_channels": 1, "classes": 3}
+    es = EarlyStopping(patience=2, path=tmp_path / "m.pytorch", model_dict=struct)
+    es(0.5, m, torch.optim.AdamW(m.parameters()), {"a": 1})
+    es(0.6, m, None, {})
+    es(0.7, m, None, {})
+    assert es.early_stop and es.counter == 2
+    d = torch.load(tmp_path / "m.pytorch", weights_only=False)
+    assert set(d) == {"model_state_dict", "model_struc_dict", "optimizer_state_dict", "loss_val", "label_codes"}
+    assert d["model_struc_dict"]["type"].name == "U_NET" and d["loss_val"] == 0.5 and d["label_codes"] == {"a": 1}
+    m2 = VolSegUnet(3, seed=9)
+    m2.load_state_dict(d["model_state_dict"])
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # an smp / oracle-shaped module loads the same file
+    from oracle.unet_resnet34_torch import OracleUnetResnet34
+    OracleUnetResnet34(1, 3).load_state_dict(d["model_state_dict"])
+
+
+def test_predictor_orchestration_with_cpu_standin_matches_reference_goldens(golden):
+    """Single process: the predictor's direction / index-map / key-merge logic, computed by the test-only oracle
+    backend, reproduces the goldens generated by the reference's own predictor bit for bit."""
+    from conftest import fingerprint
+    from cpu_backend import OracleBackend
+    from oracle.unet_resnet34_torch import seeded_oracle
+    g = golden("g3_predict_29x64x40_c4.npz")
+    net = seeded_oracle(4, 0).eval()
+    if not np.array_equal(fingerprint(net), g["fingerprint"]):
+        pytest.skip("torch RNG stream differs from the build container")
+    pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
+    pred.model, pred.num_labels, pred.settings = net, 4, SimpleNamespace(prediction_batch_size=4, cuda_device=0)
+    pred.backend_factory = OracleBackend
+    vol = g["vol"]
+    for ax, name in ((Axis.Z, "z"), (Axis.Y, "y"), (Axis.X, "x")):
+        l, p = pred._predict_single_axis(vol, axis=ax)
+        assert np.array_equal(l, g[f"single_{name}_labels"]) and np.array_equal(p.view(np.uint16), g[f"single_{name}_probs"].view(np.uint16))
+    l, p = pred._predict_3_ways_max_probs(vol)
+    assert np.array_equal(l, g["three_labels"]) and np.array_equal(p, g["three_probs"])
+    assert np.array_equal(pred._predict_3_ways_one_hot(vol), g["onehot_three"])
+    assert np.array_equal(pred._predict_single_axis_to_one_hot(vol), g["onehot_z"])

@@ -1,0 +1,106 @@
+"""Slice datasets feeding the trainer (reference: volume_segmantics/data/datasets.py:12-181, dataloaders.py:15-71,
+augmentations.py).  PNG slices are read with PIL.  The reference's stochastic albumentations pipeline (elastic / grid /
+optical distortion, CLAHE, brightness, gamma) is CPU-side data preparation outside the accelerated path (SURVEY.md
+section 2 row 5); the geometric subset that needs no third-party library is provided: random flips, 90-degree
+rotations and transposes."""
+from __future__ import annotations
+
+import re
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset, Subset
+
+from ..utilities import base_data_utils as utils
+from ..utilities import config as cfg
+
+
+def natsort_key(item):
+    return [int(t) if t.isdigit() else t.lower() for t in re.split(r"(\d+)", str(item))]
+
+
+def _read_gray(path: Path) -> np.ndarray:
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im.convert("L"))
+
+
+def fit_to_square(image: np.ndarray, mask: np.ndarray | None, size: int):
+    """LongestMaxSize(size) then centred PadIfNeeded(size, size) with reflect-101 borders (augmentations.py:12-27)."""
+    from PIL import Image
+    h, w = image.shape
+    scale = size / max(h, w)
+    if scale != 1.0:
+        nh, nw = max(1, int(round(h * scale))), max(1, int(round(w * scale)))
+        image = np.array(Image.fromarray(image).resize((nw, nh), Image.BILINEAR))
+        if mask is not None:
+            mask = np.array(Image.fromarray(mask).resize((nw, nh), Image.NEAREST))
+        h, w = nh, nw
+    top, left = (size - h) // 2, (size - w) // 2
+    pads = ((top, size - h - top), (left, size - w - left))
+    if any(p for pair in pads for p in pair):
+        mode = "reflect" if min(h, w) > 1 else "edge"
+        image = np.pad(image, pads, mode=mode)
+        if mask is not None:
+            mask = np.pad(mask, pads, mode=mode)
+    return image, mask
+
+
+def normalise(image: np.ndarray) -> np.ndarray:
+    """datasets.py:63-69: /255 for integer images, then the single-channel ImageNet mean / std."""
+    if np.issubdtype(image.dtype, np.integer):
+        image = image.astype(np.float32) / 255
+    return (image - cfg.IMAGENET_MEAN) / cfg.IMAGENET_STD
+
+
+class VolSeg2dDataset(Dataset):
+    def __init__(self, images_dir: Path, masks_dir: Path, img_size: int, augment: bool, seed: int = 0):
+        self.images_fps = sorted(Path(images_dir).glob("*.png"), key=natsort_key)
+        self.masks_fps = sorted(Path(masks_dir).glob("*.png"), key=natsort_key)
+        if len(self.images_fps) != len(self.masks_fps):
+            raise ValueError("image / label slice counts differ")
+        self.img_size, self.augment = img_size, augment
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return len(self.images_fps)
+
+    def __getitem__(self, i):
+        image, mask = fit_to_square(_read_gray(self.images_fps[i]), _read_gray(self.masks_fps[i]), self.img_size)
+        if self.augment:
+            if self.rng.random() < 0.5:
+                image, mask = image[::-1], mask[::-1]
+            k = int(self.rng.integers(0, 4)) if self.rng.random() < 0.5 else 0
+            image, mask = np.rot90(image, k), np.rot90(mask, k)
+            if self.rng.random() < 0.5:
+                image, mask = image.T, mask.T
+        image = normalise(np.ascontiguousarray(image)).astype(np.float32)
+        return torch.from_numpy(image).unsqueeze(0), torch.from_numpy(np.ascontiguousarray(mask))
+
+
+class ArraySliceDataset(Dataset):
+    """In-memory (image, mask) slices - used by the synthetic benchmarks and tests (no PNG round trip)."""
+
+    def __init__(self, images: np.ndarray, masks: np.ndarray):
+        self.images, self.masks = images, masks
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return torch.from_numpy(normalise(self.images[i]).astype(np.float32)).unsqueeze(0), torch.from_numpy(self.masks[i])
+
+
+def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings):
+    """80/20 random split, drop_last training loader (dataloaders.py:15-57)."""
+    batch_size = utils.get_batch_size(settings)
+    train_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=True)
+    valid_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=False)
+    n = len(train_full)
+    indices = torch.randperm(n).tolist()
+    cut = int(n * settings.training_set_proportion)
+    workers = int(getattr(settings, "num_workers", cfg.NUM_WORKERS))
+    common = dict(batch_size=batch_size, num_workers=workers, pin_memory=cfg.PIN_CUDA_MEMORY and torch.cuda.is_available())
+    return (DataLoader(Subset(train_full, indices[:cut]), shuffle=True, drop_last=True, **common),
+            DataLoader(Subset(valid_full, indices[cut:]), shuffle=False, **common))

@@ -1,0 +1,101 @@
+"""Losses and metrics the trainer can select (reference: volume_segmantics/data/pytorch3dunet_losses.py:15-184 and
+pytorch3dunet_metrics.py:16-106, themselves vendored from pytorch-3dunet).  Restated on (N, C, H, W) tensors; torch
+ops on the logits the engine returns - SURVEY.md section 8f row N3 lists their fusion as a next step."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+def _per_channel(t: torch.Tensor) -> torch.Tensor:
+    """(N, C, ...) -> (C, N * ...)"""
+    return t.transpose(0, 1).reshape(t.size(1), -1)
+
+
+def compute_per_channel_dice(input, target, epsilon=1e-6, weight=None):
+    """2 * sum(x t) / clamp(sum(x^2) + sum(t^2)) per channel (V-Net form, pytorch3dunet_losses.py:15-41)."""
+    if input.size() != target.size():
+        raise ValueError("'input' and 'target' must have the same shape")
+    x, t = _per_channel(input), _per_channel(target).float()
+    inter = (x * t).sum(-1)
+    if weight is not None:
+        inter = weight * inter
+    denom = (x * x).sum(-1) + (t * t).sum(-1)
+    return 2 * (inter / denom.clamp(min=epsilon))
+
+
+class DiceLoss(nn.Module):
+    """1 - mean per-channel Dice; ``normalization`` in {'sigmoid', 'softmax', 'none'} (the trainer uses 'none',
+    vol_seg_2d_trainer.py:133-135, i.e. the loss acts on raw logits)."""
+
+    def __init__(self, weight=None, normalization="sigmoid"):
+        super().__init__()
+        if normalization not in ("sigmoid", "softmax", "none"):
+            raise ValueError(normalization)
+        self.register_buffer("weight", weight)
+        self.normalization = {"sigmoid": torch.sigmoid, "softmax": lambda x: torch.softmax(x, 1), "none": lambda x: x}[normalization]
+
+    def forward(self, input, target):
+        return 1.0 - torch.mean(compute_per_channel_dice(self.normalization(input), target, weight=self.weight))
+
+
+class GeneralizedDiceLoss(nn.Module):
+    """pytorch3dunet_losses.py:138-169: label contributions weighted by the inverse squared label volume."""
+
+    def __init__(self, normalization="sigmoid", epsilon=1e-6):
+        super().__init__()
+        self.epsilon = epsilon
+        self.normalization = {"sigmoid": torch.sigmoid, "softmax": lambda x: torch.softmax(x, 1), "none": lambda x: x}[normalization]
+
+    def forward(self, input, target):
+        x, t = _per_channel(self.normalization(input)), _per_channel(target).float()
+        if x.size(0) == 1:  # put foreground and background in separate channels
+            x, t = torch.cat((x, 1 - x), 0), torch.cat((t, 1 - t), 0)
+        w = t.sum(-1)
+        w = (1 / (w * w).clamp(min=self.epsilon)).detach()
+        inter = ((x * t).sum(-1) * w).sum()
+        denom = ((x + t).sum(-1) * w).clamp(min=self.epsilon).sum()
+        return 1.0 - 2 * (inter / denom)
+
+
+class BCEDiceLoss(nn.Module):
+    def __init__(self, alpha, beta):
+        super().__init__()
+        self.alpha, self.beta = alpha, beta
+        self.bce, self.dice = nn.BCEWithLogitsLoss(), DiceLoss()
+
+    def forward(self, input, target):
+        return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
+
+
+class DiceCoefficient:
+    def __init__(self, epsilon=1e-6, **kwargs):
+        self.epsilon = epsilon
+
+    def __call__(self, input, target):
+        return torch.mean(compute_per_channel_dice(input.flatten(2), target.flatten(2), epsilon=self.epsilon))
+
+
+class MeanIoU:
+    """Per-sample argmax one-hot, per-class Jaccard, mean over classes then samples (pytorch3dunet_metrics.py:34-106).
+    Accepts the (N, C, 1, H, W) tensors the reference's trainer builds or plain (N, C, H, W)."""
+
+    def __init__(self, skip_channels=(), ignore_index=None, **kwargs):
+        self.skip_channels, self.ignore_index = skip_channels, ignore_index
+
+    def __call__(self, input, target):
+        n_classes = input.size(1)
+        scores = []
+        for p, t in zip(input, target):
+            if n_classes == 1:
+                pred = (p > 0.5).to(torch.uint8)
+            else:
+                pred = torch.zeros_like(p, dtype=torch.uint8).scatter_(0, torch.argmax(p, dim=0, keepdim=True), 1)
+            t = t.to(torch.uint8)
+            if self.ignore_index is not None:
+                keep = t != self.ignore_index
+                pred, t = pred * keep, t * keep
+            ious = [torch.sum(pred[c] & t[c]).float() / torch.clamp(torch.sum(pred[c] | t[c]).float(), min=1e-8)
+                    for c in range(n_classes) if c not in self.skip_channels]
+            scores.append(torch.mean(torch.stack(ious)))
+        return torch.mean(torch.stack(scores))

@@ -1,0 +1,56 @@
+"""One-process-per-GPU helpers on top of torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" for the
+CPU tests).  The prediction path shards the slices of every direction across ranks and needs exactly ONE exchange:
+an elementwise max all-reduce of the packed (prob, direction, label) keys (or a sum of the one-hot votes).  Training
+shards the minibatch and all-reduces the flat gradient buffer (engine.VolSegUnet._allreduce_grads)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> tuple[int, int]:
+    """(rank, world_size); (0, 1) when no process group is initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise the default process group from torchrun's environment; returns (rank, world, local_rank)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, ws, local
+
+
+def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) share of n items for this rank; shares differ by at most one item."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_max_keys(keys: torch.Tensor, group=None) -> None:
+    """In-place elementwise max of uint32 packed keys across ranks.  Keys are < 2**31 (fp16 bits of a probability
+    <= 1.0 are <= 0x3C00), so they are reduced as int32 - the order is the same."""
+    if world()[1] == 1:
+        return
+    dist.all_reduce(keys.view(torch.int32), op=dist.ReduceOp.MAX, group=group)
+
+
+def allreduce_sum_votes(votes: torch.Tensor, group=None) -> None:
+    if world()[1] == 1:
+        return
+    dist.all_reduce(votes, op=dist.ReduceOp.SUM, group=group)

@@ -1,0 +1,80 @@
+"""The drop-in seam: ``create_model_on_device`` / ``create_model_from_file``
+(volume_segmantics/model/model_2d.py:10-57).  For U_NET + resnet34 the returned ``nn.Module`` is the
+HIP engine (engine.VolSegUnet); the other seven smp topologies of the reference are rows of SURVEY.md
+section 8f ("next") and are refused loudly rather than routed through a fallback."""
+from __future__ import annotations
+
+import logging
+import os
+from pathlib import Path
+from typing import Tuple
+
+import torch
+
+from ..engine import VolSegUnet
+from ..utilities import base_data_utils as utils
+
+
+def _device(device_num) -> torch.device:
+    if isinstance(device_num, torch.device):
+        return device_num
+    if isinstance(device_num, str):
+        return torch.device(device_num)
+    return torch.device("cuda", int(device_num))
+
+
+def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.Module:
+    struct = dict(model_struc_dict)
+    model_type = utils.create_enum_from_setting(struct.pop("type"), utils.ModelType)
+    encoder = struct.get("encoder_name", "resnet34")
+    if model_type != utils.ModelType.U_NET or encoder != "resnet34":
+        raise NotImplementedError(
+            f"the MI355X engine implements U_NET + resnet34 (requested {model_type.name} + {encoder}); "
+            "the other smp topologies are listed as next rows in SURVEY.md section 8f")
+    if int(struct.get("in_channels", 1)) != 1:
+        raise NotImplementedError("the engine implements the reference's single-channel input (config.MODEL_INPUT_CHANNELS)")
+    model = VolSegUnet(int(struct["classes"]), device=_device(device_num), precision=struct.get("precision"))
+    weights = struct.get("encoder_weights")
+    if weights:
+        # smp downloads ImageNet weights here; there is no network, so an explicit local torchvision
+        # resnet34 state dict can be supplied instead (env VOLSEG_RESNET34_WEIGHTS)
+        path = os.environ.get("VOLSEG_RESNET34_WEIGHTS")
+        if path and Path(path).exists():
+            load_torchvision_resnet34(model, torch.load(path, map_location="cpu"))
+            logging.info(f"Loaded {weights} encoder weights from {path}")
+        else:
+            logging.warning(f"encoder_weights={weights!r} requested but no local weights available "
+                            "(set VOLSEG_RESNET34_WEIGHTS); using smp's random initialisation")
+    logging.info(f"Sending the U-Net model to device {device_num}")
+    return model
+
+
+def load_torchvision_resnet34(model: VolSegUnet, sd: dict) -> None:
+    """Copy a torchvision resnet34 state dict into the encoder; the 3-channel stem is summed over its input
+    channels exactly as smp's patch_first_conv does for in_channels=1."""
+    own = model.state_dict()
+    for k, v in sd.items():
+        name = "encoder." + k
+        if name not in own:
+            continue  # fc.*
+        if k == "conv1.weight" and v.shape[1] == 3:
+            v = v.sum(1, keepdim=True)
+        own[name] = v
+    model.load_state_dict(own)
+
+
+def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int = 0) -> Tuple[torch.nn.Module, int, dict]:
+    """Checkpoint -> (model, number of labels, label codes).  The checkpoint pickles the ModelType enum under the
+    reference's module path, so ``weights_only=False`` and an importable ``volume_segmantics.utilities.base_data_utils``
+    (or this package's alias, see checkpoint_compat) are needed for files written by the reference."""
+    from ..checkpoint_compat import install_reference_aliases
+    install_reference_aliases()
+    weights_fn = Path(weights_fn).resolve()
+    logging.info("Loading model dictionary from file.")
+    model_dict = torch.load(weights_fn, map_location="cpu", weights_only=False)
+    struct = dict(model_dict["model_struc_dict"])
+    struct["encoder_weights"] = None  # weights come from the file; never touch the network
+    model = create_model_on_device(device_num, struct)
+    logging.info("Loading in the saved weights.")
+    model.load_state_dict(model_dict["model_state_dict"])
+    return model, model_dict["model_struc_dict"]["classes"], model_dict["label_codes"]

@@ -1,0 +1,172 @@
+"""VolSeg2dPredictor - slice-wise prediction of a 3-D volume along 1, 3 or 12 (axis x rotation) directions and
+max-probability merge (reference: volume_segmantics/model/operations/vol_seg_2d_predictor.py:16-136).
+
+Same methods, same return types (labels uint8, probabilities float16, one-hot votes uint8) - but the volume is
+uploaded ONCE, every direction reads its slices straight from the resident uint8 volume through an index map
+(np.rot90 / swapaxes are pure index maps, :34,:108), the network runs in libvolseg_hip, and softmax -> argmax ->
+max-prob -> crop -> scatter writes each voxel's packed key (prob<<16 | (15-dir)<<8 | label) back at the voxel's own
+address.  The running maximum of that key over directions equals the reference's chain of first-wins pairwise merges
+(:90-98), is order independent, and is what the ranks exchange (one max all-reduce) when the slices of every
+direction are sharded over several GPUs.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ... import _lib, dist as vdist
+from ..._lib import check, lib, ptr
+from ...utilities import base_data_utils as utils
+from ...utilities.base_data_utils import Axis
+
+
+def direction_views(vol: np.ndarray, n_dirs: int):
+    """The slice stacks of the 1 / 3 / 12 directions in the reference's call order, as numpy views of ``vol``
+    (Z, Y, X per rotation; rotations are cumulative np.rot90 in the (0, 1) plane, :73-87 and :105-115)."""
+    views, v = [], vol
+    for k in range(4 if n_dirs == 12 else 1):
+        if k:
+            v = np.rot90(v)
+        for axis in ((Axis.Z, Axis.Y, Axis.X) if n_dirs >= 3 else (Axis.Z,)):
+            views.append(utils.rotate_array_to_axis(v, axis))
+    return views
+
+
+def dirmap_of(vol: np.ndarray, view: np.ndarray) -> _lib.DirMap:
+    """vs_dirmap of a view: element strides and base offset are read off numpy's own view object."""
+    item = vol.itemsize
+    base = (view.__array_interface__["data"][0] - vol.__array_interface__["data"][0]) // item
+    d, h, w = view.shape
+    hp, top, ctop = utils.pad_crop_offsets(h)
+    wp, left, cleft = utils.pad_crop_offsets(w)
+    return _lib.DirMap(base=base, ss=view.strides[0] // item, sh=view.strides[1] // item, sw=view.strides[2] // item,
+                       depth=d, h=h, w=w, hp=hp, wp=wp, pad_top=top, pad_left=left, crop_top=ctop, crop_left=cleft)
+
+
+class HipBackend:
+    """Device side of one prediction pass: resident volume + output volumes + the per-batch kernels."""
+
+    def __init__(self, model, vol_u8: np.ndarray, classes: int, mode: int, want_probs: bool):
+        self.model, self.classes, self.mode = model, classes, mode
+        dev = model.device
+        self.vol = torch.from_numpy(vol_u8).to(dev)
+        n = vol_u8.size
+        self.nvox = n
+        self.labels = torch.zeros(n, dtype=torch.uint8, device=dev) if mode == 0 else None
+        self.probs = torch.zeros(n, dtype=torch.float16, device=dev) if (mode == 0 and want_probs) else None
+        self.keys = torch.zeros(n, dtype=torch.int32, device=dev) if mode == 1 else None
+        self.votes = torch.zeros((classes, n), dtype=torch.uint8, device=dev) if mode == 2 else None
+        self._x = None
+
+    def run_batch(self, dmap: _lib.DirMap, direction: int, s0: int, nb: int) -> None:
+        need = nb * dmap.hp * dmap.wp
+        if self._x is None or self._x.numel() < need:
+            self._x = torch.empty(need, dtype=torch.float32, device=self.model.device)
+        x = self._x[:need].view(nb, 1, dmap.hp, dmap.wp)
+        st = _lib.stream_ptr()
+        check(lib.vs_slices_gather(ptr(self.vol), dmap, s0, nb, ptr(x), st))
+        logits = self.model._forward_impl(x, training=False)
+        check(lib.vs_logits_to_volume(ptr(logits), self.classes, dmap, s0, nb, self.mode, direction, ptr(self.labels),
+                                      ptr(self.probs), ptr(self.keys), ptr(self.votes), self.nvox, st))
+
+    def exchange(self) -> None:
+        if self.mode == 1:
+            vdist.allreduce_max_keys(self.keys)
+        elif self.mode == 2:
+            vdist.allreduce_sum_votes(self.votes)
+
+    def results(self, shape, want_probs: bool):
+        if self.mode == 2:
+            return self.votes.cpu().numpy().reshape((self.classes,) + tuple(shape)), None
+        if self.mode == 1:
+            labels = torch.empty(self.nvox, dtype=torch.uint8, device=self.keys.device)
+            probs = torch.empty(self.nvox, dtype=torch.float16, device=self.keys.device) if want_probs else None
+            check(lib.vs_keys_unpack(ptr(self.keys), ptr(labels), ptr(probs), self.nvox, _lib.stream_ptr()))
+        else:
+            labels, probs = self.labels, self.probs
+        out_l = labels.cpu().numpy().reshape(shape)
+        out_p = probs.cpu().numpy().reshape(shape) if (want_probs and probs is not None) else None
+        return out_l, out_p
+
+
+class VolSeg2dPredictor:
+    """Class that performs U-Net prediction operations. Does not interact with disk."""
+
+    backend_factory = HipBackend  # tests of the sharding / merge logic substitute a CPU stand-in here
+
+    def __init__(self, model_file_path: str, settings: SimpleNamespace) -> None:
+        from ..model_2d import create_model_from_file
+        self.model_file_path = Path(model_file_path)
+        self.settings = settings
+        self.model_device_num = int(settings.cuda_device)
+        self.model, self.num_labels, self.label_codes = create_model_from_file(
+            self.model_file_path, device_num=self.model_device_num)
+
+    def _get_model_from_trainer(self, trainer):
+        self.model = trainer.model
+
+    # ---- engine ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _as_uint8(data_vol: np.ndarray) -> np.ndarray:
+        """The device path reads a uint8 volume (the reference's default: clip_data -> uint8,
+        data/base_data_manager.py:38-40).  Other integer volumes whose values fit a byte are cast losslessly (the
+        reference divides every integer dtype by 255, data/datasets.py:128-131)."""
+        if data_vol.dtype == np.uint8:
+            return np.ascontiguousarray(data_vol)
+        if np.issubdtype(data_vol.dtype, np.integer) and data_vol.size and 0 <= data_vol.min() and data_vol.max() <= 255:
+            return np.ascontiguousarray(data_vol.astype(np.uint8))
+        raise NotImplementedError(
+            f"the HIP prediction path takes uint8 volumes (got {data_vol.dtype}); enable clip_data or convert first")
+
+    def _run(self, data_vol: np.ndarray, n_dirs: int, mode: int, want_probs: bool, first_axis: Axis = Axis.Z):
+        vol = self._as_uint8(data_vol)
+        if vol.ndim != 3:
+            raise ValueError(f"expected a 3-D volume, got shape {vol.shape}")
+        rank, world = vdist.world()
+        if world > 1 and mode == 0:
+            mode = 1  # shards meet through the key volume
+        backend = self.backend_factory(self.model, vol, self.num_labels, mode, want_probs)
+        batch = utils.get_batch_size(self.settings, prediction=True)
+        if hasattr(self.model, "eval"):
+            self.model.eval()
+        views = direction_views(vol, n_dirs) if n_dirs > 1 else [utils.rotate_array_to_axis(vol, first_axis)]
+        with torch.no_grad():
+            for d, view in enumerate(views):
+                dmap = dirmap_of(vol, view)
+                lo, hi = vdist.shard_range(dmap.depth, rank, world)
+                logging.info(f"Predicting direction {d + 1}/{len(views)}: slices [{lo}, {hi}) of stack {view.shape}.")
+                for s0 in range(lo, hi, batch):
+                    backend.run_batch(dmap, d, s0, min(batch, hi - s0))
+        backend.exchange()
+        return backend.results(vol.shape, want_probs)
+
+    # ---- the reference's methods --------------------------------------------------------------------------------
+    def _predict_single_axis(self, data_vol, output_probs=True, axis=Axis.Z):
+        return self._run(data_vol, 1, 0, output_probs, axis)
+
+    def _predict_3_ways_max_probs(self, data_vol):
+        return self._run(data_vol, 3, 1, True)
+
+    def _predict_12_ways_max_probs(self, data_vol):
+        return self._run(data_vol, 12, 1, True)
+
+    def _merge_vols_in_mem(self, prob_container, label_container):
+        """The reference's pairwise merge on host containers (2, Z, Y, X), executed by vs_merge_maxprob."""
+        dev = self.model.device
+        l0, p0 = torch.from_numpy(label_container[0]).to(dev), torch.from_numpy(prob_container[0]).to(dev)
+        l1, p1 = torch.from_numpy(label_container[1]).to(dev), torch.from_numpy(prob_container[1]).to(dev)
+        check(lib.vs_merge_maxprob(ptr(l0), ptr(p0), ptr(l1), ptr(p1), l0.numel(), _lib.stream_ptr()))
+        label_container[0], prob_container[0] = l0.cpu().numpy(), p0.cpu().numpy()
+
+    def _predict_single_axis_to_one_hot(self, data_vol, axis=Axis.Z):
+        return self._run(data_vol, 1, 2, False, axis)[0]
+
+    def _predict_3_ways_one_hot(self, data_vol):
+        return self._run(data_vol, 3, 2, False)[0]
+
+    def _predict_12_ways_one_hot(self, data_vol):
+        return self._run(data_vol, 12, 2, False)[0]
