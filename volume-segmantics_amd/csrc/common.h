@@ -128,3 +128,5 @@ struct WgradParams {
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
+// dw[i] = sum_k partials[k*n + i], fixed summation order
+int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);

@@ -1,18 +1,22 @@
 // Implicit-GEMM NHWC convolution on MFMA (gfx950), im2col-free.
 //
-// One workgroup (4 waves) computes a TH x TW patch of output pixels of one image times BN
-// output channels.  For every chunk of CK input channels (64 bytes per pixel: 32 bf16 / 16 f32)
-// the input halo patch and the BN x taps weight slab are staged in LDS once and reused by all
-// KH*KW taps: a tap is just a constant byte offset into the staged patch, so there is no
-// im2col buffer anywhere.  MFMA orientation: A = weights (rows = cout), B = pixels (cols), so
-// each lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+// One workgroup (4 waves) computes a TH x TW patch of output pixels of one image times BN output channels.
+// For every chunk of CK input channels (64 bytes per pixel: 32 bf16 / 16 f32) the input halo patch and the
+// BN x taps weight slab are staged in LDS once and reused by all KH*KW taps: a tap is just a constant byte
+// offset into the staged patch, so there is no im2col buffer anywhere.  MFMA orientation: A = weights
+// (rows = cout), B = pixels (cols), so each lane ends up with 4 consecutive output channels of one pixel
+// -> 8/16-byte NHWC stores.
 //
-// bf16: v_mfma_f32_16x16x32_bf16 (one per 32-channel chunk-tap); f32: 4 x v_mfma_f32_16x16x4_f32
-// on the same 16-byte fragments (exact fp32 FMA chain - the parity path).
+// Pipeline: the 16-byte global loads of chunk c+1 are all issued (into registers) BEFORE the MFMAs of
+// chunk c and written to LDS after them, so HBM/L2 latency hides under the matrix work (one LDS buffer,
+// two barriers per chunk; >= 2 workgroups per CU cover the barrier bubbles).
 //
-// Serves: every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
-// vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample +
-// concat folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
+// bf16: v_mfma_f32_16x16x32_bf16 (one per 32-channel chunk-tap); f32: 4 x v_mfma_f32_16x16x4_f32 on the
+// same 16-byte fragments (exact fp32 FMA chain - the parity path).
+//
+// Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
+// vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat
+// folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
 #include "common.h"
 
 namespace {
@@ -46,15 +50,18 @@ struct TileGeom {
     int out_nchw;
 };
 
-template <typename T, int BN, int PT>
+constexpr int patch_items(int pt, int stride) { return stride == 2 ? 5 : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)); }
+
+template <typename T, int BN, int PT, int NTAPS, int STRIDE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom g) {
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
-    constexpr int NJ = BN / 16;
+    constexpr int NJ = BN / 16, KW = NTAPS == 9 ? 3 : 1;
+    constexpr int PITEMS = patch_items(PT, STRIDE);
+    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int TW = 1 << g.tw_shift;
-    const int ntaps = p.KH * p.KW;
     const int Cin = p.C0 + p.C1;
     const int P = g.PH * g.PW;
     char* patch = smem;
@@ -66,8 +73,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
     const int n = bid / g.tiles_h;
     const int h0 = ty * g.TH, w0 = tx * TW;
     const int n0 = blockIdx.y * BN;
-    const int hbase = h0 * p.stride - p.pad, wbase = w0 * p.stride - p.pad;
+    const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
     const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+
+    // ---- chunk-invariant staging addresses (element offsets; -1 = zero fill) ----
+    long poff0[PITEMS], poff1[PITEMS];
+    int pdst[PITEMS];
+#pragma unroll
+    for (int i = 0; i < PITEMS; ++i) {
+        const int item = tid + i * 256;
+        const int pp = item >> 2, seg = item & 3;
+        const int ph = pp / g.PW, pw = pp - ph * g.PW;
+        const int hi = hbase + ph, wi = wbase + pw;
+        const bool ok = item < P * 4 && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+        poff0[i] = ok ? (((long)n * H0 + (hi >> p.up0)) * W0 + (wi >> p.up0)) * p.C0 + seg * EPS : -1;
+        poff1[i] = ok ? (((long)n * p.Hin + hi) * p.Win + wi) * p.C1 + seg * EPS : -1;
+        pdst[i] = item < P * 4 ? pp * kPS + seg * 16 : -1;
+    }
+    long woff[WITEMS];
+    int wdst[WITEMS];
+#pragma unroll
+    for (int i = 0; i < WITEMS; ++i) {
+        const int item = tid + i * 256;
+        const int row = item >> 2, seg = item & 3;
+        const int tap = row / BN, nr = row % BN;
+        const int co = n0 + nr;
+        const bool in = item < WTOTAL;
+        woff[i] = (in && co < p.Cout) ? ((long)co * NTAPS + tap) * Cin + seg * EPS : -1;
+        wdst[i] = in ? row * kPS + seg * 16 : -1;
+    }
+
+    uint4 preg[PITEMS], wreg[WITEMS];
+    auto load_chunk = [&](int c0) {
+        const bool from0 = c0 < p.C0;
+        const T* src = from0 ? (const T*)p.src0 : (const T*)p.src1;
+        const int cs = from0 ? p.C0 : p.C1;
+        const int cb = from0 ? c0 : c0 - p.C0;
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) {
+            const long off = from0 ? poff0[i] : poff1[i];
+            const int seg = (tid + i * 256) & 3;
+            preg[i] = make_uint4(0, 0, 0, 0);
+            if (off >= 0 && cb + seg * EPS < cs) preg[i] = *reinterpret_cast<const uint4*>(src + off + cb);
+        }
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) {
+            const int seg = (tid + i * 256) & 3;
+            wreg[i] = make_uint4(0, 0, 0, 0);
+            if (woff[i] >= 0 && c0 + seg * EPS < Cin) wreg[i] = *reinterpret_cast<const uint4*>((const T*)p.w + woff[i] + c0);
+        }
+    };
 
     // per-lane LDS read bases
     int xbase[PT];
@@ -75,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
     for (int i = 0; i < PT; ++i) {
         const int pl = wave * (PT * 16) + i * 16 + lr;
         const int th = pl >> g.tw_shift, tw = pl & (TW - 1);
-        xbase[i] = ((th * p.stride) * g.PW + tw * p.stride) * kPS + lq * 16;
+        xbase[i] = ((th * STRIDE) * g.PW + tw * STRIDE) * kPS + lq * 16;
     }
     const int wbase_l = lr * kPS + lq * 16;
 
@@ -85,58 +140,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    load_chunk(0);
     for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();  // every wave is done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i)
+            if (pdst[i] >= 0) *reinterpret_cast<uint4*>(patch + pdst[i]) = preg[i];
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i)
+            if (wdst[i] >= 0) *reinterpret_cast<uint4*>(wl + wdst[i]) = wreg[i];
         __syncthreads();
-        // ---- stage the input patch chunk ----
-        const bool from0 = c0 < p.C0;
-        const T* src = from0 ? (const T*)p.src0 : (const T*)p.src1;
-        const int cs = from0 ? p.C0 : p.C1;
-        const int cb = from0 ? c0 : c0 - p.C0;
-        const int sh = from0 ? p.up0 : 0;
-        const int Hs = from0 ? H0 : p.Hin, Ws = from0 ? W0 : p.Win;
-        for (int item = tid; item < P * 4; item += 256) {
-            const int pp = item >> 2, seg = item & 3;
-            const int ph = pp / g.PW, pw = pp - ph * g.PW;
-            const int hi = hbase + ph, wi = wbase + pw;
-            const int c = cb + seg * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win && c < cs) {
-                const size_t off = (((size_t)n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs + c;
-                v = *reinterpret_cast<const uint4*>(src + off);
-            }
-            *reinterpret_cast<uint4*>(patch + pp * kPS + seg * 16) = v;
-        }
-        // ---- stage the weight slab chunk: rows (tap, cout) ----
-        for (int item = tid; item < ntaps * BN * 4; item += 256) {
-            const int row = item >> 2, seg = item & 3;
-            const int tap = row / BN, nr = row % BN;
-            const int co = n0 + nr, c = c0 + seg * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (co < p.Cout && c < Cin)
-                v = *reinterpret_cast<const uint4*>((const T*)p.w + ((size_t)co * ntaps + tap) * Cin + c);
-            *reinterpret_cast<uint4*>(wl + row * kPS + seg * 16) = v;
-        }
-        __syncthreads();
-        // ---- taps ----
-        for (int kh = 0; kh < p.KH; ++kh) {
-            for (int kw = 0; kw < p.KW; ++kw) {
-                const int tap = kh * p.KW + kw;
-                const int xoff = (kh * g.PW + kw) * kPS;
-                uint4 wf[NJ], xf[PT];
+        if (c0 + CK < Cin) load_chunk(c0 + CK);  // in flight while the MFMAs below run
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    wf[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int kh = tap / KW, kw = tap % KW;
+            const int xoff = (kh * g.PW + kw) * kPS;
+            uint4 wf[NJ], xf[PT];
 #pragma unroll
-                for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + xbase[i] + xoff);
+            for (int j = 0; j < NJ; ++j)
+                wf[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
 #pragma unroll
-                for (int i = 0; i < PT; ++i)
+            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + xbase[i] + xoff);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], wf[j], xf[i]);
-            }
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], wf[j], xf[i]);
         }
     }
 
     // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
+    const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int pl = wave * (PT * 16) + i * 16 + lr;
@@ -148,48 +181,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
             const int c = n0 + j * 16 + lq * 4;
             if (c >= p.Cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const int nv = min(4, p.Cout - c);
-            if (p.scale) {
-                for (int r = 0; r < nv; ++r) v[r] = v[r] * p.scale[c + r] + p.shift[c + r];
-            } else if (p.shift) {
-                for (int r = 0; r < nv; ++r) v[r] += p.shift[c + r];
-            }
-            // destination (possibly split across two tensors: dgrad through a channel concat)
-            char* dst = (char*)p.out;
-            int cd = c, cstride = p.Cout;
-            if (p.out1) {
-                if (c >= p.split_c) { dst = (char*)p.out1; cd = c - p.split_c; cstride = p.Cout - p.split_c; }
-                else cstride = p.split_c;
-            }
-            if (p.residual && dst == (char*)p.out) {
-                const T* r = (const T*)p.residual + pix * cstride + cd;
-                if (nv == 4) { const float4 rv = ld4(r); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-                else for (int q = 0; q < nv; ++q) v[q] += Elem<T>::ld(r + q);
-            }
-            if (p.relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            if (g.out_nchw) {  // fp32 NCHW (head logits)
-                float* o = (float*)dst;
-                for (int r = 0; r < nv; ++r)
-                    o[(((size_t)n * p.Cout + c + r) * p.Hout + ho) * p.Wout + wo] = v[r];
-            } else if (p.out_f32) {
-                float* o = (float*)dst + pix * cstride + cd;
-                if (nv == 4 && (cstride & 3) == 0) st4(o, make_float4(v[0], v[1], v[2], v[3]));
-                else for (int r = 0; r < nv; ++r) o[r] = v[r];
+            if (!ragged) {
+                if (p.scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                } else if (p.shift) {
+                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                    v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+                }
+                // destination (possibly split across two tensors: dgrad through a channel concat)
+                char* dst = (char*)p.out;
+                int cd = c, cstride = p.Cout;
+                if (p.out1) {
+                    if (c >= p.split_c) { dst = (char*)p.out1; cd = c - p.split_c; cstride = p.Cout - p.split_c; }
+                    else cstride = p.split_c;
+                }
+                const size_t o = pix * cstride + cd;
+                if (p.residual && dst == (char*)p.out) {
+                    const float4 rv = ld4((const T*)p.residual + o);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.out_f32) st4((float*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
+                else st4((T*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
             } else {
-                T* o = (T*)dst + pix * cstride + cd;
-                if (nv == 4 && (cstride & 3) == 0) st4(o, make_float4(v[0], v[1], v[2], v[3]));
-                else for (int r = 0; r < nv; ++r) Elem<T>::st(o + r, v[r]);
+                const int nv = min(4, p.Cout - c);
+                for (int r = 0; r < nv; ++r) {
+                    float x = v[r];
+                    if (p.scale) x = x * p.scale[c + r] + p.shift[c + r];
+                    else if (p.shift) x += p.shift[c + r];
+                    if (p.residual) x += Elem<T>::ld((const T*)p.residual + pix * p.Cout + c + r);
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (g.out_nchw) ((float*)p.out)[(((size_t)n * p.Cout + c + r) * p.Hout + ho) * p.Wout + wo] = x;
+                    else if (p.out_f32) ((float*)p.out)[pix * p.Cout + c + r] = x;
+                    else Elem<T>::st((T*)p.out + pix * p.Cout + c + r, x);
+                }
             }
         }
     }
 }
 
-template <typename T, int BN, int PT>
+template <typename T, int BN, int PT, int NTAPS, int STRIDE>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<T, BN, PT>;
-    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)p.KH * p.KW * BN * kPS;
+    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE>;
+    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS;
     VS_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS request %zu too large", lds);
+    VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, STRIDE) * 256, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -200,6 +239,23 @@ int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     return VS_OK;
 }
 
+template <typename T, int BN, int PT>
+int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
+    const int nt = p.KH * p.KW;
+    if constexpr (PT == 1) {
+        if (p.stride == 2) return nt == 9 ? launch_one<T, BN, 1, 9, 2>(p, g, s) : launch_one<T, BN, 1, 1, 2>(p, g, s);
+    }
+    return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
+}
+
+int choose_pt(const ConvParams& p, int BN) {
+    if (p.stride != 1 || p.Hout * p.Wout < 128 || p.Wout < 16) return 1;
+    // 256-pixel tiles halve the weight-slab traffic per FLOP; take them when the grid still fills the chip
+    const long wg256 = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * cdiv(p.Cout, BN);
+    if (p.Hout * p.Wout >= 256 && wg256 >= 1024) return 4;
+    return 2;
+}
+
 template <typename T>
 int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
@@ -207,26 +263,28 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(Cin % EPS == 0 && p.C0 % EPS == 0, "conv_igemm: channel counts must be multiples of %d", EPS);
     VS_REQUIRE(p.C1 == 0 || p.C0 % CK == 0, "conv_igemm: concat boundary must be a multiple of %d", CK);
     VS_REQUIRE(p.up0 == 0 || p.up0 == 1, "conv_igemm: up0 must be 0 or 1");
-    VS_REQUIRE(p.KH >= 1 && p.KH <= 3 && p.KW >= 1 && p.KW <= 3 && (p.stride == 1 || p.stride == 2),
+    VS_REQUIRE(((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1)) && (p.stride == 1 || p.stride == 2),
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - p.KH) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - p.KW) / p.stride + 1,
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && p.out, "conv_igemm: null pointer");
+    VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
+    const int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
+    if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
+    const int PT = choose_pt(p, BN);
     TileGeom g;
     g.tw_shift = p.Wout >= 16 ? 4 : 3;
     const int TW = 1 << g.tw_shift;
-    int PT = (p.stride == 1 && p.Hout * p.Wout >= 128) ? 2 : 1;
     g.TH = 64 * PT / TW;
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
     g.PH = (g.TH - 1) * p.stride + p.KH;
     g.PW = (TW - 1) * p.stride + p.KW;
     g.out_nchw = out_nchw;
-    int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
-    if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
-#define VS_CONV_CASE(bn, pt) if (BN == bn && PT == pt) return launch_one<T, bn, pt>(p, g, s)
-    VS_CONV_CASE(64, 2); VS_CONV_CASE(64, 1); VS_CONV_CASE(32, 2); VS_CONV_CASE(32, 1);
-    VS_CONV_CASE(16, 2); VS_CONV_CASE(16, 1);
+#define VS_CONV_CASE(bn, pt) if (BN == bn && PT == pt) return launch_tk<T, bn, pt>(p, g, s)
+    VS_CONV_CASE(64, 4); VS_CONV_CASE(64, 2); VS_CONV_CASE(64, 1);
+    VS_CONV_CASE(32, 4); VS_CONV_CASE(32, 2); VS_CONV_CASE(32, 1);
+    VS_CONV_CASE(16, 4); VS_CONV_CASE(16, 2); VS_CONV_CASE(16, 1);
 #undef VS_CONV_CASE
     vs_set_error("conv_igemm: no kernel for BN=%d PT=%d", BN, PT);
     return VS_ERR_UNSUPPORTED;

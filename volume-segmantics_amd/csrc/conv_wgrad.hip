@@ -22,7 +22,7 @@ template <> struct WT<bf16_t> { static constexpr int CK = 32, EPS = 8, NCI = 2, 
 template <> struct WT<float> { static constexpr int CK = 16, EPS = 4, NCI = 1, KSTEP = 4; };
 
 struct WGeom {
-    int tw_shift, TH, tiles_h, tiles_w, PH, PW;
+    int tw_shift, TH, tiles_h, tiles_w, PH, PW, PT;
     int ctiles, cchunks, nsplit, total_tiles, dys;  // dys: LDS bytes per dy pixel row
 };
 
@@ -31,15 +31,19 @@ __device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int WO, int NTAPS>
+constexpr int wg_patch_items(int pt, int stride) { return stride == 2 ? 5 : (pt == 2 ? 3 : 2); }
+
+template <typename T, int WO, int NTAPS, int STRIDE, int PT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g) {
     constexpr int CK = WT<T>::CK, EPS = WT<T>::EPS, NCI = WT<T>::NCI, KSTEP = WT<T>::KSTEP;
-    constexpr int WK = 4 / WO, BNO = 16 * WO;
+    constexpr int WK = 4 / WO, BNO = 16 * WO, KW = NTAPS == 9 ? 3 : 1;
+    constexpr int BM = 64 * PT, SEGS = BNO / EPS;      // SEGS: 16-byte segments per dy pixel row
+    constexpr int PITEMS = wg_patch_items(PT, STRIDE), DTOTAL = BM * SEGS, DITEMS = (DTOTAL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int wo = wave % WO, wk = wave / WO;
-    const int TW = 1 << g.tw_shift, BM = g.TH * TW;
+    const int TW = 1 << g.tw_shift;
     const int Cin = p.C0 + p.C1;
     const int P = g.PH * g.PW;
     char* patch = smem;
@@ -58,48 +62,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
     const int sh = from0 ? p.up0 : 0;
     const int Hs = from0 ? H0 : p.Hin, Ws = from0 ? W0 : p.Win;
 
+    // tile-invariant staging coordinates
+    int pph[PITEMS], ppw[PITEMS], pdst[PITEMS];
+    bool pcv[PITEMS];
+#pragma unroll
+    for (int i = 0; i < PITEMS; ++i) {
+        const int item = tid + i * 256;
+        const int pp = item >> 2, seg = item & 3;
+        pph[i] = pp / g.PW; ppw[i] = pp - pph[i] * g.PW;
+        pdst[i] = item < P * 4 ? pp * kXS + seg * 16 : -1;
+        pcv[i] = item < P * 4 && cb + seg * EPS < cs;
+    }
+    int dpl[DITEMS], dseg[DITEMS];
+#pragma unroll
+    for (int i = 0; i < DITEMS; ++i) {
+        const int item = tid + i * 256;
+        dpl[i] = item < DTOTAL ? item / SEGS : -1;
+        dseg[i] = item % SEGS;
+    }
+    uint4 preg[PITEMS], dreg[DITEMS];
+    auto load_tile = [&](int tile) {
+        int b = tile;
+        const int tx = b % g.tiles_w; b /= g.tiles_w;
+        const int ty = b % g.tiles_h;
+        const int n = b / g.tiles_h;
+        const int h0 = ty * g.TH, w0 = tx * TW;
+        const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) {
+            const int hi = hbase + pph[i], wi = wbase + ppw[i];
+            const int seg = (tid + i * 256) & 3;
+            preg[i] = make_uint4(0, 0, 0, 0);
+            if (pcv[i] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
+                preg[i] = *reinterpret_cast<const uint4*>(src + (((size_t)n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs + cb + seg * EPS);
+        }
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i) {
+            dreg[i] = make_uint4(0, 0, 0, 0);
+            if (dpl[i] < 0) continue;
+            const int ho = h0 + (dpl[i] >> g.tw_shift), wo_ = w0 + (dpl[i] & (TW - 1));
+            const int co = co0 + dseg[i] * EPS;
+            if (ho < p.Hout && wo_ < p.Wout && co < p.Cout) {
+                const T* sp = (const T*)p.dy + (((size_t)n * p.Hout + ho) * p.Wout + wo_) * p.Cout + co;
+                if (co + EPS <= p.Cout) dreg[i] = *reinterpret_cast<const uint4*>(sp);
+                else {  // ragged channel tail
+                    alignas(16) T tmp[EPS];
+                    for (int e = 0; e < EPS; ++e) tmp[e] = (co + e < p.Cout) ? sp[e] : (T)0;
+                    dreg[i] = *reinterpret_cast<const uint4*>(tmp);
+                }
+            }
+        }
+    };
+
     f32x4 acc[NTAPS][NCI];
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int c = 0; c < NCI; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (t0 < t1) load_tile(t0);
     for (int tile = t0; tile < t1; ++tile) {
-        int b = tile;
-        const int tx = b % g.tiles_w; b /= g.tiles_w;
-        const int ty = b % g.tiles_h;
-        const int n = b / g.tiles_h;
-        const int h0 = ty * g.TH, w0 = tx * TW;
-        const int hbase = h0 * p.stride - p.pad, wbase = w0 * p.stride - p.pad;
         __syncthreads();
-        for (int item = tid; item < P * 4; item += 256) {
-            const int pp = item >> 2, seg = item & 3;
-            const int ph = pp / g.PW, pw = pp - ph * g.PW;
-            const int hi = hbase + ph, wi = wbase + pw;
-            const int c = cb + seg * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win && c < cs)
-                v = *reinterpret_cast<const uint4*>(src + (((size_t)n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs + c);
-            *reinterpret_cast<uint4*>(patch + pp * kXS + seg * 16) = v;
-        }
-        constexpr int SEGS = BNO / EPS;  // 16-byte segments per dy pixel row
-        for (int item = tid; item < BM * SEGS; item += 256) {
-            const int pl = item / SEGS, seg = item % SEGS;
-            const int ho = h0 + (pl >> g.tw_shift), wo_ = w0 + (pl & (TW - 1));
-            const int co = co0 + seg * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ho < p.Hout && wo_ < p.Wout && co < p.Cout) {
-                const T* s = (const T*)p.dy + (((size_t)n * p.Hout + ho) * p.Wout + wo_) * p.Cout + co;
-                if (co + EPS <= p.Cout) v = *reinterpret_cast<const uint4*>(s);
-                else {  // ragged channel tail (segmentation head: Cout = classes)
-                    T tmp[EPS];
-                    for (int e = 0; e < EPS; ++e) tmp[e] = (co + e < p.Cout) ? s[e] : (T)0;
-                    v = *reinterpret_cast<const uint4*>(tmp);
-                }
-            }
-            *reinterpret_cast<uint4*>(dyl + pl * g.dys + seg * 16) = v;
-        }
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i)
+            if (pdst[i] >= 0) *reinterpret_cast<uint4*>(patch + pdst[i]) = preg[i];
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i)
+            if (dpl[i] >= 0) *reinterpret_cast<uint4*>(dyl + dpl[i] * g.dys + dseg[i] * 16) = dreg[i];
         __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);  // in flight while the MFMAs below run
 
         for (int ks = wk; ks < BM / KSTEP; ks += WK) {
             if constexpr (sizeof(T) == 2) {
@@ -112,12 +143,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
                     const uint2 hi = ds_read_tr16(dyl + pb * g.dys + wo * 32 + coff);
                     af = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
-                const int xa = (((pa >> g.tw_shift) * p.stride) * g.PW + (pa & (TW - 1)) * p.stride) * kXS + coff;
-                const int xb = (((pb >> g.tw_shift) * p.stride) * g.PW + (pb & (TW - 1)) * p.stride) * kXS + coff;
+                const int xa = (((pa >> g.tw_shift) * STRIDE) * g.PW + (pa & (TW - 1)) * STRIDE) * kXS + coff;
+                const int xb = (((pb >> g.tw_shift) * STRIDE) * g.PW + (pb & (TW - 1)) * STRIDE) * kXS + coff;
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    const int kh = t / p.KW, kw = t - kh * p.KW;
-                    const int toff = (kh * g.PW + kw) * kXS;
+                    const int toff = ((t / KW) * g.PW + (t % KW)) * kXS;
 #pragma unroll
                     for (int c = 0; c < NCI; ++c) {
                         const uint2 lo = ds_read_tr16(patch + xa + toff + c * 32);
@@ -130,11 +160,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
             } else {
                 const int pk = ks * 4 + lq;
                 const float a = *reinterpret_cast<const float*>(dyl + pk * g.dys + (wo * 16 + lr) * 4);
-                const int xo = (((pk >> g.tw_shift) * p.stride) * g.PW + (pk & (TW - 1)) * p.stride) * kXS + lr * 4;
+                const int xo = (((pk >> g.tw_shift) * STRIDE) * g.PW + (pk & (TW - 1)) * STRIDE) * kXS + lr * 4;
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    const int kh = t / p.KW, kw = t - kh * p.KW;
-                    const float bv = *reinterpret_cast<const float*>(patch + xo + (kh * g.PW + kw) * kXS);
+                    const float bv = *reinterpret_cast<const float*>(patch + xo + ((t / KW) * g.PW + (t % KW)) * kXS);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t][0], 0, 0, 0);
                 }
             }
@@ -211,6 +240,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     const int TW = 1 << g.tw_shift;
     const int PT = (p.stride == 1 && p.Hout * p.Wout >= 128) ? 2 : 1;
     g.TH = 64 * PT / TW;
+    g.PT = PT;
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
     g.PH = (g.TH - 1) * p.stride + p.KH;
@@ -228,10 +258,11 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     return VS_OK;
 }
 
-template <typename T, int WO, int NTAPS>
+template <typename T, int WO, int NTAPS, int STRIDE, int PT>
 int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_wgrad_kernel<T, WO, NTAPS>;
+    auto kern = conv_wgrad_kernel<T, WO, NTAPS, STRIDE, PT>;
+    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
     const int BM = g.TH << g.tw_shift;
     size_t lds = (size_t)g.PH * g.PW * kXS + (size_t)BM * g.dys;
     if (WO < 4) lds = std::max(lds, (size_t)WO * NTAPS * WT<T>::NCI * 256 * sizeof(float));  // K-wave combine buffer
@@ -256,13 +287,23 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     const size_t need = (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
     VS_REQUIRE(p.partials && p.partial_bytes >= need, "conv_wgrad: workspace %zu < %zu", p.partial_bytes, need);
     const int nt = p.KH * p.KW;
-#define VS_WG_CASE(wo, t) if (WO == wo && nt == t) return launch_one<T, wo, t>(p, g, s)
-    VS_WG_CASE(4, 9); VS_WG_CASE(2, 9); VS_WG_CASE(1, 9); VS_WG_CASE(4, 1); VS_WG_CASE(2, 1); VS_WG_CASE(1, 1);
+#define VS_WG_CASE(wo, t)                                                                  \
+    if (WO == wo && nt == t) {                                                             \
+        if (p.stride == 2) return launch_one<T, wo, t, 2, 1>(p, g, s);                     \
+        return g.PT == 2 ? launch_one<T, wo, t, 1, 2>(p, g, s) : launch_one<T, wo, t, 1, 1>(p, g, s); \
+    }
+    VS_WG_CASE(4, 9) VS_WG_CASE(2, 9) VS_WG_CASE(1, 9) VS_WG_CASE(4, 1) VS_WG_CASE(2, 1) VS_WG_CASE(1, 1)
 #undef VS_WG_CASE
     return VS_ERR_UNSUPPORTED;
 }
 
 }  // namespace
+
+int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, partials, dw, n, nparts);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
 
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {
     WGeom g; int WO;

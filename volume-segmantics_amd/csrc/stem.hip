@@ -204,7 +204,5 @@ extern "C" int vs_stem_wgrad(int dtype, const float* x, const void* dy, float* d
         hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, (const float*)dy,
                            workspace, n, h, w_, total, per);
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stem_reduce_kernel, dim3(cdiv(64 * 49, 256)), dim3(256), 0, (hipStream_t)stream, workspace, dw, blocks);
-    VS_LAUNCH_CHECK();
-    return VS_OK;
+    return launch_slab_reduce(workspace, dw, 64 * 49, blocks, (hipStream_t)stream);
 }
