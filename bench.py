@@ -96,6 +96,59 @@ def cpu_baseline(batch: int, steps: int):
                       f"({torch.get_num_threads()} threads) after 1 warm-up step"}
 
 
+def synth_volume(n: int, seed: int) -> np.ndarray:
+    """uint8 n^3 volume: box-blurred gaussian noise, mean 128 / sd 40, built in float16-free
+    chunks so that 512^3 stays cheap on the host."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, n, n), dtype=np.float32)
+    for ax in range(3):
+        v = (np.roll(v, 1, ax) + v + np.roll(v, -1, ax)) * (1.0 / 3.0)
+    v -= v.mean()
+    v *= 40.0 / v.std()
+    v += 128.0
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, batch: int):
+    """Time VolSeg2dPredictor on a synthetic cube: upload once, n_dirs directions sharded over the ranks, packed-key
+    max merge, ONE max all-reduce, unpack, labels + probabilities back on the host (the reference API's contract)."""
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    model = VolSegUnet(classes, device=dev, precision=precision, seed=1)
+    with torch.no_grad():  # non-trivial BN statistics
+        model._bnstate.uniform_(0.5, 1.5)
+    if world > 1:
+        dist.broadcast(model._flat, 0)
+        dist.broadcast(model._bnstate, 0)
+    pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
+    pred.model, pred.num_labels, pred.label_codes = model, classes, {}
+    pred.settings = SimpleNamespace(cuda_device=dev.index, prediction_batch_size=batch)
+    vol = synth_volume(cube, seed=5678 if cube == 512 else 1234)
+    fn = {1: pred._predict_single_axis, 3: pred._predict_3_ways_max_probs, 12: pred._predict_12_ways_max_probs}[n_dirs]
+    fn(vol[:32])  # warm-up: plans, workspaces, code objects
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    labels, probs = fn(vol)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    n_slices = n_dirs * cube
+    flop = {(256, 2): 15.44e9, (512, 4): 61.92e9}.get((cube, classes), 0.0) * n_slices
+    return {"seconds": round(dt, 4), "slices": n_slices, "slices_per_s": round(n_slices / dt, 1),
+            "mfma_frac": round(flop / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world, 4), "batch": batch,
+            "label_hist": np.bincount(labels.ravel(), minlength=classes).tolist(),
+            "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +158,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
     ap.add_argument("--per-unit", default="", help="write a per-layer kernel-time table (instrumented steps) to this file")
     args = ap.parse_args()
 
@@ -190,6 +244,17 @@ def main():
                         f"{fl / (ms * 1e-3) / 1e12 if ms else 0:.1f}\t{by / (ms * 1e-3) / 1e9 if ms else 0:.0f}\n")
     log("instrumented steps done")
 
+    predict = {}
+    if not args.no_predict:
+        del opt, sched
+        model._plans.clear()
+        torch.cuda.empty_cache()
+        log("predict: 256^3 single axis")
+        predict["predict_256cube_low_2class"] = predict_bench(dev, world, args.precision, 256, 2, 1, 32)
+        log("predict: 512^3 12 directions")
+        predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 16)
+        log("predict done")
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         slices_per_s = args.batch * world * args.steps / elapsed
@@ -219,6 +284,7 @@ def main():
                          "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else 0.0,
                          "note": "algorithmic conv FLOPs of the class / HIP-event time of its launches, instrumented steps"},
             "kernel_classes": breakdown,
+            **predict,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(12, args.cpu_steps)

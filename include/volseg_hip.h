@@ -79,6 +79,11 @@ int vs_bn_apply(int dtype, const void* x, const float* mean, const float* invstd
 int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
               const float* gamma, int relu, void* dx, void* dres, float* dgamma, float* dbeta,
               int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream);
+/* same, but with y == NULL the ReLU mask is recomputed as (x-mean)*invstd*gamma + beta > 0 (units without a
+ * residual input): two tensor reads fewer. */
+int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int relu, void* dx, void* dres, float* dgamma,
+                        float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream);
 /* eval-mode folding: scale = gamma / sqrt(var + eps), shift = beta - mean * scale */
 int vs_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                float eps, float* scale, float* shift, int c, void* stream);

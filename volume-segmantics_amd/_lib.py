@@ -51,6 +51,7 @@ _SIGS = {
     "vs_bn_workspace": (SZ, [I64, I]),
     "vs_bn_apply": (I, [I, P, P, P, P, P, P, I, P, I64, I, P]),
     "vs_bn_bwd": (I, [I, P, P, P, P, P, P, I, P, P, P, P, I64, I, P, SZ, P]),
+    "vs_bn_bwd_recompute": (I, [I, P, P, P, P, P, P, P, I, P, P, P, P, I64, I, P, SZ, P]),
     "vs_bn_fold": (I, [P, P, P, P, F, P, P, I, P]),
     "vs_maxpool_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "vs_maxpool_bwd": (I, [I, P, P, P, I, I, I, I, I, P]),

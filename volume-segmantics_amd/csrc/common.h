@@ -116,8 +116,15 @@ struct ConvParams {
     const void* residual;                // same shape as out, added after the affine (may be null)
     int relu;
     int out_f32;                         // store fp32 regardless of the compute dtype
+    int pool0;                           // dgrad through nearest-x2 upsampling: channels < (out1 ? split_c : Cout) are summed
+                                         // over 2x2 pixel blocks and written to `out` at half resolution
+    float* stats_partial;                // optional [tiles][2][Cout]: per-tile sum / sum of squares of the raw accumulators
 };
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
+bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
+int conv_igemm_stat_rows(const ConvParams& p);      // number of partial rows stats_partial receives
+int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
+                                float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
 
 struct WgradParams {
     const void* src0; const void* src1; int C0, C1, up0;  // the forward conv's virtual input

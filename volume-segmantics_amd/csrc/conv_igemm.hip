@@ -17,6 +17,8 @@
 // Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
 // vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat
 // folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -170,16 +172,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
 
     // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
     const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
-#pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        const int pl = wave * (PT * 16) + i * 16 + lr;
-        const int ho = h0 + (pl >> g.tw_shift), wo = w0 + (pl & (TW - 1));
-        if (ho >= p.Hout || wo >= p.Wout) continue;
-        const size_t pix = ((size_t)n * p.Hout + ho) * p.Wout + wo;
+    // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
+    if (p.stats_partial) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+        __syncthreads();                               // staged tiles are dead
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int c = n0 + j * 16 + lq * 4;
-            if (c >= p.Cout) continue;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int pl = wave * (PT * 16) + i * 16 + lr;
+                const bool ok = h0 + (pl >> g.tw_shift) < p.Hout && w0 + (pl & (TW - 1)) < p.Wout;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = ok ? acc[i][j][r] : 0.f;
+                    s1[r] += x; s2[r] += x * x;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+            }
+            if (lr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wave * 2 + 0) * BN + j * 16 + lq * 4 + r] = s1[r];
+                    red[(wave * 2 + 1) * BN + j * 16 + lq * 4 + r] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, cc = tid % BN;
+            if (n0 + cc < p.Cout)
+                p.stats_partial[((size_t)blockIdx.x * 2 + k) * p.Cout + n0 + cc] =
+                    (red[(0 * 2 + k) * BN + cc] + red[(1 * 2 + k) * BN + cc]) + (red[(2 * 2 + k) * BN + cc] + red[(3 * 2 + k) * BN + cc]);
+        }
+    }
+    // (2) outputs
+    const int pool_c = p.pool0 ? (p.out1 ? p.split_c : p.Cout) : 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = n0 + j * 16 + lq * 4;
+        if (PT >= 2 && c < pool_c) {
+            // dgrad through nearest-x2 upsampling: sum the 2x2 block (rows i, i+1 of this wave; lanes lr, lr^1)
+            if constexpr (PT >= 2) {
+#pragma unroll
+                for (int ip = 0; ip < PT / 2; ++ip) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[2 * ip][j][r] + acc[2 * ip + 1][j][r];
+                        v[r] += __shfl_xor(v[r], 1, 64);
+                    }
+                    const int ho = h0 + wave * PT + 2 * ip, wo = w0 + lr;
+                    if ((lr & 1) == 0 && ho < p.Hout && wo < p.Wout && c < p.Cout) {
+                        const size_t o = (((size_t)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1)) * pool_c + c;
+                        st4((T*)p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int pl = wave * (PT * 16) + i * 16 + lr;
+            const int ho = h0 + (pl >> g.tw_shift), wo = w0 + (pl & (TW - 1));
+            if (ho >= p.Hout || wo >= p.Wout || c >= p.Cout) continue;
+            const size_t pix = ((size_t)n * p.Hout + ho) * p.Wout + wo;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (!ragged) {
                 if (p.scale) {
@@ -256,6 +317,20 @@ int choose_pt(const ConvParams& p, int BN) {
     return 2;
 }
 
+int choose_bn(const ConvParams& p) {
+    int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
+    // small grids (deep, low-resolution layers): one 64-wide workgroup per CU cannot hide load latency;
+    // 32-wide cout tiles double the workgroups (and halve the weight slab each one stages)
+    static const int min_wgs = getenv("VS_CONV_MIN_WGS") ? atoi(getenv("VS_CONV_MIN_WGS")) : 512;
+    if (BN == 64) {
+        const int pt = choose_pt(p, 64);
+        const int tw = p.Wout >= 16 ? 16 : 8, th = 64 * pt / tw;
+        const long wgs = (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, 64);
+        if (wgs < min_wgs) BN = 32;
+    }
+    return BN;
+}
+
 template <typename T>
 int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
@@ -269,9 +344,14 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && p.out, "conv_igemm: null pointer");
     VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
-    const int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
+    const int BN = choose_bn(p);
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
     const int PT = choose_pt(p, BN);
+    if (p.pool0) {
+        VS_REQUIRE(PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
+                   "conv_igemm: pooled dgrad epilogue not available for this geometry");
+        VS_REQUIRE((p.out1 ? p.split_c : p.Cout) % 4 == 0, "conv_igemm: pooled channel count must be a multiple of 4");
+    }
     TileGeom g;
     g.tw_shift = p.Wout >= 16 ? 4 : 3;
     const int TW = 1 << g.tw_shift;
@@ -291,6 +371,18 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
 }
 
 }  // namespace
+
+bool conv_igemm_can_pool(const ConvParams& p) {
+    const int BN = choose_bn(p);
+    return choose_pt(p, BN) >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);
+}
+
+int conv_igemm_stat_rows(const ConvParams& p) {
+    const int BN = choose_bn(p);
+    const int PT = choose_pt(p, BN);
+    const int TW = p.Wout >= 16 ? 16 : 8, TH = 64 * PT / TW;
+    return p.N * cdiv(p.Hout, TH) * cdiv(p.Wout, TW);
+}
 
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s) {
     const int nchw = p.out_f32 >> 1;  // out_f32: bit0 = fp32 store, bit1 = NCHW layout

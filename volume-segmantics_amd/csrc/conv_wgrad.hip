@@ -10,6 +10,7 @@
 //
 // Replaces the conv weight gradients of loss.backward() (vol_seg_2d_trainer.py:429).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -249,7 +250,9 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.ctiles = cdiv(p.Cout, 16 * WO);
     g.cchunks = cdiv(Cin, CK);
     g.total_tiles = p.N * g.tiles_h * g.tiles_w;
-    int want = 1024 / (g.ctiles * g.cchunks);
+    // fp32 slab traffic is nsplit * |dw| written + read: keep the grid near `target` workgroups, not more
+    static const int target = getenv("VS_WGRAD_TARGET") ? atoi(getenv("VS_WGRAD_TARGET")) : 512;
+    int want = target / (g.ctiles * g.cchunks);
     if (want < 1) want = 1;
     g.nsplit = want < g.total_tiles ? want : g.total_tiles;
     const int per = cdiv(g.total_tiles, g.nsplit);

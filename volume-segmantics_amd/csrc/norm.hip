@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void bn_stats_finalize(const float* __restrict_
     const double dm = s / (double)rows;  // mean of (x - K)
     double var = q / (double)rows - dm * dm;
     if (var < 0.0) var = 0.0;
-    const double mu = dm + (double)Elem<T>::ld(x + ch);
+    const double mu = dm + (x ? (double)Elem<T>::ld(x + ch) : 0.0);
     mean[ch] = (float)mu;
     invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
@@ -144,20 +144,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---- backward ----------------------------------------------------------------------------------
-template <typename T>
+// relu mask: from the stored activation y when given, otherwise recomputed as (x - mean) * invstd * gamma + beta > 0
+// (bit-identical to the forward's expression; only valid for units without a residual input)
+template <typename T, bool RECOMPUTE>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, const T* __restrict__ y,
                                                     const T* __restrict__ x, const float* __restrict__ mean,
-                                                    const float* __restrict__ invstd, int relu, int64_t rows, int c,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int relu, int64_t rows, int c,
                                                     RowMap m, float* __restrict__ partial) {
     __shared__ float red[2][256][kVec + 1];
     const int tid = threadIdx.x;
     const int cvi = tid % m.cv, rl = tid / m.cv;
-    float s[kVec], q[kVec], mu[kVec], is[kVec];
+    float s[kVec], q[kVec], mu[kVec], is[kVec], ga[RECOMPUTE ? kVec : 1], be[RECOMPUTE ? kVec : 1];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
         s[k] = q[k] = 0.f;
-        mu[k] = mean[(cvi * kVec + k) % c];
-        is[k] = invstd[(cvi * kVec + k) % c];
+        mu[k] = mean[cvi * kVec + k];
+        is[k] = invstd[cvi * kVec + k];
+        if constexpr (RECOMPUTE) {
+            ga[k] = invstd[cvi * kVec + k] * gamma[cvi * kVec + k];
+            be[k] = beta[cvi * kVec + k];
+        }
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
@@ -168,10 +175,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, 
             ld8(dy + o, g);
             ld8(x + o, xv);
             if (relu) {
-                float yv[kVec];
-                ld8(y + o, yv);
+                if constexpr (!RECOMPUTE) {
+                    float yv[kVec];
+                    ld8(y + o, yv);
 #pragma unroll
-                for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                    for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) g[k] = ((xv[k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+                }
             }
 #pragma unroll
             for (int k = 0; k < kVec; ++k) { s[k] += g[k]; q[k] += g[k] * (xv[k] - mu[k]) * is[k]; }
@@ -202,23 +214,24 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize(const float* __restrict__ 
     if (lane == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
 }
 
-template <typename T>
+template <typename T, bool RECOMPUTE>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y,
                                                   const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                  int relu, T* __restrict__ dx, T* __restrict__ dres, int64_t rows,
-                                                  int c, RowMap m) {
+                                                  const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                  const float* __restrict__ dbeta, int relu, T* __restrict__ dx,
+                                                  T* __restrict__ dres, int64_t rows, int c, RowMap m) {
     const int tid = threadIdx.x;
     const int cvi = tid % m.cv, rl = tid / m.cv;
     if (rl >= m.rpb) return;
     const float inv_m = 1.0f / (float)rows;
-    float mu[kVec], is[kVec], gi[kVec], db[kVec], dg[kVec];
+    float mu[kVec], is[kVec], gi[kVec], db[kVec], dg[kVec], be[RECOMPUTE ? kVec : 1], ga[RECOMPUTE ? kVec : 1];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
         const int ch = cvi * kVec + k;
         mu[k] = mean[ch]; is[k] = invstd[ch]; gi[k] = gamma[ch] * invstd[ch];
         db[k] = dbeta[ch] * inv_m; dg[k] = dgamma[ch] * inv_m;
+        if constexpr (RECOMPUTE) { be[k] = beta[ch]; ga[k] = invstd[ch] * gamma[ch]; }
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
@@ -228,10 +241,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
         ld8(dy + o, g);
         ld8(x + o, xv);
         if (relu) {
-            float yv[kVec];
-            ld8(y + o, yv);
+            if constexpr (!RECOMPUTE) {
+                float yv[kVec];
+                ld8(y + o, yv);
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) g[k] = ((xv[k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+            }
         }
         if (dres) st8(dres + o, g);
         float o8[kVec];
@@ -263,6 +281,14 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
 }
 
 }  // namespace
+
+int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
+                                float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s) {
+    hipLaunchKernelGGL(bn_stats_finalize<float>, dim3(c), dim3(64), 0, s, partial, (const float*)nullptr, nparts, c, rows, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
 
 extern "C" size_t vs_bn_workspace(int64_t rows, int c) {
     (void)rows;
@@ -299,26 +325,35 @@ extern "C" int vs_bn_apply(int dtype, const void* x, const float* mean, const fl
 extern "C" int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x, const float* mean,
                          const float* invstd, const float* gamma, int relu, void* dx, void* dres, float* dgamma,
                          float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(!relu || y, "bn_bwd: the ReLU mask needs the activation y (or use vs_bn_bwd_recompute with beta)");
+    return vs_bn_bwd_recompute(dtype, dy, y, x, mean, invstd, gamma, nullptr, relu, dx, dres, dgamma, dbeta, rows, c,
+                               workspace, workspace_bytes, stream);
+}
+
+extern "C" int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, const void* x, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, int relu, void* dx,
+                                   void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
+                                   size_t workspace_bytes, void* stream) {
     VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_bwd: unsupported channel count %d", c);
+    VS_REQUIRE(!relu || y || beta, "bn_bwd: need y or beta for the ReLU mask");
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_bwd: workspace too small");
     RowMap m = make_rowmap(rows, c);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(bn_bwd_partial<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y,
-                           (const bf16_t*)x, mean, invstd, relu, rows, c, m, workspace);
-    else
-        hipLaunchKernelGGL(bn_bwd_partial<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)dy, (const float*)y,
-                           (const float*)x, mean, invstd, relu, rows, c, m, workspace);
+    const bool rc = relu && !y;
+#define VS_BWD_PARTIAL(T, R) hipLaunchKernelGGL((bn_bwd_partial<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \
+                                                (const T*)x, mean, invstd, gamma, beta, relu, rows, c, m, workspace)
+#define VS_BWD_APPLY(T, R) hipLaunchKernelGGL((bn_bwd_apply<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \
+                                              (const T*)x, mean, invstd, gamma, beta, dgamma, dbeta, relu, (T*)dx, (T*)dres, rows, c, m)
+    if (dtype == VS_BF16) { if (rc) VS_BWD_PARTIAL(bf16_t, true); else VS_BWD_PARTIAL(bf16_t, false); }
+    else { if (rc) VS_BWD_PARTIAL(float, true); else VS_BWD_PARTIAL(float, false); }
     VS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(64), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y,
-                           (const bf16_t*)x, mean, invstd, gamma, dgamma, dbeta, relu, (bf16_t*)dx, (bf16_t*)dres, rows, c, m);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)dy, (const float*)y,
-                           (const float*)x, mean, invstd, gamma, dgamma, dbeta, relu, (float*)dx, (float*)dres, rows, c, m);
+    if (dtype == VS_BF16) { if (rc) VS_BWD_APPLY(bf16_t, true); else VS_BWD_APPLY(bf16_t, false); }
+    else { if (rc) VS_BWD_APPLY(float, true); else VS_BWD_APPLY(float, false); }
     VS_LAUNCH_CHECK();
+#undef VS_BWD_PARTIAL
+#undef VS_BWD_APPLY
     return VS_OK;
 }
 

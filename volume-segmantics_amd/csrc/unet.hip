@@ -7,6 +7,7 @@
 // call per pass.  Forward in training mode keeps the pre-BN (z) and post-activation (a) tensors;
 // backward walks the units in reverse with a statically known first-write / accumulate discipline for
 // the gradients of tensors with two consumers (ResNet identities, U-Net skips).
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -191,7 +192,7 @@ size_t plan_workspace(vs_unet* net) {
         }
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
-    net->bnws_bytes = vs_bn_workspace(0, 512);
+    net->bnws_bytes = 4 * vs_bn_workspace(0, 512);  // also receives the conv epilogue's per-tile statistics
     net->off_bnws = take(net->bnws_bytes);
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
@@ -372,6 +373,7 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
     int unit_index = -1;
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
+        int fused_stat_rows = 0;
         float* rm = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 2).offset : nullptr;
         float* rv = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 3).offset : nullptr;
         switch (u.kind) {
@@ -395,6 +397,14 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
             if (training) {
                 p.out = c.z(u.out);
+                static const bool fuse_stats = getenv("VS_FUSE_STATS") ? atoi(getenv("VS_FUSE_STATS")) != 0 : true;
+                if (dt == VS_BF16 && fuse_stats) {  // batch statistics straight from the fp32 accumulators
+                    const int rows_needed = conv_igemm_stat_rows(p);
+                    if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
+                        p.stats_partial = (float*)(c.ws + net->off_bnws);
+                        fused_stat_rows = rows_needed;
+                    }
+                }
             } else {
                 p.out = c.a(u.out);
                 p.scale = c.bnc(u, 0); p.shift = c.bnc(u, 1);
@@ -413,7 +423,11 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
         }
         }
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
-            {
+            if (fused_stat_rows) {
+                ProfScope prof(PK_BN_STATS, 0, 0, c.s);
+                if ((rc = launch_bn_finalize_partials((const float*)(c.ws + net->off_bnws), fused_stat_rows, u.cout, c.rows(u),
+                                                      1e-5f, 0.1f, c.bnc(u, 2), c.bnc(u, 3), rm, rv, c.s))) return rc;
+            } else {
                 ProfScope prof(PK_BN_STATS, 0, act_bytes(c, u, 1), c.s);
                 if ((rc = vs_bn_stats(dt, c.z(u.out), c.rows(u), u.cout, 1e-5f, 0.1f, c.bnc(u, 2), c.bnc(u, 3), rm, rv,
                                       (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
@@ -464,10 +478,13 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
                 written[u.res] = 1;
             }
             // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
-            ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, (u.relu ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
-            if ((rc = vs_bn_bwd(dt, c.da(u.out), c.a(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), u.relu,
-                                c.dz(u.out), dres, grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u),
-                                u.cout, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            static const bool want_recompute = getenv("VS_RECOMPUTE_MASK") ? atoi(getenv("VS_RECOMPUTE_MASK")) != 0 : false;
+            const bool recompute_mask = want_recompute && u.relu && u.res < 0;  // mask from x: two tensor reads fewer
+            ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, ((u.relu && !recompute_mask) ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
+            if ((rc = vs_bn_bwd_recompute(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
+                                          c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
+                                          grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
+                                          (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             dzp = c.dz(u.out); dz_c = u.cout;
         }
         const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
@@ -516,14 +533,21 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         p.w = c.ws + u.off_wt; p.Cout = u.cin0 + u.cin1;
         if (u.up0) {
             VS_REQUIRE(!written[u.src0] && (u.src1 < 0 || !written[u.src1]), "backward: decoder input gradient written twice");
-            p.out = c.ws + net->off_dup;
             if (u.src1 >= 0) { p.out1 = c.da(u.src1); p.split_c = u.cin0; written[u.src1] = 1; }
-            {
+            if (conv_igemm_can_pool(p)) {  // 2x2 sum of the upsampled part inside the dgrad epilogue
+                p.pool0 = 1;
+                p.out = c.da(u.src0);
                 ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            } else {
+                p.out = c.ws + net->off_dup;
+                {
+                    ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
+                    if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                }
+                ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cin0 * net->esz * 1.25, c.s);
+                if ((rc = vs_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, stream))) return rc;
             }
-            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cin0 * net->esz * 1.25, c.s);
-            if ((rc = vs_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, stream))) return rc;
             written[u.src0] = 1;
         } else {
             p.out = c.da(u.src0);
