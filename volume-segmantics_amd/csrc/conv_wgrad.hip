@@ -250,7 +250,8 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.ctiles = cdiv(p.Cout, 16 * WO);
     g.cchunks = cdiv(Cin, CK);
     g.total_tiles = p.N * g.tiles_h * g.tiles_w;
-    // fp32 slab traffic is nsplit * |dw| written + read: keep the grid near `target` workgroups, not more
+    // split-K policy (measured on MI355X, batch 32): ~512 workgroups per launch is the sweet spot between latency
+    // hiding and the fp32 slab traffic (nsplit * |dw| written once, read once); 256 / 1024 / byte budgets all lose
     static const int target = getenv("VS_WGRAD_TARGET") ? atoi(getenv("VS_WGRAD_TARGET")) : 512;
     int want = target / (g.ctiles * g.cchunks);
     if (want < 1) want = 1;

@@ -5,12 +5,16 @@
 //
 // Semantics = torch.nn.BatchNorm2d defaults used by smp/torchvision: eps 1e-5, momentum 0.1,
 // biased variance for normalisation, unbiased variance for the running estimate.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int kVec = 8;  // channels per thread (C is always a multiple of 8 in this network)
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 2048;
+static int g_bn_blocks = getenv("VS_BN_BLOCKS") ? atoi(getenv("VS_BN_BLOCKS")) : 1024;
+static int g_bn_iters = getenv("VS_BN_ITERS") ? atoi(getenv("VS_BN_ITERS")) : 4;
 
 struct RowMap {
     int cv;       // channel vectors per row = C / 8
@@ -25,8 +29,8 @@ RowMap make_rowmap(int64_t rows, int c) {
     if (m.cv > 256) m.cv = 256;  // C <= 2048
     m.rpb = 256 / m.cv;
     int64_t iters = (rows + m.rpb - 1) / m.rpb;
-    int64_t nb = (iters + 3) / 4;  // >= 4 iterations per block when possible
-    if (nb > kMaxBlocks) nb = kMaxBlocks;
+    int64_t nb = (iters + g_bn_iters - 1) / g_bn_iters;  // >= g_bn_iters iterations per block when possible
+    if (nb > g_bn_blocks) nb = g_bn_blocks;
     if (nb < 1) nb = 1;
     m.nblocks = (int)nb;
     int64_t ipb = (iters + nb - 1) / nb;
@@ -77,20 +81,31 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// one 256-thread block per channel: threads stride over the per-block partials, fp64 wave butterflies, 4 waves meet in LDS
+__device__ __forceinline__ void block_sum2_f64(double& s, double& q) {
+    __shared__ double red[2][4];
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x,
-                                                        int nblocks, int c, int64_t rows, float eps, float momentum,
-                                                        float* mean, float* invstd, float* running_mean,
-                                                        float* running_var) {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x,
+                                                         int nblocks, int c, int64_t rows, float eps, float momentum,
+                                                         float* mean, float* invstd, float* running_mean,
+                                                         float* running_var) {
+    const int ch = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
         s += (double)partial[((size_t)b * 2 + 0) * c + ch];
         q += (double)partial[((size_t)b * 2 + 1) * c + ch];
     }
-    s = wave_sum_f64(s);
-    q = wave_sum_f64(q);
-    if (lane != 0) return;
+    block_sum2_f64(s, q);
+    if (threadIdx.x != 0) return;
     const double dm = s / (double)rows;  // mean of (x - K)
     double var = q / (double)rows - dm * dm;
     if (var < 0.0) var = 0.0;
@@ -201,17 +216,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, 
     }
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int c,
-                                                      float* dgamma, float* dbeta) {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int c,
+                                                       float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
         s += (double)partial[((size_t)b * 2 + 0) * c + ch];
         q += (double)partial[((size_t)b * 2 + 1) * c + ch];
     }
-    s = wave_sum_f64(s);
-    q = wave_sum_f64(q);
-    if (lane == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
+    block_sum2_f64(s, q);
+    if (threadIdx.x == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
 }
 
 template <typename T, bool RECOMPUTE>
@@ -274,7 +288,7 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
     RowMap m = make_rowmap(rows, c);
     hipLaunchKernelGGL(bn_stats_partial<T>, dim3(m.nblocks), dim3(256), 0, s, (const T*)x, rows, c, m, ws);
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize<T>, dim3(c), dim3(64), 0, s, ws, (const T*)x, m.nblocks, c, rows, eps,
+    hipLaunchKernelGGL(bn_stats_finalize<T>, dim3(c), dim3(256), 0, s, ws, (const T*)x, m.nblocks, c, rows, eps,
                        momentum, mean, invstd, rm, rv);
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -284,7 +298,7 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
 
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s) {
-    hipLaunchKernelGGL(bn_stats_finalize<float>, dim3(c), dim3(64), 0, s, partial, (const float*)nullptr, nparts, c, rows, eps,
+    hipLaunchKernelGGL(bn_stats_finalize<float>, dim3(c), dim3(256), 0, s, partial, (const float*)nullptr, nparts, c, rows, eps,
                        momentum, mean, invstd, running_mean, running_var);
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -347,7 +361,7 @@ extern "C" int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, con
     if (dtype == VS_BF16) { if (rc) VS_BWD_PARTIAL(bf16_t, true); else VS_BWD_PARTIAL(bf16_t, false); }
     else { if (rc) VS_BWD_PARTIAL(float, true); else VS_BWD_PARTIAL(float, false); }
     VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(64), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
     if (dtype == VS_BF16) { if (rc) VS_BWD_APPLY(bf16_t, true); else VS_BWD_APPLY(bf16_t, false); }
     else { if (rc) VS_BWD_APPLY(float, true); else VS_BWD_APPLY(float, false); }

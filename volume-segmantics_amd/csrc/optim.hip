@@ -51,6 +51,51 @@ __global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict
     }
 }
 
+// all layers in ONE launch: the descriptor table travels in the kernel arguments; a block finds its layer by a linear
+// scan over the (<= 64) cumulative block counts
+struct PrepTable {
+    int n;
+    int first_block[65];
+    long w_off[64], wc_off[64], wt_off[64];  // element offset into params; BYTE offsets into the workspace (-1 = none)
+    short cout[64], cin[64], cout_pad[64];
+    unsigned char taps[64];
+};
+
+template <typename T>
+__global__ void weight_prepare_all_kernel(const float* __restrict__ params, char* __restrict__ ws, PrepTable t) {
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < t.n && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
+    const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l];
+    const int cib = (cin + 31) / 32, cob = ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
+    int b = blockIdx.x - t.first_block[l];
+    const int bx = b % cib; b /= cib;
+    const int by = b % cob;
+    const int tap = b / cob;
+    const float* w = params + t.w_off[l];
+    T* wc = t.wc_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wc_off[l]) : nullptr;
+    T* wt = t.wt_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wt_off[l]) : nullptr;
+    const int ci0 = bx * 32, co0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < cout && ci < cin) {
+            v = w[((size_t)co * taps + tap) * cin + ci];
+            if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int ci = ci0 + r, co = co0 + tx;
+            if (ci < cin && co < cout_pad)
+                Elem<T>::st(wt + ((size_t)ci * taps + (taps - 1 - tap)) * cout_pad + co, tile[tx][r]);
+        }
+    }
+}
+
 // dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels) + per-class sums (bias gradient)
 template <typename T>
 __global__ void dlogits_to_nhwc16_kernel(const float* __restrict__ d, T* __restrict__ o, int n, int k, int64_t hw) {
@@ -126,6 +171,28 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
     else
         hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cin,
                            cout_pad);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
+                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
+                              hipStream_t s) {
+    VS_REQUIRE(n <= 64, "weight_prepare_all: too many layers (%d)", n);
+    PrepTable t{};
+    t.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        t.first_block[i] = blocks;
+        t.w_off[i] = w_off[i]; t.wc_off[i] = wc_off[i]; t.wt_off[i] = wt_off[i];
+        t.cout[i] = (short)cout[i]; t.cin[i] = (short)cin[i]; t.cout_pad[i] = (short)cout_pad[i]; t.taps[i] = (unsigned char)taps[i];
+        blocks += cdiv(cin[i], 32) * cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32) * taps[i];
+    }
+    t.first_block[n] = blocks;
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(weight_prepare_all_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t);
+    else
+        hipLaunchKernelGGL(weight_prepare_all_kernel<float>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -16,6 +16,9 @@
 
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s);
+int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
+                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
+                              hipStream_t s);
 int launch_bias_grad(const float* d, float* db, float* partial, int n, int k, int64_t hw, hipStream_t s);
 
 namespace {
@@ -340,17 +343,25 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
     VS_REQUIRE(net && params && bnstate && workspace, "unet_prepare: null pointer");
     Ctx c{net, (char*)workspace, params, const_cast<float*>(bnstate), (hipStream_t)stream, 0};
     ProfScope prof(PK_PREPARE, 0, (double)net->layout.n_params * (4 + net->esz * (training ? 2 : 1)), c.s);
-    for (auto& u : net->units) {
-        if (u.kind == U_CONV || u.kind == U_HEAD) {
-            const int taps = u.k * u.k, cin = u.cin0 + u.cin1;
-            void* wc = net->dtype == VS_BF16 ? (void*)(c.ws + u.off_wc) : nullptr;
-            void* wt = training ? (void*)(c.ws + u.off_wt) : nullptr;
-            if (wc || wt) {
-                int rc = launch_weight_prepare(net->dtype, c.P(u.w_idx), wc, wt, u.cout, taps, cin,
-                                               u.kind == U_HEAD ? 16 : u.cout, c.s);
-                if (rc) return rc;
-            }
+    {   // every conv layer's low-precision copy and flipped/transposed dgrad copy in one launch
+        long w_off[64], wc_off[64], wt_off[64];
+        int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+        for (auto& u : net->units) {
+            if (u.kind != U_CONV && u.kind != U_HEAD) continue;
+            const bool wc = net->dtype == VS_BF16, wt = training != 0;
+            if (!wc && !wt) continue;
+            w_off[nl] = c.t(u.w_idx).offset;
+            wc_off[nl] = wc ? (long)u.off_wc : -1;
+            wt_off[nl] = wt ? (long)u.off_wt : -1;
+            cout[nl] = u.cout; taps[nl] = u.k * u.k; cin[nl] = u.cin0 + u.cin1; cpad[nl] = u.kind == U_HEAD ? 16 : u.cout;
+            ++nl;
         }
+        if (nl) {
+            int rc = launch_weight_prepare_all(net->dtype, params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, c.s);
+            if (rc) return rc;
+        }
+    }
+    for (auto& u : net->units) {
         if (u.bn_idx >= 0 && !training) {  // eval-mode folding from the running statistics
             const float* rm = bnstate + c.t(u.bn_idx + 2).offset;
             const float* rv = bnstate + c.t(u.bn_idx + 3).offset;
