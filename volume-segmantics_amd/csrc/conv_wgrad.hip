@@ -246,18 +246,32 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.tiles_w = cdiv(p.Wout, TW);
     g.PH = (g.TH - 1) * p.stride + p.KH;
     g.PW = (TW - 1) * p.stride + p.KW;
-    WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);
-    g.ctiles = cdiv(p.Cout, 16 * WO);
     g.cchunks = cdiv(Cin, CK);
     g.total_tiles = p.N * g.tiles_h * g.tiles_w;
-    // split-K policy (measured on MI355X, batch 32): ~512 workgroups per launch is the sweet spot between latency
-    // hiding and the fp32 slab traffic (nsplit * |dw| written once, read once); 256 / 1024 / byte budgets all lose
+    // Decomposition policy.  Workgroups = (cout tiles) x (cin chunks) x nsplit.  Splitting K (pixels) costs an fp32 slab
+    // of |dw| bytes per split, written once and read once by the reduce; deep layers (big |dw|, few pixels) have enough
+    // output-dimension parallelism, so they take narrower cout tiles (WO = 2 / 1 waves of 16 couts, the other waves split
+    // K inside the workgroup and meet in LDS) instead of more slabs.
     static const int target = getenv("VS_WGRAD_TARGET") ? atoi(getenv("VS_WGRAD_TARGET")) : 512;
-    int want = target / (g.ctiles * g.cchunks);
-    if (want < 1) want = 1;
-    g.nsplit = want < g.total_tiles ? want : g.total_tiles;
-    const int per = cdiv(g.total_tiles, g.nsplit);
-    g.nsplit = cdiv(g.total_tiles, per);  // no empty splits
+    static const double budget = (getenv("VS_WGRAD_SLAB_MB") ? atof(getenv("VS_WGRAD_SLAB_MB")) : 1.0e9) * 1048576.0;  // default: never trade tile width for slabs (measured slower)
+    const double dw_bytes = (double)p.Cout * p.KH * p.KW * Cin * 4.0;
+    const int wo_max = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);
+    const int BMt = g.TH << g.tw_shift;
+    int best_wo = wo_max, best_ns = 1;
+    double best_slab = 1e30;
+    for (int wo = wo_max; wo >= 1; wo >>= 1) {
+        if ((4 / wo) > BMt / WT<T>::KSTEP) continue;  // not enough K-steps in a tile to feed the K-waves
+        const int base = cdiv(p.Cout, 16 * wo) * g.cchunks;
+        int ns = cdiv(target, base);
+        if (ns > g.total_tiles) ns = g.total_tiles;
+        ns = cdiv(g.total_tiles, cdiv(g.total_tiles, ns));
+        const double slab = ns > 1 ? ns * dw_bytes : 0.0;
+        if (slab <= budget) { best_wo = wo; best_ns = ns; best_slab = slab; break; }
+        if (slab < best_slab) { best_wo = wo; best_ns = ns; best_slab = slab; }
+    }
+    WO = best_wo;
+    g.nsplit = best_ns;
+    g.ctiles = cdiv(p.Cout, 16 * WO);
     g.dys = 16 * WO * (int)sizeof(T) + 16;
     return VS_OK;
 }
@@ -274,8 +288,11 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, p, g);
+    WgradParams q = p;
+    if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
+    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
+    if (g.nsplit == 1) return VS_OK;
     const size_t n = (size_t)p.Cout * NTAPS * (p.C0 + p.C1);
     const int nparts = g.nsplit;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, p.partials, p.dw, n, nparts);
