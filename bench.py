@@ -44,6 +44,17 @@ def synth_batch(batch: int, size: int, classes: int, seed: int):
     return torch.from_numpy(x).unsqueeze(1), torch.from_numpy(lab)
 
 
+def load_traffic(kernel_name: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.json, collected with
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs and the gfx950 FETCH_SIZE x2 correction), or None."""
+    try:
+        with open(REPO / "profiles" / "r1_pmc_traffic.json") as f:
+            t = json.load(f)
+        return t.get(kernel_name)
+    except Exception:
+        return None
+
+
 def dice_loss(output, target, eps=1e-6):
     """DiceLoss(normalization='none') of the reference (data/pytorch3dunet_losses.py:15-41,89-135)."""
     inter = (output * target).sum((0, 2, 3))
@@ -149,6 +160,31 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
             "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs"}
 
 
+def merge_bench(dev, cube: int = 512, reps: int = 11):
+    """The reference's pairwise max-probability merge (_merge_vols_in_mem, vol_seg_2d_predictor.py:90-98) as vs_merge_maxprob on
+    resident volumes: 9 algorithmic bytes per voxel per merge (HBM-bound row B7 of SURVEY.md section 8a)."""
+    from volume_segmantics_amd import _lib
+    n = cube ** 3
+    g = torch.Generator(device=dev).manual_seed(3)
+    l0 = torch.randint(0, 4, (n,), dtype=torch.uint8, device=dev, generator=g)
+    l1 = torch.randint(0, 4, (n,), dtype=torch.uint8, device=dev, generator=g)
+    p0 = torch.rand(n, device=dev, generator=g).half()
+    p1 = torch.rand(n, device=dev, generator=g).half()
+    st = _lib.stream_ptr()
+    _lib.check(_lib.lib.vs_merge_maxprob(_lib.ptr(l0), _lib.ptr(p0), _lib.ptr(l1), _lib.ptr(p1), n, st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(_lib.lib.vs_merge_maxprob(_lib.ptr(l0), _lib.ptr(p0), _lib.ptr(l1), _lib.ptr(p1), n, st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 9.0 * n / (ms * 1e-3) / 1e9
+    return {"kernel": "merge_maxprob_kernel", "voxels": n, "ms_per_merge": round(ms, 4), "algorithmic_bytes_per_voxel": 9,
+            "achieved_gbs": round(gbs, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "eleven_merges_ms": round(ms * 11, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +259,10 @@ def main():
 
     # ---- roofline block: per-kernel-class HIP-event timing of the same step (separate, instrumented steps) ----
     prof_steps = 3
+    side = _lib.lib.vs_get_option(b"side_stream")
+    _lib.set_option("side_stream", 0)   # one kernel at a time: clean per-kernel durations (the timed region above overlaps)
+    step()
+    torch.cuda.synchronize()
     _lib.check(_lib.lib.vs_profile_enable(1))
     for _ in range(prof_steps):
         step()
@@ -230,10 +270,11 @@ def main():
     prof = _lib.profile_read()
     raw = _lib.profile_read_raw()
     _lib.check(_lib.lib.vs_profile_enable(0))
+    _lib.set_option("side_stream", side)
     if rank == 0 and args.per_unit:
         names = _lib.unit_names(model._plans[(256, 256)]["handle"])
         agg = {}
-        for kind, tag, ms, fl, by in raw:
+        for kind, tag, ms, fl, by, _var in raw:
             a = agg.setdefault((kind, tag), [0.0, 0.0, 0.0])
             a[0] += ms / prof_steps; a[1] += fl / prof_steps; a[2] += by / prof_steps
         rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
@@ -254,13 +295,24 @@ def main():
         log("predict: 512^3 12 directions")
         predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 16)
         log("predict done")
+        if rank == 0:
+            predict["merge_512cube"] = merge_bench(dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         slices_per_s = args.batch * world * args.steps / elapsed
         mfma_kinds = ("conv_fwd", "conv_dgrad", "conv_wgrad")
-        dom = max(mfma_kinds, key=lambda k: prof[k]["ms"])
-        ach = prof[dom]["flops"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else 0.0
+        # dominant kernel symbol: forward and dgrad share conv_igemm_kernel<T,BN,PT,TAPS,STRIDE>; group its launches by instantiation
+        byvar = {}
+        for kind, tag, ms, fl, by, var in raw:
+            if kind in ("conv_fwd", "conv_dgrad") and var:
+                v = byvar.setdefault(var, [0.0, 0.0, 0])
+                v[0] += ms; v[1] += fl; v[2] += 1
+        dvar = max(byvar, key=lambda k: byvar[k][0])
+        tname = "unsigned short" if args.precision == "bf16" else "float"
+        dom_name = f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {dvar % 10}>"
+        dom_ms, dom_fl, dom_calls = byvar[dvar]
+        ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         conv_ms = sum(prof[k]["ms"] for k in mfma_kinds) / prof_steps
         conv_fl = sum(prof[k]["flops"] for k in mfma_kinds) / prof_steps
         breakdown = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["calls"] // prof_steps,
@@ -277,12 +329,14 @@ def main():
                        "global_batch": args.batch * world, "slice": "256x256", "parallelism": f"dp{world}",
                        "master_weights": "fp32", "final_loss": round(final_loss, 5)},
             "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "launches_per_step": prof[dom]["calls"] // prof_steps,
-                         "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["calls"]), 5),
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(dom_name),
+                         "launches_per_step": dom_calls // prof_steps,
+                         "avg_launch_ms": round(dom_ms / max(1, dom_calls), 5),
+                         "algorithmic_gflop_per_launch": round(dom_fl / max(1, dom_calls) / 1e9, 3),
                          "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else 0.0,
-                         "note": "algorithmic conv FLOPs of the class / HIP-event time of its launches, instrumented steps"},
+                         "note": "sum of algorithmic conv FLOPs of this kernel's launches / sum of their HIP-event durations, "
+                                 "3 serialised instrumented steps (side stream off); the timed region overlaps wgrad on a side stream"},
             "kernel_classes": breakdown,
             **predict,
         }

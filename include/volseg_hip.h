@@ -7,8 +7,9 @@
  * by the max-probability merges (vol_seg_2d_predictor.py:90-98).  Every entry point below
  * cites the reference lines it replaces.  All pointers are DEVICE pointers unless named
  * ``host_*``; all activations are NHWC; nothing here allocates device memory or copies
- * host<->device; all work is enqueued on the caller's HIP stream (``void* stream`` is a
- * hipStream_t).  Functions return VS_OK (0) or a negative error code; the message is
+ * host<->device; all work is ordered on the caller's HIP stream (``void* stream`` is a
+ * hipStream_t; vs_unet_backward forks its weight-gradient kernels onto an internal side
+ * stream and joins it back with events before returning, so stream order is preserved).  Functions return VS_OK (0) or a negative error code; the message is
  * available from vs_last_error() (thread local).
  */
 #ifndef VOLSEG_HIP_H
@@ -145,7 +146,11 @@ int vs_profile_num_kinds(void);
 const char* vs_profile_kind_name(int kind);
 int vs_profile_read(double* ms, double* flops, double* bytes, int64_t* calls);
 /* raw records in launch order (tag = unit index inside the network plan); returns the count or -1 */
-int vs_profile_read_raw(int max_n, int* kind, int* tag, double* ms, double* flops, double* bytes);
+int vs_profile_read_raw(int max_n, int* kind, int* tag, int* variant, double* ms, double* flops, double* bytes);
+/* Runtime options: "side_stream" (1), "wgrad_target" (256), "conv_min_wgs" (512), "fuse_stats" (1),
+ * "recompute_mask" (0); initial values can come from the environment as VS_<NAME>. */
+int vs_set_option(const char* name, int value);
+int vs_get_option(const char* name);
 
 /* AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, vol_seg_2d_trainer.py:395-396,430);
  * ``mask`` (uint8 per element, may be null) = 0 freezes an element (requires_grad False). */

@@ -74,7 +74,9 @@ _SIGS = {
     "vs_profile_num_kinds": (I, []),
     "vs_profile_kind_name": (C.c_char_p, [I]),
     "vs_profile_read": (I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(I64)]),
-    "vs_profile_read_raw": (I, [I, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vs_profile_read_raw": (I, [I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vs_set_option": (I, [C.c_char_p, I]),
+    "vs_get_option": (I, [C.c_char_p]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
@@ -141,13 +143,17 @@ def profile_read():
 
 
 def profile_read_raw(max_n: int = 1 << 16):
-    """[(kind_name, unit_index, ms, flops, bytes)] in launch order."""
-    kind, tag = (I * max_n)(), (I * max_n)()
+    """[(kind_name, unit_index, ms, flops, bytes, variant)] in launch order."""
+    kind, tag, var = (I * max_n)(), (I * max_n)(), (I * max_n)()
     ms, fl, by = (C.c_double * max_n)(), (C.c_double * max_n)(), (C.c_double * max_n)()
-    n = lib.vs_profile_read_raw(max_n, kind, tag, ms, fl, by)
+    n = lib.vs_profile_read_raw(max_n, kind, tag, var, ms, fl, by)
     if n < 0:
         raise RuntimeError("vs_profile_read_raw failed")
-    return [(lib.vs_profile_kind_name(kind[i]).decode(), tag[i], ms[i], fl[i], by[i]) for i in range(n)]
+    return [(lib.vs_profile_kind_name(kind[i]).decode(), tag[i], ms[i], fl[i], by[i], var[i]) for i in range(n)]
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib.vs_set_option(name.encode(), int(value)))
 
 
 def unit_names(handle) -> list[str]:

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -323,7 +324,7 @@ int choose_bn(const ConvParams& p) {
     int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
     // small grids (deep, low-resolution layers): one 64-wide workgroup per CU cannot hide load latency;
     // 32-wide cout tiles double the workgroups (and halve the weight slab each one stages)
-    static const int min_wgs = getenv("VS_CONV_MIN_WGS") ? atoi(getenv("VS_CONV_MIN_WGS")) : 512;
+    const int min_wgs = vs_option("conv_min_wgs");
     if (BN == 64) {
         const int pt = choose_pt(p, 64);
         const int tw = p.Wout >= 16 ? 16 : 8, th = 64 * pt / tw;
@@ -377,6 +378,13 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
 bool conv_igemm_can_pool(const ConvParams& p) {
     const int BN = choose_bn(p);
     return choose_pt(p, BN) >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);
+}
+
+// instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + stride (dtype independent)
+int conv_igemm_variant(int dtype, const ConvParams& p) {
+    (void)dtype;
+    const int BN = choose_bn(p), PT = choose_pt(p, BN);
+    return BN * 1000 + PT * 100 + (p.KH * p.KW) * 10 + ((PT == 1 && p.stride == 2) ? 2 : 1);
 }
 
 int conv_igemm_stat_rows(const ConvParams& p) {

@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -252,7 +253,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     // of |dw| bytes per split, written once and read once by the reduce; deep layers (big |dw|, few pixels) have enough
     // output-dimension parallelism, so they take narrower cout tiles (WO = 2 / 1 waves of 16 couts, the other waves split
     // K inside the workgroup and meet in LDS) instead of more slabs.
-    static const int target = getenv("VS_WGRAD_TARGET") ? atoi(getenv("VS_WGRAD_TARGET")) : 512;
+    const int target = vs_option("wgrad_target");
     static const double budget = (getenv("VS_WGRAD_SLAB_MB") ? atof(getenv("VS_WGRAD_SLAB_MB")) : 1.0e9) * 1048576.0;  // default: never trade tile width for slabs (measured slower)
     const double dw_bytes = (double)p.Cout * p.KH * p.KW * Cin * 4.0;
     const int wo_max = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);

@@ -75,19 +75,50 @@ __global__ void logits_to_volume_kernel(const float* __restrict__ logits, int cl
     }
 }
 
-__global__ void merge_maxprob_kernel(uint8_t* __restrict__ l0, uint16_t* __restrict__ p0, const uint8_t* __restrict__ l1,
-                                     const uint16_t* __restrict__ p1, int64_t n) {
+// 16 voxels per thread: 16-byte label loads/stores, 2 x 16-byte probability loads/stores per operand.
+// Algorithmic traffic 9 B / voxel (read 2 x (u8 + f16), write u8 + f16) - HBM-bound.
+__global__ __launch_bounds__(256) void merge_maxprob_kernel(uint8_t* __restrict__ l0, uint16_t* __restrict__ p0,
+                                                          const uint8_t* __restrict__ l1, const uint16_t* __restrict__ p1,
+                                                          int64_t n) {
     // np.argmax over the 2 slots: slot 1 wins only when strictly greater (ties keep slot 0)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nvec = n / 16;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        uint4 la = reinterpret_cast<const uint4*>(l0)[v];
+        const uint4 lb = reinterpret_cast<const uint4*>(l1)[v];
+        uint4 pa[2] = {reinterpret_cast<const uint4*>(p0)[2 * v], reinterpret_cast<const uint4*>(p0)[2 * v + 1]};
+        const uint4 pb[2] = {reinterpret_cast<const uint4*>(p1)[2 * v], reinterpret_cast<const uint4*>(p1)[2 * v + 1]};
+        uint8_t* la8 = reinterpret_cast<uint8_t*>(&la);
+        const uint8_t* lb8 = reinterpret_cast<const uint8_t*>(&lb);
+        uint16_t* pa16 = reinterpret_cast<uint16_t*>(pa);
+        const uint16_t* pb16 = reinterpret_cast<const uint16_t*>(pb);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float a = __half2float(__builtin_bit_cast(__half, pa16[k]));
+            const float b = __half2float(__builtin_bit_cast(__half, pb16[k]));
+            if (b > a) { pa16[k] = pb16[k]; la8[k] = lb8[k]; }
+        }
+        reinterpret_cast<uint4*>(l0)[v] = la;
+        reinterpret_cast<uint4*>(p0)[2 * v] = pa[0];
+        reinterpret_cast<uint4*>(p0)[2 * v + 1] = pa[1];
+    }
+    // ragged tail
+    for (int64_t i = nvec * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float a = __half2float(__builtin_bit_cast(__half, p0[i]));
         const float b = __half2float(__builtin_bit_cast(__half, p1[i]));
         if (b > a) { p0[i] = p1[i]; l0[i] = l1[i]; }
     }
 }
 
-__global__ void keys_unpack_kernel(const uint32_t* __restrict__ keys, uint8_t* __restrict__ labels,
-                                   uint16_t* __restrict__ probs, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void keys_unpack_kernel(const uint32_t* __restrict__ keys, uint8_t* __restrict__ labels,
+                                                        uint16_t* __restrict__ probs, int64_t n) {
+    const int64_t nvec = n / 4;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 k = reinterpret_cast<const uint4*>(keys)[v];
+        if (labels)
+            reinterpret_cast<uint32_t*>(labels)[v] = (k.x & 0xff) | ((k.y & 0xff) << 8) | ((k.z & 0xff) << 16) | ((k.w & 0xff) << 24);
+        if (probs) reinterpret_cast<uint2*>(probs)[v] = make_uint2((k.x >> 16) | (k.y & 0xffff0000u), (k.z >> 16) | (k.w & 0xffff0000u));
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t k = keys[i];
         if (labels) labels[i] = (uint8_t)(k & 0xff);
         if (probs) probs[i] = (uint16_t)(k >> 16);
@@ -151,7 +182,9 @@ extern "C" int vs_merge_maxprob(uint8_t* label0, uint16_t* prob0, const uint8_t*
                                 int64_t n, void* stream) {
     VS_REQUIRE(label0 && prob0 && label1 && prob1 && n >= 0, "merge_maxprob: bad arguments");
     if (n == 0) return VS_OK;
-    hipLaunchKernelGGL(merge_maxprob_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, label0, prob0, label1, prob1, n);
+    VS_REQUIRE(((uintptr_t)label0 | (uintptr_t)label1 | (uintptr_t)prob0 | (uintptr_t)prob1) % 16 == 0,
+               "merge_maxprob: volumes must be 16-byte aligned");
+    hipLaunchKernelGGL(merge_maxprob_kernel, dim3(grid_for(n / 16 + 1)), dim3(256), 0, (hipStream_t)stream, label0, prob0, label1, prob1, n);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -159,7 +192,7 @@ extern "C" int vs_merge_maxprob(uint8_t* label0, uint16_t* prob0, const uint8_t*
 extern "C" int vs_keys_unpack(const uint32_t* keys, uint8_t* labels, uint16_t* probs, int64_t n, void* stream) {
     VS_REQUIRE(keys && n >= 0, "keys_unpack: bad arguments");
     if (n == 0) return VS_OK;
-    hipLaunchKernelGGL(keys_unpack_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, keys, labels, probs, n);
+    hipLaunchKernelGGL(keys_unpack_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, keys, labels, probs, n);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

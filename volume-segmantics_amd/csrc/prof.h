@@ -19,6 +19,8 @@ bool prof_on();
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
 void prof_set_tag(int tag);  // attached to subsequent records (unit index)
+void prof_set_variant(int v);  // kernel instantiation code of the next records (0 = n/a)
+int vs_option(const char* name);  // runtime option (vs_set_option / environment VS_<NAME>)
 
 struct ProfScope {
     hipStream_t s;

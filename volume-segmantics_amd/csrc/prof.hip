@@ -1,12 +1,14 @@
 #include "prof.h"
 
+#include <cctype>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
 
 namespace {
-struct Rec { int kind, tag; double flops, bytes; hipEvent_t e0, e1; };
-int g_tag = -1;
+struct Rec { int kind, tag, variant; double flops, bytes; hipEvent_t e0, e1; };
+int g_tag = -1, g_variant = 0;
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -25,23 +27,24 @@ const char* kNames[PK_COUNT] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "stem", 
 
 bool prof_on() { return g_on; }
 void prof_begin(int kind, double flops, double bytes, hipStream_t s) {
-    Rec r{kind, g_tag, flops, bytes, get_event(), get_event()};
+    Rec r{kind, g_tag, g_variant, flops, bytes, get_event(), get_event()};
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 
 void prof_set_tag(int tag) { g_tag = tag; }
+void prof_set_variant(int v) { g_variant = v; }
 
 // raw records (kind, tag = unit index, ms, flops, bytes) in launch order; returns the number written
-extern "C" int vs_profile_read_raw(int max_n, int* kind, int* tag, double* ms, double* flops, double* bytes) {
+extern "C" int vs_profile_read_raw(int max_n, int* kind, int* tag, int* variant, double* ms, double* flops, double* bytes) {
     int n = 0;
     for (auto& r : g_recs) {
         if (n >= max_n) break;
         if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
         float t = 0;
         if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
-        kind[n] = r.kind; tag[n] = r.tag; ms[n] = t; flops[n] = r.flops; bytes[n] = r.bytes;
+        kind[n] = r.kind; tag[n] = r.tag; variant[n] = r.variant; ms[n] = t; flops[n] = r.flops; bytes[n] = r.bytes;
         ++n;
     }
     return n;
@@ -66,3 +69,30 @@ extern "C" int vs_profile_read(double* ms, double* flops, double* bytes, int64_t
     }
     return VS_OK;
 }
+
+// ---- runtime options (defaults can also come from the environment: VS_<NAME>) -----------------------------------------
+namespace {
+struct Opt { const char* name; int value; bool init; };
+Opt g_opts[] = {{"side_stream", 1, false}, {"wgrad_target", 256, false}, {"conv_min_wgs", 512, false},
+                {"fuse_stats", 1, false}, {"recompute_mask", 0, false}};
+}
+int vs_option(const char* name) {
+    for (auto& o : g_opts) {
+        if (strcmp(o.name, name)) continue;
+        if (!o.init) {
+            char env[64] = "VS_";
+            for (size_t i = 0; name[i] && i < 50; ++i) env[3 + i] = (char)toupper(name[i]), env[4 + i] = 0;
+            if (const char* e = getenv(env)) o.value = atoi(e);
+            o.init = true;
+        }
+        return o.value;
+    }
+    return 0;
+}
+extern "C" int vs_set_option(const char* name, int value) {
+    for (auto& o : g_opts)
+        if (!strcmp(o.name, name)) { o.value = value; o.init = true; return VS_OK; }
+    vs_set_error("unknown option %s", name);
+    return VS_ERR_INVALID;
+}
+extern "C" int vs_get_option(const char* name) { return vs_option(name); }

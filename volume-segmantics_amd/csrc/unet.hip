@@ -93,6 +93,18 @@ struct vs_unet {
            off_zs = 0, off_idx = 0;
     size_t ws_eval = 0, ws_train = 0;
     int last_n = 0;
+    // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
+    static constexpr int kSide = 2;
+    hipStream_t side[kSide] = {nullptr, nullptr};
+    std::vector<hipEvent_t> fork_events;
+    hipEvent_t join_event[kSide] = {nullptr, nullptr};
+    ~vs_unet() {
+        for (auto e : fork_events) (void)hipEventDestroy(e);
+        for (int i = 0; i < kSide; ++i) {
+            if (join_event[i]) (void)hipEventDestroy(join_event[i]);
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+        }
+    }
 };
 
 namespace {
@@ -220,7 +232,7 @@ size_t plan_workspace(vs_unet* net) {
         if (b > wg) wg = b;
     }
     net->wgws_bytes = wg;
-    net->off_wgws = take(wg);
+    net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
     net->off_headdw = take(16 * 9 * 16 * sizeof(float));
     net->off_dyh = take(N * net->h * net->w * 16 * esz);
     size_t dup = 0, zs = 0;
@@ -405,11 +417,12 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
         }
         case U_CONV: {
             ConvParams p = conv_params(c, u);
+            prof_set_variant(conv_igemm_variant(dt, p));
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
+            prof_set_variant(0);
             if (training) {
                 p.out = c.z(u.out);
-                static const bool fuse_stats = getenv("VS_FUSE_STATS") ? atoi(getenv("VS_FUSE_STATS")) != 0 : true;
-                if (dt == VS_BF16 && fuse_stats) {  // batch statistics straight from the fp32 accumulators
+                if (dt == VS_BF16 && vs_option("fuse_stats")) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(p);
                     if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
@@ -461,6 +474,30 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
     int rc;
     std::vector<char> written(net->acts.size(), 0);
     float* wgws = (float*)(c.ws + net->off_wgws);
+    const int n_side = vs_option("side_stream");  // 0 = everything in order on the caller's stream
+    const bool use_side = n_side > 0;
+    hipStream_t ws_stream = c.s;  // stream of the current unit's weight-gradient work
+    if (use_side) {
+        for (int i = 0; i < vs_unet::kSide; ++i) {
+            if (net->side[i]) continue;
+            VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+            VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
+        }
+        while (net->fork_events.size() < net->units.size()) {
+            hipEvent_t e;
+            VS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            net->fork_events.push_back(e);
+        }
+    }
+    auto fork = [&](int ui) -> int {  // everything enqueued on the caller's stream so far happens-before the side work
+        if (!use_side) return VS_OK;
+        const int k = n_side >= 2 ? (ui & 1) : 0;
+        ws_stream = net->side[k];
+        wgws = (float*)(c.ws + net->off_wgws + (size_t)k * net->wgws_bytes);
+        VS_CHECK_HIP(hipEventRecord(net->fork_events[ui], c.s));
+        VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
+        return VS_OK;
+    };
     for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
@@ -489,8 +526,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
                 written[u.res] = 1;
             }
             // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
-            static const bool want_recompute = getenv("VS_RECOMPUTE_MASK") ? atoi(getenv("VS_RECOMPUTE_MASK")) != 0 : false;
-            const bool recompute_mask = want_recompute && u.relu && u.res < 0;  // mask from x: two tensor reads fewer
+            const bool recompute_mask = vs_option("recompute_mask") && u.relu && u.res < 0;  // mask from x: two tensor reads fewer
             ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, ((u.relu && !recompute_mask) ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
             if ((rc = vs_bn_bwd_recompute(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
                                           c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
@@ -500,17 +536,19 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         }
         const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
         if (u.kind == U_STEM) {  // no data gradient: the input image needs none
-            ProfScope prof(PK_STEM, want_w ? 2.0 * n * u.hout * u.wout * 64 * 49 : 0, 0, c.s);
+            if ((rc = fork(ui))) return rc;
+            ProfScope prof(PK_STEM, want_w ? 2.0 * n * u.hout * u.wout * 64 * 49 : 0, 0, ws_stream);
             if (want_w) {
-                if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, stream))) return rc;
+                if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, (void*)ws_stream))) return rc;
             } else {
-                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), c.s));
+                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
             }
             continue;
         }
         // ---- weight gradient ----
+        if ((rc = fork(ui))) return rc;
         if (want_w) {
-            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, c.s);
+            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
             WgradParams p{};
             p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
             p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
@@ -519,16 +557,16 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
             if (u.kind == U_HEAD) {
                 p.dw = (float*)(c.ws + net->off_headdw);
-                if ((rc = launch_conv_wgrad(dt, p, c.s))) return rc;
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
                 VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
-                                            hipMemcpyDeviceToDevice, c.s));
+                                            hipMemcpyDeviceToDevice, ws_stream));
             } else {
                 p.dw = grads + c.t(u.w_idx).offset;
-                if ((rc = launch_conv_wgrad(dt, p, c.s))) return rc;
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
             }
         } else {
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
-                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), c.s));
+                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
         }
         // ---- data gradient ----
         ConvParams p{};
@@ -548,7 +586,9 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
             if (conv_igemm_can_pool(p)) {  // 2x2 sum of the upsampled part inside the dgrad epilogue
                 p.pool0 = 1;
                 p.out = c.da(u.src0);
+                prof_set_variant(conv_igemm_variant(dt, p));
                 ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
+                prof_set_variant(0);
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             } else {
                 p.out = c.ws + net->off_dup;
@@ -563,9 +603,17 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         } else {
             p.out = c.da(u.src0);
             p.residual = written[u.src0] ? c.da(u.src0) : nullptr;
+            prof_set_variant(conv_igemm_variant(dt, p));
             ProfScope prof(PK_CONV_DGRAD, u.kind == U_HEAD ? 2.0 * n * u.hout * u.wout * net->classes * 9 * 16 : conv_flops(c, u), 0, c.s);
+            prof_set_variant(0);
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             written[u.src0] = 1;
+        }
+    }
+    if (use_side) {  // join: the caller's stream continues only after every weight gradient is in place
+        for (int i = 0; i < vs_unet::kSide; ++i) {
+            VS_CHECK_HIP(hipEventRecord(net->join_event[i], net->side[i]));
+            VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->join_event[i], 0));
         }
     }
     return VS_OK;
