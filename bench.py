@@ -128,17 +128,21 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
     from volume_segmantics_amd.engine import VolSegUnet
     from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
     model = VolSegUnet(classes, device=dev, precision=precision, seed=1)
-    with torch.no_grad():  # non-trivial BN statistics
-        model._bnstate.uniform_(0.5, 1.5)
+    with torch.no_grad():  # random-init networks collapse onto one class: centre the head bias on a few slices
+        model.eval()
+        probe = torch.randn(4, 1, min(cube, 256), min(cube, 256), device=dev)
+        mean_logit = model(probe).mean(dim=(0, 2, 3))
+        dict(model.named_parameters())["segmentation_head.0.bias"].sub_(mean_logit)
     if world > 1:
         dist.broadcast(model._flat, 0)
         dist.broadcast(model._bnstate, 0)
     pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
     pred.model, pred.num_labels, pred.label_codes = model, classes, {}
-    pred.settings = SimpleNamespace(cuda_device=dev.index, prediction_batch_size=batch)
+    pred.settings = SimpleNamespace(cuda_device=dev.index, prediction_batch_size=batch, profile_phases=True)
+    pred.result_ranks = "rank0"   # every rank holds the merged keys; only rank 0 ships the volume to the host
     vol = synth_volume(cube, seed=5678 if cube == 512 else 1234)
     fn = {1: pred._predict_single_axis, 3: pred._predict_3_ways_max_probs, 12: pred._predict_12_ways_max_probs}[n_dirs]
-    fn(vol[:32])  # warm-up: plans, workspaces, code objects
+    fn(vol)  # warm-up at full size: plans, workspaces, pinned staging buffers, key volume, code objects
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,11 +156,14 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    if labels is None:
+        labels = np.zeros(1, np.uint8)
     n_slices = n_dirs * cube
     flop = {(256, 2): 15.44e9, (512, 4): 61.92e9}.get((cube, classes), 0.0) * n_slices
     return {"seconds": round(dt, 4), "slices": n_slices, "slices_per_s": round(n_slices / dt, 1),
             "mfma_frac": round(flop / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world, 4), "batch": batch,
             "label_hist": np.bincount(labels.ravel(), minlength=classes).tolist(),
+            "phases_rank0": {k: round(v, 4) for k, v in pred.last_timings.items()},
             "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs"}
 
 
