@@ -232,10 +232,13 @@ def main():
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total + 1, pct_start=0.3)
     model.train()
 
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    criterion = HipDiceLoss()
+
     def step():
         opt.zero_grad()
         out = model(x)
-        loss = dice_loss(out, target)
+        loss = criterion(out, target)
         loss.backward()
         opt.step()
         sched.step()

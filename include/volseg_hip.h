@@ -158,6 +158,16 @@ int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   void* stream);
 
+/* DiceLoss(normalization="none") on raw logits and its gradient (data/pytorch3dunet_losses.py:15-41,89-135; the
+ * trainer's default criterion, vol_seg_2d_trainer.py:133-135,425-428).  logits (n, K, h*w) fp32 NCHW, targets one-hot
+ * (n, K, h*w) uint8 or fp32; loss: 1 device float; workspace (vs_dice_workspace bytes) carries the per-class sums from
+ * the forward to the backward; grad_out: device scalar d(total)/d(loss) or NULL (= 1). */
+size_t vs_dice_workspace(int classes);
+int vs_dice_loss_fwd(const float* logits, const void* targets, int target_is_f32, int n, int classes, int64_t hw, float eps,
+                     float* loss, float* workspace, size_t workspace_bytes, void* stream);
+int vs_dice_loss_bwd(const float* logits, const void* targets, int target_is_f32, const float* grad_out, int n, int classes,
+                     int64_t hw, float eps, const float* workspace, float* dlogits, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Prediction path (vol_seg_2d_predictor.py:31-136)
  * ---------------------------------------------------------------------------------------- */

@@ -333,3 +333,22 @@ def test_adamw_matches_torch():
     sync()
     frozen = mask == 0
     assert torch.equal(p.cpu()[frozen], before.cpu()[frozen]) and not torch.equal(p.cpu()[~frozen], before.cpu()[~frozen])
+
+
+@pytest.mark.parametrize("classes,tdtype", [(2, torch.uint8), (4, torch.float32), (1, torch.uint8)])
+def test_fused_dice_loss_matches_reference_formula(classes, tdtype):
+    """vs_dice_loss_fwd/_bwd against the torch restatement of DiceLoss(normalization='none') (pinned to the reference by G6)."""
+    from oracle import predictor_numpy as P
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    g = torch.Generator().manual_seed(20)
+    x = torch.randn(3, classes, 40, 56, generator=g, requires_grad=True)
+    lab = torch.randint(0, max(classes, 2), (3, 40, 56), generator=g)
+    t = torch.nn.functional.one_hot(lab, max(classes, 2)).permute(0, 3, 1, 2)[:, :classes].contiguous()
+    ref = P.dice_loss_none(x, t.float())
+    (ref * 1.7).backward()
+    xd = x.detach().to(DEV).requires_grad_()
+    loss = HipDiceLoss()(xd, t.to(DEV, tdtype))
+    (loss * 1.7).backward()
+    sync()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert torch.allclose(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-9)

@@ -78,6 +78,9 @@ _SIGS = {
     "vs_set_option": (I, [C.c_char_p, I]),
     "vs_get_option": (I, [C.c_char_p]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
+    "vs_dice_workspace": (SZ, [I]),
+    "vs_dice_loss_fwd": (I, [P, P, I, I, I, I64, F, P, P, SZ, P]),
+    "vs_dice_loss_bwd": (I, [P, P, I, P, I, I, I64, F, P, P, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
     "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),

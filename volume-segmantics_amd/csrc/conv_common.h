@@ -1,0 +1,149 @@
+// Pieces shared by the convolution kernels (register-staged conv_igemm.hip and LDS-DMA conv_igemm_dma.hip).
+#pragma once
+#include "common.h"
+
+template <typename T> struct CT;
+template <> struct CT<bf16_t> { static constexpr int CK = 32, EPS = 8; };
+template <> struct CT<float> { static constexpr int CK = 16, EPS = 4; };
+
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b) {
+    if constexpr (sizeof(T) == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    } else {
+        // lane (l>>4)=q holds channels 4q..4q+3 of the chunk for both operands: step s pairs element s
+        const float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+}
+
+
+// Epilogue of an implicit-GEMM tile: lane (lq, lr) of wave `wave` holds, for pixel tile i and cout tile j, the 4 output
+// channels n0 + 16j + 4lq .. +3 of pixel  wave*PT*16 + 16i + lr  of the TH x TW patch at (n, h0, w0).
+// Optional: per-channel sum / sum-of-squares partials of the raw accumulators (row `tile` of p.stats_partial), fused
+// affine + residual + ReLU, split output (dgrad through a concat), 2x2 sum-pool (dgrad through nearest x2 upsampling),
+// fp32 / NCHW stores (segmentation head).  `smem` must provide 8*BN floats that no wave is reading any more.
+template <typename T, int BN, int PT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift, int out_nchw, int n, int h0, int w0, int n0,
+                                              int tile, f32x4 (&acc)[PT][BN / 16], char* smem) {
+    constexpr int NJ = BN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int TW = 1 << tw_shift;
+    struct { int tw_shift, out_nchw; } g{tw_shift, out_nchw};
+    // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
+    const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
+    // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
+    if (p.stats_partial) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+        __syncthreads();                               // staged tiles are dead
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int pl = wave * (PT * 16) + i * 16 + lr;
+                const bool ok = h0 + (pl >> g.tw_shift) < p.Hout && w0 + (pl & (TW - 1)) < p.Wout;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = ok ? acc[i][j][r] : 0.f;
+                    s1[r] += x; s2[r] += x * x;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+            }
+            if (lr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wave * 2 + 0) * BN + j * 16 + lq * 4 + r] = s1[r];
+                    red[(wave * 2 + 1) * BN + j * 16 + lq * 4 + r] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, cc = tid % BN;
+            if (n0 + cc < p.Cout)
+                p.stats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] =
+                    (red[(0 * 2 + k) * BN + cc] + red[(1 * 2 + k) * BN + cc]) + (red[(2 * 2 + k) * BN + cc] + red[(3 * 2 + k) * BN + cc]);
+        }
+    }
+    // (2) outputs
+    const int pool_c = p.pool0 ? (p.out1 ? p.split_c : p.Cout) : 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = n0 + j * 16 + lq * 4;
+        if (PT >= 2 && c < pool_c) {
+            // dgrad through nearest-x2 upsampling: sum the 2x2 block (rows i, i+1 of this wave; lanes lr, lr^1)
+            if constexpr (PT >= 2) {
+#pragma unroll
+                for (int ip = 0; ip < PT / 2; ++ip) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[2 * ip][j][r] + acc[2 * ip + 1][j][r];
+                        v[r] += __shfl_xor(v[r], 1, 64);
+                    }
+                    const int ho = h0 + wave * PT + 2 * ip, wo = w0 + lr;
+                    if ((lr & 1) == 0 && ho < p.Hout && wo < p.Wout && c < p.Cout) {
+                        const size_t o = (((size_t)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1)) * pool_c + c;
+                        st4((T*)p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int pl = wave * (PT * 16) + i * 16 + lr;
+            const int ho = h0 + (pl >> g.tw_shift), wo = w0 + (pl & (TW - 1));
+            if (ho >= p.Hout || wo >= p.Wout || c >= p.Cout) continue;
+            const size_t pix = ((size_t)n * p.Hout + ho) * p.Wout + wo;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (!ragged) {
+                if (p.scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                } else if (p.shift) {
+                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                    v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+                }
+                // destination (possibly split across two tensors: dgrad through a channel concat)
+                char* dst = (char*)p.out;
+                int cd = c, cstride = p.Cout;
+                if (p.out1) {
+                    if (c >= p.split_c) { dst = (char*)p.out1; cd = c - p.split_c; cstride = p.Cout - p.split_c; }
+                    else cstride = p.split_c;
+                }
+                const size_t o = pix * cstride + cd;
+                if (p.residual && dst == (char*)p.out) {
+                    const float4 rv = ld4((const T*)p.residual + o);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.out_f32) st4((float*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
+                else st4((T*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+                const int nv = min(4, p.Cout - c);
+                for (int r = 0; r < nv; ++r) {
+                    float x = v[r];
+                    if (p.scale) x = x * p.scale[c + r] + p.shift[c + r];
+                    else if (p.shift) x += p.shift[c + r];
+                    if (p.residual) x += Elem<T>::ld((const T*)p.residual + pix * p.Cout + c + r);
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (g.out_nchw) ((float*)p.out)[(((size_t)n * p.Cout + c + r) * p.Hout + ho) * p.Wout + wo] = x;
+                    else if (p.out_f32) ((float*)p.out)[pix * p.Cout + c + r] = x;
+                    else Elem<T>::st((T*)p.out + pix * p.Cout + c + r, x);
+                }
+            }
+        }
+    }
+}

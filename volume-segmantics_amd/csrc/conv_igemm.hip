@@ -19,33 +19,16 @@
 // folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
 #include <cstdlib>
 
-#include "common.h"
+#include "conv_common.h"
 #include "prof.h"
 
 namespace {
 
-constexpr int kPS = 96;  // LDS bytes per staged pixel / weight row: 64 data + 32 pad. With gfx950's ds_read_b128 lane groups
-                         // ({0-3,12-15,20-27}, ...) a 96-byte stride puts the 16 lanes of a group on 16 distinct 16-byte slots
-                         // (80 bytes is 2-way conflicted: tools/lds_bank_sim.py)
-
-template <typename T> struct CT;
-template <> struct CT<bf16_t> { static constexpr int CK = 32, EPS = 8; };
-template <> struct CT<float> { static constexpr int CK = 16, EPS = 4; };
-
-template <typename T>
-__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b) {
-    if constexpr (sizeof(T) == 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                      acc, 0, 0, 0);
-    } else {
-        // lane (l>>4)=q holds channels 4q..4q+3 of the chunk for both operands: step s pairs element s
-        const float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc, 0, 0, 0);
-    }
-}
+constexpr int kPS = 64;  // LDS bytes per staged pixel / weight row: unpadded; the 16-byte segment s of row r lives in slot
+                         // s ^ ((r >> 1) & 3).  With gfx950's ds_read_b128 lane groups this XOR makes the fragment reads
+                         // conflict-free for every row alignment (tools/lds_bank_sim.py; 80-byte padded rows are 2-way
+                         // conflicted, 96-byte ones conflict-free but 50 % bigger)
+__device__ __forceinline__ int swz(int row, int seg) { return row * kPS + ((seg ^ ((row >> 1) & 3)) << 4); }
 
 struct TileGeom {
     int tw_shift;  // TW = 1 << tw_shift (8 or 16)
@@ -93,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
         const bool ok = item < P * 4 && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
         poff0[i] = ok ? (((long)n * H0 + (hi >> p.up0)) * W0 + (wi >> p.up0)) * p.C0 + seg * EPS : -1;
         poff1[i] = ok ? (((long)n * p.Hin + hi) * p.Win + wi) * p.C1 + seg * EPS : -1;
-        pdst[i] = item < P * 4 ? pp * kPS + seg * 16 : -1;
+        pdst[i] = item < P * 4 ? swz(pp, seg) : -1;
     }
     long woff[WITEMS];
     int wdst[WITEMS];
@@ -105,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
         const int co = n0 + nr;
         const bool in = item < WTOTAL;
         woff[i] = (in && co < p.Cout) ? ((long)co * NTAPS + tap) * Cin + seg * EPS : -1;
-        wdst[i] = in ? row * kPS + seg * 16 : -1;
+        wdst[i] = in ? swz(row, seg) : -1;
     }
 
     uint4 preg[PITEMS], wreg[WITEMS];
@@ -135,9 +118,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
     for (int i = 0; i < PT; ++i) {
         const int pl = wave * (PT * 16) + i * 16 + lr;
         const int th = pl >> g.tw_shift, tw = pl & (TW - 1);
-        xbase[i] = ((th * STRIDE) * g.PW + tw * STRIDE) * kPS + lq * 16;
+        xbase[i] = (th * STRIDE) * g.PW + tw * STRIDE;   // patch row of this lane's pixel for tap (0, 0)
     }
-    const int wbase_l = lr * kPS + lq * 16;
+    const int wbase_l = swz(lr, lq);                      // (tap*BN + 16j) is a multiple of 16: it does not change the swizzle
 
     f32x4 acc[PT][NJ];
 #pragma unroll
@@ -159,13 +142,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
             const int kh = tap / KW, kw = tap % KW;
-            const int xoff = (kh * g.PW + kw) * kPS;
+            const int xoff = kh * g.PW + kw;
             uint4 wf[NJ], xf[PT];
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 wf[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
 #pragma unroll
-            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + xbase[i] + xoff);
+            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + swz(xbase[i] + xoff, lq));
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
@@ -173,117 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
         }
     }
 
-    // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
-    const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
-    // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
-    if (p.stats_partial) {
-        float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
-        __syncthreads();                               // staged tiles are dead
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < PT; ++i) {
-                const int pl = wave * (PT * 16) + i * 16 + lr;
-                const bool ok = h0 + (pl >> g.tw_shift) < p.Hout && w0 + (pl & (TW - 1)) < p.Wout;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = ok ? acc[i][j][r] : 0.f;
-                    s1[r] += x; s2[r] += x * x;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
-            }
-            if (lr == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[(wave * 2 + 0) * BN + j * 16 + lq * 4 + r] = s1[r];
-                    red[(wave * 2 + 1) * BN + j * 16 + lq * 4 + r] = s2[r];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int k = tid / BN, cc = tid % BN;
-            if (n0 + cc < p.Cout)
-                p.stats_partial[((size_t)blockIdx.x * 2 + k) * p.Cout + n0 + cc] =
-                    (red[(0 * 2 + k) * BN + cc] + red[(1 * 2 + k) * BN + cc]) + (red[(2 * 2 + k) * BN + cc] + red[(3 * 2 + k) * BN + cc]);
-        }
-    }
-    // (2) outputs
-    const int pool_c = p.pool0 ? (p.out1 ? p.split_c : p.Cout) : 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = n0 + j * 16 + lq * 4;
-        if (PT >= 2 && c < pool_c) {
-            // dgrad through nearest-x2 upsampling: sum the 2x2 block (rows i, i+1 of this wave; lanes lr, lr^1)
-            if constexpr (PT >= 2) {
-#pragma unroll
-                for (int ip = 0; ip < PT / 2; ++ip) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[2 * ip][j][r] + acc[2 * ip + 1][j][r];
-                        v[r] += __shfl_xor(v[r], 1, 64);
-                    }
-                    const int ho = h0 + wave * PT + 2 * ip, wo = w0 + lr;
-                    if ((lr & 1) == 0 && ho < p.Hout && wo < p.Wout && c < p.Cout) {
-                        const size_t o = (((size_t)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1)) * pool_c + c;
-                        st4((T*)p.out + o, make_float4(v[0], v[1], v[2], v[3]));
-                    }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int pl = wave * (PT * 16) + i * 16 + lr;
-            const int ho = h0 + (pl >> g.tw_shift), wo = w0 + (pl & (TW - 1));
-            if (ho >= p.Hout || wo >= p.Wout || c >= p.Cout) continue;
-            const size_t pix = ((size_t)n * p.Hout + ho) * p.Wout + wo;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (!ragged) {
-                if (p.scale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
-                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
-                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                } else if (p.shift) {
-                    const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
-                    v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-                }
-                // destination (possibly split across two tensors: dgrad through a channel concat)
-                char* dst = (char*)p.out;
-                int cd = c, cstride = p.Cout;
-                if (p.out1) {
-                    if (c >= p.split_c) { dst = (char*)p.out1; cd = c - p.split_c; cstride = p.Cout - p.split_c; }
-                    else cstride = p.split_c;
-                }
-                const size_t o = pix * cstride + cd;
-                if (p.residual && dst == (char*)p.out) {
-                    const float4 rv = ld4((const T*)p.residual + o);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                if (p.out_f32) st4((float*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
-                else st4((T*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
-            } else {
-                const int nv = min(4, p.Cout - c);
-                for (int r = 0; r < nv; ++r) {
-                    float x = v[r];
-                    if (p.scale) x = x * p.scale[c + r] + p.shift[c + r];
-                    else if (p.shift) x += p.shift[c + r];
-                    if (p.residual) x += Elem<T>::ld((const T*)p.residual + pix * p.Cout + c + r);
-                    if (p.relu) x = fmaxf(x, 0.f);
-                    if (g.out_nchw) ((float*)p.out)[(((size_t)n * p.Cout + c + r) * p.Hout + ho) * p.Wout + wo] = x;
-                    else if (p.out_f32) ((float*)p.out)[pix * p.Cout + c + r] = x;
-                    else Elem<T>::st((T*)p.out + pix * p.Cout + c + r, x);
-                }
-            }
-        }
-    }
+    conv_epilogue<T, BN, PT>(p, g.tw_shift, g.out_nchw, n, h0, w0, n0, (int)blockIdx.x, acc, smem);
 }
 
 template <typename T, int BN, int PT, int NTAPS, int STRIDE>
@@ -312,12 +185,19 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
 }
 
-int choose_pt(const ConvParams& p, int BN) {
+int choose_pt_reg(const ConvParams& p, int BN) {
     if (p.stride != 1 || p.Hout * p.Wout < 128 || p.Wout < 16) return 1;
     // 256-pixel tiles halve the weight-slab traffic per FLOP; take them when the grid still fills the chip
     const long wg256 = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * cdiv(p.Cout, BN);
-    if (p.Hout * p.Wout >= 256 && wg256 >= 1024 && BN <= 32) return 4;  // BN=64: 86 KB of LDS would leave one workgroup per CU
+    if (p.Hout * p.Wout >= 256 && wg256 >= vs_option("conv_pt4_min_wgs")) return 4;
     return 2;
+}
+
+int choose_bn(const ConvParams& p);
+static int g_dtype_hint = VS_BF16;
+int choose_pt(const ConvParams& p, int BN) {
+    if (conv_igemm_dma_ok(g_dtype_hint, p, BN)) return 2;   // ring kernel: fixed 8x16 tiles
+    return choose_pt_reg(p, BN);
 }
 
 int choose_bn(const ConvParams& p) {
@@ -326,7 +206,7 @@ int choose_bn(const ConvParams& p) {
     // 32-wide cout tiles double the workgroups (and halve the weight slab each one stages)
     const int min_wgs = vs_option("conv_min_wgs");
     if (BN == 64) {
-        const int pt = choose_pt(p, 64);
+        const int pt = choose_pt_reg(p, 64);
         const int tw = p.Wout >= 16 ? 16 : 8, th = 64 * pt / tw;
         const long wgs = (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, 64);
         if (wgs < min_wgs) BN = 32;
@@ -349,6 +229,11 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
     const int BN = choose_bn(p);
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
+    if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN)) {
+        if (p.pool0) VS_REQUIRE(!(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
+                                "conv_igemm: pooled dgrad epilogue not available for this geometry");
+        return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
+    }
     const int PT = choose_pt(p, BN);
     if (p.pool0) {
         VS_REQUIRE(PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
@@ -382,8 +267,9 @@ bool conv_igemm_can_pool(const ConvParams& p) {
 
 // instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + stride (dtype independent)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
-    (void)dtype;
+    g_dtype_hint = dtype;
     const int BN = choose_bn(p), PT = choose_pt(p, BN);
+    if (conv_igemm_dma_ok(dtype, p, BN)) return BN * 1000 + 2 * 100 + 9 * 10 + 3;   // stride code 3 = LDS-DMA ring kernel
     return BN * 1000 + PT * 100 + (p.KH * p.KW) * 10 + ((PT == 1 && p.stride == 2) ? 2 : 1);
 }
 
@@ -395,6 +281,7 @@ int conv_igemm_stat_rows(const ConvParams& p) {
 }
 
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s) {
+    g_dtype_hint = dtype;
     const int nchw = p.out_f32 >> 1;  // out_f32: bit0 = fp32 store, bit1 = NCHW layout
     ConvParams q = p;
     q.out_f32 = p.out_f32 & 1;

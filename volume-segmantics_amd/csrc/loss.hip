@@ -1,0 +1,108 @@
+// DiceLoss(normalization="none") of the reference (volume_segmantics/data/pytorch3dunet_losses.py:15-41,89-135; selected
+// at vol_seg_2d_trainer.py:133-135) and its gradient, fused: per class c over all (n, pixel):
+//   I_c = sum x t,  D_c = sum x^2 + sum t^2,  loss = 1 - mean_c 2 I_c / max(D_c, eps)
+//   dloss/dx = -(2/K) * (t D_c - 2 x I_c) / D_c^2      (D_c > eps;  -(2/K) t / eps otherwise)
+// x: logits (N, K, H, W) fp32 NCHW (what vs_unet_forward returns), t: one-hot targets (N, K, H, W) uint8 or fp32.
+// Two HBM sweeps (reduce, then gradient) instead of ~20 elementwise torch kernels; sums finalised in fp64, fixed order.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlocks = 512;
+
+template <typename TT> __device__ __forceinline__ float tval(const TT* t, size_t i) { return (float)t[i]; }
+
+template <typename TT>
+__global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restrict__ x, const TT* __restrict__ t, int n, int k,
+                                                         int64_t hw, float* __restrict__ partial) {
+    __shared__ float red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < k; ++c) {
+        float si = 0.f, sx = 0.f, st = 0.f;
+        for (int b = 0; b < n; ++b) {
+            const size_t base = ((size_t)b * k + c) * hw;
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+                const float xv = x[base + i], tv = tval(t, base + i);
+                si += xv * tv; sx += xv * xv; st += tv * tv;
+            }
+        }
+        si = wave_sum(si); sx = wave_sum(sx); st = wave_sum(st);
+        if (lane == 0) { red[0][wave] = si; red[1][wave] = sx; red[2][wave] = st; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            partial[((size_t)blockIdx.x * k + c) * 3 + threadIdx.x] =
+                (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        __syncthreads();
+    }
+}
+
+// one wave per class; stats[c] = {I_c, D_c}; loss written by class 0's wave after all classes are known -> single block
+__global__ __launch_bounds__(64) void dice_finalize_kernel(const float* __restrict__ partial, int nblocks, int k, float eps,
+                                                         float* __restrict__ stats, float* __restrict__ loss) {
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int c = 0; c < k; ++c) {
+        double si = 0.0, sx = 0.0, st = 0.0;
+        for (int b = lane; b < nblocks; b += 64) {
+            const float* p = partial + ((size_t)b * k + c) * 3;
+            si += p[0]; sx += p[1]; st += p[2];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { si += __shfl_xor(si, o, 64); sx += __shfl_xor(sx, o, 64); st += __shfl_xor(st, o, 64); }
+        const double d = sx + st;
+        if (lane == 0) { stats[2 * c] = (float)si; stats[2 * c + 1] = (float)d; }
+        acc += 2.0 * si / (d > (double)eps ? d : (double)eps);
+    }
+    if (lane == 0) *loss = (float)(1.0 - acc / k);
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void dice_grad_kernel(const float* __restrict__ x, const TT* __restrict__ t,
+                                                      const float* __restrict__ stats, const float* __restrict__ gout,
+                                                      float eps, int n, int k, int64_t hw, float* __restrict__ dx) {
+    const int64_t total = (int64_t)n * k * hw;
+    const float g = (gout ? *gout : 1.f) * (-2.f / (float)k);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / hw) % k);
+        const float I = stats[2 * c], D = stats[2 * c + 1];
+        const float xv = x[i], tv = tval(t, i);
+        dx[i] = D > eps ? g * (tv * D - 2.f * xv * I) / (D * D) : g * tv / eps;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vs_dice_workspace(int classes) { return ((size_t)kBlocks * classes * 3 + 2 * (size_t)classes) * sizeof(float); }
+
+// loss (1 float, device) and per-class stats are produced by the forward; the backward multiplies by *grad_out (device
+// scalar, may be null = 1).  target_is_f32: targets are fp32 (the reference passes targets.float()) instead of uint8.
+extern "C" int vs_dice_loss_fwd(const float* logits, const void* targets, int target_is_f32, int n, int classes, int64_t hw,
+                                float eps, float* loss, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(logits && targets && loss && workspace && workspace_bytes >= vs_dice_workspace(classes) && classes >= 1,
+               "dice_loss_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* stats = workspace + (size_t)kBlocks * classes * 3;
+    if (target_is_f32)
+        hipLaunchKernelGGL(dice_partial_kernel<float>, dim3(kBlocks), dim3(256), 0, s, logits, (const float*)targets, n, classes, hw, workspace);
+    else
+        hipLaunchKernelGGL(dice_partial_kernel<uint8_t>, dim3(kBlocks), dim3(256), 0, s, logits, (const uint8_t*)targets, n, classes, hw, workspace);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, s, workspace, kBlocks, classes, eps, stats, loss);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_dice_loss_bwd(const float* logits, const void* targets, int target_is_f32, const float* grad_out, int n,
+                                int classes, int64_t hw, float eps, const float* workspace, float* dlogits, void* stream) {
+    VS_REQUIRE(logits && targets && workspace && dlogits, "dice_loss_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const float* stats = workspace + (size_t)kBlocks * classes * 3;
+    const int64_t total = (int64_t)n * classes * hw;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (target_is_f32)
+        hipLaunchKernelGGL(dice_grad_kernel<float>, dim3(grid), dim3(256), 0, s, logits, (const float*)targets, stats, grad_out, eps, n, classes, hw, dlogits);
+    else
+        hipLaunchKernelGGL(dice_grad_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, logits, (const uint8_t*)targets, stats, grad_out, eps, n, classes, hw, dlogits);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

@@ -39,6 +39,54 @@ class DiceLoss(nn.Module):
         return 1.0 - torch.mean(compute_per_channel_dice(self.normalization(input), target, weight=self.weight))
 
 
+class _FusedDiceFn(torch.autograd.Function):
+    """DiceLoss(normalization="none") forward + gradient as two HIP sweeps (vs_dice_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, eps):
+        from .. import _lib
+        n, k = logits.shape[:2]
+        hw = logits[0, 0].numel()
+        logits = logits.contiguous()
+        targets = targets.contiguous()
+        is_f32 = targets.dtype == torch.float32
+        if not is_f32 and targets.dtype != torch.uint8:
+            targets, is_f32 = targets.float(), True
+        ws = torch.empty(_lib.lib.vs_dice_workspace(k) // 4, dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.lib.vs_dice_loss_fwd(_lib.ptr(logits), _lib.ptr(targets), int(is_f32), n, k, hw, eps, _lib.ptr(loss),
+                                            _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()))
+        ctx.save_for_backward(logits, targets, ws)
+        ctx.meta = (n, k, hw, eps, is_f32)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import _lib
+        logits, targets, ws = ctx.saved_tensors
+        n, k, hw, eps, is_f32 = ctx.meta
+        dx = torch.empty_like(logits)
+        g = grad_out.contiguous().float()
+        _lib.check(_lib.lib.vs_dice_loss_bwd(_lib.ptr(logits), _lib.ptr(targets), int(is_f32), _lib.ptr(g), n, k, hw, eps,
+                                            _lib.ptr(ws), _lib.ptr(dx), _lib.stream_ptr()))
+        return dx, None, None
+
+
+class HipDiceLoss(nn.Module):
+    """Drop-in for DiceLoss(normalization="none") on GPU tensors (falls through to the torch ops for anything else,
+    e.g. class weights or CPU tensors in the tests of the host logic)."""
+
+    def __init__(self, epsilon: float = 1e-6):
+        super().__init__()
+        self.epsilon = epsilon
+        self._torch = DiceLoss(normalization="none")
+
+    def forward(self, input, target):
+        if input.is_cuda and input.dtype == torch.float32 and input.dim() >= 3 and input.shape == target.shape:
+            return _FusedDiceFn.apply(input, target, self.epsilon)
+        return self._torch(input, target)
+
+
 class GeneralizedDiceLoss(nn.Module):
     """pytorch3dunet_losses.py:138-169: label contributions weighted by the inverse squared label volume."""
 

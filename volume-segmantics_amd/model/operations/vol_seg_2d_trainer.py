@@ -23,7 +23,7 @@ import torch.nn as nn
 from ... import dist as vdist
 from ...checkpoint_compat import reference_pickle_enum
 from ...data.datasets import get_2d_training_dataloaders
-from ...data.losses import BCEDiceLoss, DiceCoefficient, DiceLoss, GeneralizedDiceLoss, MeanIoU
+from ...data.losses import BCEDiceLoss, DiceCoefficient, DiceLoss, GeneralizedDiceLoss, HipDiceLoss, MeanIoU
 from ...engine import FusedAdamW, VolSegUnet
 from ...utilities import base_data_utils as utils
 from ...utilities import config as cfg
@@ -70,7 +70,7 @@ class VolSeg2dTrainer:
         if name == "BCEDiceLoss":
             return BCEDiceLoss(self.settings.alpha, self.settings.beta)
         if name == "DiceLoss":
-            return DiceLoss(normalization="none")
+            return HipDiceLoss() if torch.cuda.is_available() else DiceLoss(normalization="none")
         if name == "BCELoss":
             return nn.BCEWithLogitsLoss()
         if name == "CrossEntropyLoss":
@@ -143,6 +143,8 @@ class VolSeg2dTrainer:
     def _loss(self, output, targets):
         if self.settings.loss_criterion == "CrossEntropyLoss":
             return self.loss_criterion(output, torch.argmax(targets, dim=1))
+        if isinstance(self.loss_criterion, HipDiceLoss):
+            return self.loss_criterion(output, targets)   # reads the uint8 one-hot directly
         return self.loss_criterion(output, targets.float())
 
     def _train_one_batch(self, lr_scheduler, batch):
