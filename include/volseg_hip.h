@@ -132,6 +132,14 @@ int vs_unet_forward(vs_unet_t* net, const float* params, float* bnstate, const f
 int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                      int need_encoder_wgrad, float* grads, void* workspace, void* stream);
 
+/* The same backward restricted to the plan's units [unit_lo, unit_hi), for callers that overlap a bucketed gradient
+ * all-reduce with the rest of the backward pass: call it for consecutive ranges from the top (unit_hi = vs_unet_num_units)
+ * down to 0.  On return the gradients of the range are ordered on `stream`.  vs_unet_unit_param_offset(net, u) is the
+ * element offset in the flat parameter / gradient buffer where unit u's tensors start (u = num_units: the total). */
+int vs_unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                           int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi);
+int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit);
+
 /* Diagnostics: where a unit's activation (a), pre-BN output (z) and their gradients (da, dz) live
  * inside the workspace (byte offsets; NHWC, dtype of the plan).  Tests only. */
 int vs_unet_num_units(const vs_unet_t* net);

@@ -252,3 +252,31 @@ def test_frozen_encoder_matches_reference_predicate():
         else:
             r = ref[name].grad
             assert _cos(p.grad.cpu(), r) > 0.99, name   # ReLU-flip tolerant (see the fp32 test above)
+
+
+def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
+    """vs_unet_backward_range over the data-parallel bucket plan (decoder+head, layer4, layer3, rest) reproduces the
+    single-call backward bit for bit, and the buckets tile the flat gradient buffer exactly."""
+    from volume_segmantics_amd import _lib as L
+    oracle, model = _pair(2, 3, "fp32", perturb_bn=False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 64, 64, generator=g).to(DEV)
+    t = torch.nn.functional.one_hot((torch.rand(2, 64, 64, generator=g) > 0.5).long(), 2).permute(0, 3, 1, 2).float().to(DEV)
+    model.train()
+    P.dice_loss_none(model(x), t).backward()
+    sync()
+    ref = model._flat_grad.clone()
+    plan = model._plans[(64, 64)]
+    buckets = model._bucket_plan(plan["handle"])
+    assert [b[1] for b in buckets][0] == L.lib.vs_unet_num_units(plan["handle"]) and buckets[-1][0] == 0
+    assert buckets[0][3] == model._flat.numel() and buckets[-1][2] == 0
+    assert all(b1[2] == b0[3] for b0, b1 in zip(buckets[1:], buckets[:-1]))   # contiguous, end towards start
+    out = model(x)
+    dl = torch.autograd.grad(P.dice_loss_none(out, t), out)[0].contiguous()
+    model._flat_grad.fill_(float("nan"))
+    for lo, hi, a, b in buckets:
+        L.check(L.lib.vs_unet_backward_range(plan["handle"], L.ptr(model._flat), L.ptr(x), L.ptr(dl), 2, 1, L.ptr(model._flat_grad),
+                                             L.ptr(plan["ws"]), L.stream_ptr(), lo, hi))
+        sync()
+        assert torch.isfinite(model._flat_grad[a:b]).all()
+    assert torch.equal(model._flat_grad, ref)

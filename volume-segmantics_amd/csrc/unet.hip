@@ -93,6 +93,7 @@ struct vs_unet {
            off_zs = 0, off_idx = 0;
     size_t ws_eval = 0, ws_train = 0;
     int last_n = 0;
+    std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
     static constexpr int kSide = 2;
     hipStream_t side[kSide] = {nullptr, nullptr};
@@ -465,14 +466,45 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
 }
 
 // ---- backward --------------------------------------------------------------------------------------
+static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi);
+
 extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                 int need_encoder_wgrad, float* grads, void* workspace, void* stream) {
+    VS_REQUIRE(net, "unet_backward: null pointer");
+    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, 0, (int)net->units.size());
+}
+
+// Backward of the units [unit_lo, unit_hi) only (processed from unit_hi-1 down to unit_lo).  Calling it for consecutive
+// ranges from the top of the network down is identical to one vs_unet_backward call; when it returns, every gradient of
+// the range is ordered on the caller's stream (the side stream is joined), so a data-parallel caller can all-reduce that
+// slice of the flat gradient buffer while the next range runs.
+extern "C" int vs_unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                                      int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo,
+                                      int unit_hi) {
+    VS_REQUIRE(net && unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_backward_range: bad unit range");
+    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi);
+}
+
+// first tensor-table index (parameter-buffer element offset) owned by a unit: lets a caller map unit ranges to slices
+extern "C" int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit) {
+    if (!net || unit < 0 || unit > (int)net->units.size()) return -1;
+    if (unit == (int)net->units.size()) return net->layout.n_params;
+    for (int u = unit; u < (int)net->units.size(); ++u)
+        if (net->units[u].w_idx >= 0) return net->layout.tensors[net->units[u].w_idx].offset;
+    return net->layout.n_params;
+}
+
+static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi) {
     VS_REQUIRE(net && params && x && dlogits && grads && workspace, "unet_backward: null pointer");
     VS_REQUIRE(n == net->last_n, "unet_backward: batch %d does not match the last training forward (%d)", n, net->last_n);
     Ctx c{net, (char*)workspace, params, nullptr, (hipStream_t)stream, n};
     const int dt = net->dtype;
     int rc;
-    std::vector<char> written(net->acts.size(), 0);
+    if (unit_hi == (int)net->units.size()) net->written.assign(net->acts.size(), 0);  // a new backward pass starts at the top
+    VS_REQUIRE(net->written.size() == net->acts.size(), "unet_backward_range: ranges must start at the last unit");
+    std::vector<char>& written = net->written;
     float* wgws = (float*)(c.ws + net->off_wgws);
     const int n_side = vs_option("side_stream");  // 0 = everything in order on the caller's stream
     const bool use_side = n_side > 0;
@@ -498,7 +530,7 @@ extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float
         VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
         return VS_OK;
     };
-    for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
+    for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
         if (u.kind == U_POOL) {

@@ -98,6 +98,7 @@ class VolSegUnet(nn.Module):
         self._anchor = None
         self.dp_group = None  # torch.distributed process group for data-parallel gradient all-reduce
         self.dp_grad_dtype = torch.float32
+        self.dp_buckets = 4  # >1: bucketed, overlapped gradient all-reduce (decoder+head, layer4, layer3, rest)
         self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
         self._bnver = 0  # bumped when a training forward moves the running statistics
         if init == "smp":
@@ -260,10 +261,13 @@ class VolSegUnet(nn.Module):
         dlogits = dlogits.contiguous()
         if dlogits.dtype != torch.float32:
             dlogits = dlogits.float()
-        check(lib.vs_unet_backward(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
-                                   ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr()))
-        if self.dp_group is not None:
-            self._allreduce_grads()
+        if self.dp_group is not None and self.dp_buckets > 1 and self._world() > 1:
+            self._backward_bucketed(plan, x, dlogits, n, need_enc)
+        else:
+            check(lib.vs_unet_backward(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
+                                       ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr()))
+            if self.dp_group is not None:
+                self._allreduce_grads()
         for p, shape, kind, off, _ in self._param_cache:
             if not p.requires_grad:
                 continue
@@ -273,6 +277,41 @@ class VolSegUnet(nn.Module):
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g)
             # else: .grad already aliases the flat buffer, which now holds this step's gradient
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.dp_group) if self.dp_group is not None else 1
+
+    def _bucket_plan(self, handle):
+        """Unit ranges (top of the network first) and the flat-gradient slice each one completes: decoder + head, layer4,
+        layer3, then stem + layer1 + layer2.  Backward fills the flat buffer from its end towards its start."""
+        names = _lib.unit_names(handle)
+        cuts = [len(names)]
+        for prefix in ("decoder.blocks.0.", "encoder.layer4.0.", "encoder.layer3.0."):
+            cuts.append(next(i for i, nm in enumerate(names) if nm.startswith(prefix)))
+        cuts.append(0)
+        plan = []
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            a = lib.vs_unet_unit_param_offset(handle, lo)
+            b = lib.vs_unet_unit_param_offset(handle, hi)
+            plan.append((lo, hi, a, b))
+        return plan
+
+    def _backward_bucketed(self, plan, x, dlogits, n, need_enc):
+        """Data-parallel backward: every bucket's all-reduce (RCCL, async) overlaps with the backward of the layers below it."""
+        import torch.distributed as dist
+        if "buckets" not in plan:
+            plan["buckets"] = self._bucket_plan(plan["handle"])
+        world = self._world()
+        handles = []
+        for lo, hi, a, b in plan["buckets"]:
+            check(lib.vs_unet_backward_range(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
+                                             ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr(), lo, hi))
+            if b > a:
+                handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), a, b))
+        for h, a, b in handles:
+            h.wait()
+        self._flat_grad.div_(world)
 
     def _allreduce_grads(self):
         import torch.distributed as dist
