@@ -2,7 +2,7 @@
 import ctypes as C
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))  # repo root
 import torch
 from oracle import predictor_numpy as P
 from oracle.unet_resnet34_torch import seeded_oracle

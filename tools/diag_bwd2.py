@@ -3,7 +3,7 @@ from the engine's own saved tensors."""
 import ctypes as C
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))  # repo root
 import torch
 import torch.nn.functional as F
 from oracle import predictor_numpy as P

@@ -27,7 +27,7 @@ __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b
 // Optional: per-channel sum / sum-of-squares partials of the raw accumulators (row `tile` of p.stats_partial), fused
 // affine + residual + ReLU, split output (dgrad through a concat), 2x2 sum-pool (dgrad through nearest x2 upsampling),
 // fp32 / NCHW stores (segmentation head).  `smem` must provide 8*BN floats that no wave is reading any more.
-template <typename T, int BN, int PT>
+template <typename T, int BN, int PT, int NW = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift, int out_nchw, int n, int h0, int w0, int n0,
                                               int tile, f32x4 (&acc)[PT][BN / 16], char* smem) {
     constexpr int NJ = BN / 16;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
     const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
     // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
     if (p.stats_partial) {
-        float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+        float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][BN]
         __syncthreads();                               // staged tiles are dead
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -72,7 +72,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
             const int k = tid / BN, cc = tid % BN;
             if (n0 + cc < p.Cout)
                 p.stats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] =
-                    (red[(0 * 2 + k) * BN + cc] + red[(1 * 2 + k) * BN + cc]) + (red[(2 * 2 + k) * BN + cc] + red[(3 * 2 + k) * BN + cc]);
+                    [&] { float a = 0.f;
+#pragma unroll
+                          for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
+                          return a; }();
         }
     }
     // (2) outputs

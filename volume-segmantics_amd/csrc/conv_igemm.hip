@@ -38,14 +38,18 @@ struct TileGeom {
     int out_nchw;
 };
 
-constexpr int patch_items(int pt, int stride) { return stride == 2 ? 5 : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)); }
+// 16-byte patch items per thread (NW = waves per workgroup; the tile has NW*PT*16 pixels)
+constexpr int patch_items(int pt, int stride, int nw = 4) {
+    return nw == 8 ? 3 : (stride == 2 ? 5 : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)));
+}
 
-template <typename T, int BN, int PT, int NTAPS, int STRIDE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom g) {
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(ConvParams p, TileGeom g) {
+    constexpr int NT = NW * 64;
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
     constexpr int NJ = BN / 16, KW = NTAPS == 9 ? 3 : 1;
-    constexpr int PITEMS = patch_items(PT, STRIDE);
-    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
+    constexpr int PITEMS = patch_items(PT, STRIDE, NW);
+    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
     int pdst[PITEMS];
 #pragma unroll
     for (int i = 0; i < PITEMS; ++i) {
-        const int item = tid + i * 256;
+        const int item = tid + i * NT;
         const int pp = item >> 2, seg = item & 3;
         const int ph = pp / g.PW, pw = pp - ph * g.PW;
         const int hi = hbase + ph, wi = wbase + pw;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
     int wdst[WITEMS];
 #pragma unroll
     for (int i = 0; i < WITEMS; ++i) {
-        const int item = tid + i * 256;
+        const int item = tid + i * NT;
         const int row = item >> 2, seg = item & 3;
         const int tap = row / BN, nr = row % BN;
         const int co = n0 + nr;
@@ -100,13 +104,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i) {
             const long off = from0 ? poff0[i] : poff1[i];
-            const int seg = (tid + i * 256) & 3;
+            const int seg = (tid + i * NT) & 3;
             preg[i] = make_uint4(0, 0, 0, 0);
             if (off >= 0 && cb + seg * EPS < cs) preg[i] = *reinterpret_cast<const uint4*>(src + off + cb);
         }
 #pragma unroll
         for (int i = 0; i < WITEMS; ++i) {
-            const int seg = (tid + i * 256) & 3;
+            const int seg = (tid + i * NT) & 3;
             wreg[i] = make_uint4(0, 0, 0, 0);
             if (woff[i] >= 0 && c0 + seg * EPS < Cin) wreg[i] = *reinterpret_cast<const uint4*>((const T*)p.w + woff[i] + c0);
         }
@@ -156,22 +160,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, TileGeom 
         }
     }
 
-    conv_epilogue<T, BN, PT>(p, g.tw_shift, g.out_nchw, n, h0, w0, n0, (int)blockIdx.x, acc, smem);
+    conv_epilogue<T, BN, PT, NW>(p, g.tw_shift, g.out_nchw, n, h0, w0, n0, (int)blockIdx.x, acc, smem);
 }
 
-template <typename T, int BN, int PT, int NTAPS, int STRIDE>
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE>;
+    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW>;
     const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS;
     VS_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS request %zu too large", lds);
-    VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, STRIDE) * 256, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
+    VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, STRIDE, NW) * NW * 64, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)(p.N * g.tiles_h * g.tiles_w), (unsigned)cdiv(p.Cout, BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p, g);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -185,33 +189,29 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
 }
 
-int choose_pt_reg(const ConvParams& p, int BN) {
-    if (p.stride != 1 || p.Hout * p.Wout < 128 || p.Wout < 16) return 1;
-    // 256-pixel tiles halve the weight-slab traffic per FLOP; take them when the grid still fills the chip
-    const long wg256 = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * cdiv(p.Cout, BN);
-    if (p.Hout * p.Wout >= 256 && wg256 >= vs_option("conv_pt4_min_wgs")) return 4;
-    return 2;
-}
-
-int choose_bn(const ConvParams& p);
+struct Pick { int BN, PT, NW; };
 static int g_dtype_hint = VS_BF16;
-int choose_pt(const ConvParams& p, int BN) {
-    if (conv_igemm_dma_ok(g_dtype_hint, p, BN)) return 2;   // ring kernel: fixed 8x16 tiles
-    return choose_pt_reg(p, BN);
-}
 
-int choose_bn(const ConvParams& p) {
-    int BN = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
-    // small grids (deep, low-resolution layers): one 64-wide workgroup per CU cannot hide load latency;
-    // 32-wide cout tiles double the workgroups (and halve the weight slab each one stages)
-    const int min_wgs = vs_option("conv_min_wgs");
-    if (BN == 64) {
-        const int pt = choose_pt_reg(p, 64);
-        const int tw = p.Wout >= 16 ? 16 : 8, th = 64 * pt / tw;
-        const long wgs = (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, 64);
-        if (wgs < min_wgs) BN = 32;
-    }
-    return BN;
+// One place decides the kernel configuration (cout tile, pixel tiles per wave, waves per workgroup):
+//  * 8 waves x 2 pixel tiles = 256-pixel tiles for stride-1 layers with >= 16x16 outputs: half the weight-slab traffic per
+//    FLOP of the 128-pixel tile, twice the waves per CU for latency hiding, half the staging registers per thread;
+//  * 4 waves x 2 (128 px) or x 1 (64 px: 8x8 images, stride 2) otherwise;
+//  * 32-wide cout tiles when 64-wide ones would leave fewer than `conv_min_wgs` workgroups.
+Pick pick_cfg(const ConvParams& p) {
+    Pick c;
+    c.NW = 4;
+    c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
+    const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.Hout >= 16 && p.Wout >= 16;
+    auto wgs = [&](int bn, int px) {
+        const int tw = p.Wout >= 16 ? 16 : 8, th = px / tw;
+        return (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, bn);
+    };
+    int bn = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
+    if (can8 && wgs(bn, 256) >= vs_option("conv_nw8_min_wgs")) { c.NW = 8; c.PT = 2; }
+    if (bn == 64 && wgs(64, c.NW * c.PT * 16) < vs_option("conv_min_wgs")) bn = 32;
+    c.BN = bn;
+    if (conv_igemm_dma_ok(g_dtype_hint, p, bn)) { c.NW = 4; c.PT = 2; }
+    return c;
 }
 
 template <typename T>
@@ -227,56 +227,58 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && p.out, "conv_igemm: null pointer");
     VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
-    const int BN = choose_bn(p);
+    const Pick cfg = pick_cfg(p);
+    const int BN = cfg.BN, PT = cfg.PT, NW = cfg.NW;
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
-    if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN)) {
-        if (p.pool0) VS_REQUIRE(!(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
-                                "conv_igemm: pooled dgrad epilogue not available for this geometry");
-        return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
-    }
-    const int PT = choose_pt(p, BN);
     if (p.pool0) {
         VS_REQUIRE(PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
                    "conv_igemm: pooled dgrad epilogue not available for this geometry");
         VS_REQUIRE((p.out1 ? p.split_c : p.Cout) % 4 == 0, "conv_igemm: pooled channel count must be a multiple of 4");
     }
+    if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN))
+        return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
     TileGeom g;
     g.tw_shift = p.Wout >= 16 ? 4 : 3;
     const int TW = 1 << g.tw_shift;
-    g.TH = 64 * PT / TW;
+    g.TH = NW * 16 * PT / TW;
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
     g.PH = (g.TH - 1) * p.stride + p.KH;
     g.PW = (TW - 1) * p.stride + p.KW;
     g.out_nchw = out_nchw;
+    if (NW == 8) {
+        const bool t9 = p.KH * p.KW == 9;
+#define VS_CONV8(bn) if (BN == bn) return t9 ? launch_one<T, bn, 2, 9, 1, 8>(p, g, s) : launch_one<T, bn, 2, 1, 1, 8>(p, g, s)
+        VS_CONV8(64); VS_CONV8(32); VS_CONV8(16);
+#undef VS_CONV8
+    }
 #define VS_CONV_CASE(bn, pt) if (BN == bn && PT == pt) return launch_tk<T, bn, pt>(p, g, s)
-    VS_CONV_CASE(64, 4); VS_CONV_CASE(64, 2); VS_CONV_CASE(64, 1);
-    VS_CONV_CASE(32, 4); VS_CONV_CASE(32, 2); VS_CONV_CASE(32, 1);
-    VS_CONV_CASE(16, 4); VS_CONV_CASE(16, 2); VS_CONV_CASE(16, 1);
+    VS_CONV_CASE(64, 2); VS_CONV_CASE(64, 1);
+    VS_CONV_CASE(32, 2); VS_CONV_CASE(32, 1);
+    VS_CONV_CASE(16, 2); VS_CONV_CASE(16, 1);
 #undef VS_CONV_CASE
-    vs_set_error("conv_igemm: no kernel for BN=%d PT=%d", BN, PT);
+    vs_set_error("conv_igemm: no kernel for BN=%d PT=%d NW=%d", BN, PT, NW);
     return VS_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool conv_igemm_can_pool(const ConvParams& p) {
-    const int BN = choose_bn(p);
-    return choose_pt(p, BN) >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);
+    return pick_cfg(p).PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);
 }
 
-// instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + stride (dtype independent)
+// instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + code
+// (code 1 = stride 1, 2 = stride 2, 3 = LDS-DMA ring kernel, 8 = 8-wave 256-pixel tiles)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
     g_dtype_hint = dtype;
-    const int BN = choose_bn(p), PT = choose_pt(p, BN);
-    if (conv_igemm_dma_ok(dtype, p, BN)) return BN * 1000 + 2 * 100 + 9 * 10 + 3;   // stride code 3 = LDS-DMA ring kernel
-    return BN * 1000 + PT * 100 + (p.KH * p.KW) * 10 + ((PT == 1 && p.stride == 2) ? 2 : 1);
+    const Pick c = pick_cfg(p);
+    if (conv_igemm_dma_ok(dtype, p, c.BN)) return c.BN * 1000 + 2 * 100 + 9 * 10 + 3;
+    return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : ((c.PT == 1 && p.stride == 2) ? 2 : 1));
 }
 
 int conv_igemm_stat_rows(const ConvParams& p) {
-    const int BN = choose_bn(p);
-    const int PT = choose_pt(p, BN);
-    const int TW = p.Wout >= 16 ? 16 : 8, TH = 64 * PT / TW;
+    const Pick c = pick_cfg(p);
+    const int TW = p.Wout >= 16 ? 16 : 8, TH = c.NW * 16 * c.PT / TW;
     return p.N * cdiv(p.Hout, TH) * cdiv(p.Wout, TW);
 }
 
