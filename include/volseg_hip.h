@@ -155,6 +155,10 @@ const char* vs_profile_kind_name(int kind);
 int vs_profile_read(double* ms, double* flops, double* bytes, int64_t* calls);
 /* raw records in launch order (tag = unit index inside the network plan); returns the count or -1 */
 int vs_profile_read_raw(int max_n, int* kind, int* tag, int* variant, double* ms, double* flops, double* bytes);
+/* Diagnostics only (tools/conv_probe.py): while `buf` (device memory, 8 x u64 per workgroup, `cap_wgs` workgroups)
+ * is set, convolution launches of at most cap_wgs workgroups record per-workgroup phase timestamps.  NULL disables. */
+int vs_debug_probe(void* buf, size_t cap_wgs);
+
 /* Runtime options: "side_stream" (1), "wgrad_target" (256), "conv_min_wgs" (512), "fuse_stats" (1),
  * "recompute_mask" (0); initial values can come from the environment as VS_<NAME>. */
 int vs_set_option(const char* name, int value);

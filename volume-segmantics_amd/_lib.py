@@ -79,6 +79,7 @@ _SIGS = {
     "vs_profile_read_raw": (I, [I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vs_set_option": (I, [C.c_char_p, I]),
     "vs_get_option": (I, [C.c_char_p]),
+    "vs_debug_probe": (I, [P, SZ]),
     "vs_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, P]),
     "vs_dice_workspace": (SZ, [I]),
     "vs_dice_loss_fwd": (I, [P, P, I, I, I, I64, F, P, P, SZ, P]),

@@ -92,6 +92,18 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
     st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
 }
 
+// ---- raw buffer loads ---------------------------------------------------------------------------------
+// 16-byte load through a buffer descriptor: `voff` is a per-lane byte offset, `soff` a uniform one; an offset outside
+// [0, bytes) - use -1 - returns zeros, so padding and ragged edges need no branches.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

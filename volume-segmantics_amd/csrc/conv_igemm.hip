@@ -17,6 +17,7 @@
 // Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
 // vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat
 // folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
+#include <algorithm>
 #include <cstdlib>
 
 #include "conv_common.h"
@@ -24,11 +25,13 @@
 
 namespace {
 
-constexpr int kPS = 64;  // LDS bytes per staged pixel / weight row: unpadded; the 16-byte segment s of row r lives in slot
-                         // s ^ ((r >> 1) & 3).  With gfx950's ds_read_b128 lane groups this XOR makes the fragment reads
-                         // conflict-free for every row alignment (tools/lds_bank_sim.py; 80-byte padded rows are 2-way
-                         // conflicted, 96-byte ones conflict-free but 50 % bigger)
-__device__ __forceinline__ int swz(int row, int seg) { return row * kPS + ((seg ^ ((row >> 1) & 3)) << 4); }
+constexpr int kPS = 64;  // LDS bytes per staged pixel / weight row: unpadded; the 16-byte segment s of a patch pixel in patch
+                         // column pw lives in slot s ^ ((pw >> 1) & 3), of weight row r in slot s ^ ((r >> 1) & 3).  With
+                         // gfx950's ds_read_b128 lane groups this XOR makes the fragment reads conflict-free (tools/lds_bank_sim.py;
+                         // 80-byte padded rows are 2-way conflicted, 96-byte ones conflict-free but 50 % bigger).  Keying the
+                         // patch swizzle on the column keeps the kh tap offsets plain constants.
+__device__ __forceinline__ int swz(int row, int key, int seg) { return row * kPS + ((seg ^ ((key >> 1) & 3)) << 4); }
+
 
 struct TileGeom {
     int tw_shift;  // TW = 1 << tw_shift (8 or 16)
@@ -36,6 +39,8 @@ struct TileGeom {
     int tiles_h, tiles_w;
     int PH, PW;  // staged patch dims
     int out_nchw;
+    unsigned pw_magic, tw_magic;  // x / PW == umulhi(x, pw_magic), x / tiles_w == umulhi(x, tw_magic) for x < 65536
+    unsigned long long* probe;  // phase timestamps (tools/conv_probe.py); null in normal operation
 };
 
 // 16-byte patch items per thread (NW = waves per workgroup; the tile has NW*PT*16 pixels)
@@ -44,87 +49,103 @@ constexpr int patch_items(int pt, int stride, int nw = 4) {
 }
 
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(ConvParams p, TileGeom g) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(ConvParams p, TileGeom g) {
     constexpr int NT = NW * 64;
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
     constexpr int NJ = BN / 16, KW = NTAPS == 9 ? 3 : 1;
     constexpr int PITEMS = patch_items(PT, STRIDE, NW);
-    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + NT - 1) / NT;
+    constexpr int WROWS = NT / 4;                 // weight rows one pass of the workgroup stages
+    constexpr int TS = WROWS / BN;                // taps per pass
+    static_assert(WROWS % BN == 0, "cout tile must divide the rows of a staging pass");
+    constexpr int WITEMS = (NTAPS + TS - 1) / TS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const int TW = 1 << g.tw_shift;
+    // stride-1 kernels have a compile-time tile (16 wide; 8 wide for the 64-pixel tiles of small images), so patch
+    // row offsets are instruction immediates; stride-2 kernels take it from the launch
+    constexpr bool kStatic = STRIDE == 1;
+    constexpr int kTWS = PT == 1 ? 3 : 4, kTW = 1 << kTWS, kTH = NW * 16 * PT / kTW, kKH = NTAPS == 9 ? 3 : 1;
+    const int tw_shift = kStatic ? kTWS : g.tw_shift;
+    const int TW = 1 << tw_shift;
+    const int PW = kStatic ? kTW - 1 + KW : g.PW;
+    const int PH = kStatic ? kTH - 1 + kKH : g.PH;
+    const int TH = kStatic ? kTH : g.TH;
     const int Cin = p.C0 + p.C1;
-    const int P = g.PH * g.PW;
+    const int P = PH * PW;
     char* patch = smem;
     char* wl = smem + P * kPS;
+    unsigned long long tprobe[5];
+    if (g.probe) tprobe[0] = wall_clock64();
 
-    int bid = blockIdx.x;
-    const int tx = bid % g.tiles_w; bid /= g.tiles_w;
-    const int ty = bid % g.tiles_h;
-    const int n = bid / g.tiles_h;
-    const int h0 = ty * g.TH, w0 = tx * TW;
+    const int ty = g.tiles_w == 1 ? (int)blockIdx.x : (int)__umulhi(blockIdx.x, g.tw_magic);
+    const int tx = (int)blockIdx.x - ty * g.tiles_w;
+    const int n = blockIdx.z;
+    const int h0 = ty * TH, w0 = tx * TW;
     const int n0 = blockIdx.y * BN;
     const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
     const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    // Staging loads are raw buffer loads: one descriptor per source (base = this image, so per-lane offsets are 32-bit
+    // byte offsets), the chunk's channel offset rides in the scalar offset, and offset -1 (out of range) returns zeros -
+    // zero padding, ragged tiles and channel tails cost no branches.
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.src0 + (size_t)n * H0 * W0 * p.C0), 0, H0 * W0 * p.C0 * (int)sizeof(T), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.src1 + (size_t)n * p.Hin * p.Win * p.C1), 0, p.src1 ? p.Hin * p.Win * p.C1 * (int)sizeof(T) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * NTAPS * Cin * (int)sizeof(T), 0x00020000);
+    const int dummy = (P + NTAPS * BN) * kPS;    // 64 spare bytes behind the staged tiles: target of the stores of idle items
 
-    // ---- chunk-invariant staging addresses (element offsets; -1 = zero fill) ----
-    long poff0[PITEMS], poff1[PITEMS];
-    int pdst[PITEMS];
+    // ---- chunk-invariant staging addresses (byte offsets; -1 = zero fill) ----
+    int poff0[PITEMS], poff1[PITEMS], pdst[PITEMS];
 #pragma unroll
     for (int i = 0; i < PITEMS; ++i) {
         const int item = tid + i * NT;
         const int pp = item >> 2, seg = item & 3;
-        const int ph = pp / g.PW, pw = pp - ph * g.PW;
+        const int ph = kStatic ? pp / PW : (int)__umulhi((unsigned)pp, g.pw_magic), pw = pp - ph * PW;
         const int hi = hbase + ph, wi = wbase + pw;
-        const bool ok = item < P * 4 && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-        poff0[i] = ok ? (((long)n * H0 + (hi >> p.up0)) * W0 + (wi >> p.up0)) * p.C0 + seg * EPS : -1;
-        poff1[i] = ok ? (((long)n * p.Hin + hi) * p.Win + wi) * p.C1 + seg * EPS : -1;
-        pdst[i] = item < P * 4 ? swz(pp, seg) : -1;
+        const bool ok = pp < P && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+        poff0[i] = ok ? (((hi >> p.up0) * W0 + (wi >> p.up0)) * p.C0 + seg * EPS) * (int)sizeof(T) : -1;
+        poff1[i] = ok ? ((hi * p.Win + wi) * p.C1 + seg * EPS) * (int)sizeof(T) : -1;
+        pdst[i] = pp < P ? swz(pp, pw, seg) : dummy;
     }
-    long woff[WITEMS];
-    int wdst[WITEMS];
-#pragma unroll
-    for (int i = 0; i < WITEMS; ++i) {
-        const int item = tid + i * NT;
-        const int row = item >> 2, seg = item & 3;
-        const int tap = row / BN, nr = row % BN;
-        const int co = n0 + nr;
-        const bool in = item < WTOTAL;
-        woff[i] = (in && co < p.Cout) ? ((long)co * NTAPS + tap) * Cin + seg * EPS : -1;
-        wdst[i] = in ? swz(row, seg) : -1;
-    }
+    // weight staging: pass i covers rows i*WROWS + (tid >> 2); row = tap*BN + nr, so a pass advances TS taps
+    const int wrow0 = tid >> 2, wseg = tid & 3;
+    const int wnr = wrow0 % BN, wtap0 = wrow0 / BN;
+    const bool wok = n0 + wnr < p.Cout;
+    const int woff0 = (((n0 + wnr) * NTAPS + wtap0) * Cin + wseg * EPS) * (int)sizeof(T);
+    const int wdst0 = swz(wrow0, wrow0, wseg);   // i*WROWS is a multiple of 16 rows: same swizzle in every pass
 
     uint4 preg[PITEMS], wreg[WITEMS];
     auto load_chunk = [&](int c0) {
         const bool from0 = c0 < p.C0;
-        const T* src = from0 ? (const T*)p.src0 : (const T*)p.src1;
         const int cs = from0 ? p.C0 : p.C1;
         const int cb = from0 ? c0 : c0 - p.C0;
+        const int nseg = (cs - cb) / EPS;         // valid 16-byte segments of this chunk (< 4 only in a ragged channel tail)
+        const int nsegw = (Cin - c0) / EPS;
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i) {
-            const long off = from0 ? poff0[i] : poff1[i];
-            const int seg = (tid + i * NT) & 3;
-            preg[i] = make_uint4(0, 0, 0, 0);
-            if (off >= 0 && cb + seg * EPS < cs) preg[i] = *reinterpret_cast<const uint4*>(src + off + cb);
+            int off = from0 ? poff0[i] : poff1[i];
+            if (((tid + i * NT) & 3) >= nseg) off = -1;
+            preg[i] = from0 ? bload(r0, off, cb * (int)sizeof(T)) : bload(r1, off, cb * (int)sizeof(T));
         }
 #pragma unroll
         for (int i = 0; i < WITEMS; ++i) {
-            const int seg = (tid + i * NT) & 3;
-            wreg[i] = make_uint4(0, 0, 0, 0);
-            if (woff[i] >= 0 && c0 + seg * EPS < Cin) wreg[i] = *reinterpret_cast<const uint4*>((const T*)p.w + woff[i] + c0);
+            int off = woff0 + i * TS * Cin * (int)sizeof(T);
+            if (!wok || wtap0 + i * TS >= NTAPS || wseg >= nsegw) off = -1;
+            wreg[i] = bload(rw, off, c0 * (int)sizeof(T));
         }
     };
 
-    // per-lane LDS read bases
-    int xbase[PT];
+    // per-lane LDS read bases: pixel tile i, tap column kw (tap row kh adds the constant kh * PW * kPS)
+    int xb[PT][KW];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int pl = wave * (PT * 16) + i * 16 + lr;
-        const int th = pl >> g.tw_shift, tw = pl & (TW - 1);
-        xbase[i] = (th * STRIDE) * g.PW + tw * STRIDE;   // patch row of this lane's pixel for tap (0, 0)
+        const int th = pl >> tw_shift, tw = pl & (TW - 1);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) xb[i][kw] = swz((th * STRIDE) * PW + tw * STRIDE + kw, tw * STRIDE + kw, lq);
     }
-    const int wbase_l = swz(lr, lq);                      // (tap*BN + 16j) is a multiple of 16: it does not change the swizzle
+    const int wbase_l = swz(lr, lr, lq);                  // (tap*BN + 16j) is a multiple of 16: it does not change the swizzle
+    const int khs = PW * kPS;
 
     f32x4 acc[PT][NJ];
 #pragma unroll
@@ -133,26 +154,29 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(ConvParams p, TileG
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     load_chunk(0);
+    if (g.probe) tprobe[1] = wall_clock64();
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();  // every wave is done reading the previous chunk
 #pragma unroll
-        for (int i = 0; i < PITEMS; ++i)
-            if (pdst[i] >= 0) *reinterpret_cast<uint4*>(patch + pdst[i]) = preg[i];
+        for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(patch + pdst[i]) = preg[i];
 #pragma unroll
-        for (int i = 0; i < WITEMS; ++i)
-            if (wdst[i] >= 0) *reinterpret_cast<uint4*>(wl + wdst[i]) = wreg[i];
+        for (int i = 0; i < WITEMS; ++i) {
+            const bool full = (i + 1) * TS <= NTAPS;   // every row of this pass is a real tap
+            const int dst = (full || wtap0 + i * TS < NTAPS) ? P * kPS + wdst0 + i * WROWS * kPS : dummy;
+            *reinterpret_cast<uint4*>(smem + dst) = wreg[i];
+        }
         __syncthreads();
+        if (g.probe && c0 == 0) tprobe[2] = wall_clock64();
         if (c0 + CK < Cin) load_chunk(c0 + CK);  // in flight while the MFMAs below run
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
             const int kh = tap / KW, kw = tap % KW;
-            const int xoff = kh * g.PW + kw;
             uint4 wf[NJ], xf[PT];
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 wf[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
 #pragma unroll
-            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + swz(xbase[i] + xoff, lq));
+            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + xb[i][kw] + kh * khs);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
@@ -160,21 +184,37 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(ConvParams p, TileG
         }
     }
 
-    conv_epilogue<T, BN, PT, NW>(p, g.tw_shift, g.out_nchw, n, h0, w0, n0, (int)blockIdx.x, acc, smem);
+    if (g.probe) tprobe[3] = wall_clock64();
+    conv_epilogue<T, BN, PT, NW>(p, tw_shift, g.out_nchw, n, h0, w0, n0, (int)(blockIdx.z * gridDim.x + blockIdx.x), acc, smem);
+    if (g.probe) {
+        __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged
+        tprobe[4] = wall_clock64();
+        if (tid == 0) {
+            unsigned long long* o = g.probe + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            for (int i = 0; i < 5; ++i) o[i] = tprobe[i];
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[5] = hw; o[6] = xcc; o[7] = 0;
+        }
+    }
 }
 
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW>;
-    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS;
+    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS + 64;
+    VS_REQUIRE((double)p.Hin * p.Win * std::max(p.C0, p.C1) * sizeof(T) < 2.0e9 && (double)p.Cout * NTAPS * (p.C0 + p.C1) * sizeof(T) < 2.0e9,
+               "conv_igemm: image or weight tensor exceeds the 32-bit staging offsets");
     VS_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS request %zu too large", lds);
     VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, STRIDE, NW) * NW * 64, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)(p.N * g.tiles_h * g.tiles_w), (unsigned)cdiv(p.Cout, BN));
+    VS_REQUIRE(g.tiles_h * g.tiles_w < 65536 && p.N < 65536 && g.PH * g.PW + NW * 64 < 65536, "conv_igemm: tile grid too large");
+    dim3 grid((unsigned)(g.tiles_h * g.tiles_w), (unsigned)cdiv(p.Cout, BN), (unsigned)p.N);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p, g);
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -190,6 +230,8 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
 }
 
 struct Pick { int BN, PT, NW; };
+// tile width: static per kernel for stride 1 (see conv_igemm_kernel), by output width for stride 2
+static int tile_tw(const ConvParams& p, int PT) { return p.stride == 1 ? (PT == 1 ? 8 : 16) : (p.Wout >= 16 ? 16 : 8); }
 static int g_dtype_hint = VS_BF16;
 
 // One place decides the kernel configuration (cout tile, pixel tiles per wave, waves per workgroup):
@@ -203,7 +245,7 @@ Pick pick_cfg(const ConvParams& p) {
     c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
     const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.Hout >= 16 && p.Wout >= 16;
     auto wgs = [&](int bn, int px) {
-        const int tw = p.Wout >= 16 ? 16 : 8, th = px / tw;
+        const int tw = tile_tw(p, px == 64 ? 1 : 2), th = px / tw;
         return (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, bn);
     };
     int bn = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
@@ -238,7 +280,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN))
         return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
     TileGeom g;
-    g.tw_shift = p.Wout >= 16 ? 4 : 3;
+    g.tw_shift = tile_tw(p, PT) == 16 ? 4 : 3;
     const int TW = 1 << g.tw_shift;
     g.TH = NW * 16 * PT / TW;
     g.tiles_h = cdiv(p.Hout, g.TH);
@@ -246,6 +288,9 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     g.PH = (g.TH - 1) * p.stride + p.KH;
     g.PW = (TW - 1) * p.stride + p.KW;
     g.out_nchw = out_nchw;
+    g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;       // exact for x * PW < 2^32
+    g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;
+    g.probe = vs_probe_buffer((size_t)p.N * g.tiles_h * g.tiles_w * cdiv(p.Cout, BN));
     if (NW == 8) {
         const bool t9 = p.KH * p.KW == 9;
 #define VS_CONV8(bn) if (BN == bn) return t9 ? launch_one<T, bn, 2, 9, 1, 8>(p, g, s) : launch_one<T, bn, 2, 1, 1, 8>(p, g, s)
@@ -278,7 +323,7 @@ int conv_igemm_variant(int dtype, const ConvParams& p) {
 
 int conv_igemm_stat_rows(const ConvParams& p) {
     const Pick c = pick_cfg(p);
-    const int TW = p.Wout >= 16 ? 16 : 8, TH = c.NW * 16 * c.PT / TW;
+    const int TW = tile_tw(p, c.PT), TH = c.NW * 16 * c.PT / TW;
     return p.N * cdiv(p.Hout, TH) * cdiv(p.Wout, TW);
 }
 

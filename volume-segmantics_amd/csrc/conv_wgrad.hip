@@ -26,6 +26,8 @@ template <> struct WT<float> { static constexpr int CK = 16, EPS = 4, NCI = 1, K
 struct WGeom {
     int tw_shift, TH, tiles_h, tiles_w, PH, PW, PT;
     int ctiles, cchunks, nsplit, total_tiles, dys;  // dys: LDS bytes per dy pixel row
+    unsigned pw_magic, tw_magic, th_magic;          // x / PW, x / tiles_w, x / tiles_h by umulhi (bf16 fast path)
+    int fast;                                        // bf16 fast path (conv_wgrad_bf16_kernel) applies
 };
 
 __device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
@@ -211,6 +213,196 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
         }
 }
 
+// ---- bf16 fast path ---------------------------------------------------------------------------------------------
+// Workgroup = 16*MO couts x one 32-channel cin chunk x all taps, over a range of pixel tiles (split-K).  Wave (wc, wt):
+// cin slice wc (16 channels) of the chunk and, for 3x3 kernels, tap group wt (taps 0-4 / 5-8); 1x1 kernels split the
+// k-steps of a tile between the two waves of a slice instead and meet in LDS.  Every wave accumulates ALL 16*MO couts of
+// its taps, so one transposed x fragment feeds MO MFMAs and one dy fragment up to 5: 8 + 10 LDS reads per 20 MFMAs at
+// MO = 4 (the generic kernel below: 38 per 18, LDS-bound).
+// LDS images: x patch rows of 64 B, dy rows of 128 / 64 B; 32-byte slices XOR-swizzled (patch: by bit 3 of the patch
+// column, dy: by bits 1 and 3 of the pixel index) so every ds_read_b64_tr_b16 is conflict-free, and tap rows / k-steps
+// are immediates on top of 8 address registers.  Staging: raw buffer loads (offset -1 -> zeros), register prefetch of
+// the next tile.
+constexpr int kXP = 64;
+
+template <int MO, int NTAPS, int STRIDE, int PT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, WGeom g) {
+    constexpr int KW = NTAPS == 9 ? 3 : 1, KH = KW;
+    constexpr int BM = 64 * PT, KS = BM / 32;             // pixels / k-steps per tile
+    constexpr int BNO = 16 * MO;
+    constexpr int DYP = BNO * 2 < 64 ? 64 : BNO * 2;      // dy row pitch
+    constexpr int DSEG = BNO / 8;                          // 16-byte segments of real data per dy row
+    constexpr int NSL = DYP / 32;
+    constexpr int RPP = 256 / DSEG;                        // dy rows one staging pass of the workgroup covers
+    constexpr int DITEMS = (BM + RPP - 1) / RPP;
+    constexpr bool kStatic = STRIDE == 1;
+    constexpr int kTWS = PT == 1 ? 3 : 4;
+    constexpr int PITEMS = wg_patch_items(PT, STRIDE);
+    constexpr int TG = NTAPS == 9 ? 2 : 1, KG = 2 / TG;    // tap groups / K groups among the two waves of a cin slice
+    constexpr int TPW = NTAPS == 9 ? 5 : 1;                // taps per wave (second group: 4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int wc = wave & 1, wg2 = wave >> 1;
+    const int wt = TG == 2 ? wg2 : 0, wk = KG == 2 ? wg2 : 0;
+    const int tw_shift = kStatic ? kTWS : g.tw_shift;
+    const int TW = 1 << tw_shift, TH = BM >> tw_shift;
+    const int PW = (TW - 1) * STRIDE + KW, PH = (TH - 1) * STRIDE + KH;
+    const int P = PH * PW;
+    const int Cin = p.C0 + p.C1;
+    char* patch = smem;
+    char* dyl = smem + P * kXP;
+    const int dummy = P * kXP + BM * DYP;                  // 16 spare bytes: target of the stores of idle staging items
+
+    const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x - ct * g.cchunks;
+    const int co0 = ct * BNO, c0 = cc * 32;
+    const int split = blockIdx.y;
+    const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
+    const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
+    const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    const bool from0 = c0 < p.C0;
+    const int cs = from0 ? p.C0 : p.C1;
+    const int cb = from0 ? c0 : c0 - p.C0;
+    const int sh = from0 ? p.up0 : 0;
+    const int Hs = from0 ? H0 : p.Hin, Ws = from0 ? W0 : p.Win;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(from0 ? p.src0 : p.src1, p.N * Hs * Ws * cs * 2);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy, p.N * p.Hout * p.Wout * p.Cout * 2);
+
+    // tile-invariant staging coordinates.  Patch item i of a thread: pixel (tid + 256 i) >> 2, 16-byte segment tid & 3.
+    int ppk[PITEMS], pdst[PITEMS];                         // ppk = patch row << 16 | patch column
+#pragma unroll
+    for (int i = 0; i < PITEMS; ++i) {
+        const int pp = (tid + i * 256) >> 2, seg = tid & 3;
+        const int ph = kStatic ? pp / PW : (int)__umulhi((unsigned)pp, g.pw_magic), pw = pp - ph * PW;
+        ppk[i] = (ph << 16) | pw;
+        pdst[i] = pp < P ? pp * kXP + ((((seg >> 1) ^ (pw >> 3)) & 1) << 5) + (seg & 1) * 16 : dummy;
+    }
+    const int pco = cb + (tid & 3) * 8 < cs ? (cb + (tid & 3) * 8) * 2 : -1;          // channel byte offset; -1: beyond the source
+    // dy item i: row r0 + i * RPP (RPP is a multiple of the tile width and of 16: same column, same swizzle), segment tid % DSEG
+    const int r0 = tid / DSEG, dseg = tid % DSEG;
+    const int dgk = NSL == 4 ? (((r0 >> 1) & 1) | (((r0 >> 3) & 1) << 1)) : ((r0 >> 3) & 1);
+    const int ddst0 = P * kXP + r0 * DYP + (((dseg >> 1) ^ dgk) << 5) + (dseg & 1) * 16;
+    const int dco = co0 + dseg * 8 < p.Cout ? (co0 + dseg * 8) * 2 : -1;
+    const int dth = r0 >> tw_shift, dtw = r0 & (TW - 1);
+
+    uint4 preg[PITEMS], dreg[DITEMS];
+    auto load_tile = [&](int tile) {
+        const int q = g.tiles_w == 1 ? tile : (int)__umulhi((unsigned)tile, g.tw_magic);
+        const int tx = tile - q * g.tiles_w;
+        const int n = g.tiles_h == 1 ? q : (int)__umulhi((unsigned)q, g.th_magic);
+        const int ty = q - n * g.tiles_h;
+        const int h0 = ty * TH, w0 = tx * TW;
+        const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) {
+            const int hi = hbase + (ppk[i] >> 16), wi = wbase + (ppk[i] & 0xffff);
+            const bool ok = pco >= 0 && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+            const int off = ((n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs * 2 + pco;
+            preg[i] = bload(rx, ok ? off : -1, 0);
+        }
+        const int wo_ = w0 + dtw;
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i) {
+            const int ho = h0 + dth + i * (RPP >> tw_shift);
+            const bool ok = dco >= 0 && r0 + i * RPP < BM && ho < p.Hout && wo_ < p.Wout;
+            const int off = ((n * p.Hout + ho) * p.Wout + wo_) * p.Cout * 2 + dco;
+            dreg[i] = bload(rd, ok ? off : -1, 0);
+        }
+    };
+
+    // fragment addresses of k-step 0 (pixels pa = 8 lq + (lr >> 2), pb = pa + 4); k-step ks adds 32 pixels = whole tile
+    // rows: a constant on top of these, and it leaves the swizzle keys (patch column; pixel bits 1 and 3) unchanged
+    int a_addr[2], x_addr[2][KW];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int px = 8 * lq + (lr >> 2) + 4 * h;
+        const int gk = NSL == 4 ? (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) : ((px >> 3) & 1);
+        a_addr[h] = px * DYP + (gk << 5) + (lr & 3) * 8;                  // fragment m: ^ (m << 5)
+        const int row0 = ((px >> tw_shift) * STRIDE) * PW, col0 = (px & (TW - 1)) * STRIDE;
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+            x_addr[h][kw] = (row0 + col0 + kw) * kXP + ((wc ^ ((col0 + kw) >> 3)) & 1) * 32 + (lr & 3) * 8;
+    }
+    const int ks_rows = (32 >> tw_shift) * STRIDE * PW * kXP;            // patch bytes per k-step
+
+    f32x4 acc[TPW][MO];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int m = 0; m < MO; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (t0 < t1) load_tile(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(smem + pdst[i]) = preg[i];
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i)
+            *reinterpret_cast<uint4*>(smem + ((DITEMS * RPP <= BM || r0 + i * RPP < BM) ? ddst0 + i * RPP * DYP : dummy)) = dreg[i];
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);  // in flight while the MFMAs below run
+#pragma unroll
+        for (int ks = wk; ks < KS; ks += KG) {
+            uint4 af[MO];
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                const uint2 lo = ds_read_tr16(dyl + ((a_addr[0] ^ (m << 5)) + ks * 32 * DYP));
+                const uint2 hi = ds_read_tr16(dyl + ((a_addr[1] ^ (m << 5)) + ks * 32 * DYP));
+                af[m] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                // this wave's tt-th tap: group 0 = taps 0..4, group 1 = taps 5..8 (its 5th slot is idle)
+                if (TG == 2 && tt == TPW - 1 && wt == 1) continue;
+#pragma unroll
+                for (int g2 = 0; g2 < TG; ++g2) {
+                    if (TG == 2 && g2 != wt) continue;
+                    const int t = g2 * TPW + tt;
+                    if (t >= NTAPS) continue;
+                    const int kh = t / KW, kw = t % KW;
+                    const uint2 lo = ds_read_tr16(patch + x_addr[0][kw] + kh * PW * kXP + ks * ks_rows);
+                    const uint2 hi = ds_read_tr16(patch + x_addr[1][kw] + kh * PW * kXP + ks * ks_rows);
+                    const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                    for (int m = 0; m < MO; ++m)
+                        acc[tt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]),
+                                                                             __builtin_bit_cast(bf16x8, bf), acc[tt][m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if constexpr (KG == 2) {   // 1x1 kernels: the two K-groups of a cin slice meet in LDS
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        __syncthreads();
+        if (wk == 1) {
+#pragma unroll
+            for (int m = 0; m < MO; ++m) red[(wc * MO + m) * 64 + lane] = acc[0][m];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int m = 0; m < MO; ++m) acc[0][m] += red[(wc * MO + m) * 64 + lane];
+    }
+    // partial slab of this split: [Cout][NTAPS][Cin] fp32
+    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cin;
+    const int ci = c0 + wc * 16 + lr;
+    if (ci < Cin) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int t = wt * TPW + tt;
+            if (t >= NTAPS) continue;
+#pragma unroll
+            for (int m = 0; m < MO; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + m * 16 + lq * 4 + r;
+                    if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cin + ci] = acc[tt][m][r];
+                }
+        }
+    }
+}
+
 // dw[i] = sum over slabs, fixed order: thread (j, g) sums slabs g, g+4, ... of output 64*block + j; 4 groups meet in LDS
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
                                                          size_t n, int nparts) {
@@ -238,9 +430,10 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     VS_REQUIRE(Cin % EPS == 0 && p.C0 % EPS == 0, "conv_wgrad: channel counts must be multiples of %d", EPS);
     VS_REQUIRE(p.C1 == 0 || p.C0 % CK == 0, "conv_wgrad: concat boundary must be a multiple of %d", CK);
     VS_REQUIRE((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1), "conv_wgrad: only 3x3 and 1x1 kernels");
-    g.tw_shift = p.Wout >= 16 ? 4 : 3;
+    // tile: 16x8 pixels (PT = 2) for stride-1 layers at least 16 wide, else 64 pixels (8x8; stride 2: 16x4 when wide enough)
+    const int PT = (p.stride == 1 && p.Wout >= 16 && p.Hout * p.Wout >= 128) ? 2 : 1;
+    g.tw_shift = p.stride == 1 ? (PT == 2 ? 4 : 3) : (p.Wout >= 16 ? 4 : 3);
     const int TW = 1 << g.tw_shift;
-    const int PT = (p.stride == 1 && p.Hout * p.Wout >= 128) ? 2 : 1;
     g.TH = 64 * PT / TW;
     g.PT = PT;
     g.tiles_h = cdiv(p.Hout, g.TH);
@@ -249,13 +442,27 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.PW = (TW - 1) * p.stride + p.KW;
     g.cchunks = cdiv(Cin, CK);
     g.total_tiles = p.N * g.tiles_h * g.tiles_w;
-    // Decomposition policy.  Workgroups = (cout tiles) x (cin chunks) x nsplit.  Splitting K (pixels) costs an fp32 slab
-    // of |dw| bytes per split, written once and read once by the reduce; deep layers (big |dw|, few pixels) have enough
-    // output-dimension parallelism, so they take narrower cout tiles (WO = 2 / 1 waves of 16 couts, the other waves split
-    // K inside the workgroup and meet in LDS) instead of more slabs.
+    g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;
+    g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;   // unused when the divisor is 1
+    g.th_magic = 0xffffffffu / (unsigned)g.tiles_h + 1u;
     const int target = vs_option("wgrad_target");
-    static const double budget = (getenv("VS_WGRAD_SLAB_MB") ? atof(getenv("VS_WGRAD_SLAB_MB")) : 1.0e9) * 1048576.0;  // default: never trade tile width for slabs (measured slower)
     const double dw_bytes = (double)p.Cout * p.KH * p.KW * Cin * 4.0;
+    // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
+    g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
+             (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
+    if (g.fast) {
+        WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);   // = MO
+        g.ctiles = cdiv(p.Cout, 16 * WO);
+        const int base = g.ctiles * g.cchunks;
+        int ns = std::min(cdiv(target, base), g.total_tiles);
+        g.nsplit = cdiv(g.total_tiles, cdiv(g.total_tiles, ns));
+        g.dys = 0;
+        return VS_OK;
+    }
+    // Generic kernel.  Workgroups = (cout tiles) x (cin chunks) x nsplit.  Splitting K (pixels) costs an fp32 slab of |dw|
+    // bytes per split, written once and read once by the reduce; narrower cout tiles (WO = 2 / 1 waves of 16 couts, the
+    // other waves split K inside the workgroup and meet in LDS) trade slabs for operand re-reads.
+    static const double budget = (getenv("VS_WGRAD_SLAB_MB") ? atof(getenv("VS_WGRAD_SLAB_MB")) : 1.0e9) * 1048576.0;  // default: never trade tile width for slabs (measured slower)
     const int wo_max = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);
     const int BMt = g.TH << g.tw_shift;
     int best_wo = wo_max, best_ns = 1;
@@ -275,6 +482,26 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.ctiles = cdiv(p.Cout, 16 * WO);
     g.dys = 16 * WO * (int)sizeof(T) + 16;
     return VS_OK;
+}
+
+template <int MO, int NTAPS, int STRIDE, int PT>
+int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = conv_wgrad_bf16_kernel<MO, NTAPS, STRIDE, PT>;
+    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
+    constexpr int BM = 64 * PT, DYP = 32 * MO < 64 ? 64 : 32 * MO;
+    size_t lds = (size_t)g.PH * g.PW * kXP + (size_t)BM * DYP + 16;
+    if (NTAPS == 1) lds = std::max(lds, (size_t)2 * MO * 1024);   // K-group combine buffer
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    WgradParams q = p;
+    if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
+    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
+    VS_LAUNCH_CHECK();
+    if (g.nsplit == 1) return VS_OK;
+    return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.C0 + p.C1), g.nsplit, s);
 }
 
 template <typename T, int WO, int NTAPS, int STRIDE, int PT>
@@ -309,6 +536,18 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     const size_t need = (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
     VS_REQUIRE(p.partials && p.partial_bytes >= need, "conv_wgrad: workspace %zu < %zu", p.partial_bytes, need);
     const int nt = p.KH * p.KW;
+    if constexpr (sizeof(T) == 2) {
+        if (g.fast) {
+#define VS_WGF_CASE(mo, t)                                                                \
+    if (WO == mo && nt == t) {                                                            \
+        if (p.stride == 2) return launch_fast<mo, t, 2, 1>(p, g, s);                      \
+        return g.PT == 2 ? launch_fast<mo, t, 1, 2>(p, g, s) : launch_fast<mo, t, 1, 1>(p, g, s); \
+    }
+            VS_WGF_CASE(4, 9) VS_WGF_CASE(2, 9) VS_WGF_CASE(1, 9) VS_WGF_CASE(4, 1) VS_WGF_CASE(2, 1) VS_WGF_CASE(1, 1)
+#undef VS_WGF_CASE
+            return VS_ERR_UNSUPPORTED;
+        }
+    }
 #define VS_WG_CASE(wo, t)                                                                  \
     if (WO == wo && nt == t) {                                                             \
         if (p.stride == 2) return launch_one<T, wo, t, 2, 1>(p, g, s);                     \

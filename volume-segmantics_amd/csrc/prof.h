@@ -20,7 +20,10 @@ void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
 void prof_set_tag(int tag);  // attached to subsequent records (unit index)
 void prof_set_variant(int v);  // kernel instantiation code of the next records (0 = n/a)
-int vs_option(const char* name);  // runtime option (vs_set_option / environment VS_<NAME>)
+int vs_option(const char* name);
+// Phase probe (tools/conv_probe.py): when set, instrumented kernels store 8 x u64 per workgroup (100 MHz timestamps of
+// their phases + hardware id).  Null in normal operation.
+unsigned long long* vs_probe_buffer(size_t need_wgs);  // runtime option (vs_set_option / environment VS_<NAME>)
 
 struct ProfScope {
     hipStream_t s;

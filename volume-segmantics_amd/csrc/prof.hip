@@ -74,7 +74,7 @@ extern "C" int vs_profile_read(double* ms, double* flops, double* bytes, int64_t
 namespace {
 struct Opt { const char* name; int value; bool init; };
 Opt g_opts[] = {{"side_stream", 1, false}, {"wgrad_target", 256, false}, {"conv_min_wgs", 512, false},
-                {"fuse_stats", 1, false}, {"recompute_mask", 0, false}, {"conv_dma", 0, false}, {"conv_nw8", 1, false}, {"conv_nw8_min_wgs", 128, false}};
+                {"fuse_stats", 1, false}, {"recompute_mask", 0, false}, {"conv_dma", 0, false}, {"conv_nw8", 1, false}, {"conv_nw8_min_wgs", 128, false}, {"wgrad_fast", 1, false}};
 }
 int vs_option(const char* name) {
     for (auto& o : g_opts) {
@@ -94,5 +94,13 @@ extern "C" int vs_set_option(const char* name, int value) {
         if (!strcmp(o.name, name)) { o.value = value; o.init = true; return VS_OK; }
     vs_set_error("unknown option %s", name);
     return VS_ERR_INVALID;
+}
+static unsigned long long* g_probe = nullptr;
+static size_t g_probe_cap = 0;
+unsigned long long* vs_probe_buffer(size_t need_wgs) { return (g_probe && need_wgs <= g_probe_cap) ? g_probe : nullptr; }
+extern "C" int vs_debug_probe(void* buf, size_t cap_wgs) {
+    g_probe = (unsigned long long*)buf;
+    g_probe_cap = buf ? cap_wgs : 0;
+    return VS_OK;
 }
 extern "C" int vs_get_option(const char* name) { return vs_option(name); }
