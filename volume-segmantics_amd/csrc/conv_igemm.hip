@@ -114,8 +114,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int woff0 = (((n0 + wnr) * NTAPS + wtap0) * Cin + wseg * EPS) * (int)sizeof(T);
     const int wdst0 = swz(wrow0, wrow0, wseg);   // i*WROWS is a multiple of 16 rows: same swizzle in every pass
 
-    uint4 preg[PITEMS], wreg[WITEMS];
-    auto load_chunk = [&](int c0) {
+    // Prefetch depth: PF chunks are in flight (in registers) while one is being multiplied.  Kernels that run with one or
+    // two workgroups per CU and have registers to spare use 2, so a staging load gets two chunk periods to land.
+    constexpr int PF = ((NW == 8 && BN <= 32) || (NW == 4 && PT == 1 && STRIDE == 1)) ? 2 : 1;
+    uint4 pregs[PF][PITEMS], wregs[PF][WITEMS];
+    auto load_chunk = [&](int c0, uint4 (&preg)[PITEMS], uint4 (&wreg)[WITEMS]) {
         const bool from0 = c0 < p.C0;
         const int cs = from0 ? p.C0 : p.C1;
         const int cb = from0 ? c0 : c0 - p.C0;
@@ -153,34 +156,51 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_chunk(0);
+    load_chunk(0, pregs[0], wregs[0]);
+    if (PF == 2 && CK < Cin) load_chunk(CK, pregs[PF - 1], wregs[PF - 1]);
     if (g.probe) tprobe[1] = wall_clock64();
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-        __syncthreads();  // every wave is done reading the previous chunk
+    for (int cbase = 0; cbase < Cin; cbase += PF * CK) {
 #pragma unroll
-        for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(patch + pdst[i]) = preg[i];
+        for (int s = 0; s < PF; ++s) {
+            const int c0 = cbase + s * CK;
+            if (c0 >= Cin) break;
+            __syncthreads();  // every wave is done reading the previous chunk
 #pragma unroll
-        for (int i = 0; i < WITEMS; ++i) {
-            const bool full = (i + 1) * TS <= NTAPS;   // every row of this pass is a real tap
-            const int dst = (full || wtap0 + i * TS < NTAPS) ? P * kPS + wdst0 + i * WROWS * kPS : dummy;
-            *reinterpret_cast<uint4*>(smem + dst) = wreg[i];
-        }
-        __syncthreads();
-        if (g.probe && c0 == 0) tprobe[2] = wall_clock64();
-        if (c0 + CK < Cin) load_chunk(c0 + CK);  // in flight while the MFMAs below run
+            for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(patch + pdst[i]) = pregs[s][i];
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int kh = tap / KW, kw = tap % KW;
-            uint4 wf[NJ], xf[PT];
+            for (int i = 0; i < WITEMS; ++i) {
+                const bool full = (i + 1) * TS <= NTAPS;   // every row of this pass is a real tap
+                const int dst = (full || wtap0 + i * TS < NTAPS) ? P * kPS + wdst0 + i * WROWS * kPS : dummy;
+                *reinterpret_cast<uint4*>(smem + dst) = wregs[s][i];
+            }
+            __syncthreads();
+            if (g.probe && c0 == 0) tprobe[2] = wall_clock64();
+            if (c0 + PF * CK < Cin) load_chunk(c0 + PF * CK, pregs[s], wregs[s]);  // in flight while the MFMAs of PF chunks run
+            // fragments of tap t+1 are read while the MFMAs of tap t run (two register sets)
+            uint4 wf[2][NJ], xf[2][PT];
+            auto read_frags = [&](int tap, uint4 (&w)[NJ], uint4 (&x)[PT]) {
+                const int kh = tap / KW, kw = tap % KW;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                wf[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
+                for (int j = 0; j < NJ; ++j) w[j] = *reinterpret_cast<const uint4*>(wl + (tap * BN + j * 16) * kPS + wbase_l);
 #pragma unroll
-            for (int i = 0; i < PT; ++i) xf[i] = *reinterpret_cast<const uint4*>(patch + xb[i][kw] + kh * khs);
+                for (int i = 0; i < PT; ++i) x[i] = *reinterpret_cast<const uint4*>(patch + xb[i][kw] + kh * khs);
+            };
+            constexpr int kMfmaPerTap = NJ * PT * (sizeof(T) == 2 ? 1 : 4);
+            read_frags(0, wf[0], xf[0]);
+            constexpr bool kPin = BN <= 32;   // 64-wide tiles run out of registers under the pinned order (measured slower)
+            if (kPin) __builtin_amdgcn_sched_group_barrier(0x100, NJ + PT, 0);
 #pragma unroll
-            for (int i = 0; i < PT; ++i)
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                if (tap + 1 < NTAPS) read_frags(tap + 1, wf[(tap + 1) & 1], xf[(tap + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], wf[j], xf[i]);
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], wf[tap & 1][j], xf[tap & 1][i]);
+                // pin the software pipeline: the LDS reads of tap t+1 issue before the MFMAs of tap t (left alone, the
+                // scheduler serialises read -> wait -> MFMA to save registers)
+                if (kPin && tap + 1 < NTAPS) __builtin_amdgcn_sched_group_barrier(0x100, NJ + PT, 0);
+                if (kPin) __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerTap, 0);
+            }
         }
     }
 
