@@ -62,6 +62,56 @@ def test_conv_epilogue_affine_residual_relu(code):
     _conv_case(code, 1, 8, 8, 32, 32, 3, 1, 1, seed=4, relu=0, affine=True, residual=False)
 
 
+@pytest.fixture
+def force_direct_kernel():
+    """Route every eligible layer (3x3 stride 1, Cin within one chunk, Cout <= 16) through the direct shallow-layer
+    kernel, with short row chunks so strips start and end inside the image."""
+    L = lib()
+    old = (L.lib.vs_get_option(b"conv_direct_min_px"), L.lib.vs_get_option(b"conv_direct_rows"))
+    L.set_option("conv_direct_min_px", 1)
+    L.set_option("conv_direct_rows", 6)
+    yield
+    L.set_option("conv_direct_min_px", old[0])
+    L.set_option("conv_direct_rows", old[1])
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_conv_direct_kernel(code, force_direct_kernel):
+    _conv_case(code, 2, 32, 48, 16, 16, 3, 1, 1, seed=11)                      # 12 tiles on 3 workgroups
+    _conv_case(code, 3, 40, 24, 16, 12, 3, 1, 1, seed=12)                      # ragged strips, 12 couts
+    _conv_case(code, 2, 32, 32, 16, 16, 3, 1, 1, seed=13, relu=1, affine=True, residual=True)
+    if code == 1:
+        _conv_case(code, 2, 32, 32, 32, 16, 3, 1, 1, seed=14)                  # full 32-channel chunk (bf16 only)
+        _conv_case(code, 1, 48, 32, 24, 16, 3, 1, 1, seed=15)                  # channel tail inside the chunk
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_conv_direct_kernel_upsampled_input_and_head(code, force_direct_kernel):
+    L = lib()
+    g = torch.Generator().manual_seed(16)
+    n, h, w, c0, cout = 2, 32, 32, 16, 16
+    x0 = rounded(torch.randn(n, c0, h // 2, w // 2, generator=g), code)
+    wt = rounded(torch.randn(cout, c0, 3, 3, generator=g) / 12, code)
+    ref = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), wt, padding=1)
+    d = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, up0=1)
+    y = torch.empty((n, h, w, cout), device=DEV, dtype=tdtype(code))
+    x0d, wd = to_nhwc(x0, code), w_krsc(wt, code)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(x0d), None, L.ptr(wd), None, None, None, L.ptr(y), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
+    # segmentation head: bias, fp32 NCHW output, 3 classes
+    x = rounded(torch.randn(n, 16, h, w, generator=g), code)
+    wh = rounded(torch.randn(3, 16, 3, 3, generator=g) / 12, code)
+    b = torch.randn(3, generator=g)
+    refh = F.conv2d(x, wh, b, padding=1)
+    dh = conv_desc(L, code, n, h, w, 16, 3, 3, 1, 1, out_f32=3)
+    yh = torch.full((n, 3, h, w), float("nan"), device=DEV)
+    xd, whd, bd = to_nhwc(x, code), w_krsc(wh, code), b.to(DEV)
+    L.check(L.lib.vs_conv2d_fwd(dh, L.ptr(xd), None, L.ptr(whd), None, L.ptr(bd), None, L.ptr(yh), None, None))
+    sync()
+    assert torch.allclose(yh.cpu(), refh, rtol=1e-4, atol=1e-4 if code == 0 else 2e-2)
+
+
 @pytest.mark.parametrize("code", CODES)
 def test_conv_upsample_concat_never_materialised(code):
     """Decoder block input: cat(F.interpolate(x, 2, 'nearest'), skip) folded into the patch loader."""

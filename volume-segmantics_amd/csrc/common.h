@@ -134,7 +134,7 @@ struct ConvParams {
 };
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
-int conv_igemm_stat_rows(const ConvParams& p);
+int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
 int conv_igemm_variant(int dtype, const ConvParams& p);
 bool conv_igemm_dma_ok(int dtype, const ConvParams& p, int BN);
 int launch_conv_igemm_dma(int dtype, const ConvParams& p, int BN, int out_nchw, hipStream_t s);  // BN*1000 + PT*100 + taps*10 + stride of the chosen instantiation      // number of partial rows stats_partial receives

@@ -220,6 +220,252 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     }
 }
 
+// ---- shallow layers: all of Cin in one chunk, Cout <= 16 -----------------------------------------------------------
+// The full-resolution decoder layers (-> 16 channels at H x W), the segmentation head and the head's data gradient
+// are HBM-bound, with so little matrix work per pixel that the LDS-staged tile kernel above spends its time in
+// barriers and load latency.  Here every wave is on its own: it owns a 16-pixel-wide column strip of RH output rows and
+// walks down it with a rolling window of input rows held as MFMA B fragments that are loaded STRAIGHT from global memory
+// (one 16-byte buffer load per lane: pixel = column + kw - 1, channels 8*(lane>>4)..; padding = out-of-range offset =
+// zeros).  Each new output row costs 3 loads (the next input row at the three kw shifts; the 3x reuse across kh lives in
+// registers, the rest in L1), 9*NJ MFMAs against the weight slab (staged once per workgroup in LDS) and its stores.  No
+// barriers in the loop, many independent waves per SIMD.
+struct DirectGeom {
+    int strips_w, chunks_h, RH;      // column strips per row, row chunks per image, rows per chunk
+    unsigned sw_magic, ch_magic;     // x / strips_w, x / chunks_h by umulhi
+    int nwaves, out_nchw;
+};
+
+// MODE 0: NHWC store in T (optional per-channel affine + ReLU, optional statistics); 1: 2x2 sum-pooled NHWC store (dgrad
+// through nearest-x2 upsampling); 2: fp32 NCHW store of <= 4 channels with bias (segmentation head).
+// Every row iteration issues the same number of loads and (offset-masked, never skipped) buffer stores, so the waits on
+// the input ring are counted ones and kD rows stay in flight per wave.
+template <typename T, int BN, int MODE>
+__global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g) {
+    constexpr int EPS = CT<T>::EPS, NJ = BN / 16, NTAPS = 9, kD = (BN == 32 && MODE == 1) ? 2 : 4;   // input rows in flight
+    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
+    constexpr int kOob = (int)0x80000000;
+    __shared__ __attribute__((aligned(16))) char wl[NTAPS * BN * kPS + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int Cin = p.C0;
+    {   // weights: once per workgroup
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.Cout * NTAPS * Cin * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) {
+            const int item = tid + i * 256;
+            const int row = item >> 2, seg = item & 3;
+            const int tap = row / BN, nr = row % BN;
+            const bool ok = item < WTOTAL && nr < p.Cout && seg * EPS < Cin;
+            const uint4 v = bload(rw, ok ? ((nr * NTAPS + tap) * Cin + seg * EPS) * (int)sizeof(T) : -1, 0);
+            *reinterpret_cast<uint4*>(wl + (item < WTOTAL ? swz(row, row, seg) : NTAPS * BN * kPS)) = v;
+        }
+    }
+    __syncthreads();
+    const int gw = blockIdx.x * 4 + wave;                   // this wave's strip
+    if (gw >= g.nwaves) return;
+    const int q = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
+    const int ws = gw - q * g.strips_w;
+    const int n = g.chunks_h == 1 ? q : (int)__umulhi((unsigned)q, g.ch_magic);
+    const int hc = q - n * g.chunks_h;
+    const int w0 = ws * 16, h0 = hc * g.RH, h1 = min(p.Hout, h0 + g.RH);
+    const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    const int rowbytes = W0 * p.C0 * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const T*)p.src0 + (size_t)n * H0 * W0 * p.C0, H0 * rowbytes);
+    // per-lane column offsets of the three kw shifts (bytes inside an input row; -1 = zero: padding column / channel tail)
+    int coff[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int col = w0 + lr + kw - 1;
+        coff[kw] = (col >= 0 && col < p.Win && lq * EPS < Cin) ? ((col >> p.up0) * p.C0 + lq * EPS) * (int)sizeof(T) : -1;
+    }
+    const int wbase_l = swz(lr, lr, lq);
+    auto load_row = [&](int hi, uint4 (&x)[3]) {          // input row hi at the three kw shifts
+        const bool ok = hi >= 0 && hi < p.Hin;
+        const int soff = ok ? (hi >> p.up0) * rowbytes : 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) x[kw] = bload(rx, ok ? coff[kw] : -1, soff);
+    };
+
+    // output addressing: one descriptor per image, per-lane byte offset of (row 0, this lane's column, its first cout)
+    const int wo = w0 + lr;
+    const bool inw = wo < p.Wout;
+    __amdgpu_buffer_rsrc_t ro;
+    int ooff[NJ], orow;                                      // lane offset inside an output row; bytes per output row
+    if constexpr (MODE == 0) {
+        ro = make_rsrc((T*)p.out + (size_t)n * p.Hout * p.Wout * p.Cout, p.Hout * p.Wout * p.Cout * (int)sizeof(T));
+        orow = p.Wout * p.Cout * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ooff[j] = (inw && j * 16 + lq * 4 < p.Cout) ? (wo * p.Cout + j * 16 + lq * 4) * (int)sizeof(T) : kOob;
+    } else if constexpr (MODE == 1) {
+        const int Ho = p.Hout >> 1, Wo = p.Wout >> 1;
+        ro = make_rsrc((T*)p.out + (size_t)n * Ho * Wo * p.Cout, Ho * Wo * p.Cout * (int)sizeof(T));
+        orow = Wo * p.Cout * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            ooff[j] = (inw && !(lr & 1) && j * 16 + lq * 4 < p.Cout) ? ((wo >> 1) * p.Cout + j * 16 + lq * 4) * (int)sizeof(T) : kOob;
+    } else {
+        ro = make_rsrc((float*)p.out + (size_t)n * p.Cout * p.Hout * p.Wout, p.Cout * p.Hout * p.Wout * 4);
+        orow = p.Wout * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ooff[j] = (inw && j == 0 && lq == 0) ? wo * 4 : kOob;   // + channel plane r * H * W * 4
+    }
+    float4 sc[NJ], sh[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = j * 16 + lq * 4;
+        sc[j] = make_float4(1.f, 1.f, 1.f, 1.f); sh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE != 1) {
+            float a[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c + r < p.Cout) { if (p.scale) a[r] = p.scale[c + r]; if (p.shift) b[r] = p.shift[c + r]; }
+            sc[j] = make_float4(a[0], a[1], a[2], a[3]); sh[j] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    }
+    const bool affine = MODE != 1 && (p.scale || p.shift);
+    float s1[NJ][4], s2[NJ][4];
+    f32x4 prev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        prev[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
+    }
+
+    // Input-row major: input row hi feeds output rows hi+1 (kh = 0), hi (kh = 1) and hi-1 (kh = 2), whose accumulators
+    // a2, a1, a0 roll down by one slot per row; a ring of kD input rows is in flight.
+    f32x4 a0[NJ], a1[NJ], a2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a0[j] = a1[j] = a2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 ring[kD][3];
+#pragma unroll
+    for (int u = 0; u < kD; ++u) load_row(h0 - 1 + u, ring[u]);
+    for (int base = h0 - 1; base <= h1; base += kD) {
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const int hi = base + u;
+            if (hi > h1) break;
+            int wb = wbase_l;
+            asm volatile("" : "+v"(wb));   // keep the weight fragments in LDS, not in 36 / 72 hoisted registers
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint4 w0f = *reinterpret_cast<const uint4*>(wl + ((0 * 3 + kw) * BN + j * 16) * kPS + wb);
+                    const uint4 w1f = *reinterpret_cast<const uint4*>(wl + ((1 * 3 + kw) * BN + j * 16) * kPS + wb);
+                    const uint4 w2f = *reinterpret_cast<const uint4*>(wl + ((2 * 3 + kw) * BN + j * 16) * kPS + wb);
+                    mma16<T>(a2[j], w0f, ring[u][kw]);
+                    mma16<T>(a1[j], w1f, ring[u][kw]);
+                    mma16<T>(a0[j], w2f, ring[u][kw]);
+                }
+            load_row(hi + kD, ring[u]);
+            const int h = hi - 1;                              // this output row is complete now
+            const bool live = h >= h0;                         // (h < h1 always: hi <= h1)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (MODE == 0 && p.stats_partial && live && inw) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[j][r] += a0[j][r]; s2[j][r] += a0[j][r] * a0[j][r]; }
+                }
+                float v[4] = {a0[j][0], a0[j][1], a0[j][2], a0[j][3]};
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += prev[j][r]; v[r] += __shfl_xor(v[r], 1, 64); }
+                    prev[j] = a0[j];
+                    const int off = (live && (h & 1)) ? ooff[j] : kOob;
+                    uint2 pk;
+                    if constexpr (sizeof(T) == 2) {
+                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, off, (h >> 1) * orow, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, (h >> 1) * orow, 0);
+                    }
+                } else {
+                    if (affine) {
+                        v[0] = v[0] * sc[j].x + sh[j].x; v[1] = v[1] * sc[j].y + sh[j].y;
+                        v[2] = v[2] * sc[j].z + sh[j].z; v[3] = v[3] * sc[j].w + sh[j].w;
+                    }
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if constexpr (MODE == 0) {
+                        const int off = live ? ooff[j] : kOob;
+                        if constexpr (sizeof(T) == 2) {
+                            uint2 pk;
+                            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, off, h * orow, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, h * orow, 0);
+                        }
+                    } else if (j == 0) {   // head: channel planes of this image, 4 dword stores (channels >= Cout masked)
+                        const int plane = p.Hout * p.Wout * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (live && r < p.Cout) ? ooff[0] : kOob, h * orow + r * plane, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; a2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+    if (MODE == 0 && p.stats_partial) {   // one partial row per wave: sum / sum of squares over the strip's pixels
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[j][r] += __shfl_xor(s1[j][r], o, 64); s2[j][r] += __shfl_xor(s2[j][r], o, 64); }
+                const int c = j * 16 + lq * 4 + r;
+                if (lr == 0 && c < p.Cout) {
+                    p.stats_partial[((size_t)gw * 2 + 0) * p.Cout + c] = s1[j][r];
+                    p.stats_partial[((size_t)gw * 2 + 1) * p.Cout + c] = s2[j][r];
+                }
+            }
+    }
+}
+
+// geometry the direct kernel covers
+static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = fp32 store, bit 1 = NCHW layout
+    const int CK = dtype == VS_BF16 ? 32 : 16;
+    const bool nchw = (p.out_f32 >> 1) != 0, f32 = (p.out_f32 & 1) != 0;
+    const bool out_ok = nchw ? (f32 && p.Cout <= 4 && !p.pool0 && !p.scale) : (!f32 && !(p.Cout & 3));
+    return vs_option("conv_direct") && out_ok && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+           p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
+           (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
+           (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
+}
+static DirectGeom direct_geom(const ConvParams& p) {
+    DirectGeom g{};
+    g.strips_w = cdiv(p.Wout, 16);
+    g.RH = std::max(2, vs_option("conv_direct_rows") & ~1);
+    g.chunks_h = cdiv(p.Hout, g.RH);
+    g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
+    g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
+    g.nwaves = p.N * g.strips_w * g.chunks_h;
+    return g;
+}
+
+template <typename T, int BN>
+int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
+    DirectGeom g = direct_geom(p);
+    g.out_nchw = out_nchw;
+    VS_REQUIRE((double)p.Hin * p.Win * p.C0 * sizeof(T) < 2.0e9 && (long)g.nwaves * 16 < (1L << 32), "conv_direct: tensor too large");
+    const dim3 grid(cdiv(g.nwaves, 4));
+    const bool head = (p.Cout & 3) != 0 || out_nchw;
+    if (head) {
+        VS_REQUIRE(out_nchw && p.Cout <= 4 && BN == 16 && !p.pool0 && !p.scale, "conv_direct: unsupported ragged output");
+        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 2>), grid, dim3(256), 0, s, p, g);
+    } else if (p.pool0) {
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g);
+    } else {
+        VS_REQUIRE(!p.out_f32, "conv_direct: fp32 NHWC output is not supported");
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g);
+    }
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
@@ -297,6 +543,10 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
                    "conv_igemm: pooled dgrad epilogue not available for this geometry");
         VS_REQUIRE((p.out1 ? p.split_c : p.Cout) % 4 == 0, "conv_igemm: pooled channel count must be a multiple of 4");
     }
+    ConvParams pd = p;
+    pd.out_f32 = p.out_f32 | (out_nchw << 1);
+    if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
+        return launch_direct<T, 16>(p, out_nchw, s);
     if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN))
         return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
     TileGeom g;
@@ -333,15 +583,17 @@ bool conv_igemm_can_pool(const ConvParams& p) {
 }
 
 // instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + code
-// (code 1 = stride 1, 2 = stride 2, 3 = LDS-DMA ring kernel, 8 = 8-wave 256-pixel tiles)
+// (code 1 = stride 1, 2 = stride 2, 3 = LDS-DMA ring kernel, 4 = direct (LDS-free) shallow-layer kernel, 8 = 8-wave 256-pixel tiles)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
     g_dtype_hint = dtype;
+    if (direct_ok(dtype, p)) return 16 * 1000 + 2 * 100 + 9 * 10 + 4;
     const Pick c = pick_cfg(p);
     if (conv_igemm_dma_ok(dtype, p, c.BN)) return c.BN * 1000 + 2 * 100 + 9 * 10 + 3;
     return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : ((c.PT == 1 && p.stride == 2) ? 2 : 1));
 }
 
-int conv_igemm_stat_rows(const ConvParams& p) {
+int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
+    if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave
     const Pick c = pick_cfg(p);
     const int TW = tile_tw(p, c.PT), TH = c.NW * 16 * c.PT / TW;
     return p.N * cdiv(p.Hout, TH) * cdiv(p.Wout, TW);

@@ -411,12 +411,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t i = (size_t)blockIdx.x * 64 + j;
     float s0 = 0.f, s1 = 0.f;
     if (i < n) {
-        int k = g;
-        for (; k + 4 < nparts; k += 8) {
-            s0 += partials[(size_t)k * n + i];
-            s1 += partials[(size_t)(k + 4) * n + i];
+        // slabs g, g+4, g+8, ..: even ones into s0, odd ones into s1; eight loads are issued together (latency-bound kernel)
+        for (int k = g; k < nparts; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k + 4 * u < nparts) ? partials[(size_t)(k + 4 * u) * n + i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
         }
-        if (k < nparts) s0 += partials[(size_t)k * n + i];
     }
     red[g][j] = s0 + s1;
     __syncthreads();
@@ -454,7 +456,11 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
         WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);   // = MO
         g.ctiles = cdiv(p.Cout, 16 * WO);
         const int base = g.ctiles * g.cchunks;
-        int ns = std::min(cdiv(target, base), g.total_tiles);
+        // K splits: `target` workgroups, and up to 4x that for layers whose slabs stay small (the wide, shallow decoder
+        // layers are HBM-bound and need more workgroups per CU to cover their per-tile latency)
+        const int by_slab = (int)std::min(1.0e6, (double)vs_option("wgrad_slab_mb") * 1048576.0 / dw_bytes);
+        int ns = std::max(cdiv(target, base), std::min(cdiv(4 * target, base), by_slab));
+        ns = std::min(ns, g.total_tiles);
         g.nsplit = cdiv(g.total_tiles, cdiv(g.total_tiles, ns));
         g.dys = 0;
         return VS_OK;

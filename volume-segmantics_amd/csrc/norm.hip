@@ -93,6 +93,23 @@ __device__ __forceinline__ void block_sum2_f64(double& s, double& q) {
     q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
 }
 
+// thread t sums partial rows t, t+256, .. of channel ch (both statistics) in that order; the loads of four rows are issued
+// together so the kernel pays one memory round trip per four rows instead of one per row (these kernels are pure latency)
+__device__ __forceinline__ void strided_sum2_f64(const float* __restrict__ partial, int nblocks, int c, int ch, double& s, double& q) {
+    for (int b = threadIdx.x; b < nblocks; b += 4 * 256) {
+        float a[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = b + u * 256;
+            const bool ok = r < nblocks;
+            a[u] = ok ? partial[((size_t)r * 2 + 0) * c + ch] : 0.f;
+            d[u] = ok ? partial[((size_t)r * 2 + 1) * c + ch] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)a[u]; q += (double)d[u]; }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x,
                                                          int nblocks, int c, int64_t rows, float eps, float momentum,
@@ -100,10 +117,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
                                                          float* running_var) {
     const int ch = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
-        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
-    }
+    strided_sum2_f64(partial, nblocks, c, ch, s, q);
     block_sum2_f64(s, q);
     if (threadIdx.x != 0) return;
     const double dm = s / (double)rows;  // mean of (x - K)
@@ -220,10 +234,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
                                                        float* dgamma, float* dbeta) {
     const int ch = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
-        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
-    }
+    strided_sum2_f64(partial, nblocks, c, ch, s, q);
     block_sum2_f64(s, q);
     if (threadIdx.x == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
 }

@@ -424,7 +424,7 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
             if (training) {
                 p.out = c.z(u.out);
                 if (dt == VS_BF16 && vs_option("fuse_stats")) {  // batch statistics straight from the fp32 accumulators
-                    const int rows_needed = conv_igemm_stat_rows(p);
+                    const int rows_needed = conv_igemm_stat_rows(dt, p);
                     if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
                         fused_stat_rows = rows_needed;
