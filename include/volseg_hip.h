@@ -170,6 +170,22 @@ int vs_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   void* stream);
 
+/* The same update folded into the backward pass: every convolution's AdamW step (and the derivation of its low-precision
+ * / transposed copies for the next forward, into the plan's second weight set) is queued behind that layer's weight
+ * gradient on the library's side stream, i.e. in the shadow of the remaining backward work; the small tensors (BN affine
+ * parameters, head bias) are updated in one launch at the end.  Numerically identical to vs_unet_backward followed by
+ * vs_adamw_step with a mask that skips the frozen encoder convolutions (need_encoder_wgrad == 0).  After it returns (all
+ * work ordered on `stream`) the caller must NOT call vs_unet_prepare for this plan again before the next forward. */
+typedef struct vs_adamw_args {
+    float* params;                 /* flat fp32 parameter buffer (updated in place; also the `params` the forward read) */
+    float* exp_avg;
+    float* exp_avg_sq;
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t step;                  /* 1-based number of this update (bias correction) */
+} vs_adamw_args;
+int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
+                           float* grads, void* workspace, void* stream, const vs_adamw_args* opt);
+
 /* DiceLoss(normalization="none") on raw logits and its gradient (data/pytorch3dunet_losses.py:15-41,89-135; the
  * trainer's default criterion, vol_seg_2d_trainer.py:133-135,425-428).  logits (n, K, h*w) fp32 NCHW, targets one-hot
  * (n, K, h*w) uint8 or fp32; loss: 1 device float; workspace (vs_dice_workspace bytes) carries the per-class sums from

@@ -233,6 +233,43 @@ def test_three_reference_training_steps_fp32(golden):
                 assert cos.item() > (0.9 if k[7:].startswith(("segmentation_head", "decoder")) else 0.5), (k, cos.item())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("frozen", [False, True])
+def test_optimizer_step_fused_into_backward_is_identical(precision, frozen):
+    """vs_unet_backward_adamw (update + next forward's weight copies queued behind each layer's weight gradient) must
+    give bit-identical parameters, optimiser state and losses to backward() + step() over several steps."""
+    from volume_segmantics_amd.engine import VolSegUnet
+    x = torch.randn(3, 1, 64, 64, generator=torch.Generator().manual_seed(21)).to(DEV)
+    t = torch.nn.functional.one_hot((torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(22)) > 0.5).long(), 2)
+    t = t.permute(0, 3, 1, 2).float().to(DEV)
+    runs = []
+    for fuse in (False, True):
+        model = VolSegUnet(2, device=DEV, precision=precision, seed=5)
+        if frozen:
+            for name, p in model.named_parameters():
+                if "encoder" in name and "conv" in name:
+                    p.requires_grad = False
+        opt = model.fused_adamw(lr=1e-3, fuse_step_into_backward=fuse)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=6, pct_start=0.3)
+        model.train()
+        losses = []
+        for step in range(4):
+            opt.zero_grad()
+            loss = P.dice_loss_none(model(x), t)
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(loss.item())
+        model.eval()
+        with torch.no_grad():
+            ev = model(x).cpu()
+        runs.append((losses, model._flat.cpu().clone(), opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone(), ev))
+    a, b = runs
+    assert a[0] == b[0], (a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+
+
 def test_frozen_encoder_matches_reference_predicate():
     oracle, model = _pair(2, 3, "fp32", perturb_bn=False)
     for net in (oracle, model):

@@ -36,6 +36,11 @@ class DirMap(C.Structure):
         (n, C.c_int32) for n in ("depth", "h", "w", "hp", "wp", "pad_top", "pad_left", "crop_top", "crop_left")]
 
 
+class AdamwArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32)]
+
+
 P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "vs_last_error": (C.c_char_p, []),
@@ -68,6 +73,7 @@ _SIGS = {
     "vs_unet_forward": (I, [P, P, P, P, I, I, P, P, P]),
     "vs_unet_backward": (I, [P, P, P, P, I, I, P, P, P]),
     "vs_unet_backward_range": (I, [P, P, P, P, I, I, P, P, P, I, I]),
+    "vs_unet_backward_adamw": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs)]),
     "vs_unet_unit_param_offset": (I64, [P, I]),
     "vs_unet_num_units": (I, [P]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),

@@ -152,3 +152,9 @@ size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 // dw[i] = sum_k partials[k*n + i], fixed summation order
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);
+
+// ---- optimiser pieces used by the fused backward (optim.hip) -------------------------------------------------------------
+struct AdamwRanges { int n; long off[160]; long len[160]; };   // passed to the kernel by value
+int launch_adamw_slice(const vs_adamw_args& a, const float* grads, int64_t off, int64_t n, hipStream_t s);
+int launch_adamw_ranges(const vs_adamw_args& a, const float* grads, const AdamwRanges& r, hipStream_t s);
+int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);

@@ -1,6 +1,8 @@
 // Parameter-side kernels (gfx950): fused AdamW over the flat fp32 parameter buffer, derivation of
 // the low-precision / flipped-transposed weight copies the conv kernels read, and the small layout
 // transforms around the segmentation head's gradient.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -21,6 +23,24 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         pi -= (lr / bc1) * (mi / denom);
         p[i] = pi;
+    }
+}
+
+__global__ void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, AdamwRanges r, float lr, float b1, float b2, float eps, float wd,
+                                    float bc1, float bc2_sqrt) {
+    const long off = r.off[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.len[blockIdx.y]; i += (long)gridDim.x * blockDim.x) {
+        const long k = off + i;
+        const float gi = g[k];
+        float pi = p[k] * (1.f - lr * wd);
+        const float mi = b1 * m[k] + (1.f - b1) * gi;
+        const float vi = b2 * v[k] + (1.f - b2) * gi * gi;
+        m[k] = mi;
+        v[k] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[k] = pi;
     }
 }
 
@@ -158,6 +178,30 @@ extern "C" int vs_adamw_step(float* params, const float* grads, float* exp_avg, 
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// one slice [off, off + n) of the flat buffers
+int launch_adamw_slice(const vs_adamw_args& a, const float* grads, int64_t off, int64_t n, hipStream_t s) {
+    if (n <= 0) return VS_OK;
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step);
+    const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, a.params + off, grads + off, a.exp_avg + off,
+                       a.exp_avg_sq + off, (const uint8_t*)nullptr, n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// several slices in one launch: grid.y = slice, grid.x blocks stride over it
+int launch_adamw_ranges(const vs_adamw_args& a, const float* grads, const AdamwRanges& r, hipStream_t s) {
+    if (r.n <= 0) return VS_OK;
+    long longest = 0;
+    for (int i = 0; i < r.n; ++i) longest = std::max(longest, r.len[i]);
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step);
+    const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)std::min<long>(1024, (longest + 1023) / 1024), (unsigned)r.n), dim3(256), 0, s, a.params, grads, a.exp_avg, a.exp_avg_sq, r, a.lr, a.beta1,
+                       a.beta2, a.eps, a.weight_decay, bc1, bc2s);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -49,6 +49,7 @@ struct Unit {
     int relu = 1;
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
+    size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
 };
 
 struct Layout {
@@ -93,6 +94,8 @@ struct vs_unet {
            off_zs = 0, off_idx = 0;
     size_t ws_eval = 0, ws_train = 0;
     int last_n = 0;
+    std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
+    int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
     static constexpr int kSide = 2;
@@ -216,6 +219,12 @@ size_t plan_workspace(vs_unet* net) {
         a.off_a = take(bytes);
     }
     net->ws_eval = off;
+    for (auto& u : net->units) {
+        if (u.kind != U_CONV && u.kind != U_HEAD) continue;
+        const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
+        u.off_wc2 = take((size_t)u.cout * taps * cin * esz);
+        u.off_wt2 = take(cin * taps * (u.kind == U_HEAD ? 16 : (size_t)u.cout) * esz);
+    }
     for (auto& a : net->acts) {
         const size_t bytes = N * a.c * a.h * a.w * esz;
         if (a.has_z) { a.off_z = take(bytes); a.off_dz = take(bytes); }
@@ -263,8 +272,10 @@ struct Ctx {
     const TensorInfo& t(int idx) const { return net->layout.tensors[idx]; }
     const float* P(int idx) const { return params + t(idx).offset; }
     const void* wfwd(const Unit& u) const {  // weights in the compute dtype
-        return net->dtype == VS_F32 ? (const void*)P(u.w_idx) : (const void*)(ws + u.off_wc);
+        return net->dtype == VS_F32 ? (const void*)P(u.w_idx) : (const void*)(ws + wc_off(u, net->wset));
     }
+    static size_t wc_off(const Unit& u, int set) { return set ? u.off_wc2 : u.off_wc; }
+    static size_t wt_off(const Unit& u, int set) { return set ? u.off_wt2 : u.off_wt; }
     float* bnc(const Unit& u, int which) const { return reinterpret_cast<float*>(ws + u.off_bn) + (size_t)which * u.cout; }
     int64_t rows(const Unit& u) const { return (int64_t)n * u.hout * u.wout; }
 };
@@ -364,8 +375,8 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
             const bool wc = net->dtype == VS_BF16, wt = training != 0;
             if (!wc && !wt) continue;
             w_off[nl] = c.t(u.w_idx).offset;
-            wc_off[nl] = wc ? (long)u.off_wc : -1;
-            wt_off[nl] = wt ? (long)u.off_wt : -1;
+            wc_off[nl] = wc ? (long)Ctx::wc_off(u, net->wset) : -1;
+            wt_off[nl] = wt ? (long)Ctx::wt_off(u, net->wset) : -1;
             cout[nl] = u.cout; taps[nl] = u.k * u.k; cin[nl] = u.cin0 + u.cin1; cpad[nl] = u.kind == U_HEAD ? 16 : u.cout;
             ++nl;
         }
@@ -467,12 +478,13 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
 
 // ---- backward --------------------------------------------------------------------------------------
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
-                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi);
+                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
+                               const vs_adamw_args* opt);
 
 extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                 int need_encoder_wgrad, float* grads, void* workspace, void* stream) {
     VS_REQUIRE(net, "unet_backward: null pointer");
-    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, 0, (int)net->units.size());
+    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, 0, (int)net->units.size(), nullptr);
 }
 
 // Backward of the units [unit_lo, unit_hi) only (processed from unit_hi-1 down to unit_lo).  Calling it for consecutive
@@ -483,7 +495,7 @@ extern "C" int vs_unet_backward_range(vs_unet_t* net, const float* params, const
                                       int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo,
                                       int unit_hi) {
     VS_REQUIRE(net && unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_backward_range: bad unit range");
-    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi);
+    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi, nullptr);
 }
 
 // first tensor-table index (parameter-buffer element offset) owned by a unit: lets a caller map unit ranges to slices
@@ -496,7 +508,8 @@ extern "C" int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit) {
 }
 
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
-                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi) {
+                               int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
+                               const vs_adamw_args* opt) {
     VS_REQUIRE(net && params && x && dlogits && grads && workspace, "unet_backward: null pointer");
     VS_REQUIRE(n == net->last_n, "unet_backward: batch %d does not match the last training forward (%d)", n, net->last_n);
     Ctx c{net, (char*)workspace, params, nullptr, (hipStream_t)stream, n};
@@ -523,11 +536,64 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     }
     auto fork = [&](int ui) -> int {  // everything enqueued on the caller's stream so far happens-before the side work
         if (!use_side) return VS_OK;
-        const int k = n_side >= 2 ? (ui & 1) : 0;
+        const int k = (n_side >= 2 && !opt) ? (ui & 1) : 0;   // the fused optimiser step relies on ONE side stream's order
         ws_stream = net->side[k];
         wgws = (float*)(c.ws + net->off_wgws + (size_t)k * net->wgws_bytes);
         VS_CHECK_HIP(hipEventRecord(net->fork_events[ui], c.s));
         VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
+        return VS_OK;
+    };
+    // Fused optimiser step: the network is cut into groups (decoder + head, layer4, layer3, layer2, stem + layer1); when the
+    // first unit of a group has queued its weight gradient, every gradient of the group is complete in side-stream order
+    // (its BN / bias gradients were produced on the caller's stream before that unit's fork event), so ONE AdamW launch over
+    // the group's parameter slice and ONE launch deriving its weight copies for the next forward follow on the side stream.
+    auto group_update = [&](int ui) -> int {
+        if (net->group_first.empty()) {   // unit index -> does an optimiser group start here
+            static const char* const kCuts[] = {"decoder.blocks.0.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
+            net->group_first.assign(net->units.size(), 0);
+            net->group_first[0] = 1;
+            std::string prev;
+            for (size_t k = 0; k < net->units.size(); ++k) {
+                if (net->units[k].w_idx < 0) continue;
+                const std::string& nm = net->layout.tensors[net->units[k].w_idx].name;
+                for (const char* cut : kCuts)
+                    if (nm.rfind(cut, 0) == 0 && prev.rfind(cut, 0) != 0) net->group_first[k] = 1;
+                prev = nm;
+            }
+        }
+        if (!net->group_first[ui]) return VS_OK;
+        int hi = ui + 1;   // the group is [ui, hi): up to the next group's first unit (or the end of the network)
+        while (hi < (int)net->units.size() && !net->group_first[hi]) ++hi;
+        // parameter slices of the group: everything, minus the frozen encoder convolutions when those are not trained
+        AdamwRanges r{};
+        auto push = [&](int idx) {
+            const TensorInfo& t = c.t(idx);
+            int64_t len = 1;
+            for (int d = 0; d < t.ndim; ++d) len *= t.shape[d];
+            if (r.n > 0 && r.off[r.n - 1] + r.len[r.n - 1] == t.offset) { r.len[r.n - 1] += len; return; }
+            r.off[r.n] = t.offset; r.len[r.n] = len; ++r.n;
+        };
+        long w_off[64], wc_off[64], wt_off[64];
+        int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+        const int other = net->wset ^ 1;
+        for (int k = ui; k < hi; ++k) {
+            const Unit& v = net->units[k];
+            if (v.w_idx < 0) continue;
+            if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
+            if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
+            if (v.bias_idx >= 0) push(v.bias_idx);
+            VS_REQUIRE(r.n < 158, "unet_backward: too many parameter slices in one optimiser group");
+            if (v.kind == U_CONV || v.kind == U_HEAD) {
+                w_off[nl] = c.t(v.w_idx).offset;
+                wc_off[nl] = dt == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
+                wt_off[nl] = (long)Ctx::wt_off(v, other);
+                cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+                ++nl;
+            }
+        }
+        int rc2;
+        if ((rc2 = launch_adamw_ranges(*opt, grads, r, ws_stream))) return rc2;
+        if (nl && (rc2 = launch_weight_prepare_all(dt, opt->params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, ws_stream))) return rc2;
         return VS_OK;
     };
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
@@ -575,6 +641,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
             }
+            if (opt && (rc = group_update(ui))) return rc;
             continue;
         }
         // ---- weight gradient ----
@@ -600,6 +667,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
                                         (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
         }
+        if (opt && (rc = group_update(ui))) return rc;
         // ---- data gradient ----
         ConvParams p{};
         const void* dsrc = dzp;
@@ -611,7 +679,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         }
         p.src0 = dsrc; p.C0 = dz_c; p.N = n; p.Hin = u.hin; p.Win = u.win; p.Hout = u.hin; p.Wout = u.win;
         p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
-        p.w = c.ws + u.off_wt; p.Cout = u.cin0 + u.cin1;
+        p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0 + u.cin1;
         if (u.up0) {
             VS_REQUIRE(!written[u.src0] && (u.src1 < 0 || !written[u.src1]), "backward: decoder input gradient written twice");
             if (u.src1 >= 0) { p.out1 = c.da(u.src1); p.split_c = u.cin0; written[u.src1] = 1; }
@@ -648,7 +716,15 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->join_event[i], 0));
         }
     }
+    if (opt) net->wset ^= 1;
     return VS_OK;
+}
+
+extern "C" int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
+                                      float* grads, void* workspace, void* stream, const vs_adamw_args* opt) {
+    VS_REQUIRE(net && opt && opt->params && opt->exp_avg && opt->exp_avg_sq && opt->step >= 1, "unet_backward_adamw: bad optimiser arguments");
+    return unet_backward_range(net, opt->params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, 0,
+                               (int)net->units.size(), opt);
 }
 
 // ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------

@@ -100,6 +100,7 @@ class VolSegUnet(nn.Module):
         self.dp_grad_dtype = torch.float32
         self.dp_buckets = 4  # >1: bucketed, overlapped gradient all-reduce (decoder+head, layer4, layer3, rest)
         self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
+        self._fused_optimizer = None   # FusedAdamW(fuse_step_into_backward=True) registers itself here
         self._bnver = 0  # bumped when a training forward moves the running statistics
         if init == "smp":
             self.reset_parameters(seed)
@@ -261,7 +262,21 @@ class VolSegUnet(nn.Module):
         dlogits = dlogits.contiguous()
         if dlogits.dtype != torch.float32:
             dlogits = dlogits.float()
-        if self.dp_group is not None and self.dp_buckets > 1 and self._world() > 1:
+        fused = self._fused_optimizer
+        if fused is not None and not fused._can_fuse(self, need_enc):
+            fused = None
+        if fused is not None:
+            # the optimiser step rides on the backward's side stream (FusedAdamW(fuse_step_into_backward=True))
+            g = fused.param_groups[0]
+            args = _lib.AdamwArgs(ptr(self._flat), ptr(fused.exp_avg), ptr(fused.exp_avg_sq), float(g["lr"]),
+                                  float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                  fused.step_count + 1)
+            check(lib.vs_unet_backward_adamw(plan["handle"], ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
+                                             ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr(), _lib.C.byref(args)))
+            fused._stepped_in_backward = True
+            self._wver += 1
+            plan["prep"] = (self._flat._version, self._wver, True, None)   # the next forward's copies are already in place
+        elif self.dp_group is not None and self.dp_buckets > 1 and self._world() > 1:
             self._backward_bucketed(plan, x, dlogits, n, need_enc)
         else:
             check(lib.vs_unet_backward(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
@@ -337,8 +352,10 @@ class VolSegUnet(nn.Module):
         return self._forward_impl(x, training=self.training)
 
     # ------------------------------------------------------------------ optimizer
-    def fused_adamw(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
-        return FusedAdamW(self, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    def fused_adamw(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                    fuse_step_into_backward: bool = False):
+        return FusedAdamW(self, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                          fuse_step_into_backward=fuse_step_into_backward)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -346,15 +363,34 @@ class FusedAdamW(torch.optim.Optimizer):
     kernel over the model's flat parameter buffer.  Exposes a normal ``param_groups[0]`` with ``lr`` and
     ``betas`` so LambdaLR / OneCycleLR (which cycles beta1, :401-408) drive it unchanged."""
 
-    def __init__(self, model: VolSegUnet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, model: VolSegUnet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 fuse_step_into_backward: bool = False):
+        """``fuse_step_into_backward``: the update of every tensor is queued inside ``loss.backward()`` right behind that
+        tensor's gradient (vs_unet_backward_adamw), hidden under the rest of the backward pass; ``step()`` then only does
+        the bookkeeping.  Same numbers as the unfused path.  It assumes the reference's loop - exactly one ``step()`` per
+        ``backward()`` with the learning rate set before ``backward()`` (vol_seg_2d_trainer.py:419-432) - and falls back
+        to the plain path for data-parallel runs or unusual ``requires_grad`` patterns."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(list(model.parameters()), defaults)
         self.model = model
+        self._stepped_in_backward = False
+        model._fused_optimizer = self if fuse_step_into_backward else None
         self.exp_avg = torch.zeros_like(model._flat)
         self.exp_avg_sq = torch.zeros_like(model._flat)
         self.step_count = 0
         self._mask = None
         self._mask_key = None
+
+    def _can_fuse(self, model, need_enc: bool) -> bool:
+        if self._stepped_in_backward:
+            raise RuntimeError("FusedAdamW(fuse_step_into_backward=True): backward() called twice without step() - gradient "
+                               "accumulation needs fuse_step_into_backward=False")
+        if model.dp_group is not None:
+            return False   # gradients must be all-reduced first: plain path
+        for p, _, _, _, enc in model._param_cache:
+            if p.requires_grad != (need_enc or not enc):
+                return False   # only "everything" or "everything but the encoder convolutions" can be fused
+        return True
 
     def _grad_mask(self):
         params = list(self.model.parameters())
@@ -385,6 +421,9 @@ class FusedAdamW(torch.optim.Optimizer):
             return loss
         g = self.param_groups[0]
         self.step_count += 1
+        if self._stepped_in_backward:   # the kernels already ran inside backward()
+            self._stepped_in_backward = False
+            return loss
         mask = self._grad_mask()
         check(lib.vs_adamw_step(ptr(m._flat), ptr(m._flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(mask),
                                 m._flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),

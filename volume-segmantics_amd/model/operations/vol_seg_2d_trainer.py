@@ -121,7 +121,9 @@ class VolSeg2dTrainer:
 
     def _create_optimizer(self, learning_rate):
         if isinstance(self.model, VolSegUnet):
-            return FusedAdamW(self.model, lr=learning_rate)
+            # one step() per backward() with the lr set beforehand (_train_one_batch, LR finder): the update can ride on
+            # the backward pass
+            return FusedAdamW(self.model, lr=learning_rate, fuse_step_into_backward=True)
         return torch.optim.AdamW(self.model.parameters(), lr=learning_rate)
 
     def _lr_exp_stepper(self, x):
