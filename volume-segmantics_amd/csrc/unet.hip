@@ -534,15 +534,20 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             net->fork_events.push_back(e);
         }
     }
-    auto fork = [&](int ui) -> int {  // everything enqueued on the caller's stream so far happens-before the side work
+    auto fork_mark = [&](int ui) -> int {  // everything enqueued on the caller's stream so far happens-before the side work
+        if (!use_side) return VS_OK;
+        VS_CHECK_HIP(hipEventRecord(net->fork_events[ui], c.s));
+        return VS_OK;
+    };
+    auto fork_wait = [&](int ui) -> int {
         if (!use_side) return VS_OK;
         const int k = (n_side >= 2 && !opt) ? (ui & 1) : 0;   // the fused optimiser step relies on ONE side stream's order
         ws_stream = net->side[k];
         wgws = (float*)(c.ws + net->off_wgws + (size_t)k * net->wgws_bytes);
-        VS_CHECK_HIP(hipEventRecord(net->fork_events[ui], c.s));
         VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
         return VS_OK;
     };
+    auto fork = [&](int ui) -> int { int r = fork_mark(ui); return r ? r : fork_wait(ui); };
     // Fused optimiser step: the network is cut into groups (decoder + head, layer4, layer3, layer2, stem + layer1); when the
     // first unit of a group has queued its weight gradient, every gradient of the group is complete in side-stream order
     // (its BN / bias gradients were produced on the caller's stream before that unit's fork event), so ONE AdamW launch over
@@ -644,31 +649,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (opt && (rc = group_update(ui))) return rc;
             continue;
         }
-        // ---- weight gradient ----
-        if ((rc = fork(ui))) return rc;
-        if (want_w) {
-            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
-            WgradParams p{};
-            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
-            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
-            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
-            p.dy = dzp; p.Cout = dz_c;
-            p.partials = wgws; p.partial_bytes = net->wgws_bytes;
-            if (u.kind == U_HEAD) {
-                p.dw = (float*)(c.ws + net->off_headdw);
-                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
-                                            hipMemcpyDeviceToDevice, ws_stream));
-            } else {
-                p.dw = grads + c.t(u.w_idx).offset;
-                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-            }
-        } else {
-            VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
-                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
-        }
-        if (opt && (rc = group_update(ui))) return rc;
         // ---- data gradient ----
+        if ((rc = fork_mark(ui))) return rc;   // dz of this unit is complete at this point of the caller's stream
         ConvParams p{};
         const void* dsrc = dzp;
         if (u.stride == 2) {
@@ -709,6 +691,30 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             written[u.src0] = 1;
         }
+        // ---- weight gradient: on the side stream, queued after the data gradient so the caller's stream is fed first ----
+        if ((rc = fork_wait(ui))) return rc;
+        if (want_w) {
+            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
+            WgradParams p{};
+            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
+            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
+            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+            p.dy = dzp; p.Cout = dz_c;
+            p.partials = wgws; p.partial_bytes = net->wgws_bytes;
+            if (u.kind == U_HEAD) {
+                p.dw = (float*)(c.ws + net->off_headdw);
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
+                                            hipMemcpyDeviceToDevice, ws_stream));
+            } else {
+                p.dw = grads + c.t(u.w_idx).offset;
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+            }
+        } else {
+            VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
+                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
+        }
+        if (opt && (rc = group_update(ui))) return rc;
     }
     if (use_side) {  // join: the caller's stream continues only after every weight gradient is in place
         for (int i = 0; i < vs_unet::kSide; ++i) {
