@@ -250,12 +250,15 @@ def test_stem_fwd_and_wgrad(code):
     g = torch.Generator().manual_seed(9)
     n, h, w = 2, 64, 96
     x = torch.randn(n, 1, h, w, generator=g).requires_grad_(False)
-    wt = (torch.randn(64, 1, 7, 7, generator=g) / 7).requires_grad_()
-    y = F.conv2d(x, wt, stride=2, padding=3)
+    wt0 = torch.randn(64, 1, 7, 7, generator=g) / 7
+    # the bf16 path rounds the image and the weights to bf16 inside the kernels (bf16 MFMA): the reference sees the same
+    # values; the device still receives the fp32 originals
+    wt = rounded(wt0, code).requires_grad_()
+    y = F.conv2d(rounded(x, code), wt, stride=2, padding=3)
     dy = rounded(torch.randn(y.shape, generator=g), code)
     y.backward(dy)
     out = torch.empty((n, h // 2, w // 2, 64), device=DEV, dtype=tdtype(code))
-    xd, wd, dyd = x.to(DEV), wt.detach().reshape(64, 49).to(DEV), to_nhwc(dy, code)
+    xd, wd, dyd = x.to(DEV), wt0.reshape(64, 49).to(DEV), to_nhwc(dy, code)
     L.check(L.lib.vs_stem_fwd(code, L.ptr(xd), L.ptr(wd), None, None, 0, L.ptr(out), n, h, w, None))
     sync()
     assert torch.allclose(from_nhwc(out), y.detach(), **tol(code, y.abs().max().item()))

@@ -74,6 +74,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int P = PH * PW;
     char* patch = smem;
     char* wl = smem + P * kPS;
+    // pull every kernel argument the prologue needs into SGPRs with ONE batch of scalar loads: left to itself the compiler
+    // loads them where first used, a chain of four dependent ~0.3 us round trips at the head of every workgroup
+    asm volatile("" ::"s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.out), "s"(p.C0), "s"(p.C1), "s"(p.up0), "s"(p.Hin), "s"(p.Win),
+                 "s"(p.Hout), "s"(p.Wout), "s"(p.pad), "s"(p.Cout), "s"(g.tiles_w), "s"(g.tw_magic), "s"(g.pw_magic), "s"(g.PW),
+                 "s"(g.PH), "s"(g.tw_shift), "s"(g.probe));
     unsigned long long tprobe[5];
     if (g.probe) tprobe[0] = wall_clock64();
 
@@ -245,6 +250,9 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
     constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
     constexpr int kOob = (int)0x80000000;
     __shared__ __attribute__((aligned(16))) char wl[NTAPS * BN * kPS + 64];
+    asm volatile("" ::"s"(p.src0), "s"(p.w), "s"(p.out), "s"(p.C0), "s"(p.up0), "s"(p.Hin), "s"(p.Win), "s"(p.Hout), "s"(p.Wout),
+                 "s"(p.Cout), "s"(p.scale), "s"(p.shift), "s"(p.relu), "s"(p.stats_partial), "s"(g.strips_w), "s"(g.chunks_h),
+                 "s"(g.RH), "s"(g.sw_magic), "s"(g.ch_magic), "s"(g.nwaves));   // one batch of kernel-argument loads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int Cin = p.C0;

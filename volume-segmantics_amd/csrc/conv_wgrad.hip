@@ -241,6 +241,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     constexpr int TG = NTAPS == 9 ? 2 : 1, KG = 2 / TG;    // tap groups / K groups among the two waves of a cin slice
     constexpr int TPW = NTAPS == 9 ? 5 : 1;                // taps per wave (second group: 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // one batch of scalar loads for the kernel arguments instead of a chain of dependent ones (see conv_igemm_kernel)
+    asm volatile("" ::"s"(p.src0), "s"(p.src1), "s"(p.dy), "s"(p.partials), "s"(p.C0), "s"(p.C1), "s"(p.up0), "s"(p.N), "s"(p.Hin),
+                 "s"(p.Win), "s"(p.Hout), "s"(p.Wout), "s"(p.pad), "s"(p.Cout), "s"(g.cchunks), "s"(g.nsplit), "s"(g.total_tiles),
+                 "s"(g.tiles_w), "s"(g.tiles_h), "s"(g.tw_magic), "s"(g.th_magic), "s"(g.pw_magic), "s"(g.tw_shift));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int wc = wave & 1, wg2 = wave >> 1;

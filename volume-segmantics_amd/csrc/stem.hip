@@ -7,12 +7,18 @@
 // The input image stays fp32 (it is the caller's (B,1,H,W) tensor); the output is written in the
 // network's activation dtype.  No dgrad: the input image needs no gradient.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
 constexpr int TPH = 8, TPW = 32;              // output pixel tile
 constexpr int PH = 2 * TPH + 5, PW = 2 * TPW + 5;  // input patch (21 x 69)
 constexpr int WS = 53;                        // LDS row stride (floats) of the [64][52] weight image
+
+__device__ __forceinline__ uint2 ds_read_tr16_stem(const char* p) {
+    short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -152,6 +158,211 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---- bf16 path -------------------------------------------------------------------------------------------------------
+// With bf16 activations the stem runs on v_mfma_f32_16x16x32_bf16 as well: K is laid out as kh * 8 + kw (7 x 7 taps
+// padded to 8 x 8 = 64 = two MFMA k-steps), so the eight consecutive k of a lane are the eight consecutive input columns
+// 2*px .. 2*px+7 of ONE patch row - four aligned dword LDS reads, no im2col.  The weights (64 x 64 bf16, zero in the
+// padding taps) sit in registers for the whole workgroup; the input patch is rounded to bf16 while it is staged.
+constexpr int PWB = 72, PHB = PH + 1;          // bf16 patch: 22 rows (one spare for the zero-weight kh = 7) x 72 columns
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+__device__ __forceinline__ void stage_patch_bf16(const float* __restrict__ x, bf16_t* patch, int img, int h, int wd, int h0, int w0, int tid) {
+    for (int i = tid; i < PHB * PWB / 2; i += 256) {       // pairs of columns
+        const int ph = i / (PWB / 2), pw = (i - ph * (PWB / 2)) * 2;
+        const int hi = 2 * h0 - 3 + ph, wi = 2 * w0 - 3 + pw;
+        float a = 0.f, b = 0.f;
+        if (hi >= 0 && hi < h) {
+            const float* row = x + ((size_t)img * h + hi) * wd;
+            if (wi >= 0 && wi < wd) a = row[wi];
+            if (wi + 1 >= 0 && wi + 1 < wd) b = row[wi + 1];
+        }
+        reinterpret_cast<uint32_t*>(patch)[i] = pack_bf16(a, b);
+    }
+}
+
+// this lane's weight fragments: A[row = cout 16j + lr][k = 8 * (4s + lq) + kw]
+__device__ __forceinline__ void load_stem_weights_bf16(const float* __restrict__ w, int lr, int lq, uint4 (&wa)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kh = 4 * s + lq;
+            float v[8];
+#pragma unroll
+            for (int kw = 0; kw < 8; ++kw) v[kw] = (kh < 7 && kw < 7) ? w[(j * 16 + lr) * 49 + kh * 7 + kw] : 0.f;
+            wa[j][s] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        }
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int relu, bf16_t* __restrict__ y, int n, int h, int wd) {
+    __shared__ __attribute__((aligned(16))) bf16_t patch[PHB * PWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int ho_n = h / 2, wo_n = wd / 2;
+    const int tiles_w = (wo_n + TPW - 1) / TPW, tiles_h = (ho_n + TPH - 1) / TPH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_w; b /= tiles_w;
+    const int ty = b % tiles_h;
+    const int img = b / tiles_h;
+    const int h0 = ty * TPH, w0 = tx * TPW;
+    stage_patch_bf16(x, patch, img, h, wd, h0, w0, tid);
+    uint4 wa[4][2];
+    load_stem_weights_bf16(w, lr, lq, wa);
+    __syncthreads();
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                              // pixel tile i: tile row 2*wave + (i >> 1), columns (i & 1) * 16 + lr
+        const int py = 2 * wave + (i >> 1), px = (i & 1) * 16 + lr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(patch + (2 * py + 4 * s + lq) * PWB + 2 * px);
+            const uint4 xb = make_uint4(src[0], src[1], src[2], src[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[j][s]), __builtin_bit_cast(bf16x8, xb),
+                                                                    acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ho = h0 + 2 * wave + (i >> 1), wo = w0 + (i & 1) * 16 + lr;
+        if (ho >= ho_n || wo >= wo_n) continue;
+        bf16_t* o = y + (((size_t)img * ho_n + ho) * wo_n + wo) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = j * 16 + lq * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (scale) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * scale[c + r] + shift[c + r];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            st4(o + c, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+}
+
+// Weight gradient, bf16: D[cout][kh*8+kw] += dY^T[cout][pixel] * X[pixel][kh*8+kw], k = 32 output pixels (one tile row).
+// A: transposed reads of the [pixel][64 cout] dy tile (32-byte slices XOR-swizzled as in conv_wgrad); B: the eight pixels of
+// a lane are eight stride-2 columns of one patch row (ds_read_u16 gathers).  Wave w takes tile rows w and w + 4, all
+// 4 x 4 (cout x tap) fragments; the four waves meet in LDS once per workgroup.
+__global__ __launch_bounds__(256) void stem_wgrad_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                              float* __restrict__ partial, int n, int h, int wd,
+                                                              int total_tiles, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* patch = reinterpret_cast<bf16_t*>(smem);            // PHB * PWB bf16
+    char* dyl = smem + ((PHB * PWB * 2 + 255) & ~255);          // [256 pixels][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int ho_n = h / 2, wo_n = wd / 2;
+    const int tiles_w = (wo_n + TPW - 1) / TPW, tiles_h = (ho_n + TPH - 1) / TPH;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, n * ho_n * wo_n * 64 * 2);
+    f32x4 acc[4][4];                                             // [cout fragment][tap fragment]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B gather: tap t = 16 j + lr -> (kh, kw) = (t >> 3, t & 7); this lane's pixels are columns 8 lq .. 8 lq + 7 of the tile row
+    int goff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = 16 * j + lr;
+        goff[j] = ((t >> 3) * PWB + (t & 7) + 16 * lq) * 2;      // bytes; + 2 * tile row * PWB * 2, + 4 * pixel
+    }
+    // A (dy^T) fragment addresses: pixels 8 lq + (lr >> 2) (+4) of the tile row, slice m ^ g(pixel)
+    int a_addr[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int px = 8 * lq + (lr >> 2) + 4 * hh;
+        a_addr[hh] = px * 128 + ((((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 5) + (lr & 3) * 8;
+    }
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(total_tiles, t0 + tiles_per_block);
+    for (int tile = t0; tile < t1; ++tile) {
+        int b = tile;
+        const int tx = b % tiles_w; b /= tiles_w;
+        const int ty = b % tiles_h;
+        const int img = b / tiles_h;
+        const int h0 = ty * TPH, w0 = tx * TPW;
+        __syncthreads();
+        stage_patch_bf16(x, patch, img, h, wd, h0, w0, tid);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                            // 256 pixels x 8 segments of 16 bytes
+            const int item = tid + i * 256;
+            const int pl = item >> 3, seg = item & 7;
+            const int ho = h0 + (pl >> 5), wo = w0 + (pl & 31);
+            const bool ok = ho < ho_n && wo < wo_n;
+            const uint4 v = bload(rd, ok ? ((((img * ho_n + ho) * wo_n + wo) * 64 + seg * 8) * 2) : -1, 0);
+            const int gk = ((pl >> 1) & 1) | (((pl >> 3) & 1) << 1);
+            *reinterpret_cast<uint4*>(dyl + pl * 128 + (((seg >> 1) ^ gk) << 5) + (seg & 1) * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int trow = wave + 4 * rr;                      // k-step = tile row trow (32 pixels)
+            uint4 af[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint2 lo = ds_read_tr16_stem(dyl + trow * 32 * 128 + (a_addr[0] ^ (m << 5)));
+                const uint2 hi = ds_read_tr16_stem(dyl + trow * 32 * 128 + (a_addr[1] ^ (m << 5)));
+                af[m] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* base = reinterpret_cast<const char*>(patch) + goff[j] + 2 * trow * PWB * 2;
+                uint32_t d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t lo = *reinterpret_cast<const bf16_t*>(base + (2 * k) * 4);
+                    const uint32_t hi = *reinterpret_cast<const bf16_t*>(base + (2 * k + 1) * 4);
+                    d[k] = lo | (hi << 16);
+                }
+                const uint4 bf = make_uint4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf),
+                                                                        acc[m][j], 0, 0, 0);
+            }
+        }
+    }
+    // the four waves (different pixels, same outputs) meet in LDS; fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    for (int round = 1; round < 4; ++round) {
+        __syncthreads();
+        if (wave == round) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[(m * 4 + j) * 64 + lane] = acc[m][j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] += red[(m * 4 + j) * 64 + lane];
+        }
+    }
+    if (wave != 0) return;
+    float* out = partial + (size_t)blockIdx.x * 64 * 49;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = 16 * j + lr, kh = t >> 3, kw = t & 7;
+        if (kh >= 7 || kw >= 7) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(m * 16 + lq * 4 + r) * 49 + kh * 7 + kw] = acc[m][j][r];
+    }
+}
+
 __global__ void stem_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nparts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 64 * 49) return;
@@ -168,7 +379,10 @@ extern "C" int vs_stem_fwd(int dtype, const float* x, const float* w, const floa
                            void* y, int n, int h, int w_, void* stream) {
     VS_REQUIRE(h % 2 == 0 && w_ % 2 == 0 && x && w && y, "stem_fwd: bad arguments");
     const int tiles = n * cdiv(h / 2, TPH) * cdiv(w_ / 2, TPW);
-    if (dtype == VS_BF16)
+    if (dtype == VS_BF16 && vs_option("stem_bf16"))
+        hipLaunchKernelGGL(stem_fwd_bf16_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
+                           (bf16_t*)y, n, h, w_);
+    else if (dtype == VS_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (bf16_t*)y, n, h, w_);
     else
@@ -196,6 +410,15 @@ extern "C" int vs_stem_wgrad(int dtype, const float* x, const void* dy, float* d
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)stem_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)stem_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
+    }
+    if (dtype == VS_BF16 && vs_option("stem_bf16")) {
+        VS_REQUIRE((double)n * (h / 2) * (w_ / 2) * 128.0 < 2.0e9, "stem_wgrad: dy exceeds the 32-bit staging offsets");
+        const int per2 = cdiv(total, 512), blocks2 = cdiv(total, per2);   // fewer, longer blocks: the weights stay in registers
+        const size_t lds2 = ((PHB * PWB * 2 + 255) & ~255) + 256 * 128;
+        hipLaunchKernelGGL(stem_wgrad_bf16_kernel, dim3(blocks2), dim3(256), lds2, (hipStream_t)stream, x, (const bf16_t*)dy,
+                           workspace, n, h, w_, total, per2);
+        VS_LAUNCH_CHECK();
+        return launch_slab_reduce(workspace, dw, 64 * 49, blocks2, (hipStream_t)stream);
     }
     if (dtype == VS_BF16)
         hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, (const bf16_t*)dy,
