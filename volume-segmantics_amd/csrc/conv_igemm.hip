@@ -40,6 +40,8 @@ struct TileGeom {
     int PH, PW;  // staged patch dims
     int out_nchw;
     unsigned pw_magic, tw_magic;  // x / PW == umulhi(x, pw_magic), x / tiles_w == umulhi(x, tw_magic) for x < 65536
+    int groups, ctiles;           // pixel tiles over the whole batch, cout tiles (see the workgroup -> tile map in the kernel)
+    unsigned ct_magic, ti_magic;  // x / ctiles, x / (tiles_h * tiles_w)
     unsigned long long* probe;  // phase timestamps (tools/conv_probe.py); null in normal operation
 };
 
@@ -82,11 +84,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     unsigned long long tprobe[5];
     if (g.probe) tprobe[0] = wall_clock64();
 
-    const int ty = g.tiles_w == 1 ? (int)blockIdx.x : (int)__umulhi(blockIdx.x, g.tw_magic);
-    const int tx = (int)blockIdx.x - ty * g.tiles_w;
-    const int n = blockIdx.z;
+    // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the
+    // cout tiles that share one input patch are given ids 8 apart - they run back to back on ONE XCD and the patch comes
+    // from HBM once (ids differing only in the low 3 bits take different pixel tiles).  With the cout tile as the slow
+    // index every XCD would fetch every image: ~2x the traffic in the 256-/512-channel layers (rocprofv3 FETCH_SIZE).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gl = g.ctiles == 1 ? slot : (int)__umulhi((unsigned)slot, g.ct_magic);
+    const int ytile = slot - gl * g.ctiles;
+    const int grp = gl * 8 + xcd;                     // pixel tile index over the whole batch
+    if (grp >= g.groups) return;                      // padding of the last round (uniform per workgroup)
+    const int tiles_img = g.tiles_h * g.tiles_w;
+    const int n = tiles_img == 1 ? grp : (int)__umulhi((unsigned)grp, g.ti_magic);
+    const int timg = grp - n * tiles_img;
+    const int ty = g.tiles_w == 1 ? timg : (int)__umulhi((unsigned)timg, g.tw_magic);
+    const int tx = timg - ty * g.tiles_w;
     const int h0 = ty * TH, w0 = tx * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = ytile * BN;
     const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
     const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
     // Staging loads are raw buffer loads: one descriptor per source (base = this image, so per-lane offsets are 32-bit
@@ -210,12 +223,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     }
 
     if (g.probe) tprobe[3] = wall_clock64();
-    conv_epilogue<T, BN, PT, NW>(p, tw_shift, g.out_nchw, n, h0, w0, n0, (int)(blockIdx.z * gridDim.x + blockIdx.x), acc, smem);
+    conv_epilogue<T, BN, PT, NW>(p, tw_shift, g.out_nchw, n, h0, w0, n0, grp, acc, smem);
     if (g.probe) {
         __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged
         tprobe[4] = wall_clock64();
         if (tid == 0) {
-            unsigned long long* o = g.probe + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            unsigned long long* o = g.probe + (size_t)blockIdx.x * 8;
             for (int i = 0; i < 5; ++i) o[i] = tprobe[i];
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -488,8 +501,15 @@ int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
         attr_set = true;
     }
     VS_REQUIRE(g.tiles_h * g.tiles_w < 65536 && p.N < 65536 && g.PH * g.PW + NW * 64 < 65536, "conv_igemm: tile grid too large");
-    dim3 grid((unsigned)(g.tiles_h * g.tiles_w), (unsigned)cdiv(p.Cout, BN), (unsigned)p.N);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p, g);
+    TileGeom gg = g;
+    gg.groups = p.N * g.tiles_h * g.tiles_w;
+    gg.ctiles = cdiv(p.Cout, BN);
+    gg.ct_magic = 0xffffffffu / (unsigned)gg.ctiles + 1u;
+    gg.ti_magic = 0xffffffffu / (unsigned)(g.tiles_h * g.tiles_w) + 1u;
+    const long nwg = (long)cdiv(gg.groups, 8) * 8 * gg.ctiles;
+    VS_REQUIRE(nwg < (1L << 31) && (long)gg.groups * (g.tiles_h * g.tiles_w) < (1L << 32), "conv_igemm: tile grid too large");
+    if (g.probe) gg.probe = vs_probe_buffer((size_t)nwg);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, s, p, gg);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
