@@ -547,7 +547,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
         return VS_OK;
     };
-    auto fork = [&](int ui) -> int { int r = fork_mark(ui); return r ? r : fork_wait(ui); };
     // Fused optimiser step: the network is cut into groups (decoder + head, layer4, layer3, layer2, stem + layer1); when the
     // first unit of a group has queued its weight gradient, every gradient of the group is complete in side-stream order
     // (its BN / bias gradients were produced on the caller's stream before that unit's fork event), so ONE AdamW launch over
@@ -601,6 +600,50 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (nl && (rc2 = launch_weight_prepare_all(dt, opt->params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, ws_stream))) return rc2;
         return VS_OK;
     };
+    // Weight-gradient work of one unit, queued on the side stream (after a fork event that covers its dz).
+    struct SideItem { int ui; const void* dzp; int dz_c; };
+    std::vector<SideItem> pending;
+    auto side_wgrad = [&](const SideItem& it) -> int {
+        const int ui = it.ui;
+        const Unit& u = net->units[ui];
+        const void* dzp = it.dzp;
+        const int dz_c = it.dz_c;
+        int rc;
+        const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
+        prof_set_tag(ui);
+        if (u.kind == U_STEM) {
+            ProfScope prof(PK_STEM, want_w ? 2.0 * n * u.hout * u.wout * 64 * 49 : 0, 0, ws_stream);
+            if (want_w) {
+                if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, (void*)ws_stream))) return rc;
+            } else {
+                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
+            }
+            return opt ? group_update(ui) : VS_OK;
+        }
+        if (want_w) {
+            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
+            WgradParams p{};
+            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
+            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
+            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+            p.dy = dzp; p.Cout = dz_c;
+            p.partials = wgws; p.partial_bytes = net->wgws_bytes;
+            if (u.kind == U_HEAD) {
+                p.dw = (float*)(c.ws + net->off_headdw);
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
+                                            hipMemcpyDeviceToDevice, ws_stream));
+            } else {
+                p.dw = grads + c.t(u.w_idx).offset;
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+            }
+        } else {
+            VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
+                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
+        }
+        return opt ? group_update(ui) : VS_OK;
+    };
+    const int fork_every = std::max(1, vs_option("fork_every"));
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
@@ -637,20 +680,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                           (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             dzp = c.dz(u.out); dz_c = u.cout;
         }
-        const bool want_w = !(u.frozen_candidate && !need_encoder_wgrad);
-        if (u.kind == U_STEM) {  // no data gradient: the input image needs none
-            if ((rc = fork(ui))) return rc;
-            ProfScope prof(PK_STEM, want_w ? 2.0 * n * u.hout * u.wout * 64 * 49 : 0, 0, ws_stream);
-            if (want_w) {
-                if ((rc = vs_stem_wgrad(dt, x, dzp, grads + c.t(u.w_idx).offset, wgws, net->wgws_bytes, n, net->h, net->w, (void*)ws_stream))) return rc;
-            } else {
-                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
-            }
-            if (opt && (rc = group_update(ui))) return rc;
-            continue;
-        }
-        // ---- data gradient ----
-        if ((rc = fork_mark(ui))) return rc;   // dz of this unit is complete at this point of the caller's stream
+        // ---- fork policy: one event (a barrier packet on the caller's stream, ~7 us of command-processor time) covers the
+        // weight-gradient work of up to `fork_every` consecutive units ----
+        pending.push_back(SideItem{ui, dzp, dz_c});
+        const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
+        if (flush && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
+        if (u.kind != U_STEM) {
+        // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
         ConvParams p{};
         const void* dsrc = dzp;
         if (u.stride == 2) {
@@ -691,30 +727,21 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             written[u.src0] = 1;
         }
-        // ---- weight gradient: on the side stream, queued after the data gradient so the caller's stream is fed first ----
-        if ((rc = fork_wait(ui))) return rc;
-        if (want_w) {
-            ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
-            WgradParams p{};
-            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
-            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
-            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
-            p.dy = dzp; p.Cout = dz_c;
-            p.partials = wgws; p.partial_bytes = net->wgws_bytes;
-            if (u.kind == U_HEAD) {
-                p.dw = (float*)(c.ws + net->off_headdw);
-                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
-                                            hipMemcpyDeviceToDevice, ws_stream));
-            } else {
-                p.dw = grads + c.t(u.w_idx).offset;
-                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-            }
-        } else {
-            VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
-                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
         }
-        if (opt && (rc = group_update(ui))) return rc;
+        if (flush) {
+            if ((rc = fork_wait(ui))) return rc;
+            for (const SideItem& it : pending)
+                if ((rc = side_wgrad(it))) return rc;
+            pending.clear();
+            prof_set_tag(ui);
+        }
+    }
+    if (!pending.empty()) {   // a range that ends on a unit without weights (the max-pool)
+        const int ui = pending.back().ui;
+        if ((rc = fork_mark(ui)) || (rc = fork_wait(ui))) return rc;
+        for (const SideItem& it : pending)
+            if ((rc = side_wgrad(it))) return rc;
+        pending.clear();
     }
     if (use_side) {  // join: the caller's stream continues only after every weight gradient is in place
         for (int i = 0; i < vs_unet::kSide; ++i) {
