@@ -405,3 +405,23 @@ def test_fused_dice_loss_matches_reference_formula(classes, tdtype):
     sync()
     assert abs(loss.item() - ref.item()) < 1e-6
     assert torch.allclose(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("classes", [1, 2, 4, 7])
+def test_mean_iou_matches_oracle(classes):
+    """vs_mean_iou vs the oracle's restatement of MeanIoU.__call__ (pinned by golden g6 in the CPU suite)."""
+    from oracle import predictor_numpy as P
+    from volume_segmantics_amd.data.losses import MeanIoU
+    g = torch.Generator().manual_seed(31 + classes)
+    n, h, w = 3, 40, 56
+    logits = torch.randn(n, classes, h, w, generator=g)
+    logits[0, :, :4] = 0.25                      # ties: the first maximum must win
+    probs = torch.softmax(logits, 1) if classes > 1 else torch.sigmoid(logits)
+    lab = torch.randint(0, max(classes, 2), (n, h, w), generator=g)
+    onehot = torch.nn.functional.one_hot(lab, max(classes, 2)).permute(0, 3, 1, 2)[:, :classes].contiguous()
+    for tt in (onehot.to(torch.uint8), onehot.float()):
+        ref = P.mean_iou(probs, tt)
+        got = MeanIoU()(probs.to(DEV), tt.to(DEV))
+        assert got.is_cuda and abs(got.item() - ref.item()) < 1e-6, (got.item(), ref.item())
+        got5 = MeanIoU()(probs.to(DEV).unsqueeze(2), tt.to(DEV).unsqueeze(2))     # the trainer's 5-D form
+        assert abs(got5.item() - ref.item()) < 1e-6

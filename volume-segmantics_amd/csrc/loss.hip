@@ -4,6 +4,8 @@
 //   dloss/dx = -(2/K) * (t D_c - 2 x I_c) / D_c^2      (D_c > eps;  -(2/K) t / eps otherwise)
 // x: logits (N, K, H, W) fp32 NCHW (what vs_unet_forward returns), t: one-hot targets (N, K, H, W) uint8 or fp32.
 // Two HBM sweeps (reduce, then gradient) instead of ~20 elementwise torch kernels; sums finalised in fp64, fixed order.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -70,6 +72,65 @@ __global__ __launch_bounds__(256) void dice_grad_kernel(const float* __restrict_
     }
 }
 
+
+// ---- MeanIoU (data/pytorch3dunet_metrics.py:34-106; validation metric of vol_seg_2d_trainer.py:150-161,243) ----------------
+// Per sample: prediction = one-hot of the first arg-max over channels (input > 0.5 for a single channel), per class
+// |P & T| / max(|P | T|, 1e-8) on the byte-converted target, mean over classes, then over samples.  One sweep: integer
+// counts per (sample, class) through wave reductions and integer atomics (exact, order-free), then one tiny finalise.
+template <typename TT>
+__global__ __launch_bounds__(256) void mean_iou_count_kernel(const float* __restrict__ x, const TT* __restrict__ t, int c, int64_t hw,
+                                                           int* __restrict__ counts) {
+    constexpr int kMax = 16;
+    const int b = blockIdx.y;
+    int inter[kMax], uni[kMax];
+#pragma unroll
+    for (int k = 0; k < kMax; ++k) inter[k] = uni[k] = 0;
+    const size_t base = (size_t)b * c * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+        int arg = 0;
+        if (c == 1) {
+            arg = x[base + i] > 0.5f ? 0 : -1;
+        } else {
+            float best = x[base + i];
+            for (int k = 1; k < c; ++k) {
+                const float v = x[base + (size_t)k * hw + i];
+                if (v > best) { best = v; arg = k; }     // strict: the first maximum wins
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kMax; ++k) {
+            if (k < c) {
+                const int p = k == arg ? 1 : 0;
+                const int tb = (int)(unsigned char)t[base + (size_t)k * hw + i];   // `_target.byte()`
+                inter[k] += p & tb;
+                uni[k] += p | tb;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMax; ++k) {
+        int a = inter[k], u = uni[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
+        if (k < c && (threadIdx.x & 63) == 0) {
+            atomicAdd(counts + ((size_t)b * c + k) * 2 + 0, a);
+            atomicAdd(counts + ((size_t)b * c + k) * 2 + 1, u);
+        }
+    }
+}
+
+__global__ void mean_iou_finalize_kernel(const int* __restrict__ counts, int n, int c, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int b = 0; b < n; ++b) {
+        float s = 0.f;
+        for (int k = 0; k < c; ++k)
+            s += (float)counts[((size_t)b * c + k) * 2] / fmaxf((float)counts[((size_t)b * c + k) * 2 + 1], 1e-8f);
+        total += s / (float)c;
+    }
+    *out = total / (float)n;
+}
+
 }  // namespace
 
 extern "C" size_t vs_dice_workspace(int classes) { return ((size_t)kBlocks * classes * 3 + 2 * (size_t)classes) * sizeof(float); }
@@ -103,6 +164,25 @@ extern "C" int vs_dice_loss_bwd(const float* logits, const void* targets, int ta
         hipLaunchKernelGGL(dice_grad_kernel<float>, dim3(grid), dim3(256), 0, s, logits, (const float*)targets, stats, grad_out, eps, n, classes, hw, dlogits);
     else
         hipLaunchKernelGGL(dice_grad_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, logits, (const uint8_t*)targets, stats, grad_out, eps, n, classes, hw, dlogits);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" size_t vs_mean_iou_workspace(int n, int classes) { return (size_t)n * classes * 2 * sizeof(int); }
+
+extern "C" int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int n, int classes, int64_t hw, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(input && targets && out && n >= 1 && classes >= 1 && classes <= 16 && hw >= 1, "mean_iou: bad arguments");
+    VS_REQUIRE(workspace && workspace_bytes >= vs_mean_iou_workspace(n, classes), "mean_iou: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    VS_CHECK_HIP(hipMemsetAsync(workspace, 0, vs_mean_iou_workspace(n, classes), s));
+    const dim3 grid((unsigned)std::min<int64_t>(64, (hw + 255) / 256), (unsigned)n);
+    if (target_is_f32)
+        hipLaunchKernelGGL(mean_iou_count_kernel<float>, grid, dim3(256), 0, s, input, (const float*)targets, classes, hw, (int*)workspace);
+    else
+        hipLaunchKernelGGL(mean_iou_count_kernel<uint8_t>, grid, dim3(256), 0, s, input, (const uint8_t*)targets, classes, hw, (int*)workspace);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_iou_finalize_kernel, dim3(1), dim3(64), 0, s, (const int*)workspace, n, classes, out);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -126,12 +126,29 @@ class DiceCoefficient:
 
 class MeanIoU:
     """Per-sample argmax one-hot, per-class Jaccard, mean over classes then samples (pytorch3dunet_metrics.py:34-106).
-    Accepts the (N, C, 1, H, W) tensors the reference's trainer builds or plain (N, C, H, W)."""
+    Accepts the (N, C, 1, H, W) tensors the reference's trainer builds or plain (N, C, H, W).  GPU tensors go through
+    one HIP sweep (vs_mean_iou); the torch ops below serve CPU tensors and the skip_channels / ignore_index options."""
+
+    @staticmethod
+    def _hip(input, target):
+        from .._lib import check, lib, ptr, stream_ptr
+        n, c = input.size(0), input.size(1)
+        x, t = input.contiguous(), target.contiguous()
+        hw = x.numel() // (n * c)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        nbytes = lib.vs_mean_iou_workspace(n, c)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(lib.vs_mean_iou(ptr(x), ptr(t), 1 if t.dtype == torch.float32 else 0, n, c, hw, ptr(out), ptr(ws), nbytes,
+                              stream_ptr()))
+        return out
 
     def __init__(self, skip_channels=(), ignore_index=None, **kwargs):
         self.skip_channels, self.ignore_index = skip_channels, ignore_index
 
     def __call__(self, input, target):
+        if (input.is_cuda and input.dtype == torch.float32 and input.shape == target.shape and input.size(1) <= 16
+                and not self.skip_channels and self.ignore_index is None and target.dtype in (torch.uint8, torch.float32)):
+            return self._hip(input, target)
         n_classes = input.size(1)
         scores = []
         for p, t in zip(input, target):
