@@ -199,11 +199,17 @@ int vs_dice_loss_bwd(const float* logits, const void* targets, int target_is_f32
 /* MeanIoU, the trainer's default validation metric (data/pytorch3dunet_metrics.py:34-106; vol_seg_2d_trainer.py:150-161,
  * 243): per sample the prediction is the one-hot of the FIRST arg-max over channels (input > 0.5 for one channel), per
  * class |P & T| / max(|P | T|, 1e-8) with the target converted to bytes, mean over classes, then over samples.
- * input (n, K, h*w) fp32 (probabilities or logits - only the arg-max matters), targets one-hot (n, K, h*w) uint8 or fp32,
- * out: 1 device float; workspace: vs_mean_iou_workspace bytes (zeroed by the call). */
+ * input (n, K, h*w) fp32: probabilities, or with from_logits = 1 raw logits whose softmax(dim=1) is formed in fp32 inside the
+ * kernel (the trainer's `softmax` + metric in one sweep; ties after rounding resolve as they would on the probabilities);
+ * targets one-hot (n, K, h*w) uint8 or fp32; out: 1 device float; workspace: vs_mean_iou_workspace bytes (zeroed by the call). */
 size_t vs_mean_iou_workspace(int n, int classes);
-int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int n, int classes, int64_t hw, float* out,
-                void* workspace, size_t workspace_bytes, void* stream);
+int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int from_logits, int n, int classes, int64_t hw,
+                float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One-hot of a label batch on the device: labels (n, h*w) uint8 -> (n, K, h*w) uint8 (prepare_training_batch,
+ * utilities/base_data_utils.py:150-158: mask -> one_hot(K) -> permute to NCHW -> uint8).  Labels >= K give an all-zero
+ * column (torch.nn.functional.one_hot would raise). */
+int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t hw, uint8_t* onehot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Prediction path (vol_seg_2d_predictor.py:31-136)

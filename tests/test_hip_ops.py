@@ -425,3 +425,17 @@ def test_mean_iou_matches_oracle(classes):
         assert got.is_cuda and abs(got.item() - ref.item()) < 1e-6, (got.item(), ref.item())
         got5 = MeanIoU()(probs.to(DEV).unsqueeze(2), tt.to(DEV).unsqueeze(2))     # the trainer's 5-D form
         assert abs(got5.item() - ref.item()) < 1e-6
+        if classes > 1:
+            gl = MeanIoU().from_logits(logits.to(DEV), tt.to(DEV))                # softmax formed inside the kernel
+            assert abs(gl.item() - ref.item()) < 1e-6
+
+
+def test_onehot_matches_reference_prepare_training_batch():
+    from volume_segmantics_amd.utilities.base_data_utils import prepare_training_batch
+    g = torch.Generator().manual_seed(41)
+    for k, shape in ((2, (3, 64, 64)), (4, (2, 40, 56)), (7, (1, 33, 31))):
+        img = torch.randn(shape[0], 1, *shape[1:], generator=g)
+        lab = torch.randint(0, k, shape, generator=g, dtype=torch.uint8)
+        ref = torch.nn.functional.one_hot(lab.long(), k).permute(0, 3, 1, 2).to(torch.uint8)
+        x, t = prepare_training_batch((img, lab), DEV, k)
+        assert t.is_cuda and t.dtype == torch.uint8 and torch.equal(t.cpu(), ref) and torch.equal(x.cpu(), img)

@@ -91,7 +91,8 @@ _SIGS = {
     "vs_dice_loss_fwd": (I, [P, P, I, I, I, I64, F, P, P, SZ, P]),
     "vs_dice_loss_bwd": (I, [P, P, I, P, I, I, I64, F, P, P, P]),
     "vs_mean_iou_workspace": (SZ, [I, I]),
-    "vs_mean_iou": (I, [P, P, I, I, I, I64, P, P, SZ, P]),
+    "vs_mean_iou": (I, [P, P, I, I, I, I, I64, P, P, SZ, P]),
+    "vs_onehot_u8": (I, [P, I, I, I64, P, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
     "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),

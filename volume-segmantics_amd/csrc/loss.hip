@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void dice_grad_kernel(const float* __restrict_
 // counts per (sample, class) through wave reductions and integer atomics (exact, order-free), then one tiny finalise.
 template <typename TT>
 __global__ __launch_bounds__(256) void mean_iou_count_kernel(const float* __restrict__ x, const TT* __restrict__ t, int c, int64_t hw,
-                                                           int* __restrict__ counts) {
+                                                           int from_logits, int* __restrict__ counts) {
     constexpr int kMax = 16;
     const int b = blockIdx.y;
     int inter[kMax], uni[kMax];
@@ -90,11 +90,23 @@ __global__ __launch_bounds__(256) void mean_iou_count_kernel(const float* __rest
         int arg = 0;
         if (c == 1) {
             arg = x[base + i] > 0.5f ? 0 : -1;
-        } else {
+        } else if (!from_logits) {
             float best = x[base + i];
             for (int k = 1; k < c; ++k) {
                 const float v = x[base + (size_t)k * hw + i];
                 if (v > best) { best = v; arg = k; }     // strict: the first maximum wins
+            }
+        } else {
+            // the trainer hands the metric softmax(logits, dim=1): two distinct logits may round to the SAME probability,
+            // and then the first one wins - so the arg-max is taken over fp32 probabilities, as in vs_logits_to_volume
+            float m = x[base + i];
+            for (int k = 1; k < c; ++k) m = fmaxf(m, x[base + (size_t)k * hw + i]);
+            float sum = 0.f;
+            for (int k = 0; k < c; ++k) sum += expf(x[base + (size_t)k * hw + i] - m);
+            float best = -1.f;
+            for (int k = 0; k < c; ++k) {
+                const float pr = __fdiv_rn(expf(x[base + (size_t)k * hw + i] - m), sum);
+                if (pr > best) { best = pr; arg = k; }
             }
         }
 #pragma unroll
@@ -129,6 +141,23 @@ __global__ void mean_iou_finalize_kernel(const int* __restrict__ counts, int n, 
         total += s / (float)c;
     }
     *out = total / (float)n;
+}
+
+
+// labels (n, hw) uint8 -> one-hot (n, K, hw) uint8 (prepare_training_batch, utilities/base_data_utils.py:150-158)
+__global__ void onehot_kernel(const uint8_t* __restrict__ lab, int k, int64_t hw, uint8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hw; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= hw && (hw & 3) == 0) {
+            const uchar4 l = *reinterpret_cast<const uchar4*>(lab + (size_t)b * hw + i);
+            for (int c = 0; c < k; ++c)
+                *reinterpret_cast<uchar4*>(out + ((size_t)b * k + c) * hw + i) =
+                    make_uchar4(l.x == c, l.y == c, l.z == c, l.w == c);
+        } else {
+            for (int64_t j = i; j < min(hw, i + 4); ++j)
+                for (int c = 0; c < k; ++c) out[((size_t)b * k + c) * hw + j] = lab[(size_t)b * hw + j] == c;
+        }
+    }
 }
 
 }  // namespace
@@ -170,19 +199,27 @@ extern "C" int vs_dice_loss_bwd(const float* logits, const void* targets, int ta
 
 extern "C" size_t vs_mean_iou_workspace(int n, int classes) { return (size_t)n * classes * 2 * sizeof(int); }
 
-extern "C" int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int n, int classes, int64_t hw, float* out,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int from_logits, int n, int classes, int64_t hw,
+                           float* out, void* workspace, size_t workspace_bytes, void* stream) {
     VS_REQUIRE(input && targets && out && n >= 1 && classes >= 1 && classes <= 16 && hw >= 1, "mean_iou: bad arguments");
     VS_REQUIRE(workspace && workspace_bytes >= vs_mean_iou_workspace(n, classes), "mean_iou: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     VS_CHECK_HIP(hipMemsetAsync(workspace, 0, vs_mean_iou_workspace(n, classes), s));
     const dim3 grid((unsigned)std::min<int64_t>(64, (hw + 255) / 256), (unsigned)n);
     if (target_is_f32)
-        hipLaunchKernelGGL(mean_iou_count_kernel<float>, grid, dim3(256), 0, s, input, (const float*)targets, classes, hw, (int*)workspace);
+        hipLaunchKernelGGL(mean_iou_count_kernel<float>, grid, dim3(256), 0, s, input, (const float*)targets, classes, hw, from_logits, (int*)workspace);
     else
-        hipLaunchKernelGGL(mean_iou_count_kernel<uint8_t>, grid, dim3(256), 0, s, input, (const uint8_t*)targets, classes, hw, (int*)workspace);
+        hipLaunchKernelGGL(mean_iou_count_kernel<uint8_t>, grid, dim3(256), 0, s, input, (const uint8_t*)targets, classes, hw, from_logits, (int*)workspace);
     VS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_iou_finalize_kernel, dim3(1), dim3(64), 0, s, (const int*)workspace, n, classes, out);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t hw, uint8_t* onehot, void* stream) {
+    VS_REQUIRE(labels && onehot && n >= 1 && classes >= 1 && classes <= 255 && hw >= 1, "onehot: bad arguments");
+    const dim3 grid((unsigned)std::min<int64_t>(256, (hw / 4 + 255) / 256 + 1), (unsigned)n);
+    hipLaunchKernelGGL(onehot_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, classes, hw, onehot);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -129,8 +129,15 @@ class MeanIoU:
     Accepts the (N, C, 1, H, W) tensors the reference's trainer builds or plain (N, C, H, W).  GPU tensors go through
     one HIP sweep (vs_mean_iou); the torch ops below serve CPU tensors and the skip_channels / ignore_index options."""
 
+    def from_logits(self, logits, target):
+        """metric(softmax(logits, dim=1), target) - the trainer's validation call - without materialising the softmax."""
+        if (logits.is_cuda and logits.dtype == torch.float32 and logits.shape == target.shape and 1 < logits.size(1) <= 16
+                and not self.skip_channels and self.ignore_index is None and target.dtype in (torch.uint8, torch.float32)):
+            return self._hip(logits, target, from_logits=1)
+        return self(torch.softmax(logits, dim=1), target)
+
     @staticmethod
-    def _hip(input, target):
+    def _hip(input, target, from_logits=0):
         from .._lib import check, lib, ptr, stream_ptr
         n, c = input.size(0), input.size(1)
         x, t = input.contiguous(), target.contiguous()
@@ -138,8 +145,8 @@ class MeanIoU:
         out = torch.empty((), dtype=torch.float32, device=x.device)
         nbytes = lib.vs_mean_iou_workspace(n, c)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        check(lib.vs_mean_iou(ptr(x), ptr(t), 1 if t.dtype == torch.float32 else 0, n, c, hw, ptr(out), ptr(ws), nbytes,
-                              stream_ptr()))
+        check(lib.vs_mean_iou(ptr(x), ptr(t), 1 if t.dtype == torch.float32 else 0, from_logits, n, c, hw, ptr(out), ptr(ws),
+                              nbytes, stream_ptr()))
         return out
 
     def __init__(self, skip_channels=(), ignore_index=None, **kwargs):

@@ -186,7 +186,8 @@ class VolSeg2dTrainer:
                     inputs, targets = utils.prepare_training_batch(batch, self.model.device, self.label_no)
                     output = self.model(inputs)
                     valid_losses.append(self._loss(output, targets).item())
-                    eval_scores.append(float(self.eval_metric(torch.softmax(output, dim=1), targets)))
+                    metric = getattr(self.eval_metric, "from_logits", None)   # MeanIoU: softmax + metric in one HIP sweep
+                    eval_scores.append(float(metric(output, targets) if metric else self.eval_metric(torch.softmax(output, dim=1), targets)))
             self.avg_train_losses.append(np.average(train_losses))
             self.avg_valid_losses.append(np.average(valid_losses))
             self.avg_eval_scores.append(np.average(eval_scores))

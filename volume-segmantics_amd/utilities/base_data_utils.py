@@ -127,8 +127,15 @@ def one_hot_encode_array(input_array: np.ndarray, num_labels: int) -> np.ndarray
 def prepare_training_batch(batch, device, num_labels: int):
     """:150-158 - images to the device, masks to one-hot (B,K,H,W) uint8 (built on the device here)."""
     inputs = batch[0].to(device, non_blocking=True)
-    masks = batch[1].to(device, non_blocking=True).to(torch.int64)
-    targets = torch.nn.functional.one_hot(masks, num_classes=num_labels).permute(0, 3, 1, 2).to(torch.uint8)
+    masks = batch[1].to(device, non_blocking=True)
+    if masks.is_cuda and masks.dtype == torch.uint8 and num_labels <= 255:
+        from .._lib import check, lib, ptr, stream_ptr   # one HIP sweep instead of int64 one_hot + permute + cast
+        masks = masks.contiguous()
+        n, hw = masks.shape[0], masks[0].numel()
+        targets = torch.empty((n, num_labels) + tuple(masks.shape[1:]), dtype=torch.uint8, device=masks.device)
+        check(lib.vs_onehot_u8(ptr(masks), n, num_labels, hw, ptr(targets), stream_ptr()))
+        return inputs, targets
+    targets = torch.nn.functional.one_hot(masks.to(torch.int64), num_classes=num_labels).permute(0, 3, 1, 2).to(torch.uint8)
     return inputs, targets
 
 
