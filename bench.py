@@ -303,7 +303,7 @@ def main():
         log("predict: 256^3 single axis")
         predict["predict_256cube_low_2class"] = predict_bench(dev, world, args.precision, 256, 2, 1, 32)
         log("predict: 512^3 12 directions")
-        predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 16)
+        predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 64)   # eval mode: the batch size does not change the result
         log("predict done")
         if rank == 0:
             predict["merge_512cube"] = merge_bench(dev)
