@@ -238,6 +238,14 @@ int vs_logits_to_volume(const float* logits, int classes, const vs_dirmap* m, in
                         int direction, uint8_t* labels, uint16_t* probs, uint32_t* keys, uint8_t* votes,
                         int64_t nvox, void* stream);
 
+/* The two calls above in one: eval-mode forward of the slices x (nb, 1, hp, wp) whose segmentation head goes straight
+ * to the volume(s) - with up to 4 classes and modes 0 / 1 no logits are written at all (the head kernel's epilogue does the
+ * softmax / arg-max / crop / scatter; keys through an order-free atomic max); otherwise the logits land in the plan's
+ * workspace and vs_logits_to_volume runs on them.  Results are identical to vs_unet_forward + vs_logits_to_volume. */
+int vs_unet_forward_to_volume(vs_unet_t* net, const float* params, float* bnstate, const float* x, int nb, void* workspace,
+                              void* stream, const vs_dirmap* m, int s0, int mode, int direction, uint8_t* labels,
+                              uint16_t* probs, uint32_t* keys, uint8_t* votes, int64_t nvox);
+
 /* The reference's pairwise merge (_merge_vols_in_mem, :90-98): where prob1 > prob0 take slot 1. */
 int vs_merge_maxprob(uint8_t* label0, uint16_t* prob0, const uint8_t* label1, const uint16_t* prob1,
                      int64_t n, void* stream);

@@ -159,3 +159,41 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path):
     pred = VolSeg2dPredictor(str(out), SimpleNamespace(cuda_device=0))
     labels, probs = pred._predict_single_axis(imgs[:8])
     assert labels.shape == (8, 64, 64) and labels.max() <= 1 and probs.dtype == np.float16
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("classes", [2, 4, 6])
+def test_head_scatter_epilogue_equals_forward_plus_logits_to_volume(precision, classes):
+    """vs_unet_forward_to_volume (head kernel writes labels / probabilities / keys itself) vs vs_unet_forward +
+    vs_logits_to_volume on the same slices: bit-identical volumes.  6 classes exercises the fall-back inside the call."""
+    import numpy as np
+    from volume_segmantics_amd import _lib
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import dirmap_of
+    L = _lib
+    old = L.lib.vs_get_option(b"conv_direct_min_px")
+    L.set_option("conv_direct_min_px", 1)          # small test slices still take the direct head kernel
+    try:
+        model = VolSegUnet(classes, device=DEV, precision=precision, seed=3)
+        model.eval()
+        vol = np.zeros((5, 61, 90), np.uint8)                       # padded to 64 x 96: crop offsets are exercised
+        for view, direction in ((vol, 0), (np.swapaxes(vol, 0, 1)[:, :5], 4), (np.rot90(vol, 1, (1, 2)), 7)):
+            dmap = dirmap_of(vol, view)
+            nb = min(3, view.shape[0])
+            x = torch.randn(nb, 1, dmap.hp, dmap.wp, generator=torch.Generator().manual_seed(direction)).to(DEV)
+            n = vol.size
+            for mode in (0, 1):
+                ref = dict(labels=torch.zeros(n, dtype=torch.uint8, device=DEV), probs=torch.zeros(n, dtype=torch.float16, device=DEV),
+                           keys=torch.full((n,), 5, dtype=torch.int32, device=DEV))
+                got = {k: v.clone() for k, v in ref.items()}
+                with torch.no_grad():
+                    logits = model._forward_impl(x, training=False)
+                L.check(L.lib.vs_logits_to_volume(L.ptr(logits), classes, dmap, 1, nb, mode, direction, L.ptr(ref["labels"]),
+                                                  L.ptr(ref["probs"]), L.ptr(ref["keys"]), None, n, L.stream_ptr()))
+                model._forward_to_volume(x, dmap, 1, mode, direction, got["labels"], got["probs"], got["keys"], None, n)
+                torch.cuda.synchronize()
+                for k in ref:
+                    assert torch.equal(ref[k], got[k]), (precision, classes, direction, mode, k)
+                assert (ref["labels"] != 0).any() or mode == 1
+    finally:
+        L.set_option("conv_direct_min_px", old)

@@ -131,7 +131,16 @@ struct ConvParams {
     int pool0;                           // dgrad through nearest-x2 upsampling: channels < (out1 ? split_c : Cout) are summed
                                          // over 2x2 pixel blocks and written to `out` at half resolution
     float* stats_partial;                // optional [tiles][2][Cout]: per-tile sum / sum of squares of the raw accumulators
+    const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
+                                         // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
+// where the head's pixels land in the output volume(s): the epilogue form of vs_logits_to_volume (modes 0 and 1)
+struct VolScatter {
+    vs_dirmap m;
+    int s0, direction, mode;             // first slice of the batch; direction index (key mode); 0 = labels/probs, 1 = packed keys
+    uint8_t* labels; uint16_t* probs; uint32_t* keys;
+};
+bool conv_head_scatter_ok(int dtype, const ConvParams& p);   // whether launch_conv_igemm can honour p.scatter for this layer
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives

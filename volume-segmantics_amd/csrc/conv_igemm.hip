@@ -17,6 +17,8 @@
 // Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
 // vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat
 // folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
+#include <hip/hip_fp16.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -254,11 +256,13 @@ struct DirectGeom {
 };
 
 // MODE 0: NHWC store in T (optional per-channel affine + ReLU, optional statistics); 1: 2x2 sum-pooled NHWC store (dgrad
-// through nearest-x2 upsampling); 2: fp32 NCHW store of <= 4 channels with bias (segmentation head).
+// through nearest-x2 upsampling); 2: fp32 NCHW store of <= 4 channels with bias (segmentation head); 3: the head in
+// prediction - no logits leave the kernel: softmax -> first arg-max -> fp16 max-prob of the <= 4 classes a lane holds, cropped
+// and written at the direction's voxel address as label / probability or as a packed key through an (order-free) atomic max.
 // Every row iteration issues the same number of loads and (offset-masked, never skipped) buffer stores, so the waits on
 // the input ring are counted ones and kD rows stay in flight per wave.
 template <typename T, int BN, int MODE>
-__global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g) {
+__global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g, VolScatter vsc) {
     constexpr int EPS = CT<T>::EPS, NJ = BN / 16, NTAPS = 9, kD = (BN == 32 && MODE == 1) ? 2 : 4;   // input rows in flight
     constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
     constexpr int kOob = (int)0x80000000;
@@ -324,11 +328,15 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             ooff[j] = (inw && !(lr & 1) && j * 16 + lq * 4 < p.Cout) ? ((wo >> 1) * p.Cout + j * 16 + lq * 4) * (int)sizeof(T) : kOob;
-    } else {
+    } else if constexpr (MODE == 2) {
         ro = make_rsrc((float*)p.out + (size_t)n * p.Cout * p.Hout * p.Wout, p.Cout * p.Hout * p.Wout * 4);
         orow = p.Wout * 4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ooff[j] = (inw && j == 0 && lq == 0) ? wo * 4 : kOob;   // + channel plane r * H * W * 4
+    } else {
+        ro = make_rsrc(nullptr, 0); orow = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ooff[j] = kOob;
     }
     float4 sc[NJ], sh[NJ];
 #pragma unroll
@@ -418,11 +426,36 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, h * orow, 0);
                         }
-                    } else if (j == 0) {   // head: channel planes of this image, 4 dword stores (channels >= Cout masked)
+                    } else if (MODE == 2 && j == 0) {   // head: channel planes of this image, 4 dword stores (channels >= Cout masked)
                         const int plane = p.Hout * p.Wout * 4;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (live && r < p.Cout) ? ooff[0] : kOob, h * orow + r * plane, 0);
+                    } else if (MODE == 3 && j == 0) {   // same arithmetic, in the same order, as logits_to_volume_kernel
+                        const int K = p.Cout;
+                        float mx = v[0];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) if (r < K) mx = fmaxf(mx, v[r]);
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (r < K) sum += expf(v[r] - mx);
+                        float best = -1.f;
+                        int lab = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r < K) { const float pk = __fdiv_rn(expf(v[r] - mx), sum); if (pk > best) { best = pk; lab = r; } }
+                        const int rr = h - vsc.m.crop_top, jj = wo - vsc.m.crop_left;
+                        if (live && lq == 0 && rr >= 0 && rr < vsc.m.h && jj >= 0 && jj < vsc.m.w) {
+                            const int64_t addr = vsc.m.base + (int64_t)(vsc.s0 + n) * vsc.m.ss + (int64_t)rr * vsc.m.sh + (int64_t)jj * vsc.m.sw;
+                            const __half hv = __float2half_rn(best);
+                            const uint32_t hb = __builtin_bit_cast(uint16_t, hv);
+                            if (vsc.mode == 0) {
+                                if (vsc.labels) vsc.labels[addr] = (uint8_t)lab;
+                                if (vsc.probs) vsc.probs[addr] = (uint16_t)hb;
+                            } else {
+                                atomicMax(vsc.keys + addr, (hb << 16) | ((uint32_t)(15 - vsc.direction) << 8) | (uint32_t)lab);
+                            }
+                        }
                     }
                 }
             }
@@ -450,7 +483,8 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
 static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = fp32 store, bit 1 = NCHW layout
     const int CK = dtype == VS_BF16 ? 32 : 16;
     const bool nchw = (p.out_f32 >> 1) != 0, f32 = (p.out_f32 & 1) != 0;
-    const bool out_ok = nchw ? (f32 && p.Cout <= 4 && !p.pool0 && !p.scale) : (!f32 && !(p.Cout & 3));
+    const bool out_ok = p.scatter ? (p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
+                                  : nchw ? (f32 && p.Cout <= 4 && !p.pool0 && !p.scale) : (!f32 && !(p.Cout & 3));
     return vs_option("conv_direct") && out_ok && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
@@ -474,14 +508,20 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE((double)p.Hin * p.Win * p.C0 * sizeof(T) < 2.0e9 && (long)g.nwaves * 16 < (1L << 32), "conv_direct: tensor too large");
     const dim3 grid(cdiv(g.nwaves, 4));
     const bool head = (p.Cout & 3) != 0 || out_nchw;
-    if (head) {
+    VolScatter sc{};
+    if (p.scatter) {
+        sc = *p.scatter;
+        ConvParams q = p;
+        q.scatter = nullptr;
+        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 3>), grid, dim3(256), 0, s, q, g, sc);
+    } else if (head) {
         VS_REQUIRE(out_nchw && p.Cout <= 4 && BN == 16 && !p.pool0 && !p.scale, "conv_direct: unsupported ragged output");
-        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 2>), grid, dim3(256), 0, s, p, g);
+        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 2>), grid, dim3(256), 0, s, p, g, sc);
     } else if (p.pool0) {
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g, sc);
     } else {
         VS_REQUIRE(!p.out_f32, "conv_direct: fp32 NHWC output is not supported");
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g, sc);
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -561,7 +601,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - p.KH) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - p.KW) / p.stride + 1,
                "conv_igemm: inconsistent output dims");
-    VS_REQUIRE(p.src0 && p.w && p.out, "conv_igemm: null pointer");
+    VS_REQUIRE(p.src0 && p.w && (p.out || p.scatter), "conv_igemm: null pointer");
     VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
     const Pick cfg = pick_cfg(p);
     const int BN = cfg.BN, PT = cfg.PT, NW = cfg.NW;
@@ -575,6 +615,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
+    VS_REQUIRE(!p.scatter, "conv_igemm: the volume-scatter epilogue needs the direct kernel (check conv_head_scatter_ok first)");
     if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN))
         return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
     TileGeom g;
@@ -619,6 +660,8 @@ int conv_igemm_variant(int dtype, const ConvParams& p) {
     if (conv_igemm_dma_ok(dtype, p, c.BN)) return c.BN * 1000 + 2 * 100 + 9 * 10 + 3;
     return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : ((c.PT == 1 && p.stride == 2) ? 2 : 1));
 }
+
+bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && direct_ok(dtype, p); }
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave

@@ -92,7 +92,7 @@ struct vs_unet {
     // workspace regions (bytes)
     size_t off_bnws = 0, bnws_bytes = 0, off_wgws = 0, wgws_bytes = 0, off_headdw = 0, off_dyh = 0, off_dup = 0,
            off_zs = 0, off_idx = 0;
-    size_t ws_eval = 0, ws_train = 0;
+    size_t ws_eval = 0, ws_train = 0, off_logits = 0;
     int last_n = 0;
     std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
@@ -218,6 +218,7 @@ size_t plan_workspace(vs_unet* net) {
         const size_t bytes = N * a.c * a.h * a.w * esz;
         a.off_a = take(bytes);
     }
+    net->off_logits = take(N * net->classes * (size_t)net->h * net->w * sizeof(float));   // vs_unet_forward_to_volume's fallback path
     net->ws_eval = off;
     for (auto& u : net->units) {
         if (u.kind != U_CONV && u.kind != U_HEAD) continue;
@@ -397,14 +398,44 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
+static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
+                        float* logits, void* workspace, void* stream, const VolScatter* scatter);
+
 extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
                                float* logits, void* workspace, void* stream) {
+    VS_REQUIRE(logits, "unet_forward: null pointer");
+    return unet_forward(net, params, bnstate, x, n, training, logits, workspace, stream, nullptr);
+}
+
+// Prediction: eval-mode forward whose segmentation head writes straight into the output volume(s) - the fused form of
+// vs_unet_forward(training = 0) + vs_logits_to_volume (same arithmetic in the same order: identical labels, probabilities
+// and keys).  Falls back to exactly those two calls (logits in the plan's workspace) where the fused epilogue does not
+// apply: more than 4 classes, vote mode, or slices too small for the direct head kernel.
+extern "C" int vs_unet_forward_to_volume(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n,
+                                         void* workspace, void* stream, const vs_dirmap* m, int s0, int mode, int direction,
+                                         uint8_t* labels, uint16_t* probs, uint32_t* keys, uint8_t* votes, int64_t nvox) {
+    VS_REQUIRE(net && m, "unet_forward_to_volume: null pointer");
+    VS_REQUIRE(m->hp == net->h && m->wp == net->w, "unet_forward_to_volume: the plan is %dx%d, the padded slices are %dx%d", net->h, net->w, m->hp, m->wp);
+    VS_REQUIRE(direction >= 0 && direction < 16, "unet_forward_to_volume: direction %d out of range", direction);
+    VolScatter sc{};
+    sc.m = *m; sc.s0 = s0; sc.direction = direction; sc.mode = mode; sc.labels = labels; sc.probs = probs; sc.keys = keys;
+    float* lg = reinterpret_cast<float*>((char*)workspace + net->off_logits);
+    const bool try_fused = mode == 0 || mode == 1;
+    const int rc = unet_forward(net, params, bnstate, x, n, 0, lg, workspace, stream, try_fused ? &sc : nullptr);
+    if (rc < 0) return rc;
+    if (try_fused && rc == VS_OK) return VS_OK;   // the head kernel already wrote the volume entries
+    return vs_logits_to_volume(lg, net->classes, m, s0, n, mode, direction, labels, probs, keys, votes, nvox, stream);
+}
+
+static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
+                        float* logits, void* workspace, void* stream, const VolScatter* scatter) {
     VS_REQUIRE(net && params && bnstate && x && logits && workspace, "unet_forward: null pointer");
     VS_REQUIRE(n >= 1 && n <= net->max_batch, "unet_forward: batch %d exceeds the plan's max_batch %d", n, net->max_batch);
     Ctx c{net, (char*)workspace, params, bnstate, (hipStream_t)stream, n};
     const int dt = net->dtype;
     int rc;
     net->last_n = n;
+    bool head_scattered = false;
     int unit_index = -1;
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
@@ -454,6 +485,16 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
             ConvParams p = conv_params(c, u);
             p.out = logits; p.shift = c.P(u.bias_idx); p.out_f32 = 3;  // fp32, NCHW
             ProfScope prof(PK_HEAD, conv_flops(c, u), 0, c.s);
+            if (scatter) {
+                p.scatter = scatter;
+                if (conv_head_scatter_ok(dt, p)) {
+                    p.out = nullptr;
+                    if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                    head_scattered = true;
+                    continue;
+                }
+                p.scatter = nullptr;
+            }
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             continue;
         }
@@ -473,7 +514,7 @@ extern "C" int vs_unet_forward(vs_unet_t* net, const float* params, float* bnsta
                                   u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, stream))) return rc;
         }
     }
-    return VS_OK;
+    return (scatter && !head_scattered) ? 1 : VS_OK;   // 1: the caller still has to turn the logits into volume entries
 }
 
 // ---- backward --------------------------------------------------------------------------------------

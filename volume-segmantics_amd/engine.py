@@ -249,6 +249,15 @@ class VolSegUnet(nn.Module):
             self._bnver += 1
         return logits
 
+    def _forward_to_volume(self, x, dmap, s0, mode, direction, labels, probs, keys, votes, nvox):
+        """Prediction batch: eval forward of the padded slices x whose head lands in the output volume(s) (predictor)."""
+        n, _, h, w = x.shape
+        plan = self._plan(n, h, w, False)
+        self._prepare(plan, False)
+        check(lib.vs_unet_forward_to_volume(plan["handle"], ptr(self._flat), ptr(self._bnstate), ptr(x), n, ptr(plan["ws"]),
+                                            _lib.stream_ptr(), dmap, s0, mode, direction, ptr(labels), ptr(probs), ptr(keys),
+                                            ptr(votes), nvox))
+
     def _backward_impl(self, x, dlogits):
         n, _, h, w = x.shape
         plan = self._plans[(h, w)]

@@ -73,9 +73,9 @@ class HipBackend:
         x = self._x[:need].view(nb, 1, dmap.hp, dmap.wp)
         st = _lib.stream_ptr()
         check(lib.vs_slices_gather(ptr(self.vol), dmap, s0, nb, ptr(x), st))
-        logits = self.model._forward_impl(x, training=False)
-        check(lib.vs_logits_to_volume(ptr(logits), self.classes, dmap, s0, nb, self.mode, direction, ptr(self.labels),
-                                      ptr(self.probs), ptr(self.keys), ptr(self.votes), self.nvox, st))
+        # forward + softmax / arg-max / crop / scatter in one call: with <= 4 classes the head kernel writes labels /
+        # probabilities / keys itself and no logits exist (identical results to vs_unet_forward + vs_logits_to_volume)
+        self.model._forward_to_volume(x, dmap, s0, self.mode, direction, self.labels, self.probs, self.keys, self.votes, self.nvox)
 
     def exchange(self) -> None:
         if self.mode == 1:
