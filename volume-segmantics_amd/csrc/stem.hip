@@ -6,6 +6,8 @@
 //   wgrad   : D[cout][tap]   += dY[pixel][cout] * X[pixel][tap], k = output pixels
 // The input image stays fp32 (it is the caller's (B,1,H,W) tensor); the output is written in the
 // network's activation dtype.  No dgrad: the input image needs no gradient.
+#include <algorithm>
+
 #include "common.h"
 #include "prof.h"
 
@@ -202,14 +204,16 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
     const int ho_n = h / 2, wo_n = wd / 2;
     const int tiles_w = (wo_n + TPW - 1) / TPW, tiles_h = (ho_n + TPH - 1) / TPH;
-    int b = blockIdx.x;
+    uint4 wa[4][2];
+    load_stem_weights_bf16(w, lr, lq, wa);      // once per workgroup: it walks over tiles blockIdx.x, + gridDim.x, ..
+    for (int tile = blockIdx.x; tile < n * tiles_h * tiles_w; tile += gridDim.x) {
+    int b = tile;
     const int tx = b % tiles_w; b /= tiles_w;
     const int ty = b % tiles_h;
     const int img = b / tiles_h;
     const int h0 = ty * TPH, w0 = tx * TPW;
+    __syncthreads();                            // the previous tile's fragment reads are done
     stage_patch_bf16(x, patch, img, h, wd, h0, w0, tid);
-    uint4 wa[4][2];
-    load_stem_weights_bf16(w, lr, lq, wa);
     __syncthreads();
     f32x4 acc[4][4];
 #pragma unroll
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
             }
             st4(o + c, make_float4(v[0], v[1], v[2], v[3]));
         }
+    }
     }
 }
 
@@ -380,8 +385,8 @@ extern "C" int vs_stem_fwd(int dtype, const float* x, const float* w, const floa
     VS_REQUIRE(h % 2 == 0 && w_ % 2 == 0 && x && w && y, "stem_fwd: bad arguments");
     const int tiles = n * cdiv(h / 2, TPH) * cdiv(w_ / 2, TPW);
     if (dtype == VS_BF16 && vs_option("stem_bf16"))
-        hipLaunchKernelGGL(stem_fwd_bf16_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
-                           (bf16_t*)y, n, h, w_);
+        hipLaunchKernelGGL(stem_fwd_bf16_kernel, dim3(std::min(tiles, 1024)), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift,
+                           relu, (bf16_t*)y, n, h, w_);
     else if (dtype == VS_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (bf16_t*)y, n, h, w_);
