@@ -102,8 +102,18 @@ def test_train_forward_backward_bf16_sane():
             assert _cos(p.grad.cpu(), ref[name].grad) > 0.9, name
 
 
+@pytest.fixture(params=[0, 1], ids=["bn_bwd_separate", "bn_bwd_in_dgrad_epilogue"])
+def bn_bwd_fusion(request):
+    """Both forms of BN backward: two sweeps, or the reduction riding in the dgrad epilogue that completes the gradient."""
+    from volume_segmantics_amd import _lib
+    old = _lib.lib.vs_get_option(b"fuse_bn_bwd")
+    _lib.set_option("fuse_bn_bwd", request.param)
+    yield request.param
+    _lib.set_option("fuse_bn_bwd", old)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_backward_self_consistency_in_network(precision):
+def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
     """Every backward kernel, in the network, at the network's own shapes: recompute BN-backward, one dgrad
     per block and EVERY weight gradient in fp64 on the CPU from the engine's own saved tensors (so ReLU masks
     are identical by construction) and compare.  fp32: exact to rounding; bf16: to bf16 storage rounding."""
@@ -196,7 +206,12 @@ def test_backward_self_consistency_in_network(precision):
         if "conv2" in wn:
             src = units[wn.replace("conv2.0", "conv1.0").replace("conv2.weight", "conv1.weight")]
             ref_da = F.conv_transpose2d(t["dz"], W, padding=1)
-            assert rel(src["da"], ref_da) < tol_op, ("dgrad", wn, rel(src["da"], ref_da))
+            # the dgrad that completes this gradient also applies the producing unit's ReLU mask (its BN-backward reduction
+            # rides in the epilogue): equal where the unit is active, exactly zero elsewhere - or the raw gradient everywhere
+            # when that fusion is off
+            m = src["a"] > 0
+            assert rel(src["da"] * m, ref_da * m) < tol_op, ("dgrad", wn, rel(src["da"] * m, ref_da * m))
+            assert (src["da"][~m] == 0).all() or rel(src["da"], ref_da) < tol_op, ("dgrad outside the mask", wn)
             checked["dgrad"] += 1
     assert checked == dict(bn=46, wgrad=46, dgrad=21), checked
 

@@ -67,6 +67,16 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
     *reinterpret_cast<uint2*>(p) = u;
 }
+// 4 consecutive elements kept in their storage format (2 registers for bf16) until they are used
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ld4raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ld4raw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 unpack4(float4 v) { return v; }
+__device__ __forceinline__ float4 unpack4(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
 // 8 consecutive elements
 __device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
     uint4 u = *reinterpret_cast<const uint4*>(p);
@@ -131,6 +141,14 @@ struct ConvParams {
     int pool0;                           // dgrad through nearest-x2 upsampling: channels < (out1 ? split_c : Cout) are summed
                                          // over 2x2 pixel blocks and written to `out` at half resolution
     float* stats_partial;                // optional [tiles][2][Cout]: per-tile sum / sum of squares of the raw accumulators
+    // Optional BatchNorm-backward reduction fused into a dgrad epilogue (the output IS the gradient w.r.t. the activation of a
+    // conv+BN(+ReLU) unit, complete after this launch): the epilogue applies that unit's ReLU mask, stores the masked
+    // gradient g and writes per-tile partials of sum(g) and sum(g * xhat) - the first sweep of BN backward never runs.
+    const void* bz;                      // the unit's pre-BN conv output z (same shape / dtype as `out`); null = feature off
+    const void* by;                      // its activation y for the mask (units with a residual input); null: recompute from z
+    const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta;
+    float* bstats_partial;               // [tiles][2][Cout]
+    int brelu;
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
@@ -147,6 +165,9 @@ int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial
 int conv_igemm_variant(int dtype, const ConvParams& p);
 bool conv_igemm_dma_ok(int dtype, const ConvParams& p, int BN);
 int launch_conv_igemm_dma(int dtype, const ConvParams& p, int BN, int out_nchw, hipStream_t s);  // BN*1000 + PT*100 + taps*10 + stride of the chosen instantiation      // number of partial rows stats_partial receives
+int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
+                                void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
+                                int nparts, hipStream_t s);
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
 

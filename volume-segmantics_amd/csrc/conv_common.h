@@ -6,6 +6,15 @@ template <typename T> struct CT;
 template <> struct CT<bf16_t> { static constexpr int CK = 32, EPS = 8; };
 template <> struct CT<float> { static constexpr int CK = 16, EPS = 4; };
 
+// value as it reads back after being stored in T
+template <typename T>
+__device__ __forceinline__ float4 ld4_roundtrip(const float (&v)[4]) {
+    if constexpr (sizeof(T) == 2)
+        return make_float4(bf16_to_f32(f32_to_bf16(v[0])), bf16_to_f32(f32_to_bf16(v[1])), bf16_to_f32(f32_to_bf16(v[2])), bf16_to_f32(f32_to_bf16(v[3])));
+    else
+        return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 template <typename T>
 __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b) {
     if constexpr (sizeof(T) == 2) {
@@ -77,6 +86,93 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
                           for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
                           return a; }();
         }
+    }
+    // (1b) dgrad that completes the gradient of a conv+BN(+ReLU) unit's activation: mask, store g, BN-backward partials
+    if (p.bz) {
+        float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][BN]
+        __syncthreads();                               // staged tiles are dead
+        // all global loads of the epilogue first (residual = earlier contributions to this gradient, z, y): issued back to
+        // back they cost one memory round trip; interleaved with the stores below each would wait for the previous store
+        typename Raw4<T>::type rv[PT][NJ], zq[PT][NJ], yq[PT][NJ];
+        size_t off[PT][NJ];
+        bool live[PT][NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = n0 + j * 16 + lq * 4;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int pl = wave * (PT * 16) + i * 16 + lr;
+                const int ho = h0 + (pl >> g.tw_shift), wo = w0 + (pl & (TW - 1));
+                live[i][j] = ho < p.Hout && wo < p.Wout && c < p.Cout;
+                off[i][j] = (((size_t)n * p.Hout + ho) * p.Wout + wo) * p.Cout + c;
+                rv[i][j] = zq[i][j] = yq[i][j] = typename Raw4<T>::type{};
+                if (live[i][j]) {
+                    if (p.residual) rv[i][j] = ld4raw((const T*)p.residual + off[i][j]);
+                    zq[i][j] = ld4raw((const T*)p.bz + off[i][j]);
+                    if (p.brelu && p.by) yq[i][j] = ld4raw((const T*)p.by + off[i][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = n0 + j * 16 + lq * 4;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < p.Cout) {
+                const float4 m4 = *reinterpret_cast<const float4*>(p.bmean + c), i4 = *reinterpret_cast<const float4*>(p.binvstd + c);
+                mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+                is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+                if (p.brelu && !p.by) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(p.bgamma + c), b4 = *reinterpret_cast<const float4*>(p.bbeta + c);
+                    ga[0] = is[0] * g4.x; ga[1] = is[1] * g4.y; ga[2] = is[2] * g4.z; ga[3] = is[3] * g4.w;
+                    be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                if (!live[i][j]) continue;
+                const float4 r4 = unpack4(rv[i][j]), z4 = unpack4(zq[i][j]), y4 = unpack4(yq[i][j]);
+                float v[4] = {acc[i][j][0] + r4.x, acc[i][j][1] + r4.y, acc[i][j][2] + r4.z, acc[i][j][3] + r4.w};
+                const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+                if (p.brelu) {
+                    if (p.by) {
+                        v[0] = y4.x > 0.f ? v[0] : 0.f; v[1] = y4.y > 0.f ? v[1] : 0.f;
+                        v[2] = y4.z > 0.f ? v[2] : 0.f; v[3] = y4.w > 0.f ? v[3] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = ((zv[r] - mu[r]) * ga[r] + be[r]) > 0.f ? v[r] : 0.f;
+                    }
+                }
+                st4((T*)p.out + off[i][j], make_float4(v[0], v[1], v[2], v[3]));
+                const float4 gq = ld4_roundtrip<T>(v);   // the statistics see exactly what was stored
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[r] += gv[r]; s2[r] += gv[r] * (zv[r] - mu[r]) * is[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+            }
+            if (lr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wave * 2 + 0) * BN + j * 16 + lq * 4 + r] = s1[r];
+                    red[(wave * 2 + 1) * BN + j * 16 + lq * 4 + r] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, cc = tid % BN;
+            if (n0 + cc < p.Cout) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
+                p.bstats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] = a;
+            }
+        }
+        return;
     }
     // (2) outputs
     const int pool_c = p.pool0 ? (p.out1 ? p.split_c : p.Cout) : 0;

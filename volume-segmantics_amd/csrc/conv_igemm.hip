@@ -485,7 +485,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool nchw = (p.out_f32 >> 1) != 0, f32 = (p.out_f32 & 1) != 0;
     const bool out_ok = p.scatter ? (p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && p.Cout <= 4 && !p.pool0 && !p.scale) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.bz && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -606,6 +606,11 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     const Pick cfg = pick_cfg(p);
     const int BN = cfg.BN, PT = cfg.PT, NW = cfg.NW;
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
+    if (p.bz) {
+        VS_REQUIRE(!p.pool0 && !p.out1 && !p.scale && !p.shift && !p.relu && !p.out_f32 && !out_nchw && !(p.Cout & 3) && !p.stats_partial &&
+                   p.bmean && p.binvstd && p.bstats_partial && (!p.brelu || p.by || (p.bgamma && p.bbeta)),
+                   "conv_igemm: the BN-backward epilogue takes a plain NHWC dgrad output");
+    }
     if (p.pool0) {
         VS_REQUIRE(PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1) && !p.residual && !p.scale && !p.shift && !out_nchw,
                    "conv_igemm: pooled dgrad epilogue not available for this geometry");

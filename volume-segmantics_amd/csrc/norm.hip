@@ -315,6 +315,25 @@ int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t
     return VS_OK;
 }
 
+// BN backward whose reduction already happened in the producing dgrad's epilogue: `g` is the masked gradient, `partial` holds
+// nparts rows of per-channel (sum g, sum g * xhat).  Finalise (fp64, fixed order) and apply.
+int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
+                                void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
+                                int nparts, hipStream_t s) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_bwd: unsupported channel count %d", c);
+    RowMap m = make_rowmap(rows, c);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, partial, nparts, c, dgamma, dbeta);
+    VS_LAUNCH_CHECK();
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply<bf16_t, false>), dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr,
+                           (const bf16_t*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (bf16_t*)dx, (bf16_t*)dres, rows, c, m);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply<float, false>), dim3(m.nblocks), dim3(256), 0, s, (const float*)g, (const float*)nullptr,
+                           (const float*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (float*)dx, (float*)dres, rows, c, m);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
 extern "C" size_t vs_bn_workspace(int64_t rows, int c) {
     (void)rows;
     return (size_t)kMaxBlocks * 2 * c * sizeof(float);
