@@ -130,7 +130,7 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
     model = VolSegUnet(classes, device=dev, precision=precision, seed=1)
     with torch.no_grad():  # random-init networks collapse onto one class: centre the head bias on a few slices
         model.eval()
-        probe = torch.randn(4, 1, min(cube, 256), min(cube, 256), device=dev)
+        probe = torch.randn(4, 1, min(cube, 256), min(cube, 256), generator=torch.Generator().manual_seed(7)).to(dev)   # same on every run / rank
         mean_logit = model(probe).mean(dim=(0, 2, 3))
         dict(model.named_parameters())["segmentation_head.0.bias"].sub_(mean_logit)
     if world > 1:
@@ -210,11 +210,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # VOLSEG_BENCH_REHEARSE=gloo: every rank on GPU 0 with the gloo backend - a correctness rehearsal of the N > 1 code path on
+    # a one-GPU box (the numbers mean nothing); the real run is one rank per GPU over RCCL
+    rehearse = os.environ.get("VOLSEG_BENCH_REHEARSE", "")
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(rehearse)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from volume_segmantics_amd import _lib
     from volume_segmantics_amd.engine import VolSegUnet

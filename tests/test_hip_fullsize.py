@@ -80,7 +80,7 @@ def _predictor(classes: int, batch: int, precision: str = "bf16"):
     model = VolSegUnet(classes, device=DEV, precision=precision, seed=1)
     with torch.no_grad():   # centre the head bias so that a random-init network uses every class
         model.eval()
-        mean_logit = model(torch.randn(4, 1, 256, 256, device=DEV)).mean(dim=(0, 2, 3))
+        mean_logit = model(torch.randn(4, 1, 256, 256, generator=torch.Generator().manual_seed(7)).to(DEV)).mean(dim=(0, 2, 3))
         dict(model.named_parameters())["segmentation_head.0.bias"].sub_(mean_logit)
     pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
     pred.model, pred.num_labels, pred.label_codes = model, classes, {}
