@@ -186,6 +186,13 @@ typedef struct vs_adamw_args {
 int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
                            float* grads, void* workspace, void* stream, const vs_adamw_args* opt);
 
+/* Data-parallel form of the same idea, driven by the caller bucket by bucket: after a bucket of gradients has been
+ * all-reduced and vs_adamw_step has updated that slice of the parameters, vs_unet_prepare_range derives the weight copies of
+ * the bucket's units [unit_lo, unit_hi) into the plan's second weight set; vs_unet_flip_weight_set makes that set the one the
+ * next forward reads (call it once, after every range of the network has been refreshed). */
+int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* workspace, void* stream, int unit_lo, int unit_hi);
+int vs_unet_flip_weight_set(vs_unet_t* net);
+
 /* DiceLoss(normalization="none") on raw logits and its gradient (data/pytorch3dunet_losses.py:15-41,89-135; the
  * trainer's default criterion, vol_seg_2d_trainer.py:133-135,425-428).  logits (n, K, h*w) fp32 NCHW, targets one-hot
  * (n, K, h*w) uint8 or fp32; loss: 1 device float; workspace (vs_dice_workspace bytes) carries the per-class sums from

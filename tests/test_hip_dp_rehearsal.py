@@ -1,0 +1,24 @@
+"""-m gpu: the N > 1 training path on the real kernels - two ranks share GPU 0 and talk over gloo (the driver's multi-GPU run
+uses one rank per GPU over RCCL; this pins everything except the transport): bucketed backward + all-reduce with the
+optimiser step inside backward vs after it, bit-identical and rank-consistent (tests/dp_rehearsal_worker.py)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_data_parallel_fused_step_matches_plain_step():
+    import socket
+    repo = Path(__file__).resolve().parents[1]
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(repo / "tests" / "dp_rehearsal_worker.py")]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DP_REHEARSAL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

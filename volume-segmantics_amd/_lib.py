@@ -74,6 +74,8 @@ _SIGS = {
     "vs_unet_backward": (I, [P, P, P, P, I, I, P, P, P]),
     "vs_unet_backward_range": (I, [P, P, P, P, I, I, P, P, P, I, I]),
     "vs_unet_backward_adamw": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs)]),
+    "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
+    "vs_unet_flip_weight_set": (I, [P]),
     "vs_unet_unit_param_offset": (I64, [P, I]),
     "vs_unet_num_units": (I, [P]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),

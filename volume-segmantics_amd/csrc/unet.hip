@@ -399,6 +399,34 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
     return VS_OK;
 }
 
+// Data-parallel form of the fused optimiser step (the caller all-reduces a bucket of gradients, updates that slice of the
+// parameters and then calls this): weight copies of the units [unit_lo, unit_hi) into the plan's OTHER weight set;
+// vs_unet_flip_weight_set makes that set current once every range has been refreshed.
+extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* workspace, void* stream, int unit_lo, int unit_hi) {
+    VS_REQUIRE(net && params && workspace && unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(),
+               "unet_prepare_range: bad arguments");
+    long w_off[64], wc_off[64], wt_off[64];
+    int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+    const int other = net->wset ^ 1;
+    for (int k = unit_lo; k < unit_hi; ++k) {
+        const Unit& v = net->units[k];
+        if (v.kind != U_CONV && v.kind != U_HEAD) continue;
+        VS_REQUIRE(nl < 64, "unet_prepare_range: too many layers in one range");
+        w_off[nl] = net->layout.tensors[v.w_idx].offset;
+        wc_off[nl] = net->dtype == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
+        wt_off[nl] = (long)Ctx::wt_off(v, other);
+        cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+        ++nl;
+    }
+    if (!nl) return VS_OK;
+    return launch_weight_prepare_all(net->dtype, params, workspace, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, (hipStream_t)stream);
+}
+extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
+    VS_REQUIRE(net, "unet_flip_weight_set: null pointer");
+    net->wset ^= 1;
+    return VS_OK;
+}
+
 // ---- forward ---------------------------------------------------------------------------------------
 static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, const float* x, int n, int training,
                         float* logits, void* workspace, void* stream, const VolScatter* scatter);

@@ -101,6 +101,7 @@ class VolSegUnet(nn.Module):
         self.dp_buckets = 4  # >1: bucketed, overlapped gradient all-reduce (decoder+head, layer4, layer3, rest)
         self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
         self._fused_optimizer = None   # FusedAdamW(fuse_step_into_backward=True) registers itself here
+        self._dp_side = None           # side stream of the data-parallel fused optimiser step
         self._bnver = 0  # bumped when a training forward moves the running statistics
         if init == "smp":
             self.reset_parameters(seed)
@@ -274,7 +275,14 @@ class VolSegUnet(nn.Module):
         fused = self._fused_optimizer
         if fused is not None and not fused._can_fuse(self, need_enc):
             fused = None
-        if fused is not None:
+        if fused is not None and self.dp_group is not None and self._world() > 1:
+            # data parallel: every bucket is all-reduced, then its AdamW step and weight copies run on a side stream while the
+            # backward of the layers below it continues
+            self._backward_bucketed(plan, x, dlogits, n, need_enc, fused=fused)
+            fused._stepped_in_backward = True
+            self._wver += 1
+            plan["prep"] = (self._flat._version, self._wver, True, None)
+        elif fused is not None:
             # the optimiser step rides on the backward's side stream (FusedAdamW(fuse_step_into_backward=True))
             g = fused.param_groups[0]
             args = _lib.AdamwArgs(ptr(self._flat), ptr(fused.exp_avg), ptr(fused.exp_avg_sq), float(g["lr"]),
@@ -321,21 +329,42 @@ class VolSegUnet(nn.Module):
             plan.append((lo, hi, a, b))
         return plan
 
-    def _backward_bucketed(self, plan, x, dlogits, n, need_enc):
-        """Data-parallel backward: every bucket's all-reduce (RCCL, async) overlaps with the backward of the layers below it."""
+    def _backward_bucketed(self, plan, x, dlogits, n, need_enc, fused=None):
+        """Data-parallel backward: every bucket's all-reduce (RCCL, async) overlaps with the backward of the layers below it.
+        With ``fused`` (a FusedAdamW) each bucket's optimiser step and next-forward weight copies follow its all-reduce on a
+        side stream, so neither sits on the critical path (same numbers as all-reduce, then step(), then prepare)."""
         import torch.distributed as dist
         if "buckets" not in plan:
             plan["buckets"] = self._bucket_plan(plan["handle"])
         world = self._world()
         handles = []
+        main = torch.cuda.current_stream()
         for lo, hi, a, b in plan["buckets"]:
             check(lib.vs_unet_backward_range(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
                                              ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr(), lo, hi))
             if b > a:
-                handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), a, b))
-        for h, a, b in handles:
-            h.wait()
-        self._flat_grad.div_(world)
+                handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), lo, hi, a, b))
+        if fused is None:
+            for h, lo, hi, a, b in handles:
+                h.wait()
+            self._flat_grad.div_(world)
+            return
+        if self._dp_side is None:
+            self._dp_side = torch.cuda.Stream(device=self.device)
+        side = self._dp_side
+        g = fused.param_groups[0]
+        mask = fused._grad_mask_for(self, need_enc)
+        with torch.cuda.stream(side):
+            for h, lo, hi, a, b in handles:
+                h.wait()                                   # this (side) stream waits for the bucket's all-reduce
+                self._flat_grad[a:b].div_(world)
+                check(lib.vs_adamw_step(ptr(self._flat) + 4 * a, ptr(self._flat_grad) + 4 * a, ptr(fused.exp_avg) + 4 * a,
+                                        ptr(fused.exp_avg_sq) + 4 * a, (ptr(mask) + a) if mask is not None else None, b - a,
+                                        float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                        float(g["weight_decay"]), fused.step_count + 1, _lib.stream_ptr()))
+                check(lib.vs_unet_prepare_range(plan["handle"], ptr(self._flat), ptr(plan["ws"]), _lib.stream_ptr(), lo, hi))
+        main.wait_stream(side)
+        check(lib.vs_unet_flip_weight_set(plan["handle"]))
 
     def _allreduce_grads(self):
         import torch.distributed as dist
@@ -394,12 +423,23 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._stepped_in_backward:
             raise RuntimeError("FusedAdamW(fuse_step_into_backward=True): backward() called twice without step() - gradient "
                                "accumulation needs fuse_step_into_backward=False")
-        if model.dp_group is not None:
-            return False   # gradients must be all-reduced first: plain path
         for p, _, _, _, enc in model._param_cache:
             if p.requires_grad != (need_enc or not enc):
                 return False   # only "everything" or "everything but the encoder convolutions" can be fused
         return True
+
+    def _grad_mask_for(self, model, need_enc: bool):
+        """uint8 mask over the flat buffer for the data-parallel fused step: None (everything trains) or zeros on the frozen
+        encoder convolutions (_can_fuse has already established that these are the only two patterns)."""
+        if need_enc:
+            return None
+        if getattr(self, "_frozen_mask", None) is None:
+            m = torch.ones(model._flat.numel(), dtype=torch.uint8)
+            for (name, shape, kind, off) in [t for t in model._table if t[2] <= KIND_BIAS]:
+                if "encoder" in name and "conv" in name:
+                    m[off:off + math.prod(shape)] = 0
+            self._frozen_mask = m.to(model.device)
+        return self._frozen_mask
 
     def _grad_mask(self):
         params = list(self.model.parameters())
