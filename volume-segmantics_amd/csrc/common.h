@@ -168,6 +168,9 @@ int launch_conv_igemm_dma(int dtype, const ConvParams& p, int BN, int out_nchw, 
 int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
                                 void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
                                 int nparts, hipStream_t s);
+int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial, int nparts, float eps, float momentum, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                  const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
 

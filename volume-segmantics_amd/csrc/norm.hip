@@ -172,6 +172,75 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// Same, with the statistics finalised INSIDE the kernel: when the producing convolution left only a few partial rows
+// (<= 64: the 16x16 / 8x8-pixel layers), every workgroup sums them itself (fp64, rows in order) instead of waiting for a
+// separate finalise launch - ~1.5 us of redundant work per workgroup against ~7 us of launch + drain on the critical path.
+// Workgroup 0 also publishes mean / invstd for the backward pass and updates the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restrict__ x, const float* __restrict__ partial, int nparts,
+                                                            float eps, float momentum, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const T* __restrict__ res, int relu,
+                                                            T* __restrict__ y, int64_t rows, int c, RowMap m) {
+    extern __shared__ float s_stat[];   // [2][c]: mean, invstd
+    const int tid = threadIdx.x;
+    for (int ch = tid; ch < c; ch += 256) {
+        double s = 0.0, q = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < nparts; ++r) {
+            s += (double)partial[((size_t)r * 2 + 0) * c + ch];
+            q += (double)partial[((size_t)r * 2 + 1) * c + ch];
+        }
+        const double mu = s / (double)rows;
+        double var = q / (double)rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        s_stat[ch] = (float)mu;
+        s_stat[c + ch] = is;
+        if (blockIdx.x == 0) {
+            mean[ch] = (float)mu;
+            invstd[ch] = is;
+            if (running_mean) {
+                const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+            }
+        }
+    }
+    __syncthreads();
+    const int cvi = tid % m.cv, rl = tid / m.cv;
+    if (rl >= m.rpb) return;
+    float a[kVec], b[kVec], mu[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = cvi * kVec + k;
+        a[k] = s_stat[c + ch] * gamma[ch];
+        b[k] = beta[ch];
+        mu[k] = s_stat[ch];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
+    const int64_t r1 = min(rows, r0 + m.rows_per_block);
+    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
+        const size_t o = (size_t)r * c + cvi * kVec;
+        float v[kVec];
+        ld8(x + o, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = (v[k] - mu[k]) * a[k] + b[k];
+        if (res) {
+            float rv[kVec];
+            ld8(res + o, rv);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] += rv[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        st8(y + o, v);
+    }
+}
+
 // ---- backward ----------------------------------------------------------------------------------
 // relu mask: from the stored activation y when given, otherwise recomputed as (x - mean) * invstd * gamma + beta > 0
 // (bit-identical to the forward's expression; only valid for units without a residual input)
@@ -306,6 +375,23 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
 }
 
 }  // namespace
+
+// train-mode BN forward from the conv epilogue's partial rows in ONE launch (nparts small): finalise + normalise
+int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial, int nparts, float eps, float momentum, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                  const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_apply: unsupported channel count %d", c);
+    RowMap m = make_rowmap(rows, c);
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(bn_apply_inline_kernel<bf16_t>, dim3(m.nblocks), dim3(256), lds, s, (const bf16_t*)x, partial, nparts, eps,
+                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const bf16_t*)residual, relu, (bf16_t*)y, rows, c, m);
+    else
+        hipLaunchKernelGGL(bn_apply_inline_kernel<float>, dim3(m.nblocks), dim3(256), lds, s, (const float*)x, partial, nparts, eps,
+                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const float*)residual, relu, (float*)y, rows, c, m);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
 
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s) {

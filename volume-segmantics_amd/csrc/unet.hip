@@ -530,6 +530,13 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         }
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
+            if (fused_stat_rows && fused_stat_rows <= vs_option("bn_inline_rows")) {   // few partial rows: one launch does both
+                ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
+                if ((rc = launch_bn_apply_from_partials(dt, c.z(u.out), (const float*)(c.ws + net->off_bnws), fused_stat_rows, 1e-5f, 0.1f,
+                                                        c.bnc(u, 2), c.bnc(u, 3), rm, rv, c.P(u.bn_idx), c.P(u.bn_idx + 1),
+                                                        u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, c.s))) return rc;
+                continue;
+            }
             if (fused_stat_rows) {
                 ProfScope prof(PK_BN_STATS, 0, 0, c.s);
                 if ((rc = launch_bn_finalize_partials((const float*)(c.ws + net->off_bnws), fused_stat_rows, u.cout, c.rows(u),
