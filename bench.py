@@ -352,7 +352,7 @@ def main():
                        "master_weights": "fp32", "final_loss": round(final_loss, 5)},
             "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(dom_name),
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": (load_traffic(dom_name) or {}).get("bytes_per_launch"), "traffic_detail": load_traffic(dom_name),
                          "launches_per_step": dom_calls // prof_steps,
                          "avg_launch_ms": round(dom_ms / max(1, dom_calls), 5),
                          "algorithmic_gflop_per_launch": round(dom_fl / max(1, dom_calls) / 1e9, 3),
