@@ -1,22 +1,29 @@
-// Implicit-GEMM NHWC convolution on MFMA (gfx950), im2col-free.
+// Implicit-GEMM NHWC convolution on MFMA (gfx950), im2col-free.  Two kernels:
 //
-// One workgroup (4 waves) computes a TH x TW patch of output pixels of one image times BN output channels.
-// For every chunk of CK input channels (64 bytes per pixel: 32 bf16 / 16 f32) the input halo patch and the
-// BN x taps weight slab are staged in LDS once and reused by all KH*KW taps: a tap is just a constant byte
-// offset into the staged patch, so there is no im2col buffer anywhere.  MFMA orientation: A = weights
-// (rows = cout), B = pixels (cols), so each lane ends up with 4 consecutive output channels of one pixel
-// -> 8/16-byte NHWC stores.
+// conv_igemm_kernel - the general one.  A workgroup (8 waves on 16x16-pixel tiles; 4 waves on 8x16 / 8x8 tiles for small
+// images and stride 2) computes a tile of output pixels of one image times BN (64 / 32 / 16) output channels.  For every
+// chunk of CK input channels (64 bytes per pixel: 32 bf16 / 16 f32) the input halo patch and the BN x taps weight slab are
+// staged in LDS once and reused by all KH*KW taps: a tap is a constant byte offset into the staged patch, so there is no
+// im2col buffer anywhere.  MFMA orientation: A = weights (rows = cout), B = pixels (cols), so each lane ends up with 4
+// consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+//   * staging: raw buffer loads (one descriptor per image, 32-bit lane offsets, offset -1 -> zeros) issued one or two chunks
+//     ahead into registers, written to LDS between two barriers; compile-time tile geometry for stride 1;
+//   * LDS: unpadded 64-byte rows, 16-byte segments XOR-swizzled by the patch column (conflict-free ds_read_b128);
+//   * 32-wide tiles: fragments of tap t+1 are read while the MFMAs of tap t run, pinned with sched_group_barrier;
+//   * workgroup -> tile map is XCD-aware: cout tiles sharing an input patch run back to back on one XCD's L2;
+//   * epilogue (conv_common.h): BN-statistics partials, affine, residual, ReLU, split output, 2x2 sum-pool, fp32 / NCHW.
 //
-// Pipeline: the 16-byte global loads of chunk c+1 are all issued (into registers) BEFORE the MFMAs of
-// chunk c and written to LDS after them, so HBM/L2 latency hides under the matrix work (one LDS buffer,
-// two barriers per chunk; >= 2 workgroups per CU cover the barrier bubbles).
+// conv_direct_kernel - the HBM-bound shallow layers (<= 16 couts, Cin within one chunk, large images) and the segmentation
+// head: no LDS staging and no barriers, every wave walks down a 16-pixel-wide strip with a ring of input rows held as MFMA
+// B fragments loaded straight from global memory; in prediction the head's epilogue writes labels / probabilities / packed
+// keys into the output volume itself.
 //
-// bf16: v_mfma_f32_16x16x32_bf16 (one per 32-channel chunk-tap); f32: 4 x v_mfma_f32_16x16x4_f32 on the
-// same 16-byte fragments (exact fp32 FMA chain - the parity path).
+// bf16: v_mfma_f32_16x16x32_bf16 (one per 32-channel chunk-tap); f32: 4 x v_mfma_f32_16x16x4_f32 on the same 16-byte
+// fragments (exact fp32 FMA chain - the parity path).
 //
-// Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites
-// vol_seg_2d_trainer.py:424, vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat
-// folded into the patch loader, and - fed with flipped/transposed weights - their dgrad.
+// Serves every 3x3 / 1x1 convolution of smp.Unet(resnet34) forward (reference call sites vol_seg_2d_trainer.py:424,
+// vol_seg_2d_predictor.py:44), with the decoder's nearest-x2 upsample + concat folded into the patch loader, and - fed with
+// flipped/transposed weights - their dgrad.
 #include <hip/hip_fp16.h>
 
 #include <algorithm>

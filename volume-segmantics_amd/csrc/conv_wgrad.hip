@@ -5,8 +5,10 @@
 // for free from ds_read_b64_tr_b16 on the naturally laid out [pixel][channel] LDS tiles; f32 uses
 // v_mfma_f32_16x16x4_f32 whose fragments are one scalar per lane (plain ds_read_b32).
 // The staged input patch is the same virtual tensor cat(upsample(src0), src1) the forward conv read.
-// Split-K over pixel tiles: every (workgroup, K-wave) writes an fp32 partial slab, a second kernel
-// sums the slabs in a fixed order (bitwise reproducible, no float atomics).
+// Split-K over pixel tiles: every workgroup writes an fp32 partial slab, a second kernel sums the slabs in a fixed
+// order (bitwise reproducible, no float atomics).  Two kernels: conv_wgrad_bf16_kernel (bf16 fast path: all 16*MO couts of a
+// 16-channel cin slice and 5 / 4 of the 9 taps per wave, swizzled LDS images, buffer-load staging) and the generic
+// conv_wgrad_kernel (fp32, ragged channel counts).
 //
 // Replaces the conv weight gradients of loss.backward() (vol_seg_2d_trainer.py:429).
 #include <algorithm>
