@@ -49,46 +49,67 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
     }
 }
 
+// Gather form, one thread per 2x2 block of INPUT pixels (rows 2i, 2i+1; columns 2j, 2j+1) and 8 channels: the block lies
+// in exactly four pooling windows, (i, j), (i, j+1), (i+1, j), (i+1, j+1) - even rows / columns belong to one window row /
+// column (tap 1), odd ones to two (tap 2 of window i, tap 0 of window i+1) - so four (dy, argmax) loads serve four
+// outputs (per-pixel threads needed nine).  No atomics: every input element is written by one thread.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
                                    int accumulate, int n, int h, int w, int c) {
     const int ho_n = h / 2, wo_n = w / 2, cv = c / kVec;
-    const int64_t total = (int64_t)n * h * w * cv;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t t = i;
+    const int64_t total = (int64_t)n * ho_n * wo_n * cv;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = t0;
         const int cg = t % cv; t /= cv;
-        const int wi = t % w; t /= w;
-        const int hi = t % h;
-        const int b = t / h;
-        float g[kVec];
-        const size_t xo = (((size_t)b * h + hi) * w + wi) * c + cg * kVec;
-        if (accumulate) ld8(dx + xo, g);
-        else {
+        const int j = t % wo_n; t /= wo_n;
+        const int i = t % ho_n;
+        const int b = t / ho_n;
+        float g[2][2][kVec];    // [row parity][column parity]
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) g[k] = 0.f;
-        }
-        // windows containing (hi, wi): ho in {(hi+1)/2 (kh = hi - 2ho + 1)} and, for odd hi, also (hi-1)/2
-        for (int a = 0; a < 2; ++a) {
-            const int ho = (hi + 1) / 2 - a;
-            const int kh = hi - 2 * ho + 1;
-            if (ho < 0 || ho >= ho_n || kh < 0 || kh > 2) continue;
-            for (int bb = 0; bb < 2; ++bb) {
-                const int wo = (wi + 1) / 2 - bb;
-                const int kw = wi - 2 * wo + 1;
-                if (wo < 0 || wo >= wo_n || kw < 0 || kw > 2) continue;
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const size_t xo = (((size_t)b * h + 2 * i + a) * w + 2 * j + e) * c + cg * kVec;
+                if (accumulate) ld8(dx + xo, g[a][e]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) g[a][e][k] = 0.f;
+                }
+            }
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int ho = i + di, wo = j + dj;
+                if (ho >= ho_n || wo >= wo_n) continue;
                 const size_t o = (((size_t)b * ho_n + ho) * wo_n + wo) * c + cg * kVec;
                 const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
                 float d[kVec];
                 ld8(dy + o, d);
-                const int code = kh * 3 + kw;
+                // window (ho, wo) covers input rows 2ho-1 .. 2ho+1: of this block, row 2i (tap kh = 1) and 2i+1 (kh = 2) when
+                // di = 0, only row 2i+1 (kh = 0) when di = 1; columns alike
 #pragma unroll
-                for (int k = 0; k < kVec; ++k) {
-                    const int id = ((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff;
-                    if (id == code) g[k] += d[k];
+                for (int a = 0; a < 2; ++a) {
+                    const int kh = 2 * i + a - (2 * ho - 1);
+                    if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int kw = 2 * j + e - (2 * wo - 1);
+                        if (kw < 0 || kw > 2) continue;
+                        const int code = kh * 3 + kw;
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) {
+                            const int id = ((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff;
+                            if (id == code) g[a][e][k] += d[k];
+                        }
+                    }
                 }
             }
-        }
-        st8(dx + xo, g);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                st8(dx + (((size_t)b * h + 2 * i + a) * w + 2 * j + e) * c + cg * kVec, g[a][e]);
     }
 }
 
@@ -166,7 +187,7 @@ extern "C" int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, i
 extern "C" int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int accumulate, int n, int h,
                               int w, int c, void* stream) {
     VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0 && idx, "maxpool_bwd: bad arguments");
-    const int64_t total = (int64_t)n * h * w * (c / kVec);
+    const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
     if (dtype == VS_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dy, idx, (bf16_t*)dx, accumulate, n, h, w, c);
