@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int relu, bf16_t* __restrict__ y, int n, int h, int wd) {
     __shared__ __attribute__((aligned(16))) bf16_t patch[PHB * PWB];
+    __shared__ __attribute__((aligned(16))) char otile[256 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
     const int ho_n = h / 2, wo_n = wd / 2;
     const int tiles_w = (wo_n + TPW - 1) / TPW, tiles_h = (ho_n + TPH - 1) / TPH;
@@ -233,11 +234,11 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
                                                                     acc[i][j], 0, 0, 0);
         }
     }
+    // Output through LDS: the accumulators hold 8-byte pieces (4 couts of one pixel); transposed through a [256 pixels][128 B]
+    // tile every lane stores 16 contiguous bytes and a wave writes whole 128-byte pixel rows.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ho = h0 + 2 * wave + (i >> 1), wo = w0 + (i & 1) * 16 + lr;
-        if (ho >= ho_n || wo >= wo_n) continue;
-        bf16_t* o = y + (((size_t)img * ho_n + ho) * wo_n + wo) * 64;
+        const int pl = (2 * wave + (i >> 1)) * TPW + (i & 1) * 16 + lr;     // pixel index inside the 8 x 32 tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = j * 16 + lq * 4;
@@ -250,8 +251,20 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            st4(o + c, make_float4(v[0], v[1], v[2], v[3]));
+            // 16-byte slot (c >> 3) of the pixel's row, XOR-ed with the pixel's low bits so the 8-byte writes spread over banks
+            *reinterpret_cast<uint2*>(otile + pl * 128 + ((((c >> 3) ^ (pl & 7)) << 4) | ((c & 4) << 1))) =
+                make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                              // 256 pixels x 8 slots of 16 bytes
+        const int item = tid + k * 256;
+        const int pl = item >> 3, slot = item & 7;
+        const int ho = h0 + (pl >> 5), wo = w0 + (pl & 31);
+        if (ho < ho_n && wo < wo_n)
+            *reinterpret_cast<uint4*>(y + (((size_t)img * ho_n + ho) * wo_n + wo) * 64 + slot * 8) =
+                *reinterpret_cast<const uint4*>(otile + pl * 128 + ((slot ^ (pl & 7)) << 4));
     }
     }
 }
