@@ -197,3 +197,39 @@ def test_head_scatter_epilogue_equals_forward_plus_logits_to_volume(precision, c
                 assert (ref["labels"] != 0).any() or mode == 1
     finally:
         L.set_option("conv_direct_min_px", old)
+
+
+@pytest.mark.parametrize("classes", [2, 4])
+def test_staged_key_scatter_for_slices_along_the_contiguous_axis(classes):
+    """Directions whose slice index is the volume's contiguous axis: the head stages its keys slice-major and a transposing
+    pass merges them into the key volume (vs_unet_forward_to_volume, batch >= 8) - same keys as forward + logits_to_volume,
+    with cropping, a ragged last pixel tile, a batch that is not a multiple of anything and pre-existing larger keys."""
+    import numpy as np
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import dirmap_of
+    old = L.lib.vs_get_option(b"conv_direct_min_px")
+    L.set_option("conv_direct_min_px", 1)
+    try:
+        model = VolSegUnet(classes, device=DEV, precision="bf16", seed=5)
+        model.eval()
+        vol = np.zeros((45, 61, 13), np.uint8)
+        for view, direction in ((np.swapaxes(vol, 0, 2), 2), (np.swapaxes(np.rot90(vol, 1), 0, 2), 5)):
+            dmap = dirmap_of(vol, view)
+            assert abs(dmap.ss) == 1 and abs(dmap.sw) != 1
+            nb = 11
+            x = torch.randn(nb, 1, dmap.hp, dmap.wp, generator=torch.Generator().manual_seed(direction)).to(DEV)
+            n = vol.size
+            g = torch.Generator().manual_seed(1)
+            # a third of the voxels already hold a key no probability can beat
+            init = torch.where(torch.rand(n, generator=g) < 0.33, torch.tensor(0x7fff0000), torch.tensor(5)).to(torch.int32).to(DEV)
+            ref, got = init.clone(), init.clone()
+            with torch.no_grad():
+                logits = model._forward_impl(x, training=False)
+            L.check(L.lib.vs_logits_to_volume(L.ptr(logits), classes, dmap, 1, nb, 1, direction, None, None, L.ptr(ref), None, n, L.stream_ptr()))
+            model._forward_to_volume(x, dmap, 1, 1, direction, None, None, got, None, n)
+            torch.cuda.synchronize()
+            assert torch.equal(ref, got), (classes, direction)
+            assert (got != init).any() and (got == init).any()
+    finally:
+        L.set_option("conv_direct_min_px", old)

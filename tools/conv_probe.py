@@ -67,6 +67,12 @@ def run(name, n, hw, cin, cout, k=3, stride=1, reps=20):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "predict":       # layer shapes of a batch-64 512x512 prediction forward
+        for name, hw, cin, cout in [("layer1", 128, 64, 64), ("layer2", 64, 128, 128), ("layer3", 32, 256, 256), ("layer4", 16, 512, 512),
+                                    ("dec0.c1", 32, 768, 256), ("dec0.c2", 32, 256, 256), ("dec1.c1", 64, 384, 128), ("dec1.c2", 64, 128, 128),
+                                    ("dec2.c1", 128, 192, 64), ("dec2.c2", 128, 64, 64), ("dec3.c1", 256, 128, 32), ("dec3.c2", 256, 32, 32)]:
+            run(name, 64, hw, cin, cout, reps=10)
+        sys.exit(0)
     run("layer1", 32, 64, 64, 64)
     run("layer2", 32, 32, 128, 128)
     run("layer3", 32, 16, 256, 256)

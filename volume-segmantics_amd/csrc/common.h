@@ -157,7 +157,11 @@ struct VolScatter {
     vs_dirmap m;
     int s0, direction, mode;             // first slice of the batch; direction index (key mode); 0 = labels/probs, 1 = packed keys
     uint8_t* labels; uint16_t* probs; uint32_t* keys;
+    uint32_t* stage;                     // key mode, optional: keys go to stage[n][hp][wp] instead (launch_keys_stage_scatter follows)
 };
+// stage[n][hp][wp] packed keys -> cropped, max-merged into the key volume with the slice index as the fastest-moving lane
+// index: for directions whose slices are the volume's contiguous axis the head's own scatter would touch one line per voxel
+int launch_keys_stage_scatter(const uint32_t* stage, int nb, const vs_dirmap& m, int s0, uint32_t* keys, hipStream_t s);
 bool conv_head_scatter_ok(int dtype, const ConvParams& p);   // whether launch_conv_igemm can honour p.scatter for this layer
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry

@@ -263,13 +263,11 @@ struct DirectGeom {
 };
 
 // MODE 0: NHWC store in T (optional per-channel affine + ReLU, optional statistics); 1: 2x2 sum-pooled NHWC store (dgrad
-// through nearest-x2 upsampling); 2: fp32 NCHW store of <= 4 channels with bias (segmentation head); 3: the head in
-// prediction - no logits leave the kernel: softmax -> first arg-max -> fp16 max-prob of the <= 4 classes a lane holds, cropped
-// and written at the direction's voxel address as label / probability or as a packed key through an (order-free) atomic max.
+// through nearest-x2 upsampling).  (The segmentation head has its own kernel below.)
 // Every row iteration issues the same number of loads and (offset-masked, never skipped) buffer stores, so the waits on
 // the input ring are counted ones and kD rows stay in flight per wave.
 template <typename T, int BN, int MODE>
-__global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g, VolScatter vsc) {
+__global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g) {
     constexpr int EPS = CT<T>::EPS, NJ = BN / 16, NTAPS = 9, kD = (BN == 32 && MODE == 1) ? 2 : 4;   // input rows in flight
     constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
     constexpr int kOob = (int)0x80000000;
@@ -328,22 +326,13 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
         orow = p.Wout * p.Cout * (int)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ooff[j] = (inw && j * 16 + lq * 4 < p.Cout) ? (wo * p.Cout + j * 16 + lq * 4) * (int)sizeof(T) : kOob;
-    } else if constexpr (MODE == 1) {
+    } else {
         const int Ho = p.Hout >> 1, Wo = p.Wout >> 1;
         ro = make_rsrc((T*)p.out + (size_t)n * Ho * Wo * p.Cout, Ho * Wo * p.Cout * (int)sizeof(T));
         orow = Wo * p.Cout * (int)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             ooff[j] = (inw && !(lr & 1) && j * 16 + lq * 4 < p.Cout) ? ((wo >> 1) * p.Cout + j * 16 + lq * 4) * (int)sizeof(T) : kOob;
-    } else if constexpr (MODE == 2) {
-        ro = make_rsrc((float*)p.out + (size_t)n * p.Cout * p.Hout * p.Wout, p.Cout * p.Hout * p.Wout * 4);
-        orow = p.Wout * 4;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) ooff[j] = (inw && j == 0 && lq == 0) ? wo * 4 : kOob;   // + channel plane r * H * W * 4
-    } else {
-        ro = make_rsrc(nullptr, 0); orow = 0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) ooff[j] = kOob;
     }
     float4 sc[NJ], sh[NJ];
 #pragma unroll
@@ -433,36 +422,6 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, h * orow, 0);
                         }
-                    } else if (MODE == 2 && j == 0) {   // head: channel planes of this image, 4 dword stores (channels >= Cout masked)
-                        const int plane = p.Hout * p.Wout * 4;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (live && r < p.Cout) ? ooff[0] : kOob, h * orow + r * plane, 0);
-                    } else if (MODE == 3 && j == 0) {   // same arithmetic, in the same order, as logits_to_volume_kernel
-                        const int K = p.Cout;
-                        float mx = v[0];
-#pragma unroll
-                        for (int r = 1; r < 4; ++r) if (r < K) mx = fmaxf(mx, v[r]);
-                        float sum = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (r < K) sum += expf(v[r] - mx);
-                        float best = -1.f;
-                        int lab = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (r < K) { const float pk = __fdiv_rn(expf(v[r] - mx), sum); if (pk > best) { best = pk; lab = r; } }
-                        const int rr = h - vsc.m.crop_top, jj = wo - vsc.m.crop_left;
-                        if (live && lq == 0 && rr >= 0 && rr < vsc.m.h && jj >= 0 && jj < vsc.m.w) {
-                            const int64_t addr = vsc.m.base + (int64_t)(vsc.s0 + n) * vsc.m.ss + (int64_t)rr * vsc.m.sh + (int64_t)jj * vsc.m.sw;
-                            const __half hv = __float2half_rn(best);
-                            const uint32_t hb = __builtin_bit_cast(uint16_t, hv);
-                            if (vsc.mode == 0) {
-                                if (vsc.labels) vsc.labels[addr] = (uint8_t)lab;
-                                if (vsc.probs) vsc.probs[addr] = (uint16_t)hb;
-                            } else {
-                                atomicMax(vsc.keys + addr, (hb << 16) | ((uint32_t)(15 - vsc.direction) << 8) | (uint32_t)lab);
-                            }
-                        }
                     }
                 }
             }
@@ -486,12 +445,140 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
     }
 }
 
+// ---- segmentation head: <= 4 classes ---------------------------------------------------------------------------------
+// Same strip walk as conv_direct_kernel, but with <= 4 output channels a 16-row MFMA tile would be 3/4 empty and the
+// per-pixel epilogue (softmax / arg-max in prediction) would run on lanes that hold nothing: the kernel is VALU-bound.
+// So the FOUR output rows h, h+1, h+2, h+3 (h % 4 == 0) share one accumulator tile - row h + q lives in MFMA rows 4q..4q+3,
+// i.e. in the lanes of quad q.  An input row hi feeds output rows hi+1 (kh = 0), hi (kh = 1) and hi-1 (kh = 2): the weight
+// operand for input-row phase m = hi & 3 carries W[kh = 0] in quad (m+1)&3, W[kh = 1] in quad m, W[kh = 2] in quad (m+3)&3
+// and zeros in the fourth quad, so ONE MFMA per kw does what took three (12 phase matrices, built once per workgroup in
+// LDS).  A finished row is moved out of its quad with a select; every fourth row all 64 lanes hold one finished pixel each
+// and run the epilogue once.  Arithmetic per output value - products, order of accumulation, softmax - is unchanged.
+// MODE 2: fp32 NCHW logits + bias (training / plain forward); 3: prediction - no logits leave the kernel: softmax -> first
+// arg-max -> fp16 max-prob, cropped and written at the direction's voxel address as label / probability or as a packed key
+// through an (order-free) atomic max.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 4) void conv_head_kernel(ConvParams p, DirectGeom g, VolScatter vsc) {
+    constexpr int EPS = CT<T>::EPS, kD = 4, NMAT = 12;
+    constexpr int kOob = (int)0x80000000;
+    __shared__ __attribute__((aligned(16))) char wl[NMAT * 16 * kPS];
+    asm volatile("" ::"s"(p.src0), "s"(p.w), "s"(p.out), "s"(p.C0), "s"(p.Hin), "s"(p.Win), "s"(p.Hout), "s"(p.Wout), "s"(p.Cout),
+                 "s"(p.shift), "s"(g.strips_w), "s"(g.chunks_h), "s"(g.RH), "s"(g.sw_magic), "s"(g.ch_magic), "s"(g.nwaves));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int Cin = p.C0, K = p.Cout;
+    {   // phase matrices: row = (m * 3 + kw) * 16 + 4 * quad + class
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, K * 9 * Cin * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < NMAT * 16 * 4 / 256; ++i) {
+            const int item = tid + i * 256;
+            const int row = item >> 2, seg = item & 3;
+            const int mat = row >> 4, quad = (row >> 2) & 3, k = row & 3;
+            const int m = mat / 3, kw = mat - m * 3;
+            const int kh = quad == ((m + 1) & 3) ? 0 : quad == m ? 1 : quad == ((m + 3) & 3) ? 2 : -1;
+            const bool ok = kh >= 0 && k < K && seg * EPS < Cin;
+            *reinterpret_cast<uint4*>(wl + swz(row, row, seg)) = bload(rw, ok ? ((k * 9 + kh * 3 + kw) * Cin + seg * EPS) * (int)sizeof(T) : -1, 0);
+        }
+    }
+    __syncthreads();
+    const int gw = blockIdx.x * 4 + wave;                   // this wave's strip
+    if (gw >= g.nwaves) return;
+    const int q = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
+    const int ws = gw - q * g.strips_w;
+    const int n = g.chunks_h == 1 ? q : (int)__umulhi((unsigned)q, g.ch_magic);
+    const int hc = q - n * g.chunks_h;
+    const int w0 = ws * 16, h0 = hc * g.RH, h1 = min(p.Hout, h0 + g.RH);   // RH % 4 == 0: h0 & 3 == 0
+    const int h1r = (h1 + 3) & ~3;
+    const int rowbytes = p.Win * p.C0 * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const T*)p.src0 + (size_t)n * p.Hin * p.Win * p.C0, p.Hin * rowbytes);
+    int coff[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int col = w0 + lr + kw - 1;
+        coff[kw] = (col >= 0 && col < p.Win && lq * EPS < Cin) ? (col * p.C0 + lq * EPS) * (int)sizeof(T) : -1;
+    }
+    auto load_row = [&](int hi, uint4 (&x)[3]) {
+        const bool ok = hi >= 0 && hi < p.Hin;
+        const int soff = ok ? hi * rowbytes : 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) x[kw] = bload(rx, ok ? coff[kw] : -1, soff);
+    };
+    const int wbase_l = swz(lr, lr, lq);
+    const int wo = w0 + lr;
+    const bool inw = wo < p.Wout;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (p.shift && r < K) ? p.shift[r] : 0.f;
+    const int plane = p.Hout * p.Wout * 4;
+    const __amdgpu_buffer_rsrc_t ro = MODE == 2 ? make_rsrc((float*)p.out + (size_t)n * K * p.Hout * p.Wout, K * plane) : make_rsrc(nullptr, 0);
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, done = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 ring[kD][3];
+#pragma unroll
+    for (int u = 0; u < kD; ++u) load_row(h0 - 1 + u, ring[u]);
+    for (int base = h0 - 1; base <= h1r; base += kD) {
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const int hi = base + u;
+            if (hi > h1r) break;
+            const int m = (u + 3) & 3;                        // hi & 3 (compile time: base & 3 == 3)
+            int wb = wbase_l;
+            asm volatile("" : "+v"(wb));                      // phase matrices stay in LDS, not in 48 hoisted registers
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                mma16<T>(acc, *reinterpret_cast<const uint4*>(wl + (m * 3 + kw) * 16 * kPS + wb), ring[u][kw]);
+            load_row(hi + kD, ring[u]);
+            const int qd = (u + 2) & 3;                       // output row hi - 1 is complete; it lives in quad (hi - 1) & 3
+            if (lq == qd) { done = acc; acc = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (qd == 3) {                                    // rows hi-4 .. hi-1 are out: lane (lq, lr) owns row hi-4+lq, column wo
+                const int h = hi - 4 + lq;
+                const bool live = h >= h0 && h < h1 && inw;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = done[r] + bias[r];
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (live && r < K) ? (h * p.Wout + wo) * 4 : kOob, r * plane, 0);
+                } else {                                      // same arithmetic, in the same order, as logits_to_volume_kernel
+                    float mx = v[0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) if (r < K) mx = fmaxf(mx, v[r]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (r < K) sum += expf(v[r] - mx);
+                    float best = -1.f;
+                    int lab = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < K) { const float pk = __fdiv_rn(expf(v[r] - mx), sum); if (pk > best) { best = pk; lab = r; } }
+                    const int rr = h - vsc.m.crop_top, jj = wo - vsc.m.crop_left;
+                    if (live && rr >= 0 && rr < vsc.m.h && jj >= 0 && jj < vsc.m.w) {
+                        const int64_t addr = vsc.m.base + (int64_t)(vsc.s0 + n) * vsc.m.ss + (int64_t)rr * vsc.m.sh + (int64_t)jj * vsc.m.sw;
+                        const __half hv = __float2half_rn(best);
+                        const uint32_t hb = __builtin_bit_cast(uint16_t, hv);
+                        if (vsc.mode == 0) {
+                            if (vsc.labels) vsc.labels[addr] = (uint8_t)lab;
+                            if (vsc.probs) vsc.probs[addr] = (uint16_t)hb;
+                        } else if (!vsc.stage) {
+                            atomicMax(vsc.keys + addr, (hb << 16) | ((uint32_t)(15 - vsc.direction) << 8) | (uint32_t)lab);
+                        } else {   // un-cropped slice layout; launch_keys_stage_scatter does the volume addressing
+                            vsc.stage[((int64_t)n * p.Hout + h) * p.Wout + wo] = (hb << 16) | ((uint32_t)(15 - vsc.direction) << 8) | (uint32_t)lab;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // geometry the direct kernel covers
 static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = fp32 store, bit 1 = NCHW layout
     const int CK = dtype == VS_BF16 ? 32 : 16;
     const bool nchw = (p.out_f32 >> 1) != 0, f32 = (p.out_f32 & 1) != 0;
-    const bool out_ok = p.scatter ? (p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
-                                  : nchw ? (f32 && p.Cout <= 4 && !p.pool0 && !p.scale) : (!f32 && !(p.Cout & 3));
+    const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
+    const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
+                                  : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
     return vs_option("conv_direct") && out_ok && !p.bz && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
@@ -513,22 +600,29 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     DirectGeom g = direct_geom(p);
     g.out_nchw = out_nchw;
     VS_REQUIRE((double)p.Hin * p.Win * p.C0 * sizeof(T) < 2.0e9 && (long)g.nwaves * 16 < (1L << 32), "conv_direct: tensor too large");
+    const bool head = p.scatter || (p.Cout & 3) != 0 || out_nchw;
+    if (head) {   // four output rows per accumulator tile: strips start at multiples of 4
+        g.RH = std::max(4, g.RH & ~3);
+        g.chunks_h = cdiv(p.Hout, g.RH);
+        g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
+        g.nwaves = p.N * g.strips_w * g.chunks_h;
+        VS_REQUIRE(!p.up0 && !p.relu && !p.scale && !p.stats_partial, "conv_head: plain 3x3 head only");
+    }
     const dim3 grid(cdiv(g.nwaves, 4));
-    const bool head = (p.Cout & 3) != 0 || out_nchw;
     VolScatter sc{};
     if (p.scatter) {
         sc = *p.scatter;
         ConvParams q = p;
         q.scatter = nullptr;
-        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 3>), grid, dim3(256), 0, s, q, g, sc);
+        hipLaunchKernelGGL((conv_head_kernel<T, 3>), grid, dim3(256), 0, s, q, g, sc);
     } else if (head) {
         VS_REQUIRE(out_nchw && p.Cout <= 4 && BN == 16 && !p.pool0 && !p.scale, "conv_direct: unsupported ragged output");
-        hipLaunchKernelGGL((conv_direct_kernel<T, 16, 2>), grid, dim3(256), 0, s, p, g, sc);
+        hipLaunchKernelGGL((conv_head_kernel<T, 2>), grid, dim3(256), 0, s, p, g, sc);
     } else if (p.pool0) {
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g, sc);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g);
     } else {
         VS_REQUIRE(!p.out_f32, "conv_direct: fp32 NHWC output is not supported");
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g, sc);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g);
     }
     VS_LAUNCH_CHECK();
     return VS_OK;

@@ -125,6 +125,37 @@ __global__ __launch_bounds__(256) void keys_unpack_kernel(const uint32_t* __rest
     }
 }
 
+// Keys of one batch of slices, staged by the head kernel as stage[n][hp][wp], into the key volume.  For a direction whose
+// slice index is the volume's contiguous axis, one slice's pixels are a plane stride apart - written from the head kernel
+// every voxel is its own memory transaction.  Here a workgroup transposes a 64-pixel x 64-slice tile through LDS: reads are
+// contiguous along the pixels of a slice, the max-merge runs along the slices (lane = slice: 256 contiguous bytes per pixel).
+__global__ __launch_bounds__(256) void keys_stage_scatter_kernel(const uint32_t* __restrict__ stage, int nb, vs_dirmap m, int s0,
+                                                               uint32_t* __restrict__ keys) {
+    __shared__ uint32_t tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npx = m.h * m.w;
+    const int64_t plane = (int64_t)m.hp * m.wp;
+    for (int t0 = blockIdx.x * 64; t0 < npx; t0 += gridDim.x * 64) {
+        for (int n0 = 0; n0 < nb; n0 += 64) {
+            const int px = t0 + lane;
+            const int r = px / m.w, j = px - r * m.w;
+            const int64_t src = (int64_t)(r + m.crop_top) * m.wp + (j + m.crop_left);
+            __syncthreads();
+            for (int k = wave; k < 64; k += 4)
+                if (n0 + k < nb && px < npx) tile[k][lane] = stage[(n0 + k) * plane + src];
+            __syncthreads();
+            for (int k = wave; k < 64; k += 4) {
+                const int q = t0 + k;
+                if (q >= npx || n0 + lane >= nb) continue;
+                const int rq = q / m.w, jq = q - rq * m.w;
+                const int64_t addr = m.base + (int64_t)(s0 + n0 + lane) * m.ss + (int64_t)rq * m.sh + (int64_t)jq * m.sw;
+                const uint32_t key = tile[lane][k], old = keys[addr];
+                if (key > old) keys[addr] = key;     // one lane per voxel and launch; launches are ordered by the stream
+            }
+        }
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -174,6 +205,14 @@ extern "C" int vs_logits_to_volume(const float* logits, int classes, const vs_di
         vs_set_error("logits_to_volume: bad mode %d", mode);
         return VS_ERR_INVALID;
     }
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_keys_stage_scatter(const uint32_t* stage, int nb, const vs_dirmap& m, int s0, uint32_t* keys, hipStream_t s) {
+    VS_REQUIRE(stage && keys && nb >= 1, "keys_stage_scatter: bad arguments");
+    const int tiles = (m.h * m.w + 63) / 64;
+    hipLaunchKernelGGL(keys_stage_scatter_kernel, dim3(tiles > 8192 ? 8192 : tiles), dim3(256), 0, s, stage, nb, m, s0, keys);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

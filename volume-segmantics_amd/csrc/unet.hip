@@ -451,9 +451,14 @@ extern "C" int vs_unet_forward_to_volume(vs_unet_t* net, const float* params, fl
     sc.m = *m; sc.s0 = s0; sc.direction = direction; sc.mode = mode; sc.labels = labels; sc.probs = probs; sc.keys = keys;
     float* lg = reinterpret_cast<float*>((char*)workspace + net->off_logits);
     const bool try_fused = mode == 0 || mode == 1;
+    // slices along the volume's contiguous axis: the head stages its keys slice-major in the (otherwise unused) logits
+    // buffer and a transposing pass merges them into the volume along that axis
+    const bool staged = mode == 1 && (m->ss == 1 || m->ss == -1) && m->sw != 1 && m->sw != -1 && n >= 8 && vs_option("head_stage");
+    if (staged) sc.stage = reinterpret_cast<uint32_t*>(lg);
     const int rc = unet_forward(net, params, bnstate, x, n, 0, lg, workspace, stream, try_fused ? &sc : nullptr);
     if (rc < 0) return rc;
-    if (try_fused && rc == VS_OK) return VS_OK;   // the head kernel already wrote the volume entries
+    if (try_fused && rc == VS_OK)                 // the head kernel already wrote the volume entries (or staged the keys)
+        return staged ? launch_keys_stage_scatter(sc.stage, n, *m, s0, keys, (hipStream_t)stream) : VS_OK;
     return vs_logits_to_volume(lg, net->classes, m, s0, n, mode, direction, labels, probs, keys, votes, nvox, stream);
 }
 
