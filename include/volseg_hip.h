@@ -219,6 +219,29 @@ int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int 
 int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t hw, uint8_t* onehot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Volume pre-processing (BaseDataManager._preprocess_data, data/base_data_manager.py:29-42;
+ * clip_to_uint8, utilities/base_data_utils.py:243-287)
+ * ---------------------------------------------------------------------------------------- */
+enum { VS_VOL_F32 = 0, VS_VOL_F64 = 1, VS_VOL_U8 = 2, VS_VOL_I8 = 3, VS_VOL_U16 = 4, VS_VOL_I16 = 5, VS_VOL_U32 = 6, VS_VOL_I32 = 7 };
+
+/* One reduction pass over a C-contiguous volume of n elements, in NumPy's add.reduce order (8192-element buffers added in
+ * sequence, pairwise summation inside a buffer) and accumulation type (float for VS_VOL_F32, double otherwise), so that the
+ * np.nanmean / np.nanstd the reference takes (base_data_manager.py:33, base_data_utils.py:255) can be reproduced bit for bit:
+ *   op 0: out[0] = sum of x with NaN -> 0, out[1] = number of NaNs;
+ *   op 1: out[0] = sum of (x - avg)^2 with NaN -> 0 (avg rounded to the accumulation type).
+ * out: 2 doubles on the device.  workspace: vs_volume_sum_workspace(n) bytes on the device. */
+size_t vs_volume_sum_workspace(int64_t n);
+int vs_volume_sum(int vtype, const void* data, int64_t n, int op, double avg, void* workspace, size_t workspace_bytes,
+                  double* out, void* stream);
+
+/* out[i] = uint8(clip((clip(x, lower, upper) - lower) / (upper - lower), 0, 1) * 255), NaN -> nan_fill first, every step
+ * rounded in the volume's float type (float32 volumes) or in float64 (float64 and integer volumes) as NumPy's in-place
+ * ufuncs do (base_data_utils.py:270-287).  counts (optional, 2 x uint64 on the device, accumulated): voxels above upper /
+ * below lower (the numbers the reference logs, :259-268). */
+int vs_clip_to_uint8(int vtype, const void* data, int64_t n, double nan_fill, double lower, double upper, uint8_t* out,
+                     uint64_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Prediction path (vol_seg_2d_predictor.py:31-136)
  * ---------------------------------------------------------------------------------------- */
 /* Index map of one prediction direction: voxel address of slice s, row h, column w of the

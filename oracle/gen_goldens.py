@@ -18,6 +18,8 @@ What is real reference code in these goldens:
   * DiceLoss(normalization="none"), MeanIoU (data/pytorch3dunet_{losses,metrics}.py)
   * VolSeg2dTrainer._train_one_batch / _freeze_model / _find_lr_from_graph /
     _lr_exp_stepper (model/operations/vol_seg_2d_trainer.py)
+  * BaseDataManager.__init__ / _preprocess_data (data/base_data_manager.py:10-42) with
+    clip_to_uint8 (utilities/base_data_utils.py:243-287): g8 (`--only-g8` regenerates just that file)
 What is restated (third-party code that is not installed; [3p-memory] in SURVEY.md):
   * the network itself (oracle/unet_resnet34_torch.py, injected as predictor.model the
     way _get_model_from_trainer does, vol_seg_2d_predictor.py:28-29)
@@ -155,6 +157,35 @@ def synth_volume(shape, seed):
     return np.clip(128 + 40 * v, 0, 255).astype(np.uint8)
 
 
+def gen_g8():
+    """G8: BaseDataManager._preprocess_data + clip_to_uint8 (data/base_data_manager.py:10-42, utilities/base_data_utils.py:243-287)
+    run by the reference itself on small volumes of every input type: inputs, the mean it stores, the uint8 volume it keeps."""
+    from volume_segmantics.data.base_data_manager import BaseDataManager
+
+    rng = np.random.default_rng(88)
+    f32 = (rng.standard_normal((13, 37, 65)) * 900 + 4000).astype(np.float32)
+    f32.reshape(-1)[rng.choice(f32.size, 40, replace=False)] = np.nan
+    f32[0, 0, :3] = [3.0e4, -2.5e4, 2.0e4]                              # far outliers (infinities make the reference's result undefined)
+    f64 = rng.standard_normal((7, 40, 33)) * 3.5e-3 + 0.02
+    f64.reshape(-1)[rng.choice(f64.size, 9, replace=False)] = np.nan
+    u16 = np.clip(rng.gamma(2.0, 6000.0, (20, 64, 70)), 0, 65535).astype(np.uint16)
+    i16 = np.clip(rng.standard_normal((9, 50, 41)) * 5000 - 300, -32768, 32767).astype(np.int16)
+    u8 = rng.integers(0, 256, (16, 33, 47)).astype(np.uint8)
+    f32b = (rng.random((3, 5, 7)) * 10).astype(np.float32)             # smaller than one summation block
+    out = {}
+    for name, vol, factor in (("f32", f32, 2.575), ("f64", f64, 2.575), ("u16", u16, 2.0), ("i16", i16, 3.1), ("u8", u8, 1.5),
+                              ("f32b", f32b, 0.7)):
+        settings = SimpleNamespace(st_dev_factor=factor, downsample=False, clip_data=True, data_hdf5_path="/data")
+        dm = BaseDataManager(vol.copy(), settings)
+        assert dm.data_vol.dtype == np.uint8 and dm.data_vol.shape == vol.shape
+        out[name + "__in"] = vol
+        out[name + "__factor"] = np.float64(factor)
+        out[name + "__mean"] = np.asarray(dm.data_mean)                # keeps the scalar's dtype
+        out[name + "__out"] = dm.data_vol
+        print("g8", name, vol.dtype, "mean", repr(dm.data_mean), "hist head", np.bincount(dm.data_vol.reshape(-1), minlength=256)[[0, 1, 127, 254, 255]])
+    np.savez_compressed(OUT / "g8_clip_to_uint8.npz", **out)
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     install_stubs()
@@ -172,6 +203,9 @@ def main():
     from oracle.unet_resnet34_torch import seeded_oracle
 
     OUT.mkdir(parents=True, exist_ok=True)
+    gen_g8()
+    if "--only-g8" in sys.argv:
+        return
     utils.get_batch_size = lambda settings, prediction=False: 4 if prediction else 12  # needs CUDA in the reference
 
     # ---- G7: pad / crop tables --------------------------------------------------------------

@@ -1,0 +1,83 @@
+"""-m gpu: volume pre-processing on the device (csrc/preprocess.hip through the C ABI) against the CPU oracle
+(oracle/preprocess_numpy.py, pinned to NumPy and to the reference's BaseDataManager goldens): mean, standard deviation and
+every uint8 voxel must be EQUAL - the statistics follow NumPy's order of additions, the map NumPy's per-step rounding."""
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from hip_helpers import DEV
+from oracle import preprocess_numpy as Q
+
+pytestmark = pytest.mark.gpu
+G8_CASES = ("f32", "f64", "u16", "i16", "u8", "f32b")
+
+
+def _stats(vol):
+    from volume_segmantics_amd.utilities import base_data_utils as U
+    dev, vtype = U.volume_to_device(vol, DEV)
+    return U.device_nanmean_nanstd(dev, vtype, vol.size)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32])
+def test_statistics_equal_numpy_order(dtype):
+    rng = np.random.default_rng(3)
+    for shape in [(1, 1, 5), (1, 3, 43), (2, 5, 8191), (3, 8192), (5, 77, 131), (2, 8192 * 3 + 9)]:
+        if np.issubdtype(dtype, np.floating):
+            vol = (rng.standard_normal(shape) * 700 + 90).astype(dtype)
+            vol.reshape(-1)[::13] = np.nan
+        else:
+            info = np.iinfo(dtype)
+            vol = rng.integers(max(info.min, -40000), min(info.max, 40000) + 1, shape).astype(dtype)
+        mean, std = _stats(vol)
+        assert mean == Q.nanmean(vol) and type(mean) is type(Q.nanmean(vol)), (dtype, shape)
+        assert std == Q.nanstd(vol) and type(std) is type(Q.nanstd(vol)), (dtype, shape)
+
+
+@pytest.mark.parametrize("case", G8_CASES)
+def test_data_manager_on_device_equals_reference_golden(golden, case):
+    """BaseDataManager with a GPU present takes the device path: same stored mean, same uint8 volume as the reference's."""
+    from volume_segmantics_amd.data.base_data_manager import BaseDataManager
+    g = golden("g8_clip_to_uint8.npz")
+    s = SimpleNamespace(st_dev_factor=float(g[case + "__factor"]), downsample=False, clip_data=True, data_hdf5_path="/data", cuda_device=0)
+    vol = g[case + "__in"].copy()
+    dm = BaseDataManager(vol, s)
+    assert dm.data_mean == g[case + "__mean"] and np.asarray(dm.data_mean).dtype == g[case + "__mean"].dtype
+    assert dm.data_vol.dtype == np.uint8 and np.array_equal(dm.data_vol, g[case + "__out"])
+    assert np.array_equal(vol, g[case + "__in"], equal_nan=True)       # the caller's array is left alone
+
+
+def test_clip_counts_and_all_nan_free_float_volume():
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.utilities import base_data_utils as U
+    rng = np.random.default_rng(5)
+    vol = (rng.standard_normal((9, 64, 65)) * 3 + 1).astype(np.float32)
+    mean = U.nanmean_device(vol, DEV)
+    assert mean == Q.nanmean(vol)
+    out = U.clip_to_uint8_device(vol, mean, 1.25, DEV)
+    assert np.array_equal(out, Q.clip_to_uint8(vol, mean, 1.25))
+    dev, vtype = U.volume_to_device(vol, DEV)
+    std = Q.nanstd(vol)
+    lo, hi = mean - std * 1.25, mean + std * 1.25
+    counts = torch.zeros(2, dtype=torch.int64, device=DEV)
+    o = torch.empty(vol.size, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.vs_clip_to_uint8(vtype, L.ptr(dev), vol.size, float(mean), float(lo), float(hi), L.ptr(o), L.ptr(counts), L.stream_ptr()))
+    assert counts.tolist() == [int((vol > hi).sum()), int((vol < lo).sum())]
+
+
+def test_full_size_uint16_volume_512_cube():
+    """BASELINE config-3 size (512^3) as a 16-bit tomogram: 16 384 summation buffers, every voxel of the uint8 result."""
+    from volume_segmantics_amd.utilities import base_data_utils as U
+    rng = np.random.default_rng(11)
+    vol = np.clip(rng.gamma(2.0, 5000.0, (512, 512, 512)), 0, 65535).astype(np.uint16)
+    mean, std = _stats(vol)
+    assert mean == Q.nanmean(vol) and std == Q.nanstd(vol)
+    out = U.clip_to_uint8_device(vol, mean, 2.575, DEV)
+    ref = Q.clip_to_uint8(vol, mean, 2.575)
+    assert np.array_equal(out, ref)
+    order = np.argsort(vol[100].reshape(-1), kind="stable")             # the map is monotone
+    assert (np.diff(out[100].reshape(-1)[order].astype(np.int16)) >= 0).all()

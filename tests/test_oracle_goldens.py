@@ -126,3 +126,51 @@ def test_three_training_steps_match_reference_loop(golden):
         if k.startswith("after__"):
             assert np.allclose(sd[k[7:]].numpy(), g[k], rtol=1e-4, atol=1e-6), k
     assert int(g["n_frozen"]) == 33
+
+
+# ---- volume pre-processing (oracle/preprocess_numpy.py) ----------------------------------------------------------------
+G8_CASES = ("f32", "f64", "u16", "i16", "u8", "f32b")
+
+
+def test_preprocess_statistics_follow_numpy_bit_for_bit():
+    """The oracle writes NumPy's order of additions out; np.nanmean / np.nanstd (what base_data_manager.py:33 and
+    base_data_utils.py:255 call) are the pin: equal bits and scalar types, for every dtype, ragged sizes and NaNs."""
+    from oracle import preprocess_numpy as Q
+    rng = np.random.default_rng(1)
+    for shape in [(7, 33, 129), (3, 8192), (2, 5, 8191), (1, 1, 7), (1, 3, 43), (40, 41, 43)]:
+        for dt in (np.float32, np.float64):
+            a = (rng.standard_normal(shape) * 1000 + 50).astype(dt)
+            assert Q.np_order_sum(a) == a.sum()
+            a.reshape(-1)[::17] = np.nan
+            for mine, ref in ((Q.nanmean(a), np.nanmean(a)), (Q.nanstd(a), np.nanstd(a))):
+                assert mine == ref and type(mine) is type(ref), (shape, dt)
+        for dt in (np.uint16, np.int16, np.uint8, np.int32):
+            a = rng.integers(0, 30000, shape).astype(dt)
+            for mine, ref in ((Q.nanmean(a), np.nanmean(a)), (Q.nanstd(a), np.nanstd(a))):
+                assert mine == ref and type(mine) is type(ref), (shape, dt)
+
+
+@pytest.mark.parametrize("case", G8_CASES)
+def test_preprocess_equals_reference_data_manager(golden, case):
+    """g8: the reference's BaseDataManager (clip_data=True) on volumes of every input type - stored mean and uint8 volume."""
+    from oracle import preprocess_numpy as Q
+    g = golden("g8_clip_to_uint8.npz")
+    vol, factor = g[case + "__in"], float(g[case + "__factor"])
+    before = vol.copy()
+    mean, out = Q.preprocess(vol, factor)
+    assert mean == g[case + "__mean"] and mean.dtype == g[case + "__mean"].dtype
+    assert out.dtype == np.uint8 and np.array_equal(out, g[case + "__out"])
+    assert np.array_equal(vol, before, equal_nan=True)
+    assert len(np.unique(out)) > 100 or case == "f32b"   # the cases spread over the uint8 range
+
+
+def test_host_clip_to_uint8_equals_reference(golden):
+    """The NumPy path BaseDataManager takes on hosts without a GPU (volume_segmantics_amd.utilities.clip_to_uint8)."""
+    from types import SimpleNamespace
+    from volume_segmantics_amd.data.base_data_manager import BaseDataManager
+    g = golden("g8_clip_to_uint8.npz")
+    for case in G8_CASES:
+        s = SimpleNamespace(st_dev_factor=float(g[case + "__factor"]), downsample=False, clip_data=True, data_hdf5_path="/data",
+                            device_preprocess=False)
+        dm = BaseDataManager(g[case + "__in"].copy(), s)
+        assert dm.data_mean == g[case + "__mean"] and np.array_equal(dm.data_vol, g[case + "__out"]), case

@@ -12,6 +12,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VOLSEG_HIP_LIB", _HERE / "lib" / "libvolseg_hip.so"))
 
 VS_F32, VS_BF16 = 0, 1
+VS_VOL = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7}   # volume dtypes
 
 
 class VolsegHipMissing(ImportError):
@@ -100,6 +101,9 @@ _SIGS = {
     "vs_unet_forward_to_volume": (I, [P, P, P, P, I, P, P, C.POINTER(DirMap), I, I, I, P, P, P, P, I64]),
     "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),
     "vs_keys_unpack": (I, [P, P, P, I64, P]),
+    "vs_volume_sum_workspace": (SZ, [I64]),
+    "vs_volume_sum": (I, [I, P, I64, I, C.c_double, P, SZ, P, P]),
+    "vs_clip_to_uint8": (I, [I, P, I64, C.c_double, C.c_double, C.c_double, P, P, P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

@@ -24,13 +24,34 @@ class BaseDataManager:
             raise TypeError("data_vol must be a path or a numpy array")
         self._preprocess_data()
 
+    def _preprocess_device(self):
+        """The GPU to pre-process on, or None for the reference's NumPy path (hosts without a GPU, dtypes the device path
+        does not take).  With a GPU present a missing libvolseg_hip is an error, not a reason to fall back."""
+        import torch
+
+        if not torch.cuda.is_available() or not getattr(self.settings, "device_preprocess", True):
+            return None
+        from .. import _lib
+
+        if self.data_vol.dtype.name not in _lib.VS_VOL:
+            return None
+        return f"cuda:{getattr(self.settings, 'cuda_device', 0)}"
+
     def _preprocess_data(self):
         if self.downsample:
             self.data_vol = utils.downsample_data(self.data_vol)
         self.data_vol_shape = self.data_vol.shape
-        self.data_mean = np.nanmean(self.data_vol)
-        logging.info(f"Mean value: {self.data_mean}")
-        if self.settings.clip_data:
-            self.data_vol = utils.clip_to_uint8(self.data_vol, self.data_mean, self.st_dev_factor)
+        device = self._preprocess_device()
+        if device is not None:   # statistics and the uint8 map on the GPU: the same numbers, bit for bit (csrc/preprocess.hip)
+            uploaded = utils.volume_to_device(self.data_vol, device)
+            self.data_mean = utils.device_nanmean_nanstd(*uploaded, self.data_vol.size, want_std=False)[0]
+            logging.info(f"Mean value: {self.data_mean}")
+            if self.settings.clip_data:
+                self.data_vol = utils.clip_to_uint8_device(self.data_vol, self.data_mean, self.st_dev_factor, device, uploaded)
+        else:
+            self.data_mean = np.nanmean(self.data_vol)
+            logging.info(f"Mean value: {self.data_mean}")
+            if self.settings.clip_data:
+                self.data_vol = utils.clip_to_uint8(self.data_vol, self.data_mean, self.st_dev_factor)
         if np.isnan(self.data_vol).any():
             self.data_vol = np.nan_to_num(self.data_vol, copy=False)

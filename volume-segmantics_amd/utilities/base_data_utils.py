@@ -160,6 +160,82 @@ def clip_to_uint8(data: np.ndarray, data_mean: float, st_dev_factor: float) -> n
     return data.astype(np.uint8)
 
 
+# ---- device path of BaseDataManager._preprocess_data (base_data_manager.py:29-42) --------------------------------------
+# The same three results the reference takes with NumPy - np.nanmean, np.nanstd, the clipped uint8 volume - from
+# libvolseg_hip (csrc/preprocess.hip): sums in NumPy's own reduction order and accumulation type, so mean, standard
+# deviation, clip bounds and every uint8 voxel equal the NumPy ones bit for bit.  The scalar steps between the device passes
+# are written with the NumPy scalar types the reference's expressions produce (numpy/_core/_methods.py _mean / _var,
+# numpy/lib/_nanfunctions_impl.py nanmean / nanvar / _divide_by_count).
+def volume_to_device(data: np.ndarray, device):
+    """C-contiguous copy of a supported volume on the device (torch has no uint16/uint32: same-width signed views)."""
+    import torch
+    from .. import _lib
+
+    if data.dtype.name not in _lib.VS_VOL:
+        raise TypeError(f"volume dtype {data.dtype} has no device pre-processing path")
+    view = {"uint16": np.int16, "uint32": np.int32}.get(data.dtype.name)
+    host = np.ascontiguousarray(data)
+    return torch.from_numpy(host.view(view) if view else host).to(device), _lib.VS_VOL[data.dtype.name]
+
+
+def _device_sum(dev_data, vtype, n, op, avg):
+    import torch
+    from .. import _lib
+
+    ws = torch.empty(_lib.lib.vs_volume_sum_workspace(n), dtype=torch.uint8, device=dev_data.device)
+    out = torch.empty(2, dtype=torch.float64, device=dev_data.device)
+    _lib.check(_lib.lib.vs_volume_sum(vtype, _lib.ptr(dev_data), n, op, float(avg), _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()))
+    total, nans = out.cpu().numpy()
+    return total, int(nans)
+
+
+def device_nanmean_nanstd(dev_data, vtype: int, n: int, want_std: bool = True):
+    """(np.nanmean, np.nanstd) of the volume, as NumPy scalars of the types NumPy returns."""
+    acc = np.float32 if vtype == 0 else np.float64
+    total, nans = _device_sum(dev_data, vtype, n, 0, 0.0)
+    total = acc(total)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if vtype <= 1:                                  # inexact: nanmean / nanvar (always the masked path)
+            cnt = np.intp(n - nans)
+            mean = acc(total / cnt)                     # _divide_by_count: float64 division, result cast back
+        else:                                           # integers: np.mean / np.var with dtype f8
+            cnt = np.intp(n)
+            mean = acc(total / cnt)
+        if not want_std:
+            return mean, None
+        sq, _ = _device_sum(dev_data, vtype, n, 1, mean)
+        var = acc(acc(sq) / cnt)
+        return mean, acc(np.sqrt(var))
+
+
+def clip_to_uint8_device(data: np.ndarray, data_mean, st_dev_factor: float, device="cuda:0", uploaded=None) -> np.ndarray:
+    """clip_to_uint8 (:243-287) with the reductions and the map on the device; returns the uint8 volume on the host.
+    `uploaded`: the (tensor, dtype code) volume_to_device already returned for `data`, to skip a second upload."""
+    import torch
+    from .. import _lib
+
+    dev, vtype = uploaded if uploaded is not None else volume_to_device(data, device)
+    n = data.size
+    _, st_dev = device_nanmean_nanstd(dev, vtype, n)
+    lower = data_mean - (st_dev * st_dev_factor)        # NumPy scalar arithmetic, as in the reference (:257-258)
+    upper = data_mean + (st_dev * st_dev_factor)
+    out = torch.empty(n, dtype=torch.uint8, device=dev.device)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev.device)
+    # the map runs in float32 for float32 volumes and in float64 otherwise (integers: data.astype(float), :277-281)
+    comp = np.float32 if vtype == 0 else np.float64
+    _lib.check(_lib.lib.vs_clip_to_uint8(vtype, _lib.ptr(dev), n, float(comp(data_mean)), float(comp(lower)), float(comp(upper)),
+                                         _lib.ptr(out), _lib.ptr(counts), _lib.stream_ptr()))
+    above, below = (int(v) for v in counts.cpu())
+    logging.info(f"Lower bound: {lower}, upper bound: {upper}; clipping {above} voxels above "
+                 f"({above / n * 100:.3f}%) and {below} below ({below / n * 100:.3f}%).")
+    return out.cpu().numpy().reshape(data.shape)
+
+
+def nanmean_device(data: np.ndarray, device="cuda:0"):
+    dev, vtype = volume_to_device(data, device)
+    return device_nanmean_nanstd(dev, vtype, data.size, want_std=False)[0]
+
+
 def downsample_data(data: np.ndarray, factor: int = 2) -> np.ndarray:
     """:161-163 - block nan-mean (skimage.measure.block_reduce semantics: edge blocks are zero padded)."""
     pads = [(0, (-s) % factor) for s in data.shape]
