@@ -22,7 +22,8 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      VOLSEG_DIST_TIMEOUT_S="180")
     torch.set_num_threads(2)
     import torch.distributed as dist
     from cpu_backend import OracleBackend
@@ -63,8 +64,13 @@ def _worker(rank, world, port, out_dir):
 def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
     from oracle import predictor_numpy as P
     from oracle.unet_resnet34_torch import seeded_oracle
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for attempt in range(2):   # the port is free when picked, not necessarily when the store binds it: one retry
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+            break
+        except Exception:
+            if attempt:
+                raise
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     g = np.load(REPO / "tests" / "golden" / "g3_predict_29x64x40_c4.npz")
     vol = g["vol"][:, :32, :]

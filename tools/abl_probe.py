@@ -13,5 +13,7 @@ def run(name, n, hw, cin, cout, k=3, reps=20):
     for _ in range(reps): call()
     e1.record(); torch.cuda.synchronize(); us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"{name}: {us:.1f} us = {2.0 * n * hw * hw * cout * cin * k * k / us * 1e-6:.0f} TFLOP/s", flush=True)
+import os
+if os.environ.get("VS_OPT"): k, v = os.environ["VS_OPT"].split("="); L.set_option(k, int(v))
 run("layer4 p", 64, 16, 512, 512); run("layer3 p", 64, 32, 256, 256); run("layer2 p", 64, 64, 128, 128); run("layer1 p", 64, 128, 64, 64)
 run("layer3 t", 32, 16, 256, 256); run("layer2 t", 32, 32, 128, 128)

@@ -27,11 +27,15 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if os.environ.get("VOLSEG_DIST_TIMEOUT_S"):   # rendezvous / collective timeout (tests: fail instead of waiting for ever)
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(os.environ["VOLSEG_DIST_TIMEOUT_S"]))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     return rank, ws, local
 
 
