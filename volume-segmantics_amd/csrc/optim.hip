@@ -116,38 +116,36 @@ __global__ void weight_prepare_all_kernel(const float* __restrict__ params, char
     }
 }
 
-// dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels) + per-class sums (bias gradient)
+// dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels); the same sweep leaves per-class partial sums
+// (bias gradient): partial[block][k], finished by bias_grad_final in block order
 template <typename T>
-__global__ void dlogits_to_nhwc16_kernel(const float* __restrict__ d, T* __restrict__ o, int n, int k, int64_t hw) {
+__global__ __launch_bounds__(256) void dlogits_to_nhwc16_kernel(const float* __restrict__ d, T* __restrict__ o, int n, int k, int64_t hw,
+                                                              float* __restrict__ partial) {
+    __shared__ float red[4][16];
     const int64_t total = (int64_t)n * hw;
+    float sum[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum[c] = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / hw, px = i % hw;
         float v[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = c < k ? d[((size_t)b * k + c) * hw + px] : 0.f;
+        for (int c = 0; c < 16; ++c) { v[c] = c < k ? d[((size_t)b * k + c) * hw + px] : 0.f; sum[c] += v[c]; }
         st8(o + (size_t)i * 16, v);
         st8(o + (size_t)i * 16 + 8, v + 8);
     }
+    if (!partial) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float s = wave_sum(sum[c]);
+        if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < k) partial[(size_t)blockIdx.x * k + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// per-class sum of dlogits (n, K, hw): stage 1 = 256 blocks x K partials, stage 2 = one wave per class (fixed order)
-__global__ __launch_bounds__(256) void bias_grad_partial(const float* __restrict__ d, float* __restrict__ partial, int n,
-                                                       int k, int64_t hw) {
-    __shared__ float red[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c < k; ++c) {
-        float s = 0.f;
-        for (int b = 0; b < n; ++b) {
-            const float* base = d + ((size_t)b * k + c) * hw;
-            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) s += base[i];
-        }
-        s = wave_sum(s);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * k + c] = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-    }
-}
+// per-class sum of dlogits: stage 2 = one wave per class over the sweep's block partials (fixed order)
 __global__ __launch_bounds__(64) void bias_grad_final(const float* __restrict__ partial, float* __restrict__ db, int nblk, int k) {
     const int c = blockIdx.x;
     float s = 0.f;
@@ -241,21 +239,21 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
     return VS_OK;
 }
 
-int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s) {
+// db (optional): the bias gradient comes out of the same sweep; partial must hold kHeadBlocks * k floats
+constexpr int kHeadBlocks = 1024;
+int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, float* db, float* partial, hipStream_t s) {
     VS_REQUIRE(k >= 1 && k <= 16, "segmentation head: classes must be <= 16 (got %d)", k);
+    VS_REQUIRE(!db || partial, "segmentation head: the bias gradient needs a partial buffer");
+    const int blocks = db ? kHeadBlocks : grid_for((int64_t)n * hw);
     if (dtype == VS_BF16)
-        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<bf16_t>, dim3(grid_for((int64_t)n * hw)), dim3(256), 0, s, d, (bf16_t*)o, n, k, hw);
+        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d, (bf16_t*)o, n, k, hw, db ? partial : nullptr);
     else
-        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<float>, dim3(grid_for((int64_t)n * hw)), dim3(256), 0, s, d, (float*)o, n, k, hw);
+        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<float>, dim3(blocks), dim3(256), 0, s, d, (float*)o, n, k, hw, db ? partial : nullptr);
     VS_LAUNCH_CHECK();
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_final, dim3(k), dim3(64), 0, s, partial, db, kHeadBlocks, k);
+        VS_LAUNCH_CHECK();
+    }
     return VS_OK;
 }
 
-int launch_bias_grad(const float* d, float* db, float* partial, int n, int k, int64_t hw, hipStream_t s) {
-    constexpr int kBlocks = 256;  // partial must hold kBlocks * k floats
-    hipLaunchKernelGGL(bias_grad_partial, dim3(kBlocks), dim3(256), 0, s, d, partial, n, k, hw);
-    VS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_grad_final, dim3(k), dim3(64), 0, s, partial, db, kBlocks, k);
-    VS_LAUNCH_CHECK();
-    return VS_OK;
-}

@@ -15,11 +15,10 @@
 #include "prof.h"
 
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
-int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, hipStream_t s);
+int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, float* db, float* partial, hipStream_t s);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               hipStream_t s);
-int launch_bias_grad(const float* d, float* db, float* partial, int n, int k, int64_t hw, hipStream_t s);
 
 namespace {
 
@@ -754,8 +753,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (u.kind == U_HEAD) {
             void* dyh = c.ws + net->off_dyh;
             ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
-            if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
-            if ((rc = launch_bias_grad(dlogits, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), n, net->classes, (int64_t)net->h * net->w, c.s))) return rc;
+            if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, grads + c.t(u.bias_idx).offset,
+                                               (float*)(c.ws + net->off_bnws), c.s))) return rc;   // + bias gradient, same sweep
             dzp = dyh; dz_c = 16;
         } else {
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
