@@ -222,7 +222,8 @@ int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t hw, uint8_t*
  * Volume pre-processing (BaseDataManager._preprocess_data, data/base_data_manager.py:29-42;
  * clip_to_uint8, utilities/base_data_utils.py:243-287)
  * ---------------------------------------------------------------------------------------- */
-enum { VS_VOL_F32 = 0, VS_VOL_F64 = 1, VS_VOL_U8 = 2, VS_VOL_I8 = 3, VS_VOL_U16 = 4, VS_VOL_I16 = 5, VS_VOL_U32 = 6, VS_VOL_I32 = 7 };
+enum { VS_VOL_F32 = 0, VS_VOL_F64 = 1, VS_VOL_U8 = 2, VS_VOL_I8 = 3, VS_VOL_U16 = 4, VS_VOL_I16 = 5, VS_VOL_U32 = 6, VS_VOL_I32 = 7,
+       VS_VOL_I64 = 8, VS_VOL_U64 = 9 };
 
 /* One reduction pass over a C-contiguous volume of n elements, in NumPy's add.reduce order (8192-element buffers added in
  * sequence, pairwise summation inside a buffer) and accumulation type (float for VS_VOL_F32, double otherwise), so that the

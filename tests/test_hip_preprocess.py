@@ -23,7 +23,7 @@ def _stats(vol):
     return U.device_nanmean_nanstd(dev, vtype, vol.size)
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.int64, np.uint64])
 def test_statistics_equal_numpy_order(dtype):
     rng = np.random.default_rng(3)
     for shape in [(1, 1, 5), (1, 3, 43), (2, 5, 8191), (3, 8192), (5, 77, 131), (2, 8192 * 3 + 9)]:
@@ -81,3 +81,37 @@ def test_full_size_uint16_volume_512_cube():
     assert np.array_equal(out, ref)
     order = np.argsort(vol[100].reshape(-1), kind="stable")             # the map is monotone
     assert (np.diff(out[100].reshape(-1)[order].astype(np.int16)) >= 0).all()
+
+
+# ---- the reference's own data-manager tests (tests/test_base_data_manager.py:57-96), on the device path -----------------
+def _settings(**kw):
+    base = dict(st_dev_factor=2.575, downsample=False, clip_data=False, data_hdf5_path="/data", cuda_device=0)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+@pytest.fixture()
+def rand_size():
+    return np.random.default_rng(17).integers(10, 120, size=3)
+
+
+def test_preprocess_like_reference_suite(rand_size):
+    from volume_segmantics_amd.data.base_data_manager import BaseDataManager
+    rng = np.random.default_rng(23)
+    rand_int_volume = rng.integers(256, size=rand_size)                     # int64, as np.random.randint gives
+    rand_float_volume = rng.uniform(-1, 1, size=rand_size)
+    for vol in (rand_int_volume, rand_float_volume):                        # test_preprocess_clip_int / _float
+        dm = BaseDataManager(vol.copy(), _settings(clip_data=True))
+        host = BaseDataManager(vol.copy(), _settings(clip_data=True, device_preprocess=False))
+        assert dm._preprocess_device() == "cuda:0" or dm.data_vol.dtype == np.uint8
+        assert dm.data_vol.dtype == np.uint8 and dm.data_mean == host.data_mean and np.array_equal(dm.data_vol, host.data_vol)
+    dm = BaseDataManager(rand_int_volume.copy(), _settings(downsample=True))    # test_preprocess_downsampled
+    assert dm.data_vol.shape == tuple(int(np.ceil(s / 2)) for s in rand_int_volume.shape)
+    nan_vol = rand_float_volume.copy()
+    nan_vol[rng.integers(min(nan_vol.shape), size=3)] = np.nan                  # whole planes, as the reference's fixture does
+    assert np.isnan(nan_vol).any()
+    dm = BaseDataManager(nan_vol.copy(), _settings())                           # test_preprocess_replace_nan
+    assert not np.isnan(dm.data_vol).any() and dm.data_mean == np.nanmean(nan_vol)
+    dm = BaseDataManager(nan_vol.copy(), _settings(clip_data=True))             # test_preprocess_replace_nan_clip
+    host = BaseDataManager(nan_vol.copy(), _settings(clip_data=True, device_preprocess=False))
+    assert dm.data_vol.dtype == np.uint8 and np.array_equal(dm.data_vol, host.data_vol)

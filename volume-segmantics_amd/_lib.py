@@ -12,7 +12,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VOLSEG_HIP_LIB", _HERE / "lib" / "libvolseg_hip.so"))
 
 VS_F32, VS_BF16 = 0, 1
-VS_VOL = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7}   # volume dtypes
+VS_VOL = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7,
+          "int64": 8, "uint64": 9}   # volume dtypes
 
 
 class VolsegHipMissing(ImportError):

@@ -242,6 +242,8 @@ extern "C" size_t vs_volume_sum_workspace(int64_t n) {
     case VS_VOL_I16: return FN<int16_t, double>((const int16_t*)data, __VA_ARGS__);                  \
     case VS_VOL_U32: return FN<uint32_t, double>((const uint32_t*)data, __VA_ARGS__);                \
     case VS_VOL_I32: return FN<int32_t, double>((const int32_t*)data, __VA_ARGS__);                  \
+    case VS_VOL_I64: return FN<int64_t, double>((const int64_t*)data, __VA_ARGS__);                  \
+    case VS_VOL_U64: return FN<uint64_t, double>((const uint64_t*)data, __VA_ARGS__);                \
     default: vs_set_error("volume dtype %d not supported", vtype); return VS_ERR_UNSUPPORTED;        \
     }
 

@@ -167,13 +167,13 @@ def clip_to_uint8(data: np.ndarray, data_mean: float, st_dev_factor: float) -> n
 # are written with the NumPy scalar types the reference's expressions produce (numpy/_core/_methods.py _mean / _var,
 # numpy/lib/_nanfunctions_impl.py nanmean / nanvar / _divide_by_count).
 def volume_to_device(data: np.ndarray, device):
-    """C-contiguous copy of a supported volume on the device (torch has no uint16/uint32: same-width signed views)."""
+    """C-contiguous copy of a supported volume on the device (torch has no uint16/32/64: same-width signed views)."""
     import torch
     from .. import _lib
 
     if data.dtype.name not in _lib.VS_VOL:
         raise TypeError(f"volume dtype {data.dtype} has no device pre-processing path")
-    view = {"uint16": np.int16, "uint32": np.int32}.get(data.dtype.name)
+    view = {"uint16": np.int16, "uint32": np.int32, "uint64": np.int64}.get(data.dtype.name)
     host = np.ascontiguousarray(data)
     return torch.from_numpy(host.view(view) if view else host).to(device), _lib.VS_VOL[data.dtype.name]
 
