@@ -57,6 +57,24 @@ def test_conv_fwd_matches_torch(code, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [
+    (2, 32, 32, 64, 128, 3, 2, 1),    # 16x16 outputs: two 8x16 tiles per image
+    (1, 40, 72, 64, 64, 3, 2, 1),     # ragged: 20x36 outputs
+    (3, 16, 32, 96, 64, 3, 2, 1),     # 8x16 outputs, 3 chunks
+])
+def test_conv_stride2_wide_tiles(code, shape):
+    """The 8 x 16-output tiles the stride-2 3x3 layers take in large launches (forced here by dropping the workgroup floor)."""
+    L = lib()
+    old = L.lib.vs_get_option(b"conv_min_wgs")
+    L.set_option("conv_min_wgs", 1)
+    try:
+        _conv_case(code, *shape)
+        _conv_case(code, *shape, relu=True, affine=True)
+    finally:
+        L.set_option("conv_min_wgs", old)
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_conv_epilogue_affine_residual_relu(code):
     _conv_case(code, 2, 16, 16, 64, 64, 3, 1, 1, seed=3, relu=1, affine=True, residual=True)
     _conv_case(code, 1, 8, 8, 32, 32, 3, 1, 1, seed=4, relu=0, affine=True, residual=False)

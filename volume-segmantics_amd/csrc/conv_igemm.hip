@@ -56,7 +56,7 @@ struct TileGeom {
 
 // 16-byte patch items per thread (NW = waves per workgroup; the tile has NW*PT*16 pixels)
 constexpr int patch_items(int pt, int stride, int nw = 4) {
-    return nw == 8 ? 3 : (stride == 2 ? 5 : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)));
+    return nw == 8 ? 3 : (stride == 2 ? (pt == 2 ? 9 : 5) : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)));
 }
 
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
@@ -661,6 +661,9 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     if constexpr (PT == 1) {
         if (p.stride == 2) return nt == 9 ? launch_one<T, BN, 1, 9, 2>(p, g, s) : launch_one<T, BN, 1, 1, 2>(p, g, s);
     }
+    if constexpr (PT == 2 && BN == 64) {   // 8 x 16 output tiles of the stride-2 3x3 layers of a big batch
+        if (p.stride == 2) return launch_one<T, 64, 2, 9, 2>(p, g, s);
+    }
     return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
 }
 
@@ -672,12 +675,15 @@ static int g_dtype_hint = VS_BF16;
 // One place decides the kernel configuration (cout tile, pixel tiles per wave, waves per workgroup):
 //  * 8 waves x 2 pixel tiles = 256-pixel tiles for stride-1 layers with >= 16x16 outputs: half the weight-slab traffic per
 //    FLOP of the 128-pixel tile, twice the waves per CU for latency hiding, half the staging registers per thread;
-//  * 4 waves x 2 (128 px) or x 1 (64 px: 8x8 images, stride 2) otherwise;
+//  * 4 waves x 2 (128 px; also the stride-2 3x3 layers of large launches: 8x16 outputs) or x 1 (64 px: 8x8 images, stride 2)
+//    otherwise;
 //  * 32-wide cout tiles when 64-wide ones would leave fewer than `conv_min_wgs` workgroups.
 Pick pick_cfg(const ConvParams& p) {
     Pick c;
     c.NW = 4;
     c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
+    if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && p.Wout >= 16 && p.Hout >= 8 && vs_option("conv_s2_pt2") &&
+        (long)p.N * cdiv(p.Hout, 8) * cdiv(p.Wout, 16) * cdiv(p.Cout, 64) >= vs_option("conv_min_wgs")) c.PT = 2;
     const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.Hout >= 16 && p.Wout >= 16;
     auto wgs = [&](int bn, int px) {
         const int tw = tile_tw(p, px == 64 ? 1 : 2), th = px / tw;
@@ -764,7 +770,7 @@ int conv_igemm_variant(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return 16 * 1000 + 2 * 100 + 9 * 10 + 4;
     const Pick c = pick_cfg(p);
     if (conv_igemm_dma_ok(dtype, p, c.BN)) return c.BN * 1000 + 2 * 100 + 9 * 10 + 3;
-    return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : ((c.PT == 1 && p.stride == 2) ? 2 : 1));
+    return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : (p.stride == 2 ? 2 : 1));
 }
 
 bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && direct_ok(dtype, p); }
