@@ -825,11 +825,14 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.residual = written[u.src0] ? c.da(u.src0) : nullptr;
             // If this is the LAST contribution to the gradient of a conv+BN unit's activation and that unit is processed
             // next, its BN-backward reduction can ride in this epilogue (mask, masked store, per-tile partial sums).  Opt-in
-            // (fuse_bn_bwd = 1): measured 1.3 % SLOWER per step - the first BN sweep disappears (-0.27 ms) but the epilogue's
-            // z / y reads come from HBM at the tail of every workgroup (+0.31 ms of dgrad time).
+            // (fuse_bn_bwd = 1): measured neutral per step.  Per layer (bench.py --per-unit) the BN sweep gets 5-14 us shorter and
+            // the dgrad 3-17 us longer: the fused form saves ONE tensor read (the gradient itself) and a launch, but the
+            // epilogue reads z / y / earlier contributions as 8 bytes per lane at a pixel stride - half-used sectors - so
+            // its extra traffic costs about what the separate, fully coalesced sweep cost.  Layers the direct kernel takes
+            // are left alone (it has no such epilogue; falling back to the tile kernel cost 55 us each).
             const int pa = u.src0, pu = net->producer[pa];
             if (vs_option("fuse_bn_bwd") && pu >= 0 && pu == ui - 1 && net->first_consumer[pa] == ui && net->units[pu].kind == U_CONV &&
-                net->units[pu].bn_idx >= 0 && !(p.Cout & 3)) {
+                net->units[pu].bn_idx >= 0 && !(p.Cout & 3) && conv_igemm_variant(dt, p) % 10 != 4) {
                 const Unit& q = net->units[pu];
                 const int rows_needed = conv_igemm_stat_rows(dt, p);
                 if ((size_t)rows_needed * 2 * q.cout * sizeof(float) <= net->bnws_bytes) {
