@@ -827,8 +827,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             // next, its BN-backward reduction can ride in this epilogue (mask, masked store, per-tile partial sums).  Opt-in
             // (fuse_bn_bwd = 1): measured neutral per step.  Per layer (bench.py --per-unit) the BN sweep gets 5-14 us shorter and
             // the dgrad 3-17 us longer: the fused form saves ONE tensor read (the gradient itself) and a launch, but the
-            // epilogue reads z / y / earlier contributions as 8 bytes per lane at a pixel stride - half-used sectors - so
-            // its extra traffic costs about what the separate, fully coalesced sweep cost.  Layers the direct kernel takes
+            // epilogue reads z / y / earlier contributions 8 bytes per lane (16 scattered 32-byte pieces per instruction) at
+            // the tail of every workgroup, which costs about what the separate, fully coalesced sweep cost.  Layers the direct kernel takes
             // are left alone (it has no such epilogue; falling back to the tile kernel cost 55 us each).
             const int pa = u.src0, pu = net->producer[pa];
             if (vs_option("fuse_bn_bwd") && pu >= 0 && pu == ui - 1 && net->first_consumer[pa] == ui && net->units[pu].kind == U_CONV &&
