@@ -131,6 +131,27 @@ def test_conv_direct_kernel_upsampled_input_and_head(code, force_direct_kernel):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 30, 40, 3), (1, 33, 17, 1), (3, 8, 50, 4), (2, 5, 16, 2)])
+def test_conv_head_kernel_ragged_shapes(code, shape, force_direct_kernel):
+    """conv_head_kernel (four output rows per MFMA tile): heights that are not multiples of the 4-row groups or the strip
+    height, widths that are not multiples of 16, 1 - 4 classes, bias; fp32 NCHW logits against torch."""
+    L = lib()
+    n, h, w, k = shape
+    g = torch.Generator().manual_seed(100 + h)
+    x = rounded(torch.randn(n, 16, h, w, generator=g), code)
+    wh = rounded(torch.randn(k, 16, 3, 3, generator=g) / 12, code)
+    b = torch.randn(k, generator=g)
+    ref = F.conv2d(x, wh, b, padding=1)
+    d = conv_desc(L, code, n, h, w, 16, k, 3, 1, 1, out_f32=3)
+    y = torch.full((n, k, h, w), float("nan"), device=DEV)
+    xd, wd, bd = to_nhwc(x, code), w_krsc(wh, code), b.to(DEV)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wd), None, L.ptr(bd), None, L.ptr(y), None, None))
+    sync()
+    assert torch.isfinite(y).all()
+    assert torch.allclose(y.cpu(), ref, rtol=1e-4, atol=1e-4 if code == 0 else 2e-2), (y.cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_conv_upsample_concat_never_materialised(code):
     """Decoder block input: cat(F.interpolate(x, 2, 'nearest'), skip) folded into the patch loader."""
     L = lib()
