@@ -37,7 +37,8 @@ int vs_version(void);
 typedef struct vs_conv_desc {
     int32_t dtype;             /* VS_F32 | VS_BF16 */
     int32_t n, hin, win;       /* virtual input dims (after upsampling src0) */
-    int32_t c0, c1, up0;       /* channels of src0 / src1 (0 = absent), log2 upsample of src0 */
+    int32_t c0, c1, up0;       /* channels of src0 / src1 (0 = absent); src0: 0 = as is, 1 = nearest x2 upsampling,
+                                  2 = zero stuffing x2 (values at the even rows / columns; c1 must be 0) */
     int32_t cout, kh, kw, stride, pad;
     int32_t relu;              /* apply ReLU in the epilogue */
     int32_t out_f32;           /* store fp32 output regardless of dtype */

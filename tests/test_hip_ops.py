@@ -152,6 +152,26 @@ def test_conv_head_kernel_ragged_shapes(code, shape, force_direct_kernel):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_zero_stuffed_source_in_the_loader(code, k):
+    """up0 = 2: the source is read at the even positions and as zeros elsewhere (the data gradient of a stride-2 conv is a
+    stride-1 conv over the zero-stuffed output gradient, which is never materialised)."""
+    L = lib()
+    g = torch.Generator().manual_seed(40 + k)
+    n, h, w, c0, cout = 2, 24, 32, 64, 64
+    x0 = rounded(torch.randn(n, c0, h // 2, w // 2, generator=g), code)
+    wt = rounded(torch.randn(cout, c0, k, k, generator=g) / 12, code)
+    stuffed = torch.zeros(n, c0, h, w)
+    stuffed[:, :, ::2, ::2] = x0
+    ref = F.conv2d(stuffed, wt, padding=k // 2)
+    d = conv_desc(L, code, n, h, w, c0, cout, k, 1, k // 2, up0=2)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x0, code)), None, L.ptr(w_krsc(wt, code)), None, None, None, L.ptr(y), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_conv_upsample_concat_never_materialised(code):
     """Decoder block input: cat(F.interpolate(x, 2, 'nearest'), skip) folded into the patch loader."""
     L = lib()

@@ -110,7 +110,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int h0 = ty * TH, w0 = tx * TW;
     const int n0 = ytile * BN;
     const int hbase = h0 * STRIDE - p.pad, wbase = w0 * STRIDE - p.pad;
-    const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    // up0: 0 = plain source, 1 = nearest x2 upsampling of a half-resolution source, 2 = the same addressing with zeros at
+    // the odd rows / columns (zero stuffing: data gradient of a stride-2 convolution, never materialised)
+    const int ush = p.up0 ? 1 : 0;
+    const bool stuffed = p.up0 == 2;
+    const int H0 = p.Hin >> ush, W0 = p.Win >> ush;
     // Staging loads are raw buffer loads: one descriptor per source (base = this image, so per-lane offsets are 32-bit
     // byte offsets), the chunk's channel offset rides in the scalar offset, and offset -1 (out of range) returns zeros -
     // zero padding, ragged tiles and channel tails cost no branches.
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         const int ph = kStatic ? pp / PW : (int)__umulhi((unsigned)pp, g.pw_magic), pw = pp - ph * PW;
         const int hi = hbase + ph, wi = wbase + pw;
         const bool ok = pp < P && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-        poff0[i] = ok ? (((hi >> p.up0) * W0 + (wi >> p.up0)) * p.C0 + seg * EPS) * (int)sizeof(T) : -1;
+        poff0[i] = (ok && !(stuffed && ((hi | wi) & 1))) ? (((hi >> ush) * W0 + (wi >> ush)) * p.C0 + seg * EPS) * (int)sizeof(T) : -1;
         poff1[i] = ok ? ((hi * p.Win + wi) * p.C1 + seg * EPS) * (int)sizeof(T) : -1;
         pdst[i] = pp < P ? swz(pp, pw, seg) : dummy;
     }
@@ -579,7 +583,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && !p.bz && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.bz && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -703,7 +707,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     const int Cin = p.C0 + p.C1;
     VS_REQUIRE(Cin % EPS == 0 && p.C0 % EPS == 0, "conv_igemm: channel counts must be multiples of %d", EPS);
     VS_REQUIRE(p.C1 == 0 || p.C0 % CK == 0, "conv_igemm: concat boundary must be a multiple of %d", CK);
-    VS_REQUIRE(p.up0 == 0 || p.up0 == 1, "conv_igemm: up0 must be 0 or 1");
+    VS_REQUIRE(p.up0 >= 0 && p.up0 <= 2, "conv_igemm: up0 must be 0, 1 or 2");
+    VS_REQUIRE(p.up0 != 2 || (p.C1 == 0 && !(p.Hin & 1) && !(p.Win & 1)), "conv_igemm: a zero-stuffed source has no concat partner and even dims");
     VS_REQUIRE(((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1)) && (p.stride == 1 || p.stride == 2),
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - p.KH) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - p.KW) / p.stride + 1,

@@ -160,7 +160,7 @@ int launch_dma(const ConvParams& p, int out_nchw, hipStream_t s) {
 // geometry the ring kernel covers: 3x3, stride 1, pad 1, >= 8x16 outputs, cout tile 64 or 32, >= 2 stages of channels
 bool conv_igemm_dma_ok(int dtype, const ConvParams& p, int BN) {
     const int CK = dtype == VS_BF16 ? 32 : 16;
-    return vs_option("conv_dma") && !p.bz && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Wout >= 16 &&
+    return vs_option("conv_dma") && !p.bz && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Wout >= 16 &&
            p.Hout * p.Wout >= 128 && (BN == 64 || BN == 32) && (p.C0 + p.C1) >= 2 * CK;
 }
 

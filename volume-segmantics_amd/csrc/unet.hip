@@ -791,13 +791,15 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
         ConvParams p{};
         const void* dsrc = dzp;
-        if (u.stride == 2) {
+        const bool stuff_in_loader = u.stride == 2 && vs_option("dgrad_stuff_in_loader") && !(u.hin & 1) && !(u.win & 1);
+        if (u.stride == 2 && !stuff_in_loader) {
             void* zs = c.ws + net->off_zs;
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * dz_c * net->esz * 1.25, c.s);
             if ((rc = vs_zero_stuff2x(dt, dzp, zs, n, u.hout, u.wout, dz_c, stream))) return rc;
             dsrc = zs;
         }
         p.src0 = dsrc; p.C0 = dz_c; p.N = n; p.Hin = u.hin; p.Win = u.win; p.Hout = u.hin; p.Wout = u.win;
+        if (stuff_in_loader) p.up0 = 2;   // the patch loader reads dz at the even positions and zeros elsewhere
         p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
         p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0 + u.cin1;
         if (u.up0) {
