@@ -166,7 +166,8 @@ def test_conv_zero_stuffed_source_in_the_loader(code, k):
     ref = F.conv2d(stuffed, wt, padding=k // 2)
     d = conv_desc(L, code, n, h, w, c0, cout, k, 1, k // 2, up0=2)
     y = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(to_nhwc(x0, code)), None, L.ptr(w_krsc(wt, code)), None, None, None, L.ptr(y), None, None))
+    xd, wd = to_nhwc(x0, code), w_krsc(wt, code)      # kept alive until the launch has run
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wd), None, None, None, L.ptr(y), None, None))
     sync()
     assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
 
