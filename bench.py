@@ -235,7 +235,8 @@ def main():
         model.dp_group = dist.group.WORLD
     x, lab = synth_batch(args.batch, 256, 2, seed=1234 + rank)   # every rank: its own shard of the global batch
     x = x.to(dev)
-    target = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8).float()
+    # one-hot targets as prepare_training_batch hands them over (utilities/base_data_utils.py:150-158): NCHW uint8, contiguous
+    target = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8).contiguous()
     opt = model.fused_adamw(lr=1e-4, fuse_step_into_backward=True)   # single GPU: the step hides under the backward pass
     total = args.warmup + args.steps + 8
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total + 1, pct_start=0.3)
