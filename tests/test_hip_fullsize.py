@@ -138,3 +138,41 @@ def test_config3_twelve_way_shards_merge_to_the_unsharded_volume(monkeypatch):
     torch.cuda.synchronize()
     assert np.array_equal(labels.ravel(), lab2.cpu().numpy())
     assert np.array_equal(probs.view(np.uint16).ravel(), prb2.cpu().numpy().view(np.uint16))
+
+
+def test_odd_shaped_volume_twelve_way_equals_reference_formulation():
+    """A non-cubic volume whose sides are not multiples of 32 (pad / crop offsets differ per direction, rot90 views have
+    swapped dims, the staged key scatter sees ragged pixel tiles and batches): the one-pass packed-key 12-way prediction
+    against the reference's own sequence (vol_seg_2d_predictor.py:67-116: 3-way per rotation, rot90 back, pairwise merges),
+    built from single-axis passes and vs_merge_maxprob.  Bit-equal labels and probabilities."""
+    from volume_segmantics_amd.utilities.base_data_utils import Axis
+    pred = _predictor(4, 16)
+    vol = np.ascontiguousarray(bench.synth_volume(96, seed=31)[:70, :45, :83])
+    with torch.no_grad():   # centre the head bias on this volume's own slices so that several classes occur
+        x = torch.zeros(8, 1, 64, 96)
+        x[:, 0, :45, :83] = (torch.from_numpy(vol[::9][:8].astype(np.float32)) / 255 - 0.449) / 0.226
+        mean_logit = pred.model(x.to(DEV)).mean(dim=(0, 2, 3))
+        dict(pred.model.named_parameters())["segmentation_head.0.bias"].sub_(mean_logit)
+    labels, probs = pred._predict_12_ways_max_probs(vol)
+    assert labels.shape == vol.shape and len(np.unique(labels)) >= 2 and len(np.unique(probs)) > 100
+
+    def three_way(v):
+        lab = np.empty((2,) + v.shape, np.uint8)
+        prb = np.empty((2,) + v.shape, np.float16)
+        lab[0], prb[0] = pred._predict_single_axis(v, axis=Axis.Z)
+        for ax in (Axis.Y, Axis.X):
+            lab[1], prb[1] = pred._predict_single_axis(v, axis=ax)
+            pred._merge_vols_in_mem(prb, lab)
+        return lab[0], prb[0]
+
+    lab = np.empty((2,) + vol.shape, np.uint8)
+    prb = np.empty((2,) + vol.shape, np.float16)
+    lab[0], prb[0] = three_way(vol)
+    v = vol
+    for k in range(1, 4):
+        v = np.rot90(v)
+        l, p = three_way(np.ascontiguousarray(v))
+        lab[1], prb[1] = np.rot90(l, -k), np.rot90(p, -k)
+        pred._merge_vols_in_mem(prb, lab)
+    assert np.array_equal(labels, lab[0])
+    assert np.array_equal(probs.view(np.uint16), prb[0].view(np.uint16))
