@@ -45,14 +45,18 @@ def synth_batch(batch: int, size: int, classes: int, seed: int):
 
 
 def load_traffic(kernel_name: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.json, collected with
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs and the gfx950 FETCH_SIZE x2 correction), or None."""
-    try:
-        with open(REPO / "profiles" / "r1_pmc_traffic.json") as f:
-            t = json.load(f)
-        return t.get(kernel_name)
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/r*_pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command with the gfx950 FETCH_SIZE x2
+    correction), or None.  Counters cannot be read from inside the timed process, so the figure is a committed measurement:
+    the entry carries its source file so that it cannot pass for a live one."""
+    for f in sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            t = json.loads(f.read_text()).get(kernel_name)
+        except Exception:
+            t = None
+        if t:
+            return dict(t, source=f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run)")
+    return None
 
 
 def dice_loss(output, target, eps=1e-6):
@@ -200,6 +204,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: replay the recorded step (hipGraphs); eager: enqueue every step call by call; auto: time both "
+                         "during the untimed set-up and keep the faster one on this box")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
     ap.add_argument("--per-unit", default="", help="write a per-layer kernel-time table (instrumented steps) to this file")
@@ -238,14 +245,15 @@ def main():
     # one-hot targets as prepare_training_batch hands them over (utilities/base_data_utils.py:150-158): NCHW uint8, contiguous
     target = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8).contiguous()
     opt = model.fused_adamw(lr=1e-4, fuse_step_into_backward=True)   # single GPU: the step hides under the backward pass
-    total = args.warmup + args.steps + 8
+    setup_steps = 3   # untimed, before the warm-up: lazy initialisation + recording the step's two hipGraphs (one per weight set)
+    total = setup_steps + args.warmup + args.steps + 64
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total + 1, pct_start=0.3)
     model.train()
 
     from volume_segmantics_amd.data.losses import HipDiceLoss
     criterion = HipDiceLoss()
 
-    def step():
+    def step_eager():   # the reference's _train_one_batch, call by call (vol_seg_2d_trainer.py:419-432)
         opt.zero_grad()
         out = model(x)
         loss = criterion(out, target)
@@ -254,7 +262,36 @@ def main():
         sched.step()
         return loss
 
-    log(f"model ready on {dev}, warming up")
+    use_graph = args.step_mode != "eager"
+
+    def step():
+        # the same step as replayed hipGraphs (VolSegUnet.fused_train_step) where it applies (single process)
+        if use_graph and model.can_fuse_step(opt, x, target):
+            loss = model.fused_train_step(x, target, opt, eps=criterion.epsilon, clone_loss=False)
+            sched.step()
+            return loss
+        return step_eager()
+
+    log(f"model ready on {dev}, setting up")
+    for _ in range(setup_steps):
+        step()
+    torch.cuda.synchronize()
+    graph_mode = bool(use_graph and model._steps and all(g is not None for st in model._steps.values() for g in st["graphs"].values()))
+    autotune = {}
+    if graph_mode and args.step_mode == "auto":
+        # replayed graphs cost the host ~0.4 ms per step against ~2 ms call by call, but order the two streams range by range
+        # instead of unit by unit (~2 % more GPU time): on a box whose host keeps up, call by call is the faster of the two
+        def timed(fn, k=6):
+            fn(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / k * 1e3
+        autotune = {"graph_ms": round(timed(step), 4), "eager_ms": round(timed(step_eager), 4)}
+        use_graph = graph_mode = autotune["graph_ms"] <= autotune["eager_ms"]
+        autotune["picked"] = "graph" if use_graph else "eager"
+    log(f"setup done (replaying recorded step graphs: {graph_mode} {autotune}); warming up")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -265,6 +302,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0          # the host is done enqueueing; the GPU may still be running
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -275,17 +313,32 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     final_loss = float(loss.detach())
-    log(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step")
+    log(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step (host enqueue {t_enq / args.steps * 1e3:.3f} ms/step)")
+    # the same steps call by call (no graph): what the host costs when it enqueues ~430 launches per step itself
+    eager = {}
+    if world == 1:
+        n_e = 10
+        for _ in range(2):
+            step_eager()
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        for _ in range(n_e):
+            step_eager()
+        te_enq = time.perf_counter() - te0
+        torch.cuda.synchronize()
+        eager = {"ms_per_step": round((time.perf_counter() - te0) / n_e * 1e3, 4), "host_enqueue_ms": round(te_enq / n_e * 1e3, 4),
+                 "steps": n_e}
+        log(f"call-by-call: {eager['ms_per_step']} ms/step, host enqueue {eager['host_enqueue_ms']} ms/step")
 
     # ---- roofline block: per-kernel-class HIP-event timing of the same step (separate, instrumented steps) ----
     prof_steps = 3
     side = _lib.lib.vs_get_option(b"side_stream")
     _lib.set_option("side_stream", 0)   # one kernel at a time: clean per-kernel durations (the timed region above overlaps)
-    step()
+    step_eager()
     torch.cuda.synchronize()
     _lib.check(_lib.lib.vs_profile_enable(1))
     for _ in range(prof_steps):
-        step()
+        step_eager()
     torch.cuda.synchronize()
     prof = _lib.profile_read()
     raw = _lib.profile_read_raw()
@@ -308,7 +361,7 @@ def main():
     predict = {}
     if not args.no_predict:
         del opt, sched
-        model._plans.clear()
+        model.release_plans()     # vs_graph_destroy / vs_unet_destroy for the training plans
         torch.cuda.empty_cache()
         log("predict: 256^3 single axis")
         predict["predict_256cube_low_2class"] = predict_bench(dev, world, args.precision, 256, 2, 1, 32)
@@ -352,6 +405,21 @@ def main():
                        "global_batch": args.batch * world, "slice": "256x256", "parallelism": f"dp{world}",
                        "master_weights": "fp32", "final_loss": round(final_loss, 5)},
             "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
+            # where a step's wall time goes: a host- or gap-bound run shows ms_per_step well above the kernel sums
+            "step_timing": {
+                "mode": "hipGraph replay (forward + DiceLoss + backward + AdamW recorded once per weight set as linear graphs "
+                        "per unit range and stream)" if graph_mode else "call by call",
+                "autotune_at_setup": autotune,
+                "setup_steps_untimed": setup_steps,
+                "host_enqueue_ms": round(t_enq / args.steps * 1e3, 4),
+                "main_stream_kernel_sum_ms": round(sum(v["ms"] for k, v in prof.items() if k != "conv_wgrad") / prof_steps, 4),
+                "side_stream_kernel_sum_ms": round(prof["conv_wgrad"]["ms"] / prof_steps, 4),
+                "gpu_kernel_sum_ms": round(sum(v["ms"] for v in prof.values()) / prof_steps, 4),
+                "call_by_call": eager,
+                "note": "kernel sums: HIP-event durations of 3 serialised instrumented steps (side stream off; AdamW and the "
+                        "weight-copy kernels, ~0.2 ms on the side stream, are not in the event classes); in the timed region the "
+                        "weight gradients overlap the caller's stream.  The timed loop does not read the loss back (the "
+                        "reference's loop does, loss.item() at vol_seg_2d_trainer.py:220 - one sync per step)."},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": (load_traffic(dom_name) or {}).get("bytes_per_launch"), "traffic_detail": load_traffic(dom_name),
                          "launches_per_step": dom_calls // prof_steps,

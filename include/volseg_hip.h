@@ -59,6 +59,11 @@ size_t vs_conv2d_wgrad_workspace(const vs_conv_desc* d);
 int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const void* src1, const void* dy,
                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
+/* fp32 master weights [cout][taps][cin] -> copy in `dtype` (wc, same layout; may be NULL) and the flipped / transposed copy
+ * [cin][taps reversed][cout] the data gradient reads through vs_conv2d_fwd (wt; may be NULL).  The reference's autograd
+ * derives both from the one weight tensor (loss.backward(), vol_seg_2d_trainer.py:429). */
+int vs_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, void* stream);
+
 /* Stem: 7x7 stride-2 pad-3 conv with one input channel (encoder.conv1 after smp's
  * patch_first_conv).  x: [n][h][w] fp32 (the caller's (B,1,H,W) tensor); w: [64][49] fp32;
  * y: [n][h/2][w/2][64] in dtype; dy likewise. */
@@ -151,6 +156,7 @@ int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* weight_name, int na
  * vs_profile_enable(1) clears and starts collecting; vs_profile_read sums, per kind, the elapsed ms, the
  * algorithmic flops / bytes and the number of launches recorded since then (arrays of vs_profile_num_kinds()). */
 int vs_profile_enable(int on);
+int vs_profile_enabled(void);
 int vs_profile_num_kinds(void);
 const char* vs_profile_kind_name(int kind);
 int vs_profile_read(double* ms, double* flops, double* bytes, int64_t* calls);
@@ -183,6 +189,10 @@ typedef struct vs_adamw_args {
     float* exp_avg_sq;
     float lr, beta1, beta2, eps, weight_decay;
     int32_t step;                  /* 1-based number of this update (bias correction) */
+    const float* hyper;            /* optional, DEVICE: 8 floats written by vs_train_hyper_set; when set the kernels read lr, beta1,
+                                      beta2, eps, weight_decay and the bias corrections from there instead of the fields above, so a
+                                      captured step (vs_capture_begin) can be replayed under a scheduler (OneCycleLR moves lr and
+                                      beta1 every step, vol_seg_2d_trainer.py:401-408) */
 } vs_adamw_args;
 int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
                            float* grads, void* workspace, void* stream, const vs_adamw_args* opt);
@@ -193,6 +203,37 @@ int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits,
  * next forward reads (call it once, after every range of the network has been refreshed). */
 int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* workspace, void* stream, int unit_lo, int unit_hi);
 int vs_unet_flip_weight_set(vs_unet_t* net);
+int vs_unet_weight_set(const vs_unet_t* net);   /* 0 / 1: the weight set the next forward reads */
+
+/* ------------------------------------------------------------------------------------------
+ * Captured steps: the host loop of _train_one_batch (vol_seg_2d_trainer.py:419-432) as a replayed hipGraph
+ * ---------------------------------------------------------------------------------------- */
+/* vs_capture_begin returns the library's capture stream (NULL on error): every library call made with it as `stream`
+ * until vs_capture_end is RECORDED, not executed - including the backward pass's side-stream branches.  vs_graph_launch
+ * replays the recorded sequence, ordered on `stream`.  The recorded calls keep their pointer arguments: the buffers must
+ * stay in place and hold the new inputs before each replay.  A training step recorded with vs_unet_backward_adamw flips
+ * the plan's weight set: record one graph per vs_unet_weight_set value, and call vs_unet_flip_weight_set after each replay
+ * (a replay runs no host code of the library). */
+typedef struct vs_graph vs_graph_t;
+void* vs_capture_begin(void);
+int vs_capture_end(vs_graph_t** out);
+int vs_capture_abort(void);
+int vs_graph_launch(vs_graph_t* g, void* stream);
+int64_t vs_graph_num_nodes(const vs_graph_t* g);
+void vs_graph_destroy(vs_graph_t* g);
+/* One stream's share of vs_unet_backward_adamw for the units [unit_lo, unit_hi) (top of the network first, as
+ * vs_unet_backward_range), enqueued in order on `stream`: role 1 = the caller's-stream kernels (BatchNorm backward, data
+ * gradients), role 2 = weight gradients, AdamW and the next forward's weight copies.  Recorded separately, each share is a
+ * LINEAR graph, which the runtime replays as one batch of queue packets (0.13 ms of host time per step; a graph with
+ * parallel branches is walked node by node, 1-2.5 ms).  There are no events inside: the caller runs role 2 of a range behind
+ * role 1 of the same range (an event between two streams), range by range.  Neither role flips the weight set. */
+int vs_unet_backward_adamw_part(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
+                                float* grads, void* workspace, void* stream, const vs_adamw_args* opt, int unit_lo,
+                                int unit_hi, int role);
+/* the per-step scalars of a replayed optimiser step (see vs_adamw_args.hyper): one tiny launch on `stream` that also adds 1
+ * to the n_bn BatchNorm num_batches_tracked counters (int64, may be NULL with n_bn = 0). */
+int vs_train_hyper_set(float* hyper, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       int64_t* num_batches_tracked, int n_bn, void* stream);
 
 /* DiceLoss(normalization="none") on raw logits and its gradient (data/pytorch3dunet_losses.py:15-41,89-135; the
  * trainer's default criterion, vol_seg_2d_trainer.py:133-135,425-428).  logits (n, K, h*w) fp32 NCHW, targets one-hot

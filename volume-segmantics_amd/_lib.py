@@ -40,7 +40,8 @@ class DirMap(C.Structure):
 
 class AdamwArgs(C.Structure):
     _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32),
+                ("hyper", C.c_void_p)]
 
 
 P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -76,13 +77,23 @@ _SIGS = {
     "vs_unet_backward": (I, [P, P, P, P, I, I, P, P, P]),
     "vs_unet_backward_range": (I, [P, P, P, P, I, I, P, P, P, I, I]),
     "vs_unet_backward_adamw": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs)]),
+    "vs_unet_backward_adamw_part": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs), I, I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),
+    "vs_unet_weight_set": (I, [P]),
+    "vs_capture_begin": (P, []),
+    "vs_capture_end": (I, [C.POINTER(P)]),
+    "vs_capture_abort": (I, []),
+    "vs_graph_launch": (I, [P, P]),
+    "vs_graph_num_nodes": (I64, [P]),
+    "vs_graph_destroy": (None, [P]),
+    "vs_train_hyper_set": (I, [P, F, F, F, F, F, I, P, I, P]),
     "vs_unet_unit_param_offset": (I64, [P, I]),
     "vs_unet_num_units": (I, [P]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),
                                C.POINTER(SZ), C.POINTER(SZ)]),
     "vs_profile_enable": (I, [I]),
+    "vs_profile_enabled": (I, []),
     "vs_profile_num_kinds": (I, []),
     "vs_profile_kind_name": (C.c_char_p, [I]),
     "vs_profile_read": (I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(I64)]),

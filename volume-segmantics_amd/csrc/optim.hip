@@ -11,7 +11,8 @@ namespace {
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ mask, int64_t n, float lr, float b1,
-                             float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
         const float gi = g[i];
@@ -28,7 +29,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 __global__ void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                     float* __restrict__ v, AdamwRanges r, float lr, float b1, float b2, float eps, float wd,
-                                    float bc1, float bc2_sqrt) {
+                                    float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+    // hyper (optional): the step's scalars in device memory, written by vs_train_hyper_set - a captured graph replays this
+    // launch with a new learning rate / beta1 / bias correction every step
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; }
     const long off = r.off[blockIdx.y];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.len[blockIdx.y]; i += (long)gridDim.x * blockDim.x) {
         const long k = off + i;
@@ -175,7 +179,7 @@ extern "C" int vs_adamw_step(float* params, const float* grads, float* exp_avg, 
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                       exp_avg_sq, mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (const float*)nullptr);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -186,7 +190,7 @@ int launch_adamw_slice(const vs_adamw_args& a, const float* grads, int64_t off, 
     const float bc1 = 1.f - powf(a.beta1, (float)a.step);
     const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, a.params + off, grads + off, a.exp_avg + off,
-                       a.exp_avg_sq + off, (const uint8_t*)nullptr, n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s);
+                       a.exp_avg_sq + off, (const uint8_t*)nullptr, n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -199,7 +203,27 @@ int launch_adamw_ranges(const vs_adamw_args& a, const float* grads, const AdamwR
     const float bc1 = 1.f - powf(a.beta1, (float)a.step);
     const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
     hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)std::min<long>(1024, (longest + 1023) / 1024), (unsigned)r.n), dim3(256), 0, s, a.params, grads, a.exp_avg, a.exp_avg_sq, r, a.lr, a.beta1,
-                       a.beta2, a.eps, a.weight_decay, bc1, bc2s);
+                       a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// ---- per-step scalars of a captured training step ----------------------------------------------------------------------
+__global__ void train_hyper_kernel(float* hyper, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                   float step, int64_t* nbt, int n_nbt) {
+    if (threadIdx.x == 0) {
+        hyper[0] = lr; hyper[1] = b1; hyper[2] = b2; hyper[3] = eps; hyper[4] = wd; hyper[5] = bc1; hyper[6] = bc2s; hyper[7] = step;
+    }
+    for (int i = threadIdx.x; i < n_nbt; i += blockDim.x) nbt[i] += 1;   // BatchNorm num_batches_tracked
+}
+
+extern "C" int vs_train_hyper_set(float* hyper, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                  int64_t* num_batches_tracked, int n_bn, void* stream) {
+    VS_REQUIRE(hyper && step >= 1 && (n_bn == 0 || num_batches_tracked), "train_hyper_set: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step);          // the same host arithmetic as the scalar-argument path:
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));  // a replayed step updates the parameters bit-identically
+    hipLaunchKernelGGL(train_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, lr, beta1, beta2, eps, weight_decay,
+                       bc1, bc2s, (float)step, num_batches_tracked, n_bn);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

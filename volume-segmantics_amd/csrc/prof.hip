@@ -56,6 +56,7 @@ extern "C" int vs_profile_enable(int on) {
     if (g_on) { g_recs.clear(); g_pool_used = 0; }
     return VS_OK;
 }
+extern "C" int vs_profile_enabled(void) { return g_on ? 1 : 0; }
 extern "C" int vs_profile_num_kinds(void) { return PK_COUNT; }
 extern "C" const char* vs_profile_kind_name(int kind) { return kind >= 0 && kind < PK_COUNT ? kNames[kind] : "?"; }
 // sums over all records since vs_profile_enable(1): per kind elapsed ms, algorithmic flops, algorithmic bytes, launches

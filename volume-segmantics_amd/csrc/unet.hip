@@ -420,6 +420,7 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
     if (!nl) return VS_OK;
     return launch_weight_prepare_all(net->dtype, params, workspace, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, (hipStream_t)stream);
 }
+extern "C" int vs_unet_weight_set(const vs_unet_t* net) { return net ? net->wset : VS_ERR_INVALID; }
 extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
     VS_REQUIRE(net, "unet_flip_weight_set: null pointer");
     net->wset ^= 1;
@@ -559,9 +560,17 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
 }
 
 // ---- backward --------------------------------------------------------------------------------------
+// role: which stream's share of the work a call enqueues.  ROLE_BOTH is the normal two-stream form (fork / join events
+// inside).  ROLE_MAIN / ROLE_SIDE enqueue only the caller's-stream kernels / only the weight-gradient + optimiser kernels,
+// both on `stream`: a recorded step keeps each share as its own LINEAR hipGraph (the runtime replays a linear graph of
+// kernels as one batch of queue packets - 0.13 ms of host time per step - but walks a graph with parallel branches node by
+// node, slower than launching call by call).  The split roles use no events: the caller orders the two shares itself, range
+// by range (hipEventRecordWithFlags(hipEventRecordExternal), which would let ONE pair of graphs carry the fork events as
+// external event nodes, returns hipErrorInvalidValue under capture on ROCm 7.2).
+enum { ROLE_BOTH = 0, ROLE_MAIN = 1, ROLE_SIDE = 2 };
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
-                               const vs_adamw_args* opt);
+                               const vs_adamw_args* opt, int role = ROLE_BOTH);
 
 extern "C" int vs_unet_backward(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                 int need_encoder_wgrad, float* grads, void* workspace, void* stream) {
@@ -591,13 +600,14 @@ extern "C" int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit) {
 
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
-                               const vs_adamw_args* opt) {
+                               const vs_adamw_args* opt, int role) {
     VS_REQUIRE(net && params && x && dlogits && grads && workspace, "unet_backward: null pointer");
+    const bool do_main = role != ROLE_SIDE, do_side = role != ROLE_MAIN;
     VS_REQUIRE(n == net->last_n, "unet_backward: batch %d does not match the last training forward (%d)", n, net->last_n);
     Ctx c{net, (char*)workspace, params, nullptr, (hipStream_t)stream, n};
     const int dt = net->dtype;
     int rc;
-    if (unit_hi == (int)net->units.size()) net->written.assign(net->acts.size(), 0);  // a new backward pass starts at the top
+    if (do_main && unit_hi == (int)net->units.size()) net->written.assign(net->acts.size(), 0);  // a new backward pass starts at the top
     if (net->producer.empty()) {
         net->producer.assign(net->acts.size(), -1);
         net->first_consumer.assign(net->acts.size(), 1 << 30);
@@ -608,13 +618,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 if (a >= 0 && k < net->first_consumer[a]) net->first_consumer[a] = k;
         }
     }
-    if (unit_hi == (int)net->units.size()) net->bwd_stat_rows.assign(net->acts.size(), 0);
+    if (do_main && unit_hi == (int)net->units.size()) net->bwd_stat_rows.assign(net->acts.size(), 0);
     VS_REQUIRE(net->written.size() == net->acts.size(), "unet_backward_range: ranges must start at the last unit");
+    VS_REQUIRE(role == ROLE_BOTH || !vs_option("fuse_bn_bwd"), "unet_backward: split roles do not support fuse_bn_bwd");
     std::vector<char>& written = net->written;
     float* wgws = (float*)(c.ws + net->off_wgws);
-    const int n_side = vs_option("side_stream");  // 0 = everything in order on the caller's stream
+    const int n_side = role == ROLE_BOTH ? vs_option("side_stream") : 0;  // 0 = everything in order on the given stream
     const bool use_side = n_side > 0;
     hipStream_t ws_stream = c.s;  // stream of the current unit's weight-gradient work
+    bool side_used[vs_unet::kSide] = {false, false};   // side streams this call forked onto (only those are joined: under
+                                                       // stream capture a stream that never joined the capture must not be waited on)
     if (use_side) {
         for (int i = 0; i < vs_unet::kSide; ++i) {
             if (net->side[i]) continue;
@@ -636,6 +649,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (!use_side) return VS_OK;
         const int k = (n_side >= 2 && !opt) ? (ui & 1) : 0;   // the fused optimiser step relies on ONE side stream's order
         ws_stream = net->side[k];
+        side_used[k] = true;
         wgws = (float*)(c.ws + net->off_wgws + (size_t)k * net->wgws_bytes);
         VS_CHECK_HIP(hipStreamWaitEvent(ws_stream, net->fork_events[ui], 0));
         return VS_OK;
@@ -741,6 +755,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
         if (u.kind == U_POOL) {
+            if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * 64 * net->esz * 1.5, c.s);
             if ((rc = vs_maxpool_bwd(dt, c.da(u.out), (const uint8_t*)(c.ws + net->off_idx), c.da(u.src0), written[u.src0], n,
@@ -752,10 +767,14 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         int dz_c;
         if (u.kind == U_HEAD) {
             void* dyh = c.ws + net->off_dyh;
+            if (do_main) {
             ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
             if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, grads + c.t(u.bias_idx).offset,
                                                (float*)(c.ws + net->off_bnws), c.s))) return rc;   // + bias gradient, same sweep
+            }
             dzp = dyh; dz_c = 16;
+        } else if (!do_main) {
+            dzp = c.dz(u.out); dz_c = u.cout;
         } else {
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             void* dres = nullptr;
@@ -786,8 +805,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // weight-gradient work of up to `fork_every` consecutive units ----
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
-        if (flush && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
-        if (u.kind != U_STEM) {
+        if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
+        if (u.kind != U_STEM && do_main) {
         // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
         ConvParams p{};
         const void* dsrc = dzp;
@@ -856,27 +875,33 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         }
         }
         if (flush) {
-            if ((rc = fork_wait(ui))) return rc;
-            for (const SideItem& it : pending)
-                if ((rc = side_wgrad(it))) return rc;
+            if (do_side) {
+                if ((rc = fork_wait(ui))) return rc;
+                for (const SideItem& it : pending)
+                    if ((rc = side_wgrad(it))) return rc;
+            }
             pending.clear();
             prof_set_tag(ui);
         }
     }
     if (!pending.empty()) {   // a range that ends on a unit without weights (the max-pool)
         const int ui = pending.back().ui;
-        if ((rc = fork_mark(ui)) || (rc = fork_wait(ui))) return rc;
-        for (const SideItem& it : pending)
-            if ((rc = side_wgrad(it))) return rc;
+        if (do_main && (rc = fork_mark(ui))) return rc;
+        if (do_side) {
+            if ((rc = fork_wait(ui))) return rc;
+            for (const SideItem& it : pending)
+                if ((rc = side_wgrad(it))) return rc;
+        }
         pending.clear();
     }
     if (use_side) {  // join: the caller's stream continues only after every weight gradient is in place
         for (int i = 0; i < vs_unet::kSide; ++i) {
+            if (!side_used[i]) continue;
             VS_CHECK_HIP(hipEventRecord(net->join_event[i], net->side[i]));
             VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->join_event[i], 0));
         }
     }
-    if (opt) net->wset ^= 1;
+    if (opt && role == ROLE_BOTH) net->wset ^= 1;   // split roles: the caller flips once both shares are queued (vs_unet_flip_weight_set)
     return VS_OK;
 }
 
@@ -885,6 +910,18 @@ extern "C" int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const floa
     VS_REQUIRE(net && opt && opt->params && opt->exp_avg && opt->exp_avg_sq && opt->step >= 1, "unet_backward_adamw: bad optimiser arguments");
     return unet_backward_range(net, opt->params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, 0,
                                (int)net->units.size(), opt);
+}
+
+// One stream's share of vs_unet_backward_adamw for the units [unit_lo, unit_hi) (see ROLE_* above): role 1 = the caller's-stream
+// kernels (BatchNorm backward, data gradients), role 2 = weight gradients + AdamW + next-forward weight copies, each
+// enqueued in order on `stream`; the caller orders role 2 of a range behind role 1 of the same range.  No weight-set flip.
+extern "C" int vs_unet_backward_adamw_part(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
+                                           float* grads, void* workspace, void* stream, const vs_adamw_args* opt, int unit_lo,
+                                           int unit_hi, int role) {
+    VS_REQUIRE(net && opt && opt->params && opt->exp_avg && opt->exp_avg_sq && opt->step >= 1, "unet_backward_adamw_part: bad optimiser arguments");
+    VS_REQUIRE(unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_backward_adamw_part: bad unit range");
+    VS_REQUIRE(role == ROLE_MAIN || role == ROLE_SIDE, "unet_backward_adamw_part: role must be 1 (caller's stream) or 2 (weight gradients)");
+    return unet_backward_range(net, opt->params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi, opt, role);
 }
 
 // ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------

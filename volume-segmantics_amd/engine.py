@@ -103,6 +103,8 @@ class VolSegUnet(nn.Module):
         self._fused_optimizer = None   # FusedAdamW(fuse_step_into_backward=True) registers itself here
         self._dp_side = None           # side stream of the data-parallel fused optimiser step
         self._bnver = 0  # bumped when a training forward moves the running statistics
+        self._step_side = None         # second stream of a replayed step (weight gradients + optimiser)
+        self._steps: dict = {}         # captured training steps (fused_train_step): static buffers + one hipGraph per weight set
         if init == "smp":
             self.reset_parameters(seed)
 
@@ -173,6 +175,7 @@ class VolSegUnet(nn.Module):
             self._build_views()
             for n, p in self.named_parameters():
                 p.requires_grad = req[n]
+            self._drop_steps()
             self._plans.clear()
             self._prep_key = None
         return self
@@ -212,10 +215,24 @@ class VolSegUnet(nn.Module):
             self._plans[key] = plan
         return plan
 
+    def _drop_steps(self):
+        for st in self._steps.values():
+            for prog in st["graphs"].values():
+                for op, obj in (prog or []):
+                    if op in ("main", "side"):
+                        lib.vs_graph_destroy(obj)
+        self._steps.clear()
+
+    def release_plans(self):
+        """Free every plan (and the step graphs recorded against them); they are rebuilt on demand."""
+        self._drop_steps()
+        for plan in self._plans.values():
+            lib.vs_unet_destroy(plan["handle"])
+        self._plans.clear()
+
     def __del__(self):
         try:
-            for plan in self._plans.values():
-                lib.vs_unet_destroy(plan["handle"])
+            self.release_plans()
         except Exception:
             pass
 
@@ -300,6 +317,9 @@ class VolSegUnet(nn.Module):
                                        ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr()))
             if self.dp_group is not None:
                 self._allreduce_grads()
+        self._attach_grads()
+
+    def _attach_grads(self, accumulate: bool = True):
         for p, shape, kind, off, _ in self._param_cache:
             if not p.requires_grad:
                 continue
@@ -307,8 +327,166 @@ class VolSegUnet(nn.Module):
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
-                p.grad.add_(g)
+                if accumulate:
+                    p.grad.add_(g)
+                else:
+                    p.grad = g
             # else: .grad already aliases the flat buffer, which now holds this step's gradient
+
+    # ------------------------------------------------------------------ captured training step
+    def _ensure_param_cache(self):
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        if self._param_cache is None:
+            named = dict(self.named_parameters())
+            self._param_cache = [(named[t[0]], t[1], t[2], t[3], "encoder" in t[0] and "conv" in t[0])
+                                 for t in self._table if t[2] <= KIND_BIAS]
+        return any(p.requires_grad for p, _, _, _, enc in self._param_cache if enc)
+
+    def can_fuse_step(self, opt, x, targets) -> bool:
+        """Whether fused_train_step applies: single process, the model's own fused AdamW, Dice targets of the logits' shape,
+        "everything trains" or "everything but the encoder convolutions" (the reference's two phases)."""
+        if os.environ.get("VOLSEG_STEP_GRAPH", "1") == "0" or not self.training or self.device.type != "cuda":
+            return False
+        if not isinstance(opt, FusedAdamW) or opt.model is not self or self._fused_optimizer is not opt:
+            return False
+        if self.dp_group is not None and self._world() > 1:
+            return False
+        if x.dim() != 4 or targets.dim() != 4 or targets.shape != (x.shape[0], self.classes, x.shape[2], x.shape[3]):
+            return False
+        if targets.dtype not in (torch.uint8, torch.float32) or lib.vs_profile_enabled():
+            return False
+        need_enc = self._ensure_param_cache()
+        return all(p.requires_grad == (need_enc or not enc) for p, _, _, _, enc in self._param_cache)
+
+    def fused_train_step(self, x, targets, opt: "FusedAdamW", eps: float = 1e-6, clone_loss: bool = True):
+        """The reference's whole ``_train_one_batch`` (vol_seg_2d_trainer.py:419-432) - zero_grad, forward,
+        DiceLoss(normalization="none"), backward, AdamW step (the scheduler's current lr / beta1) - as ONE replayed hipGraph:
+        the ~430 launches of a step are recorded once per weight set (vs_capture_begin .. vs_capture_end) with the optimiser's
+        scalars in device memory, and every later step costs the host two calls.  Same kernels in the same order as
+        ``model(x)`` -> ``HipDiceLoss`` -> ``loss.backward()`` -> ``opt.step()``: bit-identical parameters, optimiser state
+        and running statistics (tests/test_hip_step_graph.py).  Call ``can_fuse_step`` first.  Returns the loss (0-dim device
+        tensor; with ``clone_loss=False`` the step's own buffer, overwritten by the next step)."""
+        x = self._check_input(x)
+        n, _, h, w = x.shape
+        k, hw = self.classes, h * w
+        need_enc = self._ensure_param_cache()
+        if opt._stepped_in_backward:
+            raise RuntimeError("fused_train_step: a backward() whose optimiser step is still pending precedes this call")
+        plan = self._plan(n, h, w, True)
+        self._prepare(plan, True)
+        is_f32 = targets.dtype == torch.float32
+        key = (n, h, w, need_enc, is_f32)
+        st = self._steps.get(key)
+        if st is not None and st["plan"] is not plan:      # the plan was rebuilt (larger batch): recorded pointers are stale
+            self._drop_steps()
+            st = None
+        if st is None:
+            dev = self.device
+            st = {"plan": plan, "x": torch.empty_like(x), "t": torch.empty_like(targets, memory_format=torch.contiguous_format),
+                  "logits": torch.empty((n, k, h, w), dtype=torch.float32, device=dev),
+                  "dlogits": torch.empty((n, k, h, w), dtype=torch.float32, device=dev),
+                  "loss": torch.zeros((), dtype=torch.float32, device=dev),
+                  "dice_ws": torch.empty(lib.vs_dice_workspace(k) // 4, dtype=torch.float32, device=dev),
+                  "hyper": torch.zeros(8, dtype=torch.float32, device=dev), "graphs": {0: None, 1: None}, "eager_done": False}
+            self._steps[key] = st
+        if x.data_ptr() != st["x"].data_ptr():
+            st["x"].copy_(x)
+        if targets.data_ptr() != st["t"].data_ptr():
+            st["t"].copy_(targets)
+        g = opt.param_groups[0]
+        stream = _lib.stream_ptr()
+        check(lib.vs_train_hyper_set(ptr(st["hyper"]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                     float(g["weight_decay"]), opt.step_count + 1, ptr(self._nbt), self._nbt.numel(), stream))
+
+        hd = plan["handle"]
+        args = _lib.AdamwArgs(ptr(self._flat), ptr(opt.exp_avg), ptr(opt.exp_avg_sq), 0.0, 0.0, 0.0, 0.0, 0.0, 1, ptr(st["hyper"]))
+
+        def enqueue_head(s):          # forward + loss + dloss/dlogits
+            check(lib.vs_unet_forward(hd, ptr(self._flat), ptr(self._bnstate), ptr(st["x"]), n, 1, ptr(st["logits"]),
+                                      ptr(plan["ws"]), s))
+            check(lib.vs_dice_loss_fwd(ptr(st["logits"]), ptr(st["t"]), int(is_f32), n, k, hw, eps, ptr(st["loss"]),
+                                       ptr(st["dice_ws"]), st["dice_ws"].numel() * 4, s))
+            check(lib.vs_dice_loss_bwd(ptr(st["logits"]), ptr(st["t"]), int(is_f32), None, n, k, hw, eps, ptr(st["dice_ws"]),
+                                       ptr(st["dlogits"]), s))
+
+        def enqueue_backward(s):      # both streams' work with fork / join events inside (flips the weight set)
+            check(lib.vs_unet_backward_adamw(hd, ptr(st["x"]), ptr(st["dlogits"]), n, 1 if need_enc else 0, ptr(self._flat_grad),
+                                             ptr(plan["ws"]), s, _lib.C.byref(args)))
+
+        def enqueue_part(s, lo, hi, role):
+            check(lib.vs_unet_backward_adamw_part(hd, ptr(st["x"]), ptr(st["dlogits"]), n, 1 if need_enc else 0,
+                                                  ptr(self._flat_grad), ptr(plan["ws"]), s, _lib.C.byref(args), lo, hi, role))
+
+        def record(fn):
+            cs = lib.vs_capture_begin()
+            if not cs:
+                raise RuntimeError(f"libvolseg_hip: {_lib.last_error()}")
+            try:
+                fn(cs)              # recorded, not executed
+            except Exception:
+                lib.vs_capture_abort()
+                raise
+            gh = _lib.C.c_void_p()
+            check(lib.vs_capture_end(_lib.C.byref(gh)))
+            return gh
+
+        mode = os.environ.get("VOLSEG_STEP_GRAPH", "seg")
+        if not st["eager_done"]:
+            # the first step runs eagerly: lazy one-time work (side streams, events, kernel attributes) must not be recorded
+            enqueue_head(stream)
+            enqueue_backward(stream)
+            st["eager_done"] = True
+        else:
+            wset = lib.vs_unet_weight_set(hd)
+            prog = st["graphs"][wset]
+            if prog is None:
+                nu = lib.vs_unet_num_units(hd)
+                if mode == "branch":      # ONE graph with the side stream as parallel branches
+                    g0 = record(lambda cs: (enqueue_head(cs), enqueue_backward(cs)))
+                    check(lib.vs_unet_flip_weight_set(hd))      # undo the capture's flip: the replay below flips
+                    prog = [("main", g0)]
+                else:
+                    # LINEAR graphs (the runtime replays those as one batch of queue packets): per range of units one graph
+                    # of the caller's-stream kernels and one of the weight-gradient / optimiser kernels, the second stream
+                    # one range behind the first, ordinary events between them
+                    seg = max(1, int(os.environ.get("VOLSEG_STEP_SEG", "4")))
+                    cuts = list(range(nu, 0, -seg)) + [0]
+                    prog = []
+                    for i, (hi_, lo_) in enumerate(zip(cuts[:-1], cuts[1:])):
+                        if i == 0:
+                            prog.append(("main", record(lambda cs: (enqueue_head(cs), enqueue_part(cs, lo_, hi_, 1)))))
+                        else:
+                            prog.append(("main", record(lambda cs: enqueue_part(cs, lo_, hi_, 1))))
+                        prog.append(("fork", torch.cuda.Event()))
+                        prog.append(("side", record(lambda cs: enqueue_part(cs, lo_, hi_, 2))))
+                    prog.append(("join", torch.cuda.Event()))
+                st["graphs"][wset] = prog
+            if self._step_side is None:
+                self._step_side = torch.cuda.Stream(device=self.device)
+            cur = torch.cuda.current_stream()
+            for op, obj in prog:
+                if op == "main":
+                    check(lib.vs_graph_launch(obj, stream))
+                elif op == "side":
+                    check(lib.vs_graph_launch(obj, self._step_side.cuda_stream))
+                elif op == "fork":
+                    obj.record(cur)
+                    self._step_side.wait_event(obj)
+                else:
+                    obj.record(self._step_side)
+                    cur.wait_event(obj)
+            check(lib.vs_unet_flip_weight_set(hd))   # neither a replay nor a split-role recording runs the library's flip
+        self._train_forward_token += 1
+        self._bnver += 1
+        self._wver += 1
+        plan["prep"] = (self._flat._version, self._wver, True, None)   # the next forward's weight copies are in place
+        opt.step_count += 1
+        opt._opt_called = True          # lr_scheduler.step() checks that an optimiser step preceded it
+        if not st.get("grads_attached"):
+            self._attach_grads(accumulate=False)    # param.grad = views of the flat gradient buffer the step writes
+            st["grads_attached"] = True
+        return st["loss"].clone() if clone_loss else st["loss"]
 
     def _world(self) -> int:
         import torch.distributed as dist

@@ -151,6 +151,12 @@ class VolSeg2dTrainer:
 
     def _train_one_batch(self, lr_scheduler, batch):
         inputs, targets = utils.prepare_training_batch(batch, self.model.device, self.label_no)
+        fuse = getattr(self.model, "can_fuse_step", None)
+        if fuse is not None and isinstance(self.loss_criterion, HipDiceLoss) and fuse(self.optimizer, inputs, targets):
+            # the whole step (zero_grad .. optimizer.step) as one replayed hipGraph - same kernels, same order, same bits
+            loss = self.model.fused_train_step(inputs, targets, self.optimizer, eps=self.loss_criterion.epsilon)
+            lr_scheduler.step()
+            return loss
         self.optimizer.zero_grad()
         output = self.model(inputs)
         loss = self._loss(output, targets)
