@@ -385,7 +385,6 @@ def main():
         tname = "unsigned short" if args.precision == "bf16" else "float"
         code = dvar % 10
         dom_name = (f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, 1, 8>" if code == 8 else
-                    f"conv_igemm_dma_kernel<{tname}, {dvar // 1000}>" if code == 3 else
                     f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {code}, 4>")
         dom_ms, dom_fl, dom_calls = byvar[dvar]
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0

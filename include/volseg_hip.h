@@ -301,6 +301,10 @@ typedef struct vs_dirmap {
 /* x[b][hp][wp] fp32 = normalised, reflect-101 padded slices s0..s0+nb-1 of the uint8 volume
  * (data/datasets.py:120-142: /255, -0.449, /0.226). */
 int vs_slices_gather(const uint8_t* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream);
+/* the same for a volume of any VS_VOL_* type, in the arithmetic numpy uses at data/datasets.py:128-134: integer types ->
+ * float32, / 255 (whatever their range: an unclipped uint16 volume gives inputs >> 1, as in the reference), float32 volumes
+ * skip the / 255, float64 volumes are normalised in float64 and rounded to float32 at the end. */
+int vs_slices_gather_typed(int vtype, const void* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream);
 
 /* softmax -> argmax (first max) -> max prob (fp32 -> fp16 RNE) on logits (nb, K, hp, wp) NCHW,
  * centre-cropped and scattered to voxel addresses (vol_seg_2d_predictor.py:45-64).

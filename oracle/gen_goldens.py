@@ -186,11 +186,99 @@ def gen_g8():
     np.savez_compressed(OUT / "g8_clip_to_uint8.npz", **out)
 
 
+def gen_g9():
+    """G9: the network input the reference builds from prediction volumes that are NOT uint8 (reachable with clip_data: False):
+    get_2d_prediction_dataset -> VolSeg2dPredictionDataset.__getitem__ (data/datasets.py:120-142,175-181) run by the reference
+    itself: integer types -> float32 / 255 whatever their range, float types without the / 255.  Shapes that need padding."""
+    from volume_segmantics.data.datasets import get_2d_prediction_dataset
+    rng = np.random.default_rng(99)
+    shape = (3, 37, 45)
+    vols = {
+        "u8": rng.integers(0, 256, shape).astype(np.uint8),
+        "u16": rng.integers(0, 65536, shape).astype(np.uint16),
+        "i16": rng.integers(-32768, 32768, shape).astype(np.int16),
+        "i32": rng.integers(-2 ** 31, 2 ** 31 - 1, shape).astype(np.int32),          # beyond float32's 24-bit integers
+        "u32": rng.integers(0, 2 ** 32 - 1, shape).astype(np.uint32),
+        "i64": rng.integers(-2 ** 40, 2 ** 40, shape).astype(np.int64),
+        "f32": (rng.standard_normal(shape) * 0.3 + 0.5).astype(np.float32),
+        "f64": rng.standard_normal(shape) * 0.3 + 0.5,
+    }
+    out = {}
+    for name, vol in vols.items():
+        ds = get_2d_prediction_dataset(vol)
+        x = np.stack([np.asarray(ds[i]) for i in range(len(ds))])       # (n, 1, hp, wp), the dtype numpy arrived at
+        assert x.shape == (3, 1, 64, 64), x.shape
+        out[name + "__in"] = vol
+        out[name + "__x"] = x
+        print("g9", name, vol.dtype, "->", x.dtype, float(x.min()), float(x.max()))
+    np.savez_compressed(OUT / "g9_prediction_inputs_typed.npz", **out)
+
+
+def gen_decidable():
+    """Which voxels of the g3 prediction goldens are DECIDABLE, i.e. where any correct fp32 implementation must reproduce the
+    reference's label bit for bit: voxels where no direction involved is within rounding of a tie.  Computed with the oracle
+    (oracle/predictor_numpy.py, pinned to g3 bit-exactly by tests/test_oracle_goldens.py) because it needs per-direction
+    logits, which the reference's predictor does not return:
+      * per direction d: margin_d = top-1 minus top-2 logit at the voxel; the direction's label is decidable if margin_d > 1e-3
+        (north_star's logit tolerance), and its fp16 probability is then right to 1 ulp;
+      * single-axis outputs: decidable = margin of that direction > 1e-3;
+      * merged outputs (first-max of the fp16 probabilities over directions, vol_seg_2d_predictor.py:90-98): decidable if every
+        direction's label is decidable AND the winner is clear - the best probability exceeds every other direction's by more
+        than 2 fp16 ulps - or all directions within 2 ulps of the best carry the same label;
+      * one-hot vote volumes: decidable if every contributing direction's label is decidable.
+    Stored bit-packed; tests assert equality on the mask and that the mask covers > 99 % of the voxels."""
+    from oracle import predictor_numpy as P
+    from oracle.unet_resnet34_torch import seeded_oracle
+    g3 = np.load(OUT / "g3_predict_29x64x40_c4.npz")
+    vol, classes = g3["vol"], int(g3["classes"])
+    net = seeded_oracle(classes=classes, seed=0).eval()
+    views, v = [], vol
+    for k in range(4):
+        if k:
+            v = np.rot90(v)
+        for ax in (0, 1, 2):
+            views.append((k, ax, v))
+    margins, labels, probs = [], [], []
+    for k, ax, v in views:
+        l, p, logits = P.predict_single_axis(net, v, ax, return_logits=True)     # logits: (slices, K, h, w) along the axis
+        top2 = np.sort(logits, axis=1)[:, -2:]
+        m = P.rotate_array_to_axis(top2[:, 1] - top2[:, 0], ax)                    # back to the rotated volume's axes
+        back = (lambda a: np.rot90(a, -k)) if k else (lambda a: a)
+        margins.append(np.ascontiguousarray(back(m)))
+        labels.append(np.ascontiguousarray(back(l)))
+        probs.append(np.ascontiguousarray(back(p)))
+    margins, labels, probs = np.stack(margins), np.stack(labels), np.stack(probs)
+    assert np.array_equal(labels[0], g3["single_z_labels"]) and np.array_equal(labels[2], g3["single_x_labels"])
+    dec_dir = margins > 1e-3
+
+    def merged(dirs):
+        pb = probs[dirs].astype(np.float16).view(np.uint16).astype(np.int32)    # fp16 bits order like the values (p >= 0)
+        best = pb.max(0)
+        near = pb >= best - 2
+        lab_near_min = np.where(near, labels[dirs], 255).min(0)
+        lab_near_max = np.where(near, labels[dirs], 0).max(0)
+        clear = (near.sum(0) == 1) | (lab_near_min == lab_near_max)
+        return dec_dir[dirs].all(0) & clear
+
+    out = {"margin_threshold": np.float32(1e-3), "ulp_window": np.int32(2)}
+    masks = {"single_z": dec_dir[0], "single_y": dec_dir[1], "single_x": dec_dir[2], "three": merged(list(range(3))),
+             "twelve": merged(list(range(12))), "votes_z": dec_dir[0], "votes_three": dec_dir[:3].all(0),
+             "votes_twelve": dec_dir.all(0)}
+    for k2, m in masks.items():
+        out[k2] = np.packbits(m.reshape(-1))
+        print("decidable", k2, f"{m.mean():.5f}")
+    out["shape"] = np.array(vol.shape)
+    np.savez_compressed(OUT / "g3_decidable.npz", **out)
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     install_stubs()
     sys.path.insert(0, str(REF))
     torch.set_num_threads(8)
+    if "--only-decidable" in sys.argv:
+        gen_decidable()
+        return
 
     import volume_segmantics.utilities.base_data_utils as utils
     from volume_segmantics.data.augmentations import get_padded_dimension
@@ -203,9 +291,13 @@ def main():
     from oracle.unet_resnet34_torch import seeded_oracle
 
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--only-g9" in sys.argv:
+        gen_g9()
+        return
     gen_g8()
     if "--only-g8" in sys.argv:
         return
+    gen_g9()
     utils.get_batch_size = lambda settings, prediction=False: 4 if prediction else 12  # needs CUDA in the reference
 
     # ---- G7: pad / crop tables --------------------------------------------------------------
@@ -337,6 +429,7 @@ def main():
                         frozen_names=np.array(frozen), fingerprint0=weight_fingerprint(seeded_oracle(2, 3, False)),
                         **{"after__" + k: sd[k].numpy() for k in keep})
     print("train goldens done; losses", losses, "lrs", lrs, "beta1", betas, "frozen", len(frozen))
+    gen_decidable()
 
 
 if __name__ == "__main__":

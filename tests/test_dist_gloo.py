@@ -68,8 +68,8 @@ def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
         try:
             mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
             break
-        except Exception:
-            if attempt:
+        except Exception as e:   # only the bind race is retried: a failed or hung collective in a worker must fail the test
+            if attempt or not any(m in str(e) for m in ("Address already in use", "EADDRINUSE", "address already in use")):
                 raise
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     g = np.load(REPO / "tests" / "golden" / "g3_predict_29x64x40_c4.npz")

@@ -26,6 +26,30 @@ def test_slices_gather_bit_exact_all_12_directions(golden):
         assert np.array_equal(x.cpu().numpy().view(np.uint32), ref.view(np.uint32))  # bit-exact fp32
 
 
+def test_typed_slices_gather_equals_reference_dataset(golden):
+    """Prediction volumes that are not uint8 (clip_data: False): vs_slices_gather_typed against g9, the network input the
+    reference's own VolSeg2dPredictionDataset builds - bit-exact (float64 volumes: the reference's float64 input rounded to
+    float32, which is what a float32 network can take)."""
+    L = lib()
+    g = golden("g9_prediction_inputs_typed.npz")
+    for name in ("u8", "u16", "i16", "i32", "u32", "i64", "f32", "f64"):
+        vol, ref = np.ascontiguousarray(g[name + "__in"]), g[name + "__x"][:, 0]
+        m = dirmap_from_view(L, vol, vol)
+        raw = torch.from_numpy(vol.reshape(-1).view(np.uint8).copy()).to(DEV)
+        x = torch.full((vol.shape[0], m.hp, m.wp), float("nan"), device=DEV)
+        L.check(L.lib.vs_slices_gather_typed(L.VS_VOL[vol.dtype.name], L.ptr(raw), m, 0, vol.shape[0], L.ptr(x), None))
+        sync()
+        assert np.array_equal(x.cpu().numpy().view(np.uint32), ref.astype(np.float32).view(np.uint32)), name
+        # a transposed direction of the same volume (strided reads of a wider type)
+        view = vol.swapaxes(0, 2)
+        mv = dirmap_from_view(L, vol, view)
+        xv = torch.empty((view.shape[0], mv.hp, mv.wp), device=DEV)
+        L.check(L.lib.vs_slices_gather_typed(L.VS_VOL[vol.dtype.name], L.ptr(raw), mv, 0, view.shape[0], L.ptr(xv), None))
+        sync()
+        refv = np.stack([P.preprocess_slice(view[i]) for i in range(view.shape[0])]).astype(np.float32)
+        assert np.array_equal(xv.cpu().numpy().view(np.uint32), refv.view(np.uint32)), name
+
+
 def test_reflect101_when_padding_exceeds_size():
     L = lib()
     vol = np.random.default_rng(0).integers(0, 256, size=(3, 10, 13), dtype=np.uint8)  # pads 11 / 9 > size-1? (10->32)

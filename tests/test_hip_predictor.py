@@ -49,41 +49,63 @@ def predictor_and_golden(golden, tmp_path_factory):
     return pred, g, net
 
 
-def _check(labels, probs, ref_l, ref_p, what):
+@pytest.fixture(scope="module")
+def decidable(golden):
+    """tests/golden/g3_decidable.npz (oracle/gen_goldens.py:gen_decidable): the voxels where no direction involved is within
+    rounding of a tie - top-2 logit margin > 1e-3 in every contributing direction and, for merges, a winner that is clear by
+    more than 2 fp16 ulps (or the same label among all near-winners).  On those the reference's label must be reproduced
+    bit for bit; elsewhere two correct fp32 implementations may legitimately differ."""
+    d = golden("g3_decidable.npz")
+    shape = tuple(d["shape"])
+    n = int(np.prod(shape))
+    return {k: np.unpackbits(d[k])[:n].astype(bool).reshape(shape) for k in d.files if d[k].dtype == np.uint8 and k != "shape"}
+
+
+def _check(labels, probs, ref_l, ref_p, what, mask, min_cover=0.99):
     assert labels.dtype == np.uint8 and labels.shape == ref_l.shape
-    mism = (labels != ref_l).mean()
-    # fp32 logits agree to ~1e-4, so the argmax / the direction choice can differ only where two candidates are
-    # that close; on this fixture that is a handful of voxels at most
-    assert mism <= 2e-4, (what, mism, int((labels != ref_l).sum()))
+    bad = labels != ref_l
+    print(f"[parity] {what}: decidable {mask.mean():.5f} of voxels; mismatches {int(bad.sum())} total, "
+          f"{int((bad & mask).sum())} on decidable voxels")
+    assert mask.mean() > min_cover, (what, mask.mean())
+    assert not (bad & mask).any(), (what, int((bad & mask).sum()))       # north_star: label volumes bit-exact
+    assert bad.mean() <= 2e-4, (what, bad.mean())                          # and the undecidable rest stays a handful
     if probs is not None:
         assert probs.dtype == np.float16
-        same = labels == ref_l
-        assert (_ulp(probs, ref_p)[same] <= 2).mean() > 0.999, what
+        # on decidable voxels the winning direction is the reference's: its fp16 probability may differ by the last bits
+        # (expf vs torch's vectorised exp, 1e-4-level logit differences): <= 2 ulp, and <= 1 ulp on 99.9 %
+        u = _ulp(probs, ref_p)[mask]
+        assert u.max() <= 2 and (u <= 1).mean() > 0.999, (what, int(u.max()))
 
 
-def test_single_axis_all_axes_vs_reference_golden(predictor_and_golden):
+def test_single_axis_all_axes_vs_reference_golden(predictor_and_golden, decidable):
     pred, g, _ = predictor_and_golden
     for ax, name in ((Axis.Z, "z"), (Axis.Y, "y"), (Axis.X, "x")):   # Y / X exercise padding and the d=3 crop quirk
         l, p = pred._predict_single_axis(g["vol"], output_probs=True, axis=ax)
-        _check(l, p, g[f"single_{name}_labels"], g[f"single_{name}_probs"], name)
+        _check(l, p, g[f"single_{name}_labels"], g[f"single_{name}_probs"], name, decidable[f"single_{name}"])
     l, p = pred._predict_single_axis(g["vol"], output_probs=False)
     assert p is None and l.dtype == np.uint8
 
 
-def test_three_and_twelve_way_merge_vs_reference_golden(predictor_and_golden):
+def test_three_and_twelve_way_merge_vs_reference_golden(predictor_and_golden, decidable):
     pred, g, _ = predictor_and_golden
     l, p = pred._predict_3_ways_max_probs(g["vol"])
-    _check(l, p, g["three_labels"], g["three_probs"], "3-way")
+    _check(l, p, g["three_labels"], g["three_probs"], "3-way", decidable["three"])
     l, p = pred._predict_12_ways_max_probs(g["vol"])
-    _check(l, p, g["twelve_labels"], g["twelve_probs"], "12-way")
+    # 12 directions of a RANDOM-INIT 4-class network: ~1.7 % of the voxels have some direction within 1e-3 of a class tie
+    _check(l, p, g["twelve_labels"], g["twelve_probs"], "12-way", decidable["twelve"], min_cover=0.98)
 
 
-def test_one_hot_votes_vs_reference_golden(predictor_and_golden):
+def test_one_hot_votes_vs_reference_golden(predictor_and_golden, decidable):
     pred, g, _ = predictor_and_golden
-    for fn, key, n in ((pred._predict_single_axis_to_one_hot, "onehot_z", 1), (pred._predict_3_ways_one_hot, "onehot_three", 3),
-                       (pred._predict_12_ways_one_hot, "onehot_twelve", 12)):
+    for fn, key, n, mk, cover in ((pred._predict_single_axis_to_one_hot, "onehot_z", 1, "votes_z", 0.99),
+                                  (pred._predict_3_ways_one_hot, "onehot_three", 3, "votes_three", 0.99),
+                                  (pred._predict_12_ways_one_hot, "onehot_twelve", 12, "votes_twelve", 0.98)):
         oh = fn(g["vol"])
         assert oh.dtype == np.uint8 and oh.shape == g[key].shape and (oh.sum(0) == n).all()
+        mask = decidable[mk]
+        bad = (oh != g[key]).any(0)
+        print(f"[parity] {key}: decidable {mask.mean():.5f}; voxels with a different vote {int(bad.sum())}, on decidable {int((bad & mask).sum())}")
+        assert mask.mean() > cover and not (bad & mask).any(), key        # every vote count equal where every direction is decidable
         assert (oh != g[key]).mean() <= 4e-4, key
 
 
@@ -106,6 +128,42 @@ def test_bit_exact_labels_where_the_oracle_margin_is_clear(predictor_and_golden)
     clear = (top2[:, 1] - top2[:, 0]) > 1e-3
     l, _ = pred._predict_single_axis(vol, axis=Axis.Z)
     assert clear.mean() > 0.99 and np.array_equal(l[clear], ref_l[clear])
+
+
+def test_unclipped_uint16_and_float_volumes_predict_like_the_oracle(predictor_and_golden):
+    """clip_data: False hands the predictor the volume in its own dtype; the reference then feeds float32(v) / 255 (integers,
+    any range) or v itself (floats) to the network (data/datasets.py:128-134).  Labels must equal the oracle's wherever its
+    top-2 logit margin is clear."""
+    pred, g, net = predictor_and_golden
+    rng = np.random.default_rng(5)
+    base = g["vol"][:9].astype(np.float32)
+    for vol in ((base * 3 + rng.integers(0, 3, base.shape)).astype(np.uint16),      # values up to ~767: inputs > 1 after / 255
+                (base / 255).astype(np.float32)):                                      # a float volume already in [0, 1]
+        ref_l, ref_p, logits = P.predict_single_axis(net, vol, 0, return_logits=True)
+        top2 = np.sort(logits, axis=1)[:, -2:]
+        # uint16 inputs of up to 3 make logits (and their fp32 rounding errors) larger: scale the margin with the logit size
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-3 * max(1.0, float(np.abs(logits).max()) / 10)
+        l, p = pred._predict_single_axis(vol, axis=Axis.Z)
+        assert l.dtype == np.uint8 and p.dtype == np.float16 and clear.mean() > 0.97
+        assert np.array_equal(l[clear], ref_l[clear]), vol.dtype
+
+
+def test_imagenet_encoder_weights_are_never_silently_random(tmp_path, monkeypatch):
+    """smp would download the ImageNet encoder; with no network that is an error, not a silent random initialisation."""
+    from volume_segmantics_amd.model.model_2d import create_model_on_device
+    monkeypatch.delenv("VOLSEG_RESNET34_WEIGHTS", raising=False)
+    struct = {"type": "U_Net", "encoder_name": "resnet34", "encoder_weights": "imagenet", "in_channels": 1, "classes": 2}
+    with pytest.raises(FileNotFoundError, match="allow_random_encoder"):
+        create_model_on_device(0, struct)
+    assert create_model_on_device(0, dict(struct, allow_random_encoder=True)).classes == 2
+    assert create_model_on_device(0, dict(struct, encoder_weights=None)).classes == 2
+    # a local torchvision-shaped state dict is used when supplied
+    tv = {k[len("encoder."):]: v for k, v in seeded_oracle(2, 5).state_dict().items() if k.startswith("encoder.")}
+    tv["conv1.weight"] = tv["conv1.weight"].repeat(1, 3, 1, 1) / 3        # 3-channel stem, summed by the loader
+    torch.save(tv, tmp_path / "r34.pth")
+    monkeypatch.setenv("VOLSEG_RESNET34_WEIGHTS", str(tmp_path / "r34.pth"))
+    m = create_model_on_device(0, struct)
+    assert torch.allclose(m.state_dict()["encoder.layer2.1.conv1.weight"].cpu(), tv["layer2.1.conv1.weight"])
 
 
 def test_prediction_manager_qualities_and_outputs(tmp_path):

@@ -147,6 +147,61 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     # an smp / oracle-shaped module loads the same file
     from oracle.unet_resnet34_torch import OracleUnetResnet34
     OracleUnetResnet34(1, 3).load_state_dict(d["model_state_dict"])
+    # the optimiser state is in torch.optim.AdamW's own format: the reference's _load_in_weights(optimizer=True) can load it
+    from volume_segmantics_amd.engine import FusedAdamW
+    fo = FusedAdamW(m, lr=1e-3)
+    fo.exp_avg.uniform_(-1, 1); fo.exp_avg_sq.uniform_(0, 1); fo.step_count = 7
+    ref_opt = torch.optim.AdamW(OracleUnetResnet34(1, 3).parameters(), lr=1e-3)
+    ref_opt.load_state_dict(fo.state_dict())
+    w = "decoder.blocks.2.conv1.0.weight"
+    idx = [n for n, _ in m.named_parameters()].index(w)
+    st = ref_opt.state[ref_opt.param_groups[0]["params"][idx]]
+    assert float(st["step"]) == 7 and torch.equal(st["exp_avg"], fo.state_dict()["state"][idx]["exp_avg"])
+    assert st["exp_avg"].shape == dict(m.named_parameters())[w].shape
+    fo2 = FusedAdamW(VolSegUnet(3, seed=1), lr=1.0)
+    fo2.load_state_dict(ref_opt.state_dict())
+    assert fo2.step_count == 7 and torch.equal(fo2.exp_avg, fo.exp_avg) and torch.equal(fo2.exp_avg_sq, fo.exp_avg_sq)
+    assert fo2.param_groups[0]["lr"] == 1e-3
+    # keys only this engine knows stay out of model_struc_dict (the reference does smp.Unet(**model_struc_dict))
+    es2 = EarlyStopping(patience=2, path=tmp_path / "m2.pytorch", model_dict=dict(struct, precision="bf16"))
+    es2(0.5, m, fo, {})
+    d2 = torch.load(tmp_path / "m2.pytorch", weights_only=False)
+    assert "precision" not in d2["model_struc_dict"] and d2["engine_settings"] == {"precision": "bf16"}
+
+
+def test_reference_enum_lookup_with_the_reference_installed_but_not_imported(tmp_path, monkeypatch):
+    """Side-by-side install: ``volume_segmantics`` is importable but nobody has imported it yet - reference_pickle_enum must
+    import it (not expect it in sys.modules), and fall back to the aliases when its import fails for missing dependencies."""
+    import sys
+    from volume_segmantics_amd import checkpoint_compat as cc
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "volume_segmantics" or k.startswith("volume_segmantics.")}
+    try:
+        pkg = tmp_path / "volume_segmantics" / "utilities"
+        pkg.mkdir(parents=True)
+        (tmp_path / "volume_segmantics" / "__init__.py").write_text("")
+        (pkg / "__init__.py").write_text("")
+        (pkg / "base_data_utils.py").write_text("from enum import Enum\nclass ModelType(Enum):\n    U_NET = 1\n    FPN = 3\n")
+        monkeypatch.syspath_prepend(str(tmp_path))
+        import importlib
+        importlib.invalidate_caches()
+        e = cc.reference_pickle_enum(ModelType.U_NET)
+        assert type(e).__module__ == "volume_segmantics.utilities.base_data_utils" and e.name == "U_NET"
+        assert "stub" not in repr(sys.modules["volume_segmantics"]) and sys.modules["volume_segmantics"].__file__.startswith(str(tmp_path))
+        # the same package, but its module fails to import (a missing third-party dependency): aliases take over
+        for k in [k for k in sys.modules if k == "volume_segmantics" or k.startswith("volume_segmantics.")]:
+            del sys.modules[k]
+        (pkg / "base_data_utils.py").write_text("import a_module_that_is_not_installed\n")
+        importlib.invalidate_caches()
+        e = cc.reference_pickle_enum(ModelType.FPN)
+        assert e.name == "FPN"
+    finally:
+        for k in [k for k in sys.modules if k == "volume_segmantics" or k.startswith("volume_segmantics.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+        from volume_segmantics_amd.utilities import base_data_utils as ours
+        for name in ("ModelType", "Quality", "Axis"):   # the alias registration renames the enums' module; keep that consistent
+            if saved:
+                getattr(ours, name).__module__ = "volume_segmantics.utilities.base_data_utils"
 
 
 def test_predictor_orchestration_with_cpu_standin_matches_reference_goldens(golden):

@@ -174,3 +174,25 @@ def test_host_clip_to_uint8_equals_reference(golden):
                             device_preprocess=False)
         dm = BaseDataManager(g[case + "__in"].copy(), s)
         assert dm.data_mean == g[case + "__mean"] and np.array_equal(dm.data_vol, g[case + "__out"]), case
+
+
+def test_typed_prediction_inputs_equal_reference_dataset(golden):
+    """g9: what the reference's VolSeg2dPredictionDataset feeds the network for volumes that are not uint8 (integer types:
+    float32 / 255 whatever their range; float types: no / 255) - the oracle's preprocess_slice reproduces it bit for bit."""
+    from oracle import predictor_numpy as P
+    g = golden("g9_prediction_inputs_typed.npz")
+    for name in ("u8", "u16", "i16", "i32", "u32", "i64", "f32", "f64"):
+        vol, x = g[name + "__in"], g[name + "__x"]
+        mine = np.stack([P.preprocess_slice(vol[i]) for i in range(vol.shape[0])])[:, None]
+        assert mine.dtype == x.dtype and np.array_equal(mine, x), name
+
+
+def test_decidable_masks_are_consistent_with_the_goldens(golden):
+    """g3_decidable: masks have the volume's shape, cover most voxels, and single-axis masks imply the merged ones' inputs."""
+    d, g = golden("g3_decidable.npz"), golden("g3_predict_29x64x40_c4.npz")
+    n = int(np.prod(d["shape"]))
+    assert tuple(d["shape"]) == g["vol"].shape
+    m = {k: np.unpackbits(d[k])[:n].astype(bool) for k in ("single_z", "single_y", "single_x", "three", "twelve", "votes_three", "votes_twelve")}
+    assert all(v.mean() > 0.98 for v in m.values()) and m["single_z"].mean() > 0.999
+    assert not (m["three"] & ~m["votes_three"]).any() and not (m["twelve"] & ~m["votes_twelve"]).any()
+    assert not (m["votes_three"] & ~(m["single_z"] & m["single_y"] & m["single_x"])).any()

@@ -109,6 +109,7 @@ _SIGS = {
     "vs_mean_iou": (I, [P, P, I, I, I, I, I64, P, P, SZ, P]),
     "vs_onehot_u8": (I, [P, I, I, I64, P, P]),
     "vs_slices_gather": (I, [P, C.POINTER(DirMap), I, I, P, P]),
+    "vs_slices_gather_typed": (I, [I, P, C.POINTER(DirMap), I, I, P, P]),
     "vs_logits_to_volume": (I, [P, I, C.POINTER(DirMap), I, I, I, I, P, P, P, P, I64, P]),
     "vs_unet_forward_to_volume": (I, [P, P, P, P, I, P, P, C.POINTER(DirMap), I, I, I, P, P, P, P, I64]),
     "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),

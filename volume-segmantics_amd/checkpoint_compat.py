@@ -10,13 +10,18 @@ import types
 
 
 def install_reference_aliases() -> bool:
-    if "volume_segmantics.utilities.base_data_utils" in sys.modules:
+    name = "volume_segmantics.utilities.base_data_utils"
+    if name in sys.modules:
         return False
     try:
         if importlib.util.find_spec("volume_segmantics") is not None:
-            return False  # the real reference is importable: let pickle use it
-    except (ImportError, ValueError):
-        pass
+            importlib.import_module(name)   # the real reference is installed: import it so that pickle (and
+            return False                    # reference_pickle_enum) find its enums in sys.modules
+    except Exception:
+        # absent, or installed without its third-party dependencies (h5py, smp, ...): drop whatever the failed import
+        # left behind and register the aliases instead
+        for k in [k for k in sys.modules if k == "volume_segmantics" or k.startswith("volume_segmantics.")]:
+            del sys.modules[k]
     from .utilities import base_data_utils as ours
     root = types.ModuleType("volume_segmantics")
     util = types.ModuleType("volume_segmantics.utilities")

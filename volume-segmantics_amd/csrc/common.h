@@ -166,9 +166,7 @@ bool conv_head_scatter_ok(int dtype, const ConvParams& p);   // whether launch_c
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
-int conv_igemm_variant(int dtype, const ConvParams& p);
-bool conv_igemm_dma_ok(int dtype, const ConvParams& p, int BN);
-int launch_conv_igemm_dma(int dtype, const ConvParams& p, int BN, int out_nchw, hipStream_t s);  // BN*1000 + PT*100 + taps*10 + stride of the chosen instantiation      // number of partial rows stats_partial receives
+int conv_igemm_variant(int dtype, const ConvParams& p);      // BN*1000 + PT*100 + taps*10 + code of the chosen instantiation
 int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
                                 void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
                                 int nparts, hipStream_t s);

@@ -1,4 +1,4 @@
-// Pieces shared by the convolution kernels (register-staged conv_igemm.hip and LDS-DMA conv_igemm_dma.hip).
+// Pieces shared by the convolution kernels of conv_igemm.hip (tile kernel, direct kernel, head kernel).
 #pragma once
 #include "common.h"
 

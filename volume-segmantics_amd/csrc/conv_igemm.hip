@@ -674,7 +674,6 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
 struct Pick { int BN, PT, NW; };
 // tile width: static per kernel for stride 1 (see conv_igemm_kernel), by output width for stride 2
 static int tile_tw(const ConvParams& p, int PT) { return p.stride == 1 ? (PT == 1 ? 8 : 16) : (p.Wout >= 16 ? 16 : 8); }
-static int g_dtype_hint = VS_BF16;
 
 // One place decides the kernel configuration (cout tile, pixel tiles per wave, waves per workgroup):
 //  * 8 waves x 2 pixel tiles = 256-pixel tiles for stride-1 layers with >= 16x16 outputs: half the weight-slab traffic per
@@ -697,7 +696,6 @@ Pick pick_cfg(const ConvParams& p) {
     if (can8 && wgs(bn, 256) >= vs_option("conv_nw8_min_wgs")) { c.NW = 8; c.PT = 2; }
     if (bn == 64 && wgs(64, c.NW * c.PT * 16) < vs_option("conv_min_wgs")) bn = 32;
     c.BN = bn;
-    if (conv_igemm_dma_ok(g_dtype_hint, p, bn)) { c.NW = 4; c.PT = 2; }
     return c;
 }
 
@@ -733,8 +731,6 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
     VS_REQUIRE(!p.scatter, "conv_igemm: the volume-scatter epilogue needs the direct kernel (check conv_head_scatter_ok first)");
-    if (conv_igemm_dma_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN))
-        return launch_conv_igemm_dma(CT<T>::CK == 32 ? VS_BF16 : VS_F32, p, BN, out_nchw, s);
     TileGeom g;
     g.tw_shift = tile_tw(p, PT) == 16 ? 4 : 3;
     const int TW = 1 << g.tw_shift;
@@ -769,12 +765,10 @@ bool conv_igemm_can_pool(const ConvParams& p) {
 }
 
 // instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + code
-// (code 1 = stride 1, 2 = stride 2, 3 = LDS-DMA ring kernel, 4 = direct (LDS-free) shallow-layer kernel, 8 = 8-wave 256-pixel tiles)
+// (code 1 = stride 1, 2 = stride 2, 4 = direct (LDS-free) shallow-layer kernel, 8 = 8-wave 256-pixel tiles)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
-    g_dtype_hint = dtype;
     if (direct_ok(dtype, p)) return 16 * 1000 + 2 * 100 + 9 * 10 + 4;
     const Pick c = pick_cfg(p);
-    if (conv_igemm_dma_ok(dtype, p, c.BN)) return c.BN * 1000 + 2 * 100 + 9 * 10 + 3;
     return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : (p.stride == 2 ? 2 : 1));
 }
 
@@ -788,7 +782,6 @@ int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
 }
 
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s) {
-    g_dtype_hint = dtype;
     const int nchw = p.out_f32 >> 1;  // out_f32: bit0 = fp32 store, bit1 = NCHW layout
     ConvParams q = p;
     q.out_f32 = p.out_f32 & 1;

@@ -19,7 +19,18 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p >= len ? m - p : p;
 }
 
-__global__ void slices_gather_kernel(const uint8_t* __restrict__ vol, vs_dirmap m, int s0, int nb, float* __restrict__ x) {
+// VolSeg2dPredictionDataset.__getitem__ (data/datasets.py:120-142) in numpy's own arithmetic: integer volumes of ANY width are
+// converted to float32 and divided by 255 (so a uint16 volume that was not clipped to bytes gives inputs far above 1, as in
+// the reference), then - 0.449, / 0.226 in float32; float32 volumes skip the / 255; float64 volumes are normalised in float64
+// (the network input is rounded to float32 afterwards - the reference would hand smp a float64 batch).
+template <typename VT> __device__ __forceinline__ float normalise_voxel(VT v) {
+    return __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.0f), 0.449f), 0.226f);    // (u / 255 - 0.449) / 0.226, every step rounded
+}
+template <> __device__ __forceinline__ float normalise_voxel<float>(float v) { return __fdiv_rn(__fsub_rn(v, 0.449f), 0.226f); }
+template <> __device__ __forceinline__ float normalise_voxel<double>(double v) { return (float)__ddiv_rn(__dsub_rn(v, 0.449), 0.226); }
+
+template <typename VT>
+__global__ void slices_gather_kernel(const VT* __restrict__ vol, vs_dirmap m, int s0, int nb, float* __restrict__ x) {
     const int64_t total = (int64_t)nb * m.hp * m.wp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = i;
@@ -27,9 +38,7 @@ __global__ void slices_gather_kernel(const uint8_t* __restrict__ vol, vs_dirmap 
         const int r = t % m.hp;
         const int b = t / m.hp;
         const int hh = reflect101(r - m.pad_top, m.h), ww = reflect101(j - m.pad_left, m.w);
-        const float u = (float)vol[m.base + (int64_t)(s0 + b) * m.ss + (int64_t)hh * m.sh + (int64_t)ww * m.sw];
-        // numpy order of operations in fp32: (u / 255 - 0.449) / 0.226
-        x[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.449f), 0.226f);
+        x[i] = normalise_voxel<VT>(vol[m.base + (int64_t)(s0 + b) * m.ss + (int64_t)hh * m.sh + (int64_t)ww * m.sw]);
     }
 }
 
@@ -171,14 +180,34 @@ int check_map(const vs_dirmap* m, int s0, int nb) {
 
 }  // namespace
 
-extern "C" int vs_slices_gather(const uint8_t* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream) {
+extern "C" int vs_slices_gather_typed(int vtype, const void* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream) {
     int rc = check_map(m, s0, nb);
     if (rc) return rc;
     VS_REQUIRE(vol && x, "slices_gather: null pointer");
     const int64_t total = (int64_t)nb * m->hp * m->wp;
-    hipLaunchKernelGGL(slices_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, vol, *m, s0, nb, x);
+    const dim3 grid(grid_for(total));
+    hipStream_t s = (hipStream_t)stream;
+#define VS_GATHER(T) hipLaunchKernelGGL(slices_gather_kernel<T>, grid, dim3(256), 0, s, (const T*)vol, *m, s0, nb, x)
+    switch (vtype) {
+    case VS_VOL_U8: VS_GATHER(uint8_t); break;
+    case VS_VOL_I8: VS_GATHER(int8_t); break;
+    case VS_VOL_U16: VS_GATHER(uint16_t); break;
+    case VS_VOL_I16: VS_GATHER(int16_t); break;
+    case VS_VOL_U32: VS_GATHER(uint32_t); break;
+    case VS_VOL_I32: VS_GATHER(int32_t); break;
+    case VS_VOL_I64: VS_GATHER(int64_t); break;
+    case VS_VOL_U64: VS_GATHER(uint64_t); break;
+    case VS_VOL_F32: VS_GATHER(float); break;
+    case VS_VOL_F64: VS_GATHER(double); break;
+    default: vs_set_error("slices_gather: unsupported volume type %d", vtype); return VS_ERR_UNSUPPORTED;
+    }
+#undef VS_GATHER
     VS_LAUNCH_CHECK();
     return VS_OK;
+}
+
+extern "C" int vs_slices_gather(const uint8_t* vol, const vs_dirmap* m, int s0, int nb, float* x, void* stream) {
+    return vs_slices_gather_typed(VS_VOL_U8, vol, m, s0, nb, x, stream);
 }
 
 extern "C" int vs_logits_to_volume(const float* logits, int classes, const vs_dirmap* m, int s0, int nb, int mode,

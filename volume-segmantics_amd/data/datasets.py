@@ -61,7 +61,18 @@ class VolSeg2dDataset(Dataset):
         if len(self.images_fps) != len(self.masks_fps):
             raise ValueError("image / label slice counts differ")
         self.img_size, self.augment = img_size, augment
-        self.rng = np.random.default_rng(seed)
+        self.seed, self.rng, self._rng_owner = seed, None, None
+
+    def _worker_rng(self):
+        """One generator per loader worker and per epoch: DataLoader re-forks its workers every epoch with a fresh
+        ``torch.utils.data.get_worker_info().seed``, so copies of ONE generator made at fork time would draw the same
+        flips in every worker and every epoch."""
+        info = torch.utils.data.get_worker_info()
+        owner = (info.id, info.seed) if info is not None else ("main", torch.initial_seed())
+        if self.rng is None or owner != self._rng_owner:
+            self.rng = np.random.default_rng([self.seed, owner[1] & 0xFFFFFFFF] if info is not None else self.seed)
+            self._rng_owner = owner
+        return self.rng
 
     def __len__(self):
         return len(self.images_fps)
@@ -69,11 +80,12 @@ class VolSeg2dDataset(Dataset):
     def __getitem__(self, i):
         image, mask = fit_to_square(_read_gray(self.images_fps[i]), _read_gray(self.masks_fps[i]), self.img_size)
         if self.augment:
-            if self.rng.random() < 0.5:
+            rng = self._worker_rng()
+            if rng.random() < 0.5:
                 image, mask = image[::-1], mask[::-1]
-            k = int(self.rng.integers(0, 4)) if self.rng.random() < 0.5 else 0
+            k = int(rng.integers(0, 4)) if rng.random() < 0.5 else 0
             image, mask = np.rot90(image, k), np.rot90(mask, k)
-            if self.rng.random() < 0.5:
+            if rng.random() < 0.5:
                 image, mask = image.T, mask.T
         image = normalise(np.ascontiguousarray(image)).astype(np.float32)
         return torch.from_numpy(image).unsqueeze(0), torch.from_numpy(np.ascontiguousarray(mask))

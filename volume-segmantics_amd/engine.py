@@ -658,16 +658,48 @@ class FusedAdamW(torch.optim.Optimizer):
         m._wver += 1  # weight copies are re-derived before the next forward
         return loss
 
+    def _param_table(self):
+        return [t for t in self.model._table if t[2] <= KIND_BIAS]   # order of model.parameters()
+
     def state_dict(self):
-        return {"state": {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq},
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.AdamW's own format - per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` with the parameter's
+        (OIHW) shape, indexed by position - so ``optimizer_state_dict`` of a checkpoint interchanges with the reference's
+        ``_load_in_weights(optimizer=True)`` (vol_seg_2d_trainer.py:276-296)."""
+        m = self.model
+        state = {}
+        for i, (name, shape, kind, off) in enumerate(self._param_table()):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": m._view_of(self.exp_avg, shape, kind, off).clone(memory_format=torch.contiguous_format),
+                        "exp_avg_sq": m._view_of(self.exp_avg_sq, shape, kind, off).clone(memory_format=torch.contiguous_format)}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.setdefault("amsgrad", False); d.setdefault("maximize", False); d.setdefault("foreach", None)
+            d.setdefault("capturable", False); d.setdefault("differentiable", False); d.setdefault("fused", None)
+            d["params"] = list(range(len(state)))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["state"]["step"])
-        self.exp_avg.copy_(sd["state"]["exp_avg"])
-        self.exp_avg_sq.copy_(sd["state"]["exp_avg_sq"])
+        st = sd["state"]
+        if "exp_avg" in st:      # round-1 flat format
+            self.step_count = int(st["step"])
+            self.exp_avg.copy_(st["exp_avg"])
+            self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        else:                    # torch.optim.AdamW format (ours, or a reference checkpoint); absent entries = never stepped
+            m = self.model
+            steps = [int(float(v["step"])) for v in st.values() if "step" in v]
+            self.step_count = max(steps) if steps else 0
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            with torch.no_grad():
+                for i, (name, shape, kind, off) in enumerate(self._param_table()):
+                    e = st.get(i, st.get(str(i)))
+                    if e is None:
+                        continue
+                    m._view_of(self.exp_avg, shape, kind, off).copy_(e["exp_avg"])
+                    m._view_of(self.exp_avg_sq, shape, kind, off).copy_(e["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})
 
 
 def load_oracle_state(model: VolSegUnet, state_dict) -> None:

@@ -42,9 +42,16 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
         if path and Path(path).exists():
             load_torchvision_resnet34(model, torch.load(path, map_location="cpu"))
             logging.info(f"Loaded {weights} encoder weights from {path}")
-        else:
+        elif struct.get("allow_random_encoder"):
             logging.warning(f"encoder_weights={weights!r} requested but no local weights available "
-                            "(set VOLSEG_RESNET34_WEIGHTS); using smp's random initialisation")
+                            "(set VOLSEG_RESNET34_WEIGHTS); allow_random_encoder is set: smp's random initialisation")
+        else:
+            # smp would download the ImageNet encoder here; the LR finder and the frozen-encoder phase are built around a
+            # pretrained encoder, so silently training from random weights would be a behaviour change
+            raise FileNotFoundError(
+                f"encoder_weights={weights!r}: no network access and no local weights - point VOLSEG_RESNET34_WEIGHTS at a "
+                "torchvision resnet34 state dict, or set `allow_random_encoder: true` (or encoder_weights: null) in the "
+                "model settings to train the encoder from random initialisation")
     logging.info(f"Sending the U-Net model to device {device_num}")
     return model
 
@@ -73,6 +80,7 @@ def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int =
     logging.info("Loading model dictionary from file.")
     model_dict = torch.load(weights_fn, map_location="cpu", weights_only=False)
     struct = dict(model_dict["model_struc_dict"])
+    struct.update(model_dict.get("engine_settings", {}))   # keys only this engine knows (compute precision)
     struct["encoder_weights"] = None  # weights come from the file; never touch the network
     model = create_model_on_device(device_num, struct)
     logging.info("Loading in the saved weights.")

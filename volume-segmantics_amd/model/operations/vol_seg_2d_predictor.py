@@ -51,14 +51,15 @@ def dirmap_of(vol: np.ndarray, view: np.ndarray) -> _lib.DirMap:
 class HipBackend:
     """Device side of one prediction pass: resident volume + output volumes + the per-batch kernels."""
 
-    def __init__(self, model, vol_u8: np.ndarray, classes: int, mode: int, want_probs: bool):
+    def __init__(self, model, vol: np.ndarray, classes: int, mode: int, want_probs: bool):
         self.model, self.classes, self.mode = model, classes, mode
         dev = model.device
-        # pinned staging: the 134 MB (512^3) upload runs at PCIe rate instead of pageable-copy rate
-        stage = torch.empty(vol_u8.shape, dtype=torch.uint8, pin_memory=True)
-        stage.numpy()[...] = vol_u8
+        self.vtype = _lib.VS_VOL[vol.dtype.name]        # the kernels read the volume in its own type (vs_slices_gather_typed)
+        # pinned staging (as raw bytes): the 134 MB (512^3) upload runs at PCIe rate instead of pageable-copy rate
+        stage = torch.empty(vol.nbytes, dtype=torch.uint8, pin_memory=True)
+        stage.numpy()[...] = vol.reshape(-1).view(np.uint8)
         self.vol = stage.to(dev, non_blocking=True)
-        n = vol_u8.size
+        n = vol.size
         self.nvox = n
         self.labels = torch.zeros(n, dtype=torch.uint8, device=dev) if mode == 0 else None
         self.probs = torch.zeros(n, dtype=torch.float16, device=dev) if (mode == 0 and want_probs) else None
@@ -72,7 +73,7 @@ class HipBackend:
             self._x = torch.empty(need, dtype=torch.float32, device=self.model.device)
         x = self._x[:need].view(nb, 1, dmap.hp, dmap.wp)
         st = _lib.stream_ptr()
-        check(lib.vs_slices_gather(ptr(self.vol), dmap, s0, nb, ptr(x), st))
+        check(lib.vs_slices_gather_typed(self.vtype, ptr(self.vol), dmap, s0, nb, ptr(x), st))
         # forward + softmax / arg-max / crop / scatter in one call: with <= 4 classes the head kernel writes labels /
         # probabilities / keys itself and no logits exist (identical results to vs_unet_forward + vs_logits_to_volume)
         self.model._forward_to_volume(x, dmap, s0, self.mode, direction, self.labels, self.probs, self.keys, self.votes, self.nvox)
@@ -122,19 +123,19 @@ class VolSeg2dPredictor:
 
     # ---- engine ---------------------------------------------------------------------------------------------
     @staticmethod
-    def _as_uint8(data_vol: np.ndarray) -> np.ndarray:
-        """The device path reads a uint8 volume (the reference's default: clip_data -> uint8,
-        data/base_data_manager.py:38-40).  Other integer volumes whose values fit a byte are cast losslessly (the
-        reference divides every integer dtype by 255, data/datasets.py:128-131)."""
-        if data_vol.dtype == np.uint8:
-            return np.ascontiguousarray(data_vol)
-        if np.issubdtype(data_vol.dtype, np.integer) and data_vol.size and 0 <= data_vol.min() and data_vol.max() <= 255:
-            return np.ascontiguousarray(data_vol.astype(np.uint8))
-        raise NotImplementedError(
-            f"the HIP prediction path takes uint8 volumes (got {data_vol.dtype}); enable clip_data or convert first")
+    def _device_volume(data_vol: np.ndarray) -> np.ndarray:
+        """The volume as the device reads it: C-contiguous, in its OWN dtype.  The reference normalises every integer dtype
+        as float32(v) / 255 and passes float volumes through without the / 255 (data/datasets.py:128-134) - reachable with
+        ``clip_data: False`` - and vs_slices_gather_typed does the same per type; uint8 (clip_data's output,
+        data/base_data_manager.py:38-40) is the common case."""
+        if data_vol.dtype.name not in _lib.VS_VOL:
+            raise TypeError(f"prediction volumes of dtype {data_vol.dtype} are not supported "
+                            f"(supported: {', '.join(sorted(_lib.VS_VOL))})")
+        vol = np.ascontiguousarray(data_vol)
+        return vol if vol.dtype.isnative else vol.astype(vol.dtype.newbyteorder("="))
 
     def _run(self, data_vol: np.ndarray, n_dirs: int, mode: int, want_probs: bool, first_axis: Axis = Axis.Z):
-        vol = self._as_uint8(data_vol)
+        vol = self._device_volume(data_vol)
         if vol.ndim != 3:
             raise ValueError(f"expected a 3-D volume, got shape {vol.shape}")
         rank, world = vdist.world()

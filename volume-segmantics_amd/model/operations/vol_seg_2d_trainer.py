@@ -54,7 +54,7 @@ class VolSeg2dTrainer:
 
     # ---- construction helpers -------------------------------------------------------------------------------
     def _get_model_struc_dict(self, settings):
-        d = settings.model
+        d = settings.model     # (the reference fills in the caller's dict too, vol_seg_2d_trainer.py:78-84)
         d["type"] = utils.get_model_type(settings)
         d["in_channels"] = cfg.MODEL_INPUT_CHANNELS
         d["classes"] = self.label_no

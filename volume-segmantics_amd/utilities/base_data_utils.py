@@ -126,6 +126,10 @@ def one_hot_encode_array(input_array: np.ndarray, num_labels: int) -> np.ndarray
 
 def prepare_training_batch(batch, device, num_labels: int):
     """:150-158 - images to the device, masks to one-hot (B,K,H,W) uint8 (built on the device here)."""
+    if batch[1].numel() and not batch[1].is_cuda and int(batch[1].max()) >= num_labels:
+        # torch.nn.functional.one_hot in the reference raises here (e.g. 0/255 PNG masks with 2 labels); the device kernel
+        # would silently give such pixels an all-zero target
+        raise RuntimeError("Class values must be smaller than num_classes.")
     inputs = batch[0].to(device, non_blocking=True)
     masks = batch[1].to(device, non_blocking=True)
     if masks.is_cuda and masks.dtype == torch.uint8 and num_labels <= 255:
