@@ -91,3 +91,104 @@ def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
     depths[3:6] = [32, 29, 40]; depths[9:12] = [32, 29, 40]   # rot90 / rot270 volumes have shape (Y, Z, X)
     for d in range(12):
         assert r0["shares"][d][0] == 0 and r0["shares"][d][1] == r1["shares"][d][0] and r1["shares"][d][1] == depths[d]
+
+
+# ---- data-parallel VolSeg2dTrainer: shards, shared decisions, early stop on every rank ---------------------------------------
+def _trainer_data(n_train=48, n_valid=21, size=32):
+    """Training slices whose label is a threshold of the image; validation slices with the INVERTED labels, so the validation
+    loss rises as training fits the training rule - an early stop is certain."""
+    rng = np.random.default_rng(0)
+    field = rng.standard_normal((n_train + n_valid, size, size)).astype(np.float32)
+    for ax in (1, 2):
+        field = (np.roll(field, 1, ax) + field + np.roll(field, -1, ax)) / 3
+    imgs = np.clip(128 + 200 * field, 0, 255).astype(np.uint8)
+    masks = (field > 0.05).astype(np.uint8)
+    masks[n_train:] = 1 - masks[n_train:]
+    return imgs, masks, n_train
+
+
+def _trainer_settings():
+    return SimpleNamespace(starting_lr=1e-5, end_lr=5.0, lr_find_epochs=1, lr_reduce_factor=500, cuda_device=0, patience=1,
+                           loss_criterion="DiceLoss", alpha=0.75, beta=0.25, eval_metric="MeanIoU", pct_lr_inc=0.3,
+                           plot_lr_graph=False, image_size=32, training_set_proportion=0.8,
+                           model={"type": "U_Net", "encoder_name": "resnet34", "encoder_weights": None})
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      VOLSEG_DIST_TIMEOUT_S="180")
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from volume_segmantics_amd import dist as vdist
+    from volume_segmantics_amd.data.datasets import ArraySliceDataset, make_training_loaders
+    from volume_segmantics_amd.model.operations import vol_seg_2d_trainer as T
+    assert vdist.init_from_env("gloo")[:2] == (rank, world)
+
+    def tiny_model(device_num, struct):          # stands in for the GPU engine: a small conv net, seeded per rank (rank 0's
+        torch.manual_seed(100 + rank)            # weights must win through the broadcast)
+        return torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(8, struct["classes"], 3, padding=1))
+    T.create_model_on_device = tiny_model
+    imgs, masks, cut = _trainer_data()
+    seen = []
+
+    class Recording(ArraySliceDataset):
+        def __getitem__(self, i):
+            seen.append(int(i))
+            return super().__getitem__(i)
+    loaders = make_training_loaders(Recording(imgs[:cut], masks[:cut]), ArraySliceDataset(imgs[cut:], masks[cut:]), 4, rank, world, seed=7)
+    tr = T.VolSeg2dTrainer(None, None, {"bg": 0, "fg": 1}, _trainer_settings(), loaders=loaders)
+    assert (tr.rank, tr.world) == (rank, world) and len(tr.training_loader) == 48 // (4 * world)
+    out = Path(out_dir) / "dp.pytorch"
+    tr.train_model(out, 12, 1, create=True, frozen=False)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()] + [b.detach().reshape(-1).float() for b in tr.model.buffers()])
+    first_epoch = seen[:len(tr.training_loader) * 4]        # the LR finder's epoch (epoch 0 of the sampler)
+    np.savez(Path(out_dir) / f"t{rank}.npz", flat=flat.numpy(), epochs=len(tr.avg_valid_losses), valid=np.array(tr.avg_valid_losses),
+             train=np.array(tr.avg_train_losses), first_epoch=np.array(first_epoch), lr=tr.optimizer.param_groups[0]["lr"])
+    dist.destroy_process_group()
+
+
+def _spawn(fn, world, tmp_path):
+    for attempt in range(2):   # the port is free when picked, not necessarily when the store binds it: one retry
+        try:
+            mp.spawn(fn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+            return
+        except Exception as e:   # only the bind race is retried
+            if attempt or not any(m in str(e) for m in ("Address already in use", "EADDRINUSE", "address already in use")):
+                raise
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_trainer_shards_decides_and_stops_together(tmp_path, world):
+    """train_model at world size 2 and 3 (LR finder -> one-cycle training -> early stop -> reload): the ranks' shards of an
+    epoch are disjoint and cover the global batches, every rank sees the same epoch losses, stops in the same epoch (no rank
+    is left waiting in a collective) and ends with bit-identical weights."""
+    _spawn(_trainer_worker, world, tmp_path)
+    rs = [np.load(tmp_path / f"t{r}.npz") for r in range(world)]
+    assert (tmp_path / "dp.pytorch").exists()
+    for r in rs[1:]:
+        assert int(r["epochs"]) == int(rs[0]["epochs"]) and np.array_equal(r["valid"], rs[0]["valid"]) and np.array_equal(r["train"], rs[0]["train"])
+        assert np.array_equal(r["flat"], rs[0]["flat"])                  # same weights (reloaded best checkpoint) on every rank
+    assert 2 <= int(rs[0]["epochs"]) < 12                                 # the inverted validation labels forced an early stop
+    shards = [set(r["first_epoch"].tolist()) for r in rs]
+    n_used = (48 // (4 * world)) * 4 * world
+    assert all(len(s) == n_used // world for s in shards)
+    assert len(set().union(*shards)) == n_used                            # disjoint, and together the epoch's global batches
+
+
+def test_sharded_batch_sampler_partitions_global_batches():
+    from volume_segmantics_amd.data.datasets import ShardedBatchSampler
+    for world in (1, 2, 3):
+        per_rank = [list(ShardedBatchSampler(50, 4, r, world, shuffle=True, drop_last=True, seed=3)) for r in range(world)]
+        assert len({len(p) for p in per_rank}) == 1 and len(per_rank[0]) == 50 // (4 * world)
+        ref = list(ShardedBatchSampler(50, 4 * world, 0, 1, shuffle=True, drop_last=True, seed=3))   # the one-process loader
+        for step, glob in enumerate(ref):
+            assert sum((p[step] for p in per_rank), []) == glob          # the ranks' shards, in rank order, ARE the global batch
+        val = [list(ShardedBatchSampler(21, 4, r, world, shuffle=False, drop_last=False)) for r in range(world)]
+        assert len({len(v) for v in val}) == 1                            # the same number of iterations on every rank
+        assert sorted(sum((sum(v, []) for v in val), [])) == list(range(21))
+    s = ShardedBatchSampler(50, 4, 0, 2, seed=3)
+    a = list(s); s.set_epoch(1); b = list(s)
+    assert a != b and len(a) == len(b)

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_data_parallel_fused_step_matches_plain_step():
+def _torchrun(worker, *args):
     import socket
     repo = Path(__file__).resolve().parents[1]
     with socket.socket() as sock:
@@ -19,6 +19,18 @@ def test_two_rank_data_parallel_fused_step_matches_plain_step():
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(repo / "tests" / "dp_rehearsal_worker.py")]
-    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", str(port), str(repo / "tests" / worker), *args]
+    return subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_two_rank_data_parallel_fused_step_matches_plain_step():
+    r = _torchrun("dp_rehearsal_worker.py")
     assert r.returncode == 0 and "DP_REHEARSAL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_two_rank_trainer_runs_through_an_early_stop_with_identical_weights(tmp_path):
+    """VolSeg2dTrainer.train_model at world size 2 on the HIP engine (tests/dp_trainer_worker.py): disjoint shards of each
+    global batch, the LR finder's learning rate and the early stop decided on all-reduced losses, rank 0 writes the
+    checkpoint, both ranks reload it and end with bit-identical parameters and running statistics."""
+    r = _torchrun("dp_trainer_worker.py", str(tmp_path))
+    assert r.returncode == 0 and "DP_TRAINER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

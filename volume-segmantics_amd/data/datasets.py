@@ -104,15 +104,78 @@ class ArraySliceDataset(Dataset):
         return torch.from_numpy(normalise(self.images[i]).astype(np.float32)).unsqueeze(0), torch.from_numpy(self.masks[i])
 
 
-def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings):
-    """80/20 random split, drop_last training loader (dataloaders.py:15-57)."""
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """The reference's ONE loader (shuffle, drop_last; data/dataloaders.py:42-57) seen from ``world`` data-parallel ranks:
+    every rank draws the SAME permutation (generator seeded with ``seed + epoch``), cuts it into global batches of
+    ``batch_size * world`` samples and takes its own contiguous ``batch_size`` of each - disjoint shards that together are the
+    global batch.  ``drop_last`` acts on the GLOBAL batch, so every rank runs the same number of steps (a rank that ran one
+    step more would wait in an all-reduce for ever).  Without ``drop_last`` (validation) the last, partial global batch is
+    dealt out as evenly as possible and a rank may receive an empty list for it.  ``set_epoch`` reshuffles."""
+
+    def __init__(self, n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = True, drop_last: bool = True,
+                 seed: int = 0):
+        self.n, self.batch_size, self.rank, self.world = int(n), int(batch_size), int(rank), int(world)
+        self.shuffle, self.drop_last, self.seed, self.epoch = shuffle, drop_last, int(seed), 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        g = self.batch_size * self.world
+        return self.n // g if self.drop_last else (self.n + g - 1) // g
+
+    def __iter__(self):
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        g = self.batch_size * self.world
+        for b in range(len(self)):
+            chunk = order[b * g:(b + 1) * g]
+            if len(chunk) == g:
+                yield chunk[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+            else:   # partial last global batch (validation): shares differ by at most one sample
+                base, rem = divmod(len(chunk), self.world)
+                lo = self.rank * base + min(self.rank, rem)
+                yield chunk[lo:lo + base + (1 if self.rank < rem else 0)]
+
+
+def _collate_maybe_empty(batch):
+    if not batch:    # this rank's share of a partial validation batch is empty: the trainer skips it (weight 0)
+        return None
+    return torch.utils.data.default_collate(batch)
+
+
+def make_training_loaders(train_ds, valid_ds, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0, **loader_kw):
+    """(training loader, validation loader) over the two datasets for rank ``rank`` of ``world`` (see ShardedBatchSampler;
+    world == 1 is exactly the reference's shuffle + drop_last loader pair)."""
+    ts = ShardedBatchSampler(len(train_ds), batch_size, rank, world, shuffle=True, drop_last=True, seed=seed)
+    vs = ShardedBatchSampler(len(valid_ds), batch_size, rank, world, shuffle=False, drop_last=False)
+    return (DataLoader(train_ds, batch_sampler=ts, **loader_kw),
+            DataLoader(valid_ds, batch_sampler=vs, collate_fn=_collate_maybe_empty, **loader_kw))
+
+
+def shared_seed(rank: int, world: int) -> int:
+    """A random seed that is the same on every rank: rank 0 draws it (the reference's split is unseeded), the others receive it."""
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+    if world > 1:
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        seed = seed.to(dev)
+        dist.broadcast(seed, 0)
+    return int(seed.item())
+
+
+def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings, rank: int = 0, world: int = 1):
+    """80/20 random split, shuffled drop_last training loader (dataloaders.py:15-57).  With several ranks: the same split on
+    every rank (one shared seed), disjoint shards of every global batch (batch_size is per rank)."""
     batch_size = utils.get_batch_size(settings)
     train_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=True)
     valid_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=False)
     n = len(train_full)
-    indices = torch.randperm(n).tolist()
+    seed = shared_seed(rank, world)
+    indices = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
     cut = int(n * settings.training_set_proportion)
     workers = int(getattr(settings, "num_workers", cfg.NUM_WORKERS))
-    common = dict(batch_size=batch_size, num_workers=workers, pin_memory=cfg.PIN_CUDA_MEMORY and torch.cuda.is_available())
-    return (DataLoader(Subset(train_full, indices[:cut]), shuffle=True, drop_last=True, **common),
-            DataLoader(Subset(valid_full, indices[cut:]), shuffle=False, **common))
+    return make_training_loaders(Subset(train_full, indices[:cut]), Subset(valid_full, indices[cut:]), batch_size, rank, world,
+                                 seed=seed + 1, num_workers=workers, pin_memory=cfg.PIN_CUDA_MEMORY and torch.cuda.is_available())

@@ -58,3 +58,58 @@ def allreduce_sum_votes(votes: torch.Tensor, group=None) -> None:
     if world()[1] == 1:
         return
     dist.all_reduce(votes, op=dist.ReduceOp.SUM, group=group)
+
+
+def _scalar_device(group=None) -> torch.device:
+    """Where a tensor must live to be reduced by the group's backend (RCCL reduces device memory only)."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def allreduce_sums(values, group=None) -> list[float]:
+    """Elementwise SUM over ranks of a few host scalars (float64), returned to the host: the trainer's loss / metric
+    bookkeeping.  Every rank receives the same numbers, so decisions taken on them (learning rate from the LR finder, early
+    stopping) are the same on every rank by construction.  Identity for a single process."""
+    vals = [float(v) for v in values]
+    if world()[1] == 1:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=_scalar_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(v) for v in t.cpu()]
+
+
+def mean_scalar(value: float, group=None) -> float:
+    """Mean of one host scalar over the ranks (the LR finder's per-step loss)."""
+    w = world()[1]
+    return allreduce_sums([value], group)[0] / w if w > 1 else float(value)
+
+
+def barrier() -> None:
+    if world()[1] > 1:
+        dist.barrier()
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
+    """Parameters and buffers of a plain nn.Module from rank ``src`` (the engine broadcasts its two flat buffers instead)."""
+    if world()[1] == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def average_gradients(module: torch.nn.Module) -> None:
+    """Mean of every parameter gradient over the ranks, for models that do not all-reduce inside backward (the engine does)."""
+    w = world()[1]
+    if w == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= w
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()

@@ -2,14 +2,21 @@
 (reference: volume_segmantics/model/operations/vol_seg_2d_trainer.py:35-535).
 
 The training step is the reference's ``_train_one_batch`` (:419-432); the model behind it is the HIP engine and the
-optimiser is its fused AdamW (same update rule, one kernel over the flat parameter buffer).  With a process group
-initialised (torchrun) every rank trains on its own shard of each minibatch and the flat gradient is all-reduced over
-RCCL inside ``loss.backward()``."""
+optimiser is its fused AdamW (same update rule, one kernel over the flat parameter buffer).
+
+Data parallel (torchrun, one process per GPU): the reference has ONE shuffled loader and ONE decision maker
+(data/dataloaders.py:42-57; vol_seg_2d_trainer.py:189-205,265-274).  Here every rank draws the same permutation and takes
+its own disjoint shard of every global batch (ShardedBatchSampler; ``batch_size`` is per rank), the flat gradient is
+all-reduced over RCCL inside ``loss.backward()``, and every number a decision hangs on - the LR finder's smoothed loss,
+the epoch's validation loss - is the all-reduced value, so all ranks pick the same learning rate and stop in the same
+epoch; rank 0 writes the checkpoint, a barrier follows, every rank reloads it.  BatchNorm statistics stay per rank (as
+torch's DistributedDataParallel without SyncBatchNorm)."""
 from __future__ import annotations
 
 import csv
 import logging
 import math
+import os
 import sys
 import time
 from pathlib import Path
@@ -35,8 +42,11 @@ class VolSeg2dTrainer:
     def __init__(self, image_dir_path: Path, label_dir_path: Path, labels: Union[int, dict], settings: SimpleNamespace,
                  loaders=None):
         """``loaders`` = (training_loader, validation_loader) bypasses the PNG directories (synthetic data, tests)."""
+        # torchrun environment -> process group (RCCL); a single process, or a group the caller has set up already, is left alone
+        self.rank, self.world, local_rank = vdist.init_from_env()
+        self.rank, self.world = vdist.world()
         if loaders is None:
-            loaders = get_2d_training_dataloaders(image_dir_path, label_dir_path, settings)
+            loaders = get_2d_training_dataloaders(image_dir_path, label_dir_path, settings, self.rank, self.world)
         self.training_loader, self.validation_loader = loaders
         self.label_no = labels if isinstance(labels, int) else len(labels)
         self.codes = labels if isinstance(labels, dict) else {}
@@ -45,7 +55,9 @@ class VolSeg2dTrainer:
         self.log_lr_ratio = self._calculate_log_lr_ratio()
         self.lr_find_epochs = settings.lr_find_epochs
         self.lr_reduce_factor = settings.lr_reduce_factor
-        self.model_device_num = int(settings.cuda_device)
+        # one GPU per rank (LOCAL_RANK); VOLSEG_DP_SINGLE_DEVICE=1 keeps every rank on settings.cuda_device (rehearsals on one GPU)
+        self.model_device_num = (local_rank if self.world > 1 and not os.environ.get("VOLSEG_DP_SINGLE_DEVICE")
+                                 else int(settings.cuda_device))
         self.patience = settings.patience
         self.loss_criterion = self._get_loss_criterion()
         self.eval_metric = self._get_eval_metric()
@@ -91,11 +103,14 @@ class VolSeg2dTrainer:
     def _create_model_and_optimiser(self, learning_rate, frozen=False):
         logging.info(f"Setting up the model on device {self.settings.cuda_device}.")
         self.model = create_model_on_device(self.model_device_num, self.model_struc_dict)
-        if vdist.world()[1] > 1:
+        if self.world > 1:   # every rank starts from rank 0's weights
             import torch.distributed as dist
-            dist.broadcast(self.model._flat, 0)
-            dist.broadcast(self.model._bnstate, 0)
-            self.model.dp_group = dist.group.WORLD
+            if isinstance(self.model, VolSegUnet):
+                dist.broadcast(self.model._flat, 0)
+                dist.broadcast(self.model._bnstate, 0)
+                self.model.dp_group = dist.group.WORLD
+            else:
+                vdist.broadcast_module(self.model)
         if frozen:
             self._freeze_model()
         logging.info(f"Model has {self._count_trainable_parameters()} trainable parameters, "
@@ -139,7 +154,9 @@ class VolSeg2dTrainer:
     def _create_early_stopping(self, output_path, patience, best_score=None):
         struct = dict(self.model_struc_dict)
         struct["type"] = reference_pickle_enum(struct["type"])  # checkpoint readable by the reference
-        return EarlyStopping(patience=patience, verbose=True, path=output_path, model_dict=struct, best_score=best_score)
+        es = EarlyStopping(patience=patience, verbose=True, path=output_path, model_dict=struct, best_score=best_score)
+        es.write = self.rank == 0
+        return es
 
     # ---- the hot loop ---------------------------------------------------------------------------------------
     def _loss(self, output, targets):
@@ -149,8 +166,12 @@ class VolSeg2dTrainer:
             return self.loss_criterion(output, targets)   # reads the uint8 one-hot directly
         return self.loss_criterion(output, targets.float())
 
+    def _device(self):
+        dev = getattr(self.model, "device", None)
+        return dev if dev is not None else next(self.model.parameters()).device
+
     def _train_one_batch(self, lr_scheduler, batch):
-        inputs, targets = utils.prepare_training_batch(batch, self.model.device, self.label_no)
+        inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no)
         fuse = getattr(self.model, "can_fuse_step", None)
         if fuse is not None and isinstance(self.loss_criterion, HipDiceLoss) and fuse(self.optimizer, inputs, targets):
             # the whole step (zero_grad .. optimizer.step) as one replayed hipGraph - same kernels, same order, same bits
@@ -161,6 +182,8 @@ class VolSeg2dTrainer:
         output = self.model(inputs)
         loss = self._loss(output, targets)
         loss.backward()
+        if self.world > 1 and not isinstance(self.model, VolSegUnet):
+            vdist.average_gradients(self.model)     # (the engine all-reduces its flat gradient inside backward)
         self.optimizer.step()
         lr_scheduler.step()
         return loss
@@ -184,30 +207,36 @@ class VolSeg2dTrainer:
         for epoch in range(1, num_epochs + 1):
             self.model.train()
             tic = time.perf_counter()
+            self._set_epoch(self._epochs_run)
             for batch in self.training_loader:
                 train_losses.append(self._train_one_batch(lr_scheduler, batch).item())
             self.model.eval()
             with torch.no_grad():
                 for batch in self.validation_loader:
-                    inputs, targets = utils.prepare_training_batch(batch, self.model.device, self.label_no)
+                    if batch is None:      # this rank's share of the last, partial global batch is empty
+                        continue
+                    inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no)
                     output = self.model(inputs)
                     valid_losses.append(self._loss(output, targets).item())
                     metric = getattr(self.eval_metric, "from_logits", None)   # MeanIoU: softmax + metric in one HIP sweep
                     eval_scores.append(float(metric(output, targets) if metric else self.eval_metric(torch.softmax(output, dim=1), targets)))
-            self.avg_train_losses.append(np.average(train_losses))
-            self.avg_valid_losses.append(np.average(valid_losses))
-            self.avg_eval_scores.append(np.average(eval_scores))
+            # epoch averages over ALL ranks' batches: every rank holds the same numbers, so the early-stopping decision below
+            # is the same everywhere (the reference has one process: np.average over its own lists)
+            sums = vdist.allreduce_sums([sum(train_losses), len(train_losses), sum(valid_losses), len(valid_losses),
+                                         sum(eval_scores), len(eval_scores)])
+            self.avg_train_losses.append(sums[0] / max(sums[1], 1))
+            self.avg_valid_losses.append(sums[2] / max(sums[3], 1))
+            self.avg_eval_scores.append(sums[4] / max(sums[5], 1))
             logging.info(f"Epoch {epoch}. Training loss: {self.avg_train_losses[-1]}, Validation Loss: "
                          f"{self.avg_valid_losses[-1]}. {self.settings.eval_metric}: {self.avg_eval_scores[-1]}")
             logging.info(f"Time taken for epoch {epoch}: {time.perf_counter() - tic:0.2f} seconds")
             train_losses, valid_losses, eval_scores = [], [], []
-            if vdist.world()[0] == 0:
-                early_stopping(self.avg_valid_losses[-1], self.model, self.optimizer, self.codes)
+            early_stopping(self.avg_valid_losses[-1], self.model, self.optimizer, self.codes)   # rank 0 writes (EarlyStopping.write)
+            vdist.barrier()                     # the file is complete before any rank goes on (and may read it)
             if early_stopping.early_stop:
                 logging.info("Early stopping")
                 break
-        if vdist.world()[0] == 0 or vdist.world()[1] == 1:
-            self._load_in_weights(output_path)
+        self._load_in_weights(output_path)      # every rank continues from the best checkpoint
 
     def _load_in_model_and_optimizer(self, learning_rate, output_path, frozen=False, optimizer=False):
         self._create_model_and_optimiser(learning_rate, frozen=frozen)
@@ -230,12 +259,23 @@ class VolSeg2dTrainer:
         logging.info(f"LR to use {lr_to_use}")
         return lr_to_use
 
+    def _set_epoch(self, epoch: int) -> None:
+        self._epochs_run = epoch + 1
+        sampler = getattr(self.training_loader, "batch_sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)           # a new shared permutation (ShardedBatchSampler)
+
+    _epochs_run = 0
+
     def _lr_finder(self, lr_scheduler, smoothing=0.05):
         losses, lrs, iters = [], [], 0
         self.model.train()
         for _ in range(self.lr_find_epochs):
+            self._set_epoch(self._epochs_run)
             for batch in self.training_loader:
                 loss = self._train_one_batch(lr_scheduler, batch).detach()
+                if self.world > 1:   # the mean over the ranks' shards: the same curve, break point and learning rate everywhere
+                    loss = torch.tensor(vdist.mean_scalar(float(loss)))
                 lrs.append(self.optimizer.param_groups[0]["lr"])
                 if iters:
                     loss = smoothing * loss + (1 - smoothing) * losses[-1]
@@ -292,7 +332,7 @@ class VolSeg2dTrainer:
         self.model.eval()
         batch = next(iter(self.validation_loader))
         with torch.no_grad():
-            inputs, targets = utils.prepare_training_batch(batch, self.model.device, self.label_no)
+            inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no)
             labels = torch.argmax(torch.softmax(self.model(inputs), dim=1), dim=1)
         try:
             import matplotlib

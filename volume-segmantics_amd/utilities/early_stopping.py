@@ -17,6 +17,7 @@ class EarlyStopping:
         self.best_score = best_score
         self.val_loss_min = np.inf if best_score is None else -best_score
         self.counter, self.early_stop = 0, False
+        self.write = True    # data-parallel runs: every rank takes the decisions (on the same reduced loss), rank 0 writes the file
 
     def __call__(self, val_loss, model, optimizer, label_codes):
         score = -val_loss
@@ -29,6 +30,9 @@ class EarlyStopping:
         self.save_checkpoint(val_loss, model, optimizer, label_codes)
 
     def save_checkpoint(self, val_loss, model, optimizer, label_codes):
+        if not self.write:
+            self.val_loss_min = val_loss
+            return
         if self.verbose:
             logging.info(f"Validation loss decreased ({self.val_loss_min:.6f} --> {val_loss:.6f}).  Saving model ...")
         ckpt = {"model_state_dict": model.state_dict(), "model_struc_dict": self.model_struc_dict,
