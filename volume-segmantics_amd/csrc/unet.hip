@@ -631,10 +631,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     if (use_side) {
         for (int i = 0; i < vs_unet::kSide; ++i) {
             if (net->side[i]) continue;
-            // side_prio: 0 = default priority; 1 = lowest (the caller's stream is the critical path: its kernels should win CUs)
-            int lo = 0, hi = 0;
-            VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));    // lo = numerically greatest = lowest priority
-            VS_CHECK_HIP(hipStreamCreateWithPriority(&net->side[i], hipStreamNonBlocking, vs_option("side_prio") ? lo : 0));
+            VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
             VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
         }
         while (net->fork_events.size() < net->units.size()) {
