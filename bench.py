@@ -44,12 +44,12 @@ def synth_batch(batch: int, size: int, classes: int, seed: int):
     return torch.from_numpy(x).unsqueeze(1), torch.from_numpy(lab)
 
 
-def load_traffic(kernel_name: str):
+def load_traffic(kernel_name: str, workload: str = "train"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/r*_pmc_traffic.json, made by
     tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command with the gfx950 FETCH_SIZE x2
     correction), or None.  Counters cannot be read from inside the timed process, so the figure is a committed measurement:
     the entry carries its source file so that it cannot pass for a live one."""
-    for f in sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+    for f in sorted((REPO / "profiles").glob(f"r*_pmc_traffic{'' if workload == 'train' else '_' + workload}.json"), reverse=True):
         try:
             t = json.loads(f.read_text()).get(kernel_name)
         except Exception:
@@ -64,6 +64,10 @@ def dice_loss(output, target, eps=1e-6):
     inter = (output * target).sum((0, 2, 3))
     denom = (output * output).sum((0, 2, 3)) + (target * target).sum((0, 2, 3))
     return 1.0 - torch.mean(2 * (inter / denom.clamp(min=eps)))
+
+
+def rank_is_zero() -> bool:
+    return int(os.environ.get("RANK", "0")) == 0
 
 
 def usable_cpus() -> int:
@@ -109,6 +113,67 @@ def cpu_baseline(batch: int, steps: int):
     return {"value": round(batch * steps / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
             "sample": f"{steps} fwd+bwd+AdamW steps, batch {batch} (reference default), 256x256, fp32, torch CPU "
                       f"({torch.get_num_threads()} threads) after 1 warm-up step"}
+
+
+def cpu_baseline_predict():
+    """BASELINE.md section 3, prediction legs: the oracle's _predict_single_axis (batch 4, the reference's default) on 16
+    slices of 256^2 (2 classes) and 512^2 (4 classes), and ONE _merge_vols_in_mem-equivalent NumPy merge
+    (vol_seg_2d_predictor.py:90-98: argmax over the two slots -> int64 index volume -> two take_along_axis) at 256^3 and
+    512^3; extrapolated linearly to the full volumes and marked as extrapolated."""
+    from oracle import predictor_numpy as P
+    from oracle.unet_resnet34_torch import seeded_oracle
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    out = {"cores": cores, "kind": "port", "batch": 4}
+    rng = np.random.default_rng(5)
+    for size, classes in ((256, 2), (512, 4)):
+        net = seeded_oracle(classes, 0).eval()
+        vol = rng.integers(0, 256, (16, size, size), dtype=np.uint8)
+        P.predict_single_axis(net, vol[:4], 0, batch_size=4)            # warm-up
+        t0 = time.perf_counter()
+        P.predict_single_axis(net, vol, 0, batch_size=4)
+        dt = time.perf_counter() - t0
+        out[f"predict_{size}sq_slices_per_s"] = round(16 / dt, 2)
+        log(f"cpu predict {size}^2: {16 / dt:.2f} slices/s")
+    for cube in (256, 512):
+        n = cube ** 3
+        prob = rng.random((2, cube, cube, cube), dtype=np.float32).astype(np.float16)
+        lab = rng.integers(0, 4, (2, cube, cube, cube), dtype=np.uint8)
+        t0 = time.perf_counter()
+        P.merge_vols_in_mem(prob, lab)
+        dt = time.perf_counter() - t0
+        out[f"merge_{cube}cube_s"] = round(dt, 3)
+        log(f"cpu merge {cube}^3: {dt:.2f} s")
+        del prob, lab
+    out["extrapolated"] = {
+        "predict_256cube_low_2class_s": round(256 / out["predict_256sq_slices_per_s"], 1),
+        "predict_512cube_12way_4class_s": round(6144 / out["predict_512sq_slices_per_s"] + 11 * out["merge_512cube_s"], 1),
+        "note": "16-slice samples scaled linearly to 256 / 6144 slices, plus 11 merges at the measured 512^3 merge time"}
+    out["sample"] = (f"oracle eval forward + softmax/argmax/max-prob, batch 4, 16 slices each of 256^2 (2 classes) and 512^2 (4 classes); "
+                     f"one NumPy pairwise merge at 256^3 and at 512^3; torch CPU fp32, {cores} threads")
+    return out
+
+
+def gemm_crosscheck(dev):
+    """A measured library bf16 GEMM next to the 2.5 PF vendor peak the roofline fractions use: 8192^3
+    torch.matmul (hipBLASLt / rocBLAS under PyTorch-ROCm) on uniform random operands, HIP-event timed."""
+    n = 8192
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        torch.matmul(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+    return {"what": "torch.matmul bf16 8192^3 (library GEMM, random operands)", "ms": round(ms, 3), "tflops": round(tf, 1),
+            "frac_of_vendor_peak": round(tf / MFMA_PEAK_BF16_TFLOPS, 4)}
 
 
 def synth_volume(n: int, seed: int) -> np.ndarray:
@@ -162,13 +227,47 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
         dt = tt.item()
     if labels is None:
         labels = np.zeros(1, np.uint8)
+    phases = dict(pred.last_timings)     # of the timed call (the instrumented pass below overwrites them)
+    roof = None
+    if rank_is_zero() and cube >= 512:
+        # roofline of the prediction's dominant kernel: HIP events around every launch of ONE direction (cube slices) on the
+        # launch stream, grouped by kernel instantiation
+        from volume_segmantics_amd import _lib
+        _lib.check(_lib.lib.vs_profile_enable(1))
+        pred._predict_single_axis(vol, output_probs=True)
+        torch.cuda.synchronize()
+        raw = _lib.profile_read_raw(1 << 18)
+        _lib.check(_lib.lib.vs_profile_enable(0))
+        byvar, total_ms = {}, 0.0
+        for kind, tag, ms, fl, by, var in raw:
+            total_ms += ms
+            if kind == "conv_fwd" and var:
+                v = byvar.setdefault(var, [0.0, 0.0, 0])
+                v[0] += ms; v[1] += fl; v[2] += 1
+        if byvar:
+            dv = max(byvar, key=lambda q: byvar[q][0])
+            dms, dfl, dn = byvar[dv]
+            tname = "unsigned short" if precision == "bf16" else "float"
+            code = dv % 10
+            name = (f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, 1, 8>" if code == 8 else
+                    f"conv_direct_kernel<{tname}, 16, 0>" if code == 4 else
+                    f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, {code}, 4>")
+            ach = dfl / (dms * 1e-3) / 1e12
+            tr = load_traffic(name, "predict")
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
+                    "avg_launch_ms": round(dms / dn, 5), "launches_per_direction": dn,
+                    "algorithmic_gflop_per_launch": round(dfl / dn / 1e9, 3), "share_of_kernel_time": round(dms / total_ms, 3),
+                    "all_conv_tflops": round(sum(v[1] for v in byvar.values()) / (sum(v[0] for v in byvar.values()) * 1e-3) / 1e12, 1),
+                    "note": "one direction (512 slices, batch 64) with HIP events around every launch; flops = 2 x MACs of the layers this instantiation serves"}
     n_slices = n_dirs * cube
     flop = {(256, 2): 15.44e9, (512, 4): 61.92e9}.get((cube, classes), 0.0) * n_slices
     return {"seconds": round(dt, 4), "slices": n_slices, "slices_per_s": round(n_slices / dt, 1),
             "mfma_frac": round(flop / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world, 4), "batch": batch,
             "label_hist": np.bincount(labels.ravel(), minlength=classes).tolist(),
-            "phases_rank0": {k: round(v, 4) for k, v in pred.last_timings.items()},
-            "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs"}
+            "phases_rank0": {k: round(v, 4) for k, v in phases.items()},
+            "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs",
+            **({"roofline": roof} if roof else {})}
 
 
 def merge_bench(dev, cube: int = 512, reps: int = 11):
@@ -207,7 +306,7 @@ def main():
     ap.add_argument("--step-mode", default="auto", choices=["auto", "graph", "eager"],
                     help="graph: replay the recorded step (hipGraphs); eager: enqueue every step call by call; auto: time both "
                          "during the untimed set-up and keep the faster one on this box")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
     ap.add_argument("--per-unit", default="", help="write a per-layer kernel-time table (instrumented steps) to this file")
     args = ap.parse_args()
@@ -447,8 +546,11 @@ def main():
             "kernel_classes": breakdown,
             **predict,
         }
+        out["peak_crosscheck"] = gemm_crosscheck(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(12, args.cpu_steps)
+            if not args.no_predict:
+                out["cpu_baseline_predict"] = cpu_baseline_predict()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
