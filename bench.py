@@ -229,7 +229,7 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
         labels = np.zeros(1, np.uint8)
     phases = dict(pred.last_timings)     # of the timed call (the instrumented pass below overwrites them)
     roof = None
-    if rank_is_zero() and cube >= 512:
+    if cube >= 512:     # (every rank runs the instrumented pass - it contains the exchange; rank 0 reports it)
         # roofline of the prediction's dominant kernel: HIP events around every launch of ONE direction (cube slices) on the
         # launch stream, grouped by kernel instantiation
         from volume_segmantics_amd import _lib

@@ -11,9 +11,11 @@ class OracleBackend:
     def __init__(self, model, vol_u8, classes, mode, want_probs):
         self.model, self.vol, self.classes, self.mode = model, vol_u8, classes, mode
         n = vol_u8.size
+        self.nvox = n
         self.labels = np.zeros(n, np.uint8)
         self.probs = np.zeros(n, np.float16)
-        self.keys = torch.zeros(n, dtype=torch.int32)
+        self.keys = torch.zeros(vdist.padded_len(n, vdist.world()[1]), dtype=torch.int32)
+        self._merged = None
         self.votes = torch.zeros((classes, n), dtype=torch.uint8)
         self.calls = []
 
@@ -48,9 +50,15 @@ class OracleBackend:
             for c in range(self.classes):
                 v[c][addr] += (lab == c).astype(np.uint8)
 
-    def exchange(self):
+    @staticmethod
+    def _unpack(keys_i32):
+        l, p = P.unpack_key(keys_i32.numpy().view(np.uint32))
+        return torch.from_numpy(l.copy()), torch.from_numpy(p.copy())
+
+    def exchange(self, want_probs=True, all_ranks=True):
+        """The product's exchange (dist.exchange_keys_sharded) with a numpy unpack in place of vs_keys_unpack."""
         if self.mode == 1:
-            vdist.allreduce_max_keys(self.keys)
+            self._merged = vdist.exchange_keys_sharded(self.keys, self._unpack, want_probs, all_ranks)
         elif self.mode == 2:
             vdist.allreduce_sum_votes(self.votes)
 
@@ -58,7 +66,9 @@ class OracleBackend:
         if self.mode == 2:
             return self.votes.numpy().reshape((self.classes,) + tuple(shape)), None
         if self.mode == 1:
-            l, p = P.unpack_key(self.keys.numpy().view(np.uint32))
+            if self._merged is None:
+                self._merged = self._unpack(self.keys)
+            l, p = (None if t is None else t.numpy()[:self.nvox] for t in self._merged)
         else:
             l, p = self.labels, self.probs
-        return l.reshape(shape), (p.reshape(shape) if want_probs else None)
+        return l.reshape(shape), (p.reshape(shape) if (want_probs and p is not None) else None)

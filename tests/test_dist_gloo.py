@@ -44,6 +44,13 @@ def _worker(rank, world, port, out_dir):
     l12, p12 = pred._predict_12_ways_max_probs(vol)
     oh3 = pred._predict_3_ways_one_hot(vol)
     l1, p1 = pred._predict_single_axis(vol)
+    pred.result_ranks = "rank0"            # labels / probabilities gathered on rank 0 only (bench.py's mode)
+    r0 = pred._predict_3_ways_max_probs(vol)
+    assert (r0[0] is None) == (rank != 0)
+    pred.result_ranks = "all"
+    l3, p3 = pred._predict_3_ways_max_probs(vol)
+    if rank == 0:
+        assert np.array_equal(r0[0], l3) and np.array_equal(r0[1].view(np.uint16), p3.view(np.uint16))
     # every rank touched only its own contiguous share of every direction
     calls = backends[0].calls
     per_dir = {}
@@ -61,17 +68,20 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.slow
-def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prediction_and_grad_allreduce(tmp_path, world):
+    """World size 2 and 3: 29 / 32 / 40 slices per direction are not divisible by 3 (uneven shards) and neither is the voxel
+    count (the key volume is padded for the reduce-scatter-shaped exchange)."""
     from oracle import predictor_numpy as P
     from oracle.unet_resnet34_torch import seeded_oracle
     for attempt in range(2):   # the port is free when picked, not necessarily when the store binds it: one retry
         try:
-            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+            mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
             break
         except Exception as e:   # only the bind race is retried: a failed or hung collective in a worker must fail the test
             if attempt or not any(m in str(e) for m in ("Address already in use", "EADDRINUSE", "address already in use")):
                 raise
-    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    rs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     g = np.load(REPO / "tests" / "golden" / "g3_predict_29x64x40_c4.npz")
     vol = g["vol"][:, :32, :]
     net = seeded_oracle(4, 0).eval()
@@ -81,16 +91,19 @@ def test_two_rank_sharded_prediction_and_grad_allreduce(tmp_path):
     ref_l, ref_p = P.predict_12_ways_max_probs(net, vol, batch_size=1)
     ref_oh = P.predict_3_ways_one_hot(net, vol, 4, batch_size=1)
     ref_l1, ref_p1 = P.predict_single_axis(net, vol, 0, batch_size=1)
-    for r in (r0, r1):   # both ranks hold the full merged result, identical to the single-process reference order
+    for r in rs:   # every rank holds the full merged result, identical to the single-process reference order
         assert np.array_equal(r["l12"], ref_l) and np.array_equal(r["p12"].view(np.uint16), ref_p.view(np.uint16))
         assert np.array_equal(r["oh3"], ref_oh)
         assert np.array_equal(r["l1"], ref_l1) and np.array_equal(r["p1"].view(np.uint16), ref_p1.view(np.uint16))
-        assert np.allclose(r["gmean"], 1.5)
+        assert np.allclose(r["gmean"], (world + 1) / 2)
     # shares are disjoint and cover every direction's stack
     depths = [29, 32, 40] * 4
     depths[3:6] = [32, 29, 40]; depths[9:12] = [32, 29, 40]   # rot90 / rot270 volumes have shape (Y, Z, X)
-    for d in range(12):
-        assert r0["shares"][d][0] == 0 and r0["shares"][d][1] == r1["shares"][d][0] and r1["shares"][d][1] == depths[d]
+    for d in range(12):   # contiguous shares in rank order, from 0 to the direction's depth, sizes differing by at most one
+        edges = [0] + [int(r["shares"][d][1]) for r in rs]
+        assert all(int(r["shares"][d][0]) == edges[i] for i, r in enumerate(rs)) and edges[-1] == depths[d]
+        sizes = np.diff(edges)
+        assert sizes.max() - sizes.min() <= 1
 
 
 # ---- data-parallel VolSeg2dTrainer: shards, shared decisions, early stop on every rank ---------------------------------------

@@ -113,3 +113,48 @@ def average_gradients(module: torch.nn.Module) -> None:
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
+
+
+def padded_len(n: int, world_size: int) -> int:
+    """n rounded up to a multiple of the world size (the key volume's length, so that it splits into equal shards)."""
+    return (n + world_size - 1) // world_size * world_size
+
+
+def exchange_keys_sharded(keys: torch.Tensor, unpack, want_probs: bool, all_ranks: bool, group=None):
+    """The ONE exchange of a sharded prediction without shipping the merged key volume to every rank:
+
+      1. reduce-scatter(MAX) of the packed keys - every rank receives the merged keys of ITS 1/N of the voxels
+         (4 B/voxel through the ring once, instead of twice for an all-reduce);
+      2. every rank unpacks its shard (``unpack(shard_int32) -> (labels uint8, probs float16 | None)``): the unpack is sharded;
+      3. the labels / probabilities (1 + 2 B/voxel) are gathered on rank 0 only, or all-gathered when every rank is to return
+         the volume (``all_ranks``).
+
+    ``keys``: int32 view of the key volume, length a multiple of the world size (padded_len; padding keys are 0).
+    Returns (labels, probs) flat tensors of that padded length on the ranks that receive the result, else (None, None).
+    gloo has no reduce-scatter: there the shard is cut out of an all-reduce (the CPU tests exercise steps 2 and 3 as written)."""
+    rank, w = world()
+    if w == 1:
+        return unpack(keys)
+    n = keys.numel()
+    assert n % w == 0, "exchange_keys_sharded: pad the key volume to a multiple of the world size (padded_len)"
+    per = n // w
+    if dist.get_backend(group) == "nccl":
+        shard = torch.empty(per, dtype=keys.dtype, device=keys.device)
+        dist.reduce_scatter_tensor(shard, keys, op=dist.ReduceOp.MAX, group=group)
+    else:
+        dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
+        shard = keys[rank * per:(rank + 1) * per].clone()
+    lab, prb = unpack(shard)
+    out = []
+    for t in ((lab, prb) if want_probs else (lab,)):
+        if all_ranks:
+            full = torch.empty(n, dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(full, t.contiguous(), group=group)
+            out.append(full)
+        else:
+            full = torch.empty(n, dtype=t.dtype, device=t.device) if rank == 0 else None
+            dist.gather(t.contiguous(), list(full.view(w, per).unbind(0)) if rank == 0 else None, dst=0, group=group)
+            out.append(full)
+    if not want_probs:
+        out.append(None)
+    return out[0], out[1]
