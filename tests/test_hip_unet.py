@@ -217,17 +217,36 @@ def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
 
 
 def test_three_reference_training_steps_fp32(golden):
-    """Golden from the reference's own _train_one_batch + AdamW + OneCycleLR (oracle/gen_goldens.py G2)."""
-    g = golden("g2_train3_b4_64.npz")
+    """Golden from the reference's own _train_one_batch + AdamW + OneCycleLR (oracle/gen_goldens.py G2).
+
+    Tolerances are not guessed: oracle/drift_g2.py measured how far the SAME oracle moves from this golden under perturbations
+    of known size (tests/golden/g2_drift.npz).  One input ulp or float64 arithmetic leave the loss of step 0 stable to 5e-8 but
+    move step 1 by 1.1e-5 and step 2 by 7.3e-4, because AdamW turns rounding-level gradient differences (ReLU masks flipping at
+    pre-activations ~1e-6 from zero) into +-lr parameter steps.  The ladder in that file relates the size of an
+    implementation difference - delta = how far the step-0 logits move - to the drift that follows: this test measures the
+    engine's own delta against the oracle's forward pass and allows 2x the drift of the first rung with at least that delta."""
+    g, drift = golden("g2_train3_b4_64.npz"), golden("g2_drift.npz")
     oracle, model = _pair(2, 3, "fp32", perturb_bn=False)
     if not np.array_equal(fingerprint(oracle), g["fingerprint0"]):
         pytest.skip("torch RNG stream differs from the build container")
+    x, m = torch.tensor(g["x"]), torch.tensor(g["mask"])
+    model.train(); oracle.train()
+    with torch.no_grad():
+        delta = (model(x.to(DEV)).cpu() - oracle(x)).abs().max().item()       # the engine's forward difference (train-mode BN)
+    model.load_state_dict(seeded_oracle(2, 3, False).state_dict())            # undo the running-statistics update of that probe
+    ladder = drift["ladder"]                                                   # eps, delta, |dloss| x3, rel dev, update cosine
+    rung = int(np.argmax(ladder[:, 1] >= delta)) if (ladder[:, 1] >= delta).any() else len(ladder) - 1
+    assert delta < 1e-3 and ladder[rung, 1] >= delta, (delta, ladder[:, 1])
+    upto = ladder[:rung + 1]
+    loss_tol = np.maximum(2 * upto[:, 2:5].max(0), 2e-5)
+    rel_tol, cos_tol = 2 * upto[:, 5].max(), 1 - 2 * (1 - upto[:, 6].min())
+    print(f"[g2] engine vs oracle step-0 logits: delta = {delta:.3e} -> ladder rung eps = {ladder[rung, 0]:g} (delta {ladder[rung, 1]:.3e}); "
+          f"allowed |dloss| {loss_tol}, parameter rel dev {rel_tol:.3e}, update cosine > {cos_tol:.4f}")
     opt = model.fused_adamw(lr=1e-3)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, steps_per_epoch=4, epochs=1, pct_start=0.3)
-    x, m = torch.tensor(g["x"]).to(DEV), torch.tensor(g["mask"])
+    x = x.to(DEV)
     _, t = P.prepare_training_batch(None, m, 2)
     t = t.to(DEV).float()
-    model.train()
     for step in range(3):
         assert np.isclose(opt.param_groups[0]["lr"], g["lrs"][step], rtol=1e-12)
         assert np.isclose(opt.param_groups[0]["betas"][0], g["beta1"][step], rtol=1e-12)
@@ -236,16 +255,20 @@ def test_three_reference_training_steps_fp32(golden):
         loss.backward()
         opt.step()
         sched.step()
-        # step 0 is a pure forward comparison; later steps sit behind AdamW updates driven by flip-sensitive gradients
-        assert abs(loss.item() - g["losses"][step]) < (2e-5 if step == 0 else 5e-3), (step, loss.item(), g["losses"][step])
+        dev = abs(loss.item() - g["losses"][step])
+        print(f"[g2] step {step}: loss {loss.item():.8f} vs reference {g['losses'][step]:.8f}: |d| = {dev:.3e} (allowed {loss_tol[step]:.3e})")
+        assert dev < loss_tol[step], (step, loss.item(), g["losses"][step])
     sd, sd0 = model.state_dict(), seeded_oracle(2, 3, False).state_dict()
     for k in g.files:   # AdamW normalises gradients: elements with ~zero gradient move by +-lr on rounding noise,
         if k.startswith("after__"):   # so compare the update as a whole (direction and size), not element by element
-            ours, ref, w0 = sd[k[7:]].cpu().double(), torch.tensor(g[k]).double(), sd0[k[7:]].double()
-            assert ((ours - ref).norm() / (ref.norm() + 1e-12)).item() < 6e-2, k
-            if "running" not in k and (ref - w0).norm() > 0:
-                cos = torch.dot((ours - w0).flatten(), (ref - w0).flatten()) / ((ours - w0).norm() * (ref - w0).norm())
-                assert cos.item() > (0.9 if k[7:].startswith(("segmentation_head", "decoder")) else 0.5), (k, cos.item())
+            name = k[7:]
+            ours, ref, w0 = sd[name].cpu().double(), torch.tensor(g[k]).double(), sd0[name].double()
+            rel = ((ours - ref).norm() / (ref.norm() + 1e-12)).item()
+            assert rel < max(rel_tol, 1e-4), (name, rel, rel_tol)
+            if "running" not in name and (ref - w0).norm() > 0:
+                cos = (torch.dot((ours - w0).flatten(), (ref - w0).flatten()) / ((ours - w0).norm() * (ref - w0).norm())).item()
+                print(f"[g2] {name}: rel dev {rel:.3e}, update cosine {cos:.4f}")
+                assert cos > cos_tol, (name, cos, cos_tol)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -23,6 +23,41 @@ def test_pad_crop_quirk_row_p():
     assert P.pad_offsets(30) == (1, 1) and P.crop_offset(32, 30) == 1
 
 
+def test_third_party_data_movement_known_answers():
+    """albumentations.PadIfNeeded and torchvision's center_crop are not installed here; the stubs behind the goldens
+    (oracle/gen_goldens.py:install_stubs) and the oracle restate them from their published behaviour.  Known answers:
+      * cv2.BORDER_REFLECT_101 ("gfedcb|abcdefgh|gfedcba": the edge sample is not repeated) of [0 1 2 3] padded by 2 | 3
+        is [2 1 0 1 2 3 2 1 0];
+      * PadIfNeeded(position=center) puts int(d / 2) pixels first and the remaining d - int(d / 2) last;
+      * center_crop starts at int(round(d / 2.0)) - Python rounds halves to even: d = 0..15 ->
+        0 0 1 2 2 2 3 4 4 4 5 6 6 6 7 8 - so pad and crop offsets differ exactly where d = 3 (mod 4)."""
+    import importlib
+    gg = importlib.import_module("oracle.gen_goldens")
+    import sys
+    saved = dict(sys.modules)
+    try:
+        gg.install_stubs()
+        A, F = sys.modules["albumentations"], sys.modules["torchvision.transforms.functional"]
+        row = np.arange(4, dtype=np.uint8)
+        img = np.tile(row, (3, 1))
+        out = A.PadIfNeeded(min_height=3, min_width=9)(image=img)["image"]
+        assert out.shape == (3, 9) and list(out[0]) == [2, 1, 0, 1, 2, 3, 2, 1, 0]            # 5 = 2 | 3 around the 4 samples
+        tall = A.PadIfNeeded(min_height=8, min_width=4)(image=np.tile(row[:, None], (1, 4))[:3])["image"]   # 3 rows -> 8: 2 | 3
+        assert list(tall[:, 0]) == [2, 1, 0, 1, 2, 1, 0, 1]
+        expect = [0, 0, 1, 2, 2, 2, 3, 4, 4, 4, 5, 6, 6, 6, 7, 8]
+        for d in range(16):
+            t = torch.arange(32 * 32).reshape(1, 32, 32)
+            assert int(F.center_crop(t, [32 - d, 32])[0, 0, 0]) // 32 == expect[d], d
+            assert P.crop_offset(32, 32 - d) == expect[d] and P.pad_offsets(32 - d) == (d // 2, d - d // 2)
+            assert (P.crop_offset(32, 32 - d) != P.pad_offsets(32 - d)[0]) == (d % 4 == 3)
+        x = P.preprocess_slice(np.tile(row, (29, 8)))        # 29 x 32 -> padded 32 x 32: rows 1 | 2 by reflect-101
+        assert x.shape == (32, 32) and np.array_equal(x[0], x[2]) and np.array_equal(x[31], x[27])
+    finally:
+        for k in [k for k in sys.modules if k not in saved]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 @pytest.fixture(scope="module")
 def pred_golden(golden):
     g = golden("g3_predict_29x64x40_c4.npz")
