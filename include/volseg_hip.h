@@ -245,6 +245,18 @@ int vs_dice_loss_fwd(const float* logits, const void* targets, int target_is_f32
 int vs_dice_loss_bwd(const float* logits, const void* targets, int target_is_f32, const float* grad_out, int n, int classes,
                      int64_t hw, float eps, const float* workspace, float* dlogits, void* stream);
 
+/* The other criteria the trainer can select (vol_seg_2d_trainer.py:124-148), each as one reduction sweep + one gradient sweep over
+ * logits (n, K, h*w) fp32 NCHW and one-hot targets (uint8 or fp32):
+ *   kind 1: BCEDiceLoss(alpha, beta) = alpha * BCEWithLogitsLoss + beta * DiceLoss(normalization="sigmoid")  (pytorch3dunet_losses.py:171-184)
+ *   kind 2: BCEWithLogitsLoss                 kind 3: CrossEntropyLoss (class index = position of the 1 in the one-hot column)
+ *   kind 4: GeneralizedDiceLoss(normalization="sigmoid", epsilon = eps)  (pytorch3dunet_losses.py:138-169)
+ * eps: the Dice / GDL clamp (1e-6 in the reference); workspace carries the gradient coefficients from fwd to bwd. */
+size_t vs_seg_loss_workspace(int classes);
+int vs_seg_loss_fwd(int kind, const float* logits, const void* targets, int target_is_f32, int n, int classes, int64_t hw,
+                    float alpha, float beta, float eps, float* loss, float* workspace, size_t workspace_bytes, void* stream);
+int vs_seg_loss_bwd(int kind, const float* logits, const void* targets, int target_is_f32, const float* grad_out, int n, int classes,
+                    int64_t hw, const float* workspace, float* dlogits, void* stream);
+
 /* MeanIoU, the trainer's default validation metric (data/pytorch3dunet_metrics.py:34-106; vol_seg_2d_trainer.py:150-161,
  * 243): per sample the prediction is the one-hot of the FIRST arg-max over channels (input > 0.5 for one channel), per
  * class |P & T| / max(|P | T|, 1e-8) with the target converted to bytes, mean over classes, then over samples.

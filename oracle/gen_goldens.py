@@ -214,6 +214,32 @@ def gen_g9():
     np.savez_compressed(OUT / "g9_prediction_inputs_typed.npz", **out)
 
 
+def gen_g10():
+    """G10: the non-default training criteria (vol_seg_2d_trainer.py:124-148) evaluated by the reference's own classes
+    (data/pytorch3dunet_losses.py: BCEDiceLoss, GeneralizedDiceLoss) and the torch modules it instantiates (BCEWithLogitsLoss,
+    CrossEntropyLoss), value + gradient, for 1, 2 and 4 classes; targets as prepare_training_batch builds them."""
+    from volume_segmantics.data.pytorch3dunet_losses import BCEDiceLoss, GeneralizedDiceLoss
+    out = {}
+    for k in (1, 2, 4):
+        tg = torch.Generator().manual_seed(40 + k)
+        logits = (torch.randn(3, k, 24, 40, generator=tg) * 2.0)
+        lab = torch.randint(0, max(k, 2), (3, 24, 40), generator=tg)
+        targets = torch.nn.functional.one_hot(lab, max(k, 2)).permute(0, 3, 1, 2)[:, :k].contiguous().to(torch.uint8)
+        out[f"k{k}__logits"], out[f"k{k}__targets"] = logits.numpy(), targets.numpy()
+        crits = {"BCEDiceLoss": (BCEDiceLoss(0.75, 0.25), lambda t: t.float()),
+                 "BCELoss": (torch.nn.BCEWithLogitsLoss(), lambda t: t.float()),
+                 "GeneralizedDiceLoss": (GeneralizedDiceLoss(), lambda t: t.float())}
+        if k > 1:
+            crits["CrossEntropyLoss"] = (torch.nn.CrossEntropyLoss(), lambda t: torch.argmax(t, dim=1))   # vol_seg_2d_trainer.py:425-428
+        for name, (crit, conv) in crits.items():
+            x = logits.clone().requires_grad_()
+            loss = crit(x, conv(targets))
+            (loss * 1.3).backward()
+            out[f"k{k}__{name}__loss"], out[f"k{k}__{name}__grad"] = loss.detach().numpy(), x.grad.numpy()
+            print("g10", k, name, float(loss))
+    np.savez_compressed(OUT / "g10_losses.npz", **out)
+
+
 def gen_decidable():
     """Which voxels of the g3 prediction goldens are DECIDABLE, i.e. where any correct fp32 implementation must reproduce the
     reference's label bit for bit: voxels where no direction involved is within rounding of a tie.  Computed with the oracle
@@ -294,10 +320,14 @@ def main():
     if "--only-g9" in sys.argv:
         gen_g9()
         return
+    if "--only-g10" in sys.argv:
+        gen_g10()
+        return
     gen_g8()
     if "--only-g8" in sys.argv:
         return
     gen_g9()
+    gen_g10()
     utils.get_batch_size = lambda settings, prediction=False: 4 if prediction else 12  # needs CUDA in the reference
 
     # ---- G7: pad / crop tables --------------------------------------------------------------

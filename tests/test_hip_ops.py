@@ -467,6 +467,32 @@ def test_fused_dice_loss_matches_reference_formula(classes, tdtype):
     assert torch.allclose(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize("classes", [1, 2, 4])
+@pytest.mark.parametrize("tdtype", [torch.uint8, torch.float32])
+def test_fused_segmentation_losses_match_the_reference_classes(golden, classes, tdtype):
+    """vs_seg_loss_fwd/_bwd (BCE-Dice, BCE, cross entropy, generalised Dice) against g10: value and gradient computed by the
+    reference's own BCEDiceLoss / GeneralizedDiceLoss and the torch modules it instantiates (oracle/gen_goldens.py:gen_g10)."""
+    from volume_segmantics_amd.data.losses import HipSegLoss
+    g = golden("g10_losses.npz")
+    x0, t = torch.tensor(g[f"k{classes}__logits"]), torch.tensor(g[f"k{classes}__targets"])
+    for name in ("BCEDiceLoss", "BCELoss", "GeneralizedDiceLoss", "CrossEntropyLoss"):
+        if f"k{classes}__{name}__loss" not in g.files:
+            continue
+        crit = HipSegLoss(name, 0.75, 0.25)
+        xd = x0.to(DEV).requires_grad_()
+        loss = crit(xd, t.to(DEV, tdtype))
+        (loss * 1.3).backward()
+        sync()
+        ref_l, ref_g = float(g[f"k{classes}__{name}__loss"]), torch.tensor(g[f"k{classes}__{name}__grad"])
+        assert abs(loss.item() - ref_l) < 2e-6 * max(1.0, abs(ref_l)), (name, loss.item(), ref_l)
+        err = (xd.grad.cpu() - ref_g).abs().max().item()
+        assert err < 2e-5 * ref_g.abs().max().item() + 1e-10, (name, err, ref_g.abs().max().item())
+        # the CPU route of the same module (torch restatement) agrees too
+        xc = x0.clone().requires_grad_()
+        lc = crit(xc, t if tdtype == torch.uint8 else t.float())
+        assert abs(lc.item() - ref_l) < 2e-6 * max(1.0, abs(ref_l)), name
+
+
 @pytest.mark.parametrize("classes", [1, 2, 4, 7])
 def test_mean_iou_matches_oracle(classes):
     """vs_mean_iou vs the oracle's restatement of MeanIoU.__call__ (pinned by golden g6 in the CPU suite)."""

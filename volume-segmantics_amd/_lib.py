@@ -105,6 +105,9 @@ _SIGS = {
     "vs_dice_workspace": (SZ, [I]),
     "vs_dice_loss_fwd": (I, [P, P, I, I, I, I64, F, P, P, SZ, P]),
     "vs_dice_loss_bwd": (I, [P, P, I, P, I, I, I64, F, P, P, P]),
+    "vs_seg_loss_workspace": (SZ, [I]),
+    "vs_seg_loss_fwd": (I, [I, P, P, I, I, I, I64, F, F, F, P, P, SZ, P]),
+    "vs_seg_loss_bwd": (I, [I, P, P, I, P, I, I, I64, P, P, P]),
     "vs_mean_iou_workspace": (SZ, [I, I]),
     "vs_mean_iou": (I, [P, P, I, I, I, I, I64, P, P, SZ, P]),
     "vs_onehot_u8": (I, [P, I, I, I64, P, P]),

@@ -223,3 +223,212 @@ extern "C" int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t h
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
+
+// ---- the other selectable criteria, fused (vol_seg_2d_trainer.py:124-148) ------------------------------------------------------
+// kind 1: BCEDiceLoss(alpha, beta) = alpha * BCEWithLogitsLoss + beta * DiceLoss(normalization = sigmoid)  (pytorch3dunet_losses.py:171-184)
+// kind 2: BCEWithLogitsLoss (mean over all elements)
+// kind 3: CrossEntropyLoss over the channel dimension, mean over pixels; the class index is the position of the 1 in the one-hot target
+// kind 4: GeneralizedDiceLoss(normalization = sigmoid, epsilon)  (pytorch3dunet_losses.py:138-169; one channel -> (p, 1-p) / (t, 1-t))
+// Same structure as the Dice kernels above: ONE reduction sweep over logits + targets (per-class sums of p t, p^2, t^2, p, t with
+// p = sigmoid(x), plus the BCE / CE sum), a one-block finalise in fp64 that also leaves per-class gradient coefficients, and ONE
+// gradient sweep: dL/dx = (a_c t + b_c p + g_c) p (1 - p) + s (p - t)  (kinds 1, 2, 4) or s (softmax - t) (kind 3).
+namespace {
+
+constexpr int kSegBlocks = 512, kSegSums = 6;   // per class: S_pt, S_pp, S_tt, S_p, S_t, BCE or CE term
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// BCEWithLogits element: max(x, 0) - x t + log(1 + exp(-|x|))   (torch's stable form)
+__device__ __forceinline__ float bce_elem(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
+
+template <typename TT>
+__global__ __launch_bounds__(256) void seg_partial_kernel(const float* __restrict__ x, const TT* __restrict__ t, int kind, int n, int k,
+                                                        int64_t hw, float* __restrict__ partial) {
+    __shared__ float red[kSegSums][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < k; ++c) {
+        float s[kSegSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < n; ++b) {
+            const size_t base = ((size_t)b * k + c) * hw;
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+                const float xv = x[base + i], tv = tval(t, base + i);
+                if (kind == 3) {
+                    if (c == 0) {   // cross entropy is per pixel across the classes: class 0's pass carries it
+                        const size_t p0 = (size_t)b * k * hw + i;
+                        float m = x[p0], xt = 0.f;
+                        for (int q = 1; q < k; ++q) m = fmaxf(m, x[p0 + (size_t)q * hw]);
+                        float se = 0.f;
+                        bool found = false;
+                        for (int q = 0; q < k; ++q) {
+                            const float xq = x[p0 + (size_t)q * hw];
+                            se += expf(xq - m);
+                            if (!found && tval(t, p0 + (size_t)q * hw) != 0.f) { xt = xq; found = true; }   // first 1 = argmax of the one-hot
+                        }
+                        if (!found) xt = x[p0];                                                                   // all-zero column: argmax = 0
+                        s[5] += (m + logf(se)) - xt;
+                    }
+                } else {
+                    const float p = sigmoidf_(xv);
+                    s[0] += p * tv; s[1] += p * p; s[2] += tv * tv; s[3] += p; s[4] += tv;
+                    if (kind <= 2) s[5] += bce_elem(xv, tv);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kSegSums; ++q) {
+            s[q] = wave_sum(s[q]);
+            if (lane == 0) red[q][wave] = s[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < kSegSums)
+            partial[((size_t)blockIdx.x * k + c) * kSegSums + threadIdx.x] =
+                (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        __syncthreads();
+    }
+}
+
+// one wave: per-class sums in fp64 (fixed order), the loss, and coef[c] = {a_c, b_c, g_c} + scal = {s}
+__global__ __launch_bounds__(64) void seg_finalize_kernel(const float* __restrict__ partial, int nblocks, int kind, int k, double m_elems,
+                                                        double n_pix, float alpha, float beta, float eps, float* __restrict__ coef,
+                                                        float* __restrict__ loss) {
+    const int lane = threadIdx.x;
+    __shared__ double S[16][kSegSums];
+    for (int c = 0; c < k; ++c) {
+        double s[kSegSums] = {0, 0, 0, 0, 0, 0};
+        for (int b = lane; b < nblocks; b += 64) {
+            const float* p = partial + ((size_t)b * k + c) * kSegSums;
+#pragma unroll
+            for (int q = 0; q < kSegSums; ++q) s[q] += p[q];
+        }
+#pragma unroll
+        for (int q = 0; q < kSegSums; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o, 64);
+            if (lane == 0) S[c][q] = s[q];
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double total = 0.0, bce = 0.0;
+    for (int c = 0; c < k; ++c) bce += S[c][5];
+    float* scal = coef + 16 * 4;
+    scal[0] = 0.f;
+    for (int c = 0; c < 16; ++c) coef[c * 4 + 0] = coef[c * 4 + 1] = coef[c * 4 + 2] = coef[c * 4 + 3] = 0.f;
+    if (kind == 1 || kind == 2) {
+        const double wb = kind == 1 ? (double)alpha : 1.0;
+        total += wb * bce / m_elems;
+        scal[0] = (float)(wb / m_elems);                         // d/dx of the mean BCE: (p - t) / M
+        if (kind == 1) {
+            double acc = 0.0;
+            for (int c = 0; c < k; ++c) {
+                const double I = S[c][0], D = S[c][1] + S[c][2];
+                const bool big = D > (double)eps;
+                const double Dc = big ? D : (double)eps;
+                acc += 2.0 * I / Dc;
+                // d(1 - mean_c 2 I / D)/dp = -(2/K) (t D - 2 p I) / D^2 ; with D clamped: -(2/K) t / eps
+                coef[c * 4 + 0] = (float)(beta * (-2.0 / k) / Dc);
+                coef[c * 4 + 1] = big ? (float)(beta * (4.0 / k) * I / (D * D)) : 0.f;
+            }
+            total += beta * (1.0 - acc / k);
+        }
+    } else if (kind == 3) {
+        total = bce / n_pix;
+        scal[0] = (float)(1.0 / n_pix);
+    } else {   // generalised Dice
+        const int kk = k == 1 ? 2 : k;
+        double Spt[16], Sp[16], St[16];
+        for (int c = 0; c < k; ++c) { Spt[c] = S[c][0]; Sp[c] = S[c][3]; St[c] = S[c][4]; }
+        if (k == 1) { Spt[1] = n_pix - Sp[0] - St[0] + Spt[0]; Sp[1] = n_pix - Sp[0]; St[1] = n_pix - St[0]; }
+        double inter = 0.0, denom = 0.0, w[16];
+        bool live[16];
+        for (int c = 0; c < kk; ++c) {
+            const double v = St[c] * St[c];
+            w[c] = 1.0 / (v > (double)eps ? v : (double)eps);
+            inter += Spt[c] * w[c];
+            const double d = (Sp[c] + St[c]) * w[c];
+            live[c] = d > (double)eps;
+            denom += live[c] ? d : (double)eps;
+        }
+        total = 1.0 - 2.0 * inter / denom;
+        // dL/dp_c = -2 [ w_c t denom - inter w_c 1{live} ] / denom^2 = a_c t + g_c
+        double a[16], gg[16];
+        for (int c = 0; c < kk; ++c) { a[c] = -2.0 * w[c] / denom; gg[c] = live[c] ? 2.0 * inter * w[c] / (denom * denom) : 0.0; }
+        if (k == 1) {   // p' = 1 - p, t' = 1 - t:  dL/dp = (a0 t + g0) - (a1 (1 - t) + g1) = (a0 + a1) t + (g0 - a1 - g1)
+            coef[0] = (float)(a[0] + a[1]); coef[2] = (float)(gg[0] - a[1] - gg[1]);
+        } else {
+            for (int c = 0; c < k; ++c) { coef[c * 4 + 0] = (float)a[c]; coef[c * 4 + 2] = (float)gg[c]; }
+        }
+    }
+    *loss = (float)total;
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void seg_grad_kernel(const float* __restrict__ x, const TT* __restrict__ t, const float* __restrict__ coef,
+                                                     const float* __restrict__ gout, int kind, int n, int k, int64_t hw,
+                                                     float* __restrict__ dx) {
+    const float g = gout ? *gout : 1.f;
+    const float sc = coef[16 * 4];
+    if (kind == 3) {
+        const int64_t total = (int64_t)n * hw;
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+            const int64_t b = j / hw, i = j - b * hw;
+            const size_t p0 = (size_t)b * k * hw + i;
+            float m = x[p0];
+            for (int q = 1; q < k; ++q) m = fmaxf(m, x[p0 + (size_t)q * hw]);
+            float se = 0.f;
+            int cls = 0;
+            bool found = false;
+            for (int q = 0; q < k; ++q) {
+                se += expf(x[p0 + (size_t)q * hw] - m);
+                if (!found && tval(t, p0 + (size_t)q * hw) != 0.f) { cls = q; found = true; }
+            }
+            for (int q = 0; q < k; ++q)
+                dx[p0 + (size_t)q * hw] = g * sc * (expf(x[p0 + (size_t)q * hw] - m) / se - (q == cls ? 1.f : 0.f));
+        }
+        return;
+    }
+    const int64_t total = (int64_t)n * k * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / hw) % k);
+        const float xv = x[i], tv = tval(t, i);
+        const float p = sigmoidf_(xv);
+        const float dldp = coef[c * 4 + 0] * tv + coef[c * 4 + 1] * p + coef[c * 4 + 2];
+        dx[i] = g * (dldp * p * (1.f - p) + sc * (p - tv));
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vs_seg_loss_workspace(int classes) { return ((size_t)kSegBlocks * classes * kSegSums + 16 * 4 + 4) * sizeof(float); }
+
+extern "C" int vs_seg_loss_fwd(int kind, const float* logits, const void* targets, int target_is_f32, int n, int classes, int64_t hw,
+                               float alpha, float beta, float eps, float* loss, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(kind >= 1 && kind <= 4, "seg_loss: kind must be 1 (BCE-Dice), 2 (BCE), 3 (cross entropy) or 4 (generalised Dice)");
+    VS_REQUIRE(logits && targets && loss && workspace && workspace_bytes >= vs_seg_loss_workspace(classes) && classes >= 1 && classes <= 16,
+               "seg_loss_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* coef = workspace + (size_t)kSegBlocks * classes * kSegSums;
+    if (target_is_f32)
+        hipLaunchKernelGGL(seg_partial_kernel<float>, dim3(kSegBlocks), dim3(256), 0, s, logits, (const float*)targets, kind, n, classes, hw, workspace);
+    else
+        hipLaunchKernelGGL(seg_partial_kernel<uint8_t>, dim3(kSegBlocks), dim3(256), 0, s, logits, (const uint8_t*)targets, kind, n, classes, hw, workspace);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_finalize_kernel, dim3(1), dim3(64), 0, s, workspace, kSegBlocks, kind, classes, (double)n * classes * (double)hw,
+                       (double)n * (double)hw, alpha, beta, eps, coef, loss);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_seg_loss_bwd(int kind, const float* logits, const void* targets, int target_is_f32, const float* grad_out, int n,
+                               int classes, int64_t hw, const float* workspace, float* dlogits, void* stream) {
+    VS_REQUIRE(kind >= 1 && kind <= 4 && logits && targets && workspace && dlogits, "seg_loss_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const float* coef = workspace + (size_t)kSegBlocks * classes * kSegSums;
+    const int64_t total = kind == 3 ? (int64_t)n * hw : (int64_t)n * classes * hw;
+    const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256);
+    if (target_is_f32)
+        hipLaunchKernelGGL(seg_grad_kernel<float>, dim3(grid), dim3(256), 0, s, logits, (const float*)targets, coef, grad_out, kind, n, classes, hw, dlogits);
+    else
+        hipLaunchKernelGGL(seg_grad_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, logits, (const uint8_t*)targets, coef, grad_out, kind, n, classes, hw, dlogits);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

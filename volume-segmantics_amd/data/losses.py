@@ -116,6 +116,63 @@ class BCEDiceLoss(nn.Module):
         return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
 
 
+class _FusedSegLossFn(torch.autograd.Function):
+    """BCE-Dice / BCE / cross entropy / generalised Dice as one HIP reduction sweep + one gradient sweep (vs_seg_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, kind, alpha, beta, eps):
+        from .. import _lib
+        n, k = logits.shape[:2]
+        hw = logits[0, 0].numel()
+        logits = logits.contiguous()
+        targets = targets.contiguous()
+        is_f32 = targets.dtype == torch.float32
+        if not is_f32 and targets.dtype != torch.uint8:
+            targets, is_f32 = targets.float(), True
+        nbytes = _lib.lib.vs_seg_loss_workspace(k)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.lib.vs_seg_loss_fwd(kind, _lib.ptr(logits), _lib.ptr(targets), int(is_f32), n, k, hw, float(alpha), float(beta),
+                                           float(eps), _lib.ptr(loss), _lib.ptr(ws), nbytes, _lib.stream_ptr()))
+        ctx.save_for_backward(logits, targets, ws)
+        ctx.meta = (kind, n, k, hw, is_f32)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import _lib
+        logits, targets, ws = ctx.saved_tensors
+        kind, n, k, hw, is_f32 = ctx.meta
+        dx = torch.empty_like(logits)
+        g = grad_out.contiguous().float()
+        _lib.check(_lib.lib.vs_seg_loss_bwd(kind, _lib.ptr(logits), _lib.ptr(targets), int(is_f32), _lib.ptr(g), n, k, hw, _lib.ptr(ws),
+                                           _lib.ptr(dx), _lib.stream_ptr()))
+        return dx, None, None, None, None, None
+
+
+class HipSegLoss(nn.Module):
+    """The trainer's non-default criteria on GPU tensors (vol_seg_2d_trainer.py:124-148): ``kind`` in {"BCEDiceLoss", "BCELoss",
+    "CrossEntropyLoss", "GeneralizedDiceLoss"}; one-hot targets (uint8 or float, the shape of the logits) - for the cross
+    entropy the class index is the position of the 1 (the trainer's ``torch.argmax(targets, dim=1)``).  Anything the fused
+    kernels do not take (CPU tensors, > 16 classes) goes through the torch restatement ``fallback``."""
+
+    KINDS = {"BCEDiceLoss": 1, "BCELoss": 2, "CrossEntropyLoss": 3, "GeneralizedDiceLoss": 4}
+
+    def __init__(self, kind: str, alpha: float = 1.0, beta: float = 1.0, epsilon: float = 1e-6):
+        super().__init__()
+        self.kind, self.alpha, self.beta, self.epsilon = kind, alpha, beta, epsilon
+        self.fallback = {"BCEDiceLoss": lambda: BCEDiceLoss(alpha, beta), "BCELoss": nn.BCEWithLogitsLoss,
+                         "CrossEntropyLoss": nn.CrossEntropyLoss, "GeneralizedDiceLoss": lambda: GeneralizedDiceLoss(epsilon=epsilon)}[kind]()
+
+    def forward(self, input, target):
+        if (input.is_cuda and input.dtype == torch.float32 and input.dim() >= 3 and input.shape == target.shape
+                and input.size(1) <= 16):
+            return _FusedSegLossFn.apply(input, target, self.KINDS[self.kind], self.alpha, self.beta, self.epsilon)
+        if self.kind == "CrossEntropyLoss":
+            return self.fallback(input, torch.argmax(target, dim=1))
+        return self.fallback(input, target.float())
+
+
 class DiceCoefficient:
     def __init__(self, epsilon=1e-6, **kwargs):
         self.epsilon = epsilon

@@ -30,7 +30,7 @@ import torch.nn as nn
 from ... import dist as vdist
 from ...checkpoint_compat import reference_pickle_enum
 from ...data.datasets import get_2d_training_dataloaders
-from ...data.losses import BCEDiceLoss, DiceCoefficient, DiceLoss, GeneralizedDiceLoss, HipDiceLoss, MeanIoU
+from ...data.losses import BCEDiceLoss, DiceCoefficient, DiceLoss, GeneralizedDiceLoss, HipDiceLoss, HipSegLoss, MeanIoU
 from ...engine import FusedAdamW, VolSegUnet
 from ...utilities import base_data_utils as utils
 from ...utilities import config as cfg
@@ -79,16 +79,17 @@ class VolSeg2dTrainer:
 
     def _get_loss_criterion(self):
         name = self.settings.loss_criterion
+        gpu = torch.cuda.is_available()     # fused HIP sweeps on device tensors; the torch restatements otherwise
         if name == "BCEDiceLoss":
-            return BCEDiceLoss(self.settings.alpha, self.settings.beta)
+            return HipSegLoss(name, self.settings.alpha, self.settings.beta) if gpu else BCEDiceLoss(self.settings.alpha, self.settings.beta)
         if name == "DiceLoss":
-            return HipDiceLoss() if torch.cuda.is_available() else DiceLoss(normalization="none")
+            return HipDiceLoss() if gpu else DiceLoss(normalization="none")
         if name == "BCELoss":
-            return nn.BCEWithLogitsLoss()
+            return HipSegLoss(name) if gpu else nn.BCEWithLogitsLoss()
         if name == "CrossEntropyLoss":
-            return nn.CrossEntropyLoss()
+            return HipSegLoss(name) if gpu else nn.CrossEntropyLoss()
         if name == "GeneralizedDiceLoss":
-            return GeneralizedDiceLoss()
+            return HipSegLoss(name) if gpu else GeneralizedDiceLoss()
         logging.error("No loss criterion specified, exiting")
         sys.exit(1)
 
@@ -160,10 +161,10 @@ class VolSeg2dTrainer:
 
     # ---- the hot loop ---------------------------------------------------------------------------------------
     def _loss(self, output, targets):
+        if isinstance(self.loss_criterion, (HipDiceLoss, HipSegLoss)):
+            return self.loss_criterion(output, targets)   # reads the uint8 one-hot directly (cross entropy: the position of the 1)
         if self.settings.loss_criterion == "CrossEntropyLoss":
             return self.loss_criterion(output, torch.argmax(targets, dim=1))
-        if isinstance(self.loss_criterion, HipDiceLoss):
-            return self.loss_criterion(output, targets)   # reads the uint8 one-hot directly
         return self.loss_criterion(output, targets.float())
 
     def _device(self):
