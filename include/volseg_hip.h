@@ -121,6 +121,15 @@ int64_t vs_unet_param_elems(int classes);
 int64_t vs_unet_bnstate_elems(int classes);
 
 int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w);
+/* The same U-Net decoder over other encoders of the reference's list (README.md:57-76; smp encoder_name): encoder = 18, 34 or
+ * 50 for resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a 1x1 shortcut).
+ * The plain entry points above are encoder = 34. */
+int vs_unet_create_ex(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w, int encoder);
+int vs_unet_num_tensors_ex(int classes, int encoder);
+int vs_unet_tensor_info_ex(int classes, int encoder, int index, char* name, int name_len, int64_t shape[4], int* ndim,
+                           int* kind, int64_t* offset);
+int64_t vs_unet_param_elems_ex(int classes, int encoder);
+int64_t vs_unet_bnstate_elems_ex(int classes, int encoder);
 void vs_unet_destroy(vs_unet_t* net);
 size_t vs_unet_workspace_bytes(const vs_unet_t* net, int training);
 /* (re)derive low-precision / transposed weight copies and folded BN constants from the fp32

@@ -1,0 +1,136 @@
+"""ORACLE (test infrastructure, never the product path): ``smp.Unet(encoder_name=E, in_channels=1, classes=K)`` for the other
+ResNet encoders of the reference's list (README.md:57-76, tests/test_model_2d.py:36-44) that the engine builds: resnet18 and
+resnet50 next to resnet34 (oracle/unet_resnet34_torch.py, whose blocks are reused here).
+
+Restated from the published architectures - segmentation-models-pytorch ^0.2.1 and torchvision are not installed here
+(oracle/unet_resnet34_torch.py explains the pinning situation; the same applies):
+  * torchvision ResNet-18: BasicBlock x (2, 2, 2, 2); ResNet-50: Bottleneck x (3, 4, 6, 3), expansion 4, the stride on the 3x3
+    convolution (the "v1.5" form torchvision ships), 1x1 projection shortcut where shape changes;
+  * smp encoder out_channels: resnet18 (3, 64, 64, 128, 256, 512), resnet50 (3, 64, 256, 512, 1024, 2048);
+  * the U-Net decoder / head as for resnet34.
+Structural pins (tests/test_oracle_topology.py): state-dict keys and shapes, and torchvision's published parameter counts -
+resnet18 11,689,512, resnet34 21,797,672, resnet50 25,557,032 with the 3-channel stem and the 1000-way fc layer added back."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .unet_resnet34_torch import DECODER_CHANNELS, BasicBlock, DecoderBlock
+
+LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3)}
+OUT_CHANNELS = {"resnet18": (1, 64, 64, 128, 256, 512), "resnet34": (1, 64, 64, 128, 256, 512), "resnet50": (1, 64, 256, 512, 1024, 2048)}
+FC_PARAMS = {"resnet18": 512 * 1000 + 1000, "resnet34": 512 * 1000 + 1000, "resnet50": 2048 * 1000 + 1000}
+TORCHVISION_PARAMS = {"resnet18": 11_689_512, "resnet34": 21_797_672, "resnet50": 25_557_032}
+
+
+class Bottleneck(nn.Module):
+    """torchvision Bottleneck: relu(bn1(conv1x1)) -> relu(bn2(conv3x3, stride)) -> bn3(conv1x1 x4) -> + identity -> relu."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class ResNetEncoder(nn.Module):
+    def __init__(self, name: str, in_channels: int = 1):
+        super().__init__()
+        block = Bottleneck if name == "resnet50" else BasicBlock
+        exp = 4 if name == "resnet50" else 1
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inplanes = 64
+        for i, (planes, blocks) in enumerate(zip((64, 128, 256, 512), LAYERS[name])):
+            layer = [block(inplanes, planes, 1 if i == 0 else 2)]
+            inplanes = planes * exp
+            layer += [block(inplanes, planes) for _ in range(1, blocks)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*layer))
+        for m in self.modules():   # torchvision ResNet init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        feats = [x]
+        x = self.relu(self.bn1(self.conv1(x)))
+        feats.append(x)
+        x = self.layer1(self.maxpool(x))
+        feats.append(x)
+        for l in (self.layer2, self.layer3, self.layer4):
+            x = l(x)
+            feats.append(x)
+        return feats
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels):
+        super().__init__()
+        enc = encoder_channels[1:][::-1]
+        cins = [enc[0]] + list(DECODER_CHANNELS[:-1])
+        cskips = list(enc[1:]) + [0]
+        self.blocks = nn.ModuleList(DecoderBlock(i, s, o) for i, s, o in zip(cins, cskips, DECODER_CHANNELS))
+
+    def forward(self, feats):
+        feats = feats[1:][::-1]
+        x, skips = feats[0], feats[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class OracleUnet(nn.Module):
+    def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2):
+        super().__init__()
+        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.decoder = UnetDecoder(OUT_CHANNELS[encoder_name])
+        self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
+        for m in self.decoder.modules():   # smp initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.xavier_uniform_(self.segmentation_head[0].weight)
+        nn.init.constant_(self.segmentation_head[0].bias, 0)
+
+    def forward(self, x):
+        return self.segmentation_head(self.decoder(self.encoder(x)))
+
+
+def seeded_oracle_unet(encoder_name: str, classes: int = 2, seed: int = 0, perturb_bn: bool = True) -> OracleUnet:
+    g = torch.Generator().manual_seed(seed)
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        net = OracleUnet(encoder_name, 1, classes)
+    finally:
+        torch.set_rng_state(state)
+    if perturb_bn:
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.copy_(1.0 + 0.2 * (torch.rand(m.weight.shape, generator=g) - 0.5))
+                    m.bias.copy_(0.2 * (torch.rand(m.bias.shape, generator=g) - 0.5))
+                    m.running_mean.copy_(0.2 * (torch.rand(m.bias.shape, generator=g) - 0.5))
+                    m.running_var.copy_(0.75 + 0.5 * torch.rand(m.bias.shape, generator=g))
+    return net

@@ -355,3 +355,66 @@ def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
         sync()
         assert torch.isfinite(model._flat_grad[a:b]).all()
     assert torch.equal(model._flat_grad, ref)
+
+
+# ---- other encoders of the reference's list behind the same decoder -------------------------------
+@pytest.mark.parametrize("encoder", ["resnet18", "resnet50"])
+def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
+    """U_NET + resnet18 (BasicBlock x 2,2,2,2) and resnet50 (Bottleneck: 1x1 - 3x3(stride) - 1x1 x4, 1x1 shortcuts, features of
+    256 .. 2048 channels) against oracle/unet_resnet_torch.py: eval logits within 1e-3 (fp32), train-mode forward / loss tight,
+    gradients with the flip-tolerant criterion of the resnet34 test, and the same steps in bf16 stay close."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle_unet(encoder, 3, seed=2)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 64, 96, generator=g)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-3, (encoder, (got - ref).abs().max().item())
+    # one training step's forward + backward
+    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False)
+    mask = (torch.rand(4, 64, 64, generator=g) > 0.6).to(torch.uint8)
+    xt = torch.randn(4, 1, 64, 64, generator=g)
+    _, t = P.prepare_training_batch(xt, mask, 2)
+    oracle.train()
+    ref_loss = P.dice_loss_none(oracle(xt), t.float())
+    ref_loss.backward()
+    refg = dict(oracle.named_parameters())
+    # (gradient tolerance: these tensors sit behind one BN + ReLU whose mask flips on pre-activations ~1e-6 from zero; the
+    # deeper resnet50 shows a few more flips than resnet34's 1e-3 - measured 1.15e-3)
+    for precision, ltol, gtol in (("fp32", 1e-5, 3e-3), ("bf16", 3e-2, 0.2)):
+        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder)
+        model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False).state_dict())
+        model.train()
+        loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
+        loss.backward()
+        sync()
+        assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
+        for name, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2")):
+                r = refg[name].grad
+                err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
+                assert err < gtol, (encoder, precision, name, err)
+            elif precision == "fp32":
+                assert _cos(p.grad.cpu(), refg[name].grad) > 0.98, (encoder, name)
+    # the recorded step (graphs) runs for these plans too and equals the call-by-call step
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    runs = []
+    for graph in (True, False):
+        m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder)
+        o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
+        m.train()
+        tt = t.to(DEV).contiguous()
+        for _ in range(4):
+            if graph:
+                assert m.can_fuse_step(o, xt.to(DEV), tt)
+                m.fused_train_step(xt.to(DEV), tt, o)
+            else:
+                o.zero_grad(); l = HipDiceLoss()(m(xt.to(DEV)), tt); l.backward(); o.step()
+        sync()
+        runs.append(m._flat.clone())
+    assert torch.equal(runs[0], runs[1]), encoder

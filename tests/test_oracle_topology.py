@@ -43,3 +43,27 @@ def test_forward_shape_multiple_of_32():
     net = OracleUnetResnet34(1, 3).eval()
     with torch.no_grad():
         assert net(torch.zeros(1, 1, 96, 64)).shape == (1, 3, 96, 64)
+
+
+def test_other_resnet_encoders_match_torchvision_published_parameter_counts():
+    """resnet18 / resnet34 / resnet50 behind the same U-Net decoder (oracle/unet_resnet_torch.py): the restated encoders carry
+    exactly torchvision's published parameter counts once the 3-channel stem and the fc layer are accounted for, the tensor
+    table of the engine's plan has the same keys / shapes in the same order, and resnet34 equals the original restatement."""
+    from oracle.unet_resnet_torch import FC_PARAMS, TORCHVISION_PARAMS, OracleUnet
+    from volume_segmantics_amd import _lib
+    for name, enc in (("resnet18", 18), ("resnet34", 34), ("resnet50", 50)):
+        net = OracleUnet(name, 3, 2)
+        n_enc = sum(p.numel() for p in net.encoder.parameters())
+        assert n_enc + FC_PARAMS[name] == TORCHVISION_PARAMS[name], (name, n_enc)
+        sd = OracleUnet(name, 1, 3).state_dict()
+        table = _lib.unet_tensor_table(3, enc)
+        keys = [k for k in sd if not k.endswith("num_batches_tracked")]
+        assert [t[0] for t in table] == keys, name                                 # same names, same (state_dict) order
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    assert OracleUnet("resnet50", 1, 2).state_dict()["decoder.blocks.0.conv1.0.weight"].shape == (256, 2048 + 1024, 3, 3)
+    assert OracleUnet("resnet50", 1, 2).state_dict()["encoder.layer1.0.downsample.0.weight"].shape == (256, 64, 1, 1)
+    a, b = OracleUnet("resnet34", 1, 2).state_dict(), OracleUnetResnet34(1, 2).state_dict()
+    assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    net = OracleUnet("resnet50", 1, 3).eval()
+    with torch.no_grad():
+        assert net(torch.zeros(1, 1, 64, 96)).shape == (1, 3, 64, 96)

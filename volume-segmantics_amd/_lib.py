@@ -70,6 +70,11 @@ _SIGS = {
     "vs_unet_param_elems": (I64, [I]),
     "vs_unet_bnstate_elems": (I64, [I]),
     "vs_unet_create": (I, [C.POINTER(P), I, I, I, I, I]),
+    "vs_unet_create_ex": (I, [C.POINTER(P), I, I, I, I, I, I]),
+    "vs_unet_num_tensors_ex": (I, [I, I]),
+    "vs_unet_tensor_info_ex": (I, [I, I, I, C.c_char_p, I, C.POINTER(I64), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
+    "vs_unet_param_elems_ex": (I64, [I, I]),
+    "vs_unet_bnstate_elems_ex": (I64, [I, I]),
     "vs_unet_destroy": (None, [P]),
     "vs_unet_workspace_bytes": (SZ, [P, I]),
     "vs_unet_prepare": (I, [P, P, P, I, P, P]),
@@ -156,9 +161,9 @@ def dtype_code(torch_dtype) -> int:
     raise ValueError(f"unsupported compute dtype {torch_dtype}")
 
 
-def unet_tensor_table(classes: int):
+def unet_tensor_table(classes: int, encoder: int = 34):
     """[(name, shape, kind, offset)] in smp state_dict order (see vs_unet_tensor_info)."""
-    n = lib.vs_unet_num_tensors(classes)
+    n = lib.vs_unet_num_tensors_ex(classes, encoder)
     if n < 0:
         raise RuntimeError(last_error())
     out = []
@@ -166,7 +171,7 @@ def unet_tensor_table(classes: int):
     shape = (I64 * 4)()
     ndim, kind, off = I(), I(), I64()
     for i in range(n):
-        check(lib.vs_unet_tensor_info(classes, i, name, 128, shape, C.byref(ndim), C.byref(kind), C.byref(off)))
+        check(lib.vs_unet_tensor_info_ex(classes, encoder, i, name, 128, shape, C.byref(ndim), C.byref(kind), C.byref(off)))
         out.append((name.value.decode(), tuple(shape[: ndim.value]), kind.value, off.value))
     return out
 

@@ -84,6 +84,7 @@ int add_bn(Layout& L, const std::string& prefix, int c) {
 
 struct vs_unet {
     int dtype, classes, max_batch, h, w;
+    int encoder = 34;   // torchvision ResNet depth behind smp's encoder_name: 18 / 34 (BasicBlock) or 50 (Bottleneck)
     Layout layout;
     std::vector<Act> acts;
     std::vector<Unit> units;
@@ -136,43 +137,57 @@ int build(vs_unet* net) {
     pool.hout = H / 4; pool.wout = W / 4; pool.out = new_act(64, H / 4, W / 4, false);
     U.push_back(pool);
     int cur = pool.out, inpl = 64, ch = H / 4, cw = W / 4;
-    const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
+    const int planes[4] = {64, 128, 256, 512};
+    const int blocks18[4] = {2, 2, 2, 2}, blocks34[4] = {3, 4, 6, 3};   // resnet50 uses the resnet34 block counts
+    const int* blocks = net->encoder == 18 ? blocks18 : blocks34;
+    const bool bottleneck = net->encoder == 50;
+    const int expansion = bottleneck ? 4 : 1;
+    int featc[6] = {0, 64, 0, 0, 0, 0};          // channels of the encoder features the decoder taps
     for (int l = 0; l < 4; ++l) {
         for (int b = 0; b < blocks[l]; ++b) {
             const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(b);
             const int stride = (b == 0 && l > 0) ? 2 : 1;
-            const int oh = ch / stride, ow = cw / stride, pl = planes[l];
-            Unit u1; u1.kind = U_CONV; u1.src0 = cur; u1.cin0 = inpl; u1.cout = pl; u1.stride = stride;
-            u1.hin = ch; u1.win = cw; u1.hout = oh; u1.wout = ow; u1.frozen_candidate = true;
-            u1.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv1.weight", {pl, inpl, 3, 3}, 0);
-            u1.bn_idx = add_bn(L, pre + ".bn1", pl);
-            u1.out = new_act(pl, oh, ow, true);
-            Unit u2; u2.kind = U_CONV; u2.src0 = u1.out; u2.cin0 = pl; u2.cout = pl;
-            u2.hin = oh; u2.win = ow; u2.hout = oh; u2.wout = ow; u2.frozen_candidate = true;
-            u2.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.weight", {pl, pl, 3, 3}, 0);
-            u2.bn_idx = add_bn(L, pre + ".bn2", pl);
-            u2.out = new_act(pl, oh, ow, true);
-            U.push_back(u1);
-            if (stride != 1 || inpl != pl) {
-                Unit ud; ud.kind = U_CONV; ud.src0 = cur; ud.cin0 = inpl; ud.cout = pl; ud.k = 1; ud.pad = 0;
-                ud.stride = stride; ud.hin = ch; ud.win = cw; ud.hout = oh; ud.wout = ow; ud.relu = 0;
-                ud.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".downsample.0.weight", {pl, inpl, 1, 1}, 0);
-                ud.bn_idx = add_bn(L, pre + ".downsample.1", pl);
-                ud.out = new_act(pl, oh, ow, true);
-                U.push_back(ud);
-                u2.res = ud.out;
+            const int oh = ch / stride, ow = cw / stride, pl = planes[l], outc = pl * expansion;
+            auto conv_unit = [&](const std::string& name, const std::string& bn, int src, int cin, int cout, int k, int st, int hi, int wi,
+                                 bool frozen) {
+                Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.stride = st;
+                u.hin = hi; u.win = wi; u.hout = hi / st; u.wout = wi / st; u.frozen_candidate = frozen;
+                u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cin, k, k}, 0);
+                u.bn_idx = add_bn(L, bn, cout);
+                u.out = new_act(cout, hi / st, wi / st, true);
+                return u;
+            };
+            // the block's convolutions in torchvision's registration order (= state_dict order): conv1 bn1 conv2 bn2 [conv3 bn3]
+            // [downsample.0 downsample.1].  BasicBlock: 3x3 (stride) - 3x3; Bottleneck (v1.5): 1x1 - 3x3 (stride) - 1x1 (x4).
+            std::vector<Unit> us;
+            if (!bottleneck) {
+                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, pl, 3, stride, ch, cw, true));
+                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, pl, pl, 3, 1, oh, ow, true));
             } else {
-                u2.res = cur;
+                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, pl, 1, 1, ch, cw, true));
+                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, pl, pl, 3, stride, ch, cw, true));
+                us.push_back(conv_unit(pre + ".conv3.weight", pre + ".bn3", us[1].out, pl, outc, 1, 1, oh, ow, true));
             }
-            U.push_back(u2);
-            cur = u2.out; inpl = pl; ch = oh; cw = ow;
+            Unit& last = us.back();
+            for (size_t q = 0; q + 1 < us.size(); ++q) U.push_back(us[q]);
+            if (stride != 1 || inpl != outc) {   // "downsample" lacks "conv" in its name: not frozen by the reference's predicate
+                Unit ud = conv_unit(pre + ".downsample.0.weight", pre + ".downsample.1", cur, inpl, outc, 1, stride, ch, cw, false);
+                ud.relu = 0;
+                U.push_back(ud);
+                last.res = ud.out;
+            } else {
+                last.res = cur;
+            }
+            U.push_back(last);
+            cur = last.out; inpl = outc; ch = oh; cw = ow;
         }
         feat[l + 2] = cur;
+        featc[l + 2] = inpl;
     }
     // ---- decoder ----
     const int dec[5] = {256, 128, 64, 32, 16};
-    const int skipc[5] = {256, 128, 64, 64, 0};
-    int xin = feat[5], xc = 512;
+    const int skipc[5] = {featc[4], featc[3], featc[2], featc[1], 0};
+    int xin = feat[5], xc = featc[5];
     for (int i = 0; i < 5; ++i) {
         const std::string pre = "decoder.blocks." + std::to_string(i);
         const int oh = ch * 2, ow = cw * 2;
@@ -212,7 +227,9 @@ size_t plan_workspace(vs_unet* net) {
         }
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
-    net->bnws_bytes = 4 * vs_bn_workspace(0, 512);  // also receives the conv epilogue's per-tile statistics
+    int cmax = 512;
+    for (auto& u : net->units) cmax = std::max(cmax, u.cout);
+    net->bnws_bytes = 4 * vs_bn_workspace(0, cmax);  // also receives the conv epilogue's per-tile statistics
     net->off_bnws = take(net->bnws_bytes);
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
@@ -303,25 +320,27 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
 }  // namespace
 
 // ---- parameter table -------------------------------------------------------------------------------
-static int with_layout(int classes, Layout& out) {
+static int with_layout(int classes, int encoder, Layout& out) {
     vs_unet tmp{};
-    tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4;
+    tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
 }
 
-extern "C" int vs_unet_num_tensors(int classes) {
+extern "C" int vs_unet_num_tensors_ex(int classes, int encoder) {
     Layout L;
-    if (with_layout(classes, L)) return VS_ERR_INVALID;
+    if (with_layout(classes, encoder, L)) return VS_ERR_INVALID;
     return (int)L.tensors.size();
 }
+extern "C" int vs_unet_num_tensors(int classes) { return vs_unet_num_tensors_ex(classes, 34); }
 
-extern "C" int vs_unet_tensor_info(int classes, int index, char* name, int name_len, int64_t shape[4], int* ndim,
-                                   int* kind, int64_t* offset) {
+extern "C" int vs_unet_tensor_info_ex(int classes, int encoder, int index, char* name, int name_len, int64_t shape[4], int* ndim,
+                                      int* kind, int64_t* offset) {
     Layout L;
-    if (with_layout(classes, L)) return VS_ERR_INVALID;
+    if (with_layout(classes, encoder, L)) return VS_ERR_INVALID;
     VS_REQUIRE(index >= 0 && index < (int)L.tensors.size(), "tensor index %d out of range", index);
     const TensorInfo& t = L.tensors[index];
     if (name && name_len > 0) { strncpy(name, t.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
@@ -330,27 +349,40 @@ extern "C" int vs_unet_tensor_info(int classes, int index, char* name, int name_
     return VS_OK;
 }
 
-extern "C" int64_t vs_unet_param_elems(int classes) {
-    Layout L;
-    if (with_layout(classes, L)) return -1;
-    return L.n_params;
+extern "C" int vs_unet_tensor_info(int classes, int index, char* name, int name_len, int64_t shape[4], int* ndim,
+                                   int* kind, int64_t* offset) {
+    return vs_unet_tensor_info_ex(classes, 34, index, name, name_len, shape, ndim, kind, offset);
 }
 
-extern "C" int64_t vs_unet_bnstate_elems(int classes) {
+extern "C" int64_t vs_unet_param_elems_ex(int classes, int encoder) {
     Layout L;
-    if (with_layout(classes, L)) return -1;
+    if (with_layout(classes, encoder, L)) return -1;
+    return L.n_params;
+}
+extern "C" int64_t vs_unet_param_elems(int classes) { return vs_unet_param_elems_ex(classes, 34); }
+
+extern "C" int64_t vs_unet_bnstate_elems_ex(int classes, int encoder) {
+    Layout L;
+    if (with_layout(classes, encoder, L)) return -1;
     return L.n_bnstate;
 }
+extern "C" int64_t vs_unet_bnstate_elems(int classes) { return vs_unet_bnstate_elems_ex(classes, 34); }
 
 // ---- lifecycle -------------------------------------------------------------------------------------
 extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w) {
+    return vs_unet_create_ex(out, dtype, classes, max_batch, h, w, 34);
+}
+
+extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder) {
     VS_REQUIRE(out, "unet_create: null out pointer");
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "unet_create: encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
                "unet_create: batch %d, %dx%d - spatial dims must be positive multiples of 32", max_batch, h, w);
     vs_unet* net = new vs_unet();
     net->dtype = dtype; net->classes = classes; net->max_batch = max_batch; net->h = h; net->w = w;
+    net->encoder = encoder;
     net->esz = dtype_size(dtype);
     build(net);
     plan_workspace(net);

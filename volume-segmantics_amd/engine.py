@@ -71,20 +71,26 @@ class _UnetFn(torch.autograd.Function):
 
 
 class VolSegUnet(nn.Module):
-    def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None):
+    ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50}
+
+    def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
+                 encoder: str = "resnet34"):
         super().__init__()
+        if encoder not in self.ENCODERS:
+            raise NotImplementedError(f"encoder {encoder!r}: the engine builds {sorted(self.ENCODERS)}")
+        self.encoder_name, self._enc = encoder, self.ENCODERS[encoder]
         precision = precision or default_precision()
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         self.classes = int(classes)
         self.precision = precision
         self._dtype_code = _lib.VS_F32 if precision == "fp32" else _lib.VS_BF16
-        self._table = _lib.unet_tensor_table(self.classes)
+        self._table = _lib.unet_tensor_table(self.classes, self._enc)
         dev = torch.device(device if device is not None else "cpu")
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        n_params = lib.vs_unet_param_elems(self.classes)
-        n_bn = lib.vs_unet_bnstate_elems(self.classes)
+        n_params = lib.vs_unet_param_elems_ex(self.classes, self._enc)
+        n_bn = lib.vs_unet_bnstate_elems_ex(self.classes, self._enc)
         self._flat = torch.zeros(n_params, dtype=torch.float32, device=dev)
         self._flat_grad = None
         self._bnstate = torch.zeros(n_bn, dtype=torch.float32, device=dev)
@@ -207,7 +213,7 @@ class VolSegUnet(nn.Module):
                 lib.vs_unet_destroy(plan["handle"])
             handle = _lib.C.c_void_p()
             max_batch = max(n, plan["max_batch"] if plan else 0)
-            check(lib.vs_unet_create(_lib.C.byref(handle), self._dtype_code, self.classes, max_batch, h, w))
+            check(lib.vs_unet_create_ex(_lib.C.byref(handle), self._dtype_code, self.classes, max_batch, h, w, self._enc))
             train_ws = training or (plan is not None and plan["training"])
             nbytes = lib.vs_unet_workspace_bytes(handle, 1 if train_ws else 0)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

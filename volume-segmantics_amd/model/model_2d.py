@@ -27,30 +27,30 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
     struct = dict(model_struc_dict)
     model_type = utils.create_enum_from_setting(struct.pop("type"), utils.ModelType)
     encoder = struct.get("encoder_name", "resnet34")
-    if model_type != utils.ModelType.U_NET or encoder != "resnet34":
+    if model_type != utils.ModelType.U_NET or encoder not in VolSegUnet.ENCODERS:
         raise NotImplementedError(
-            f"the MI355X engine implements U_NET + resnet34 (requested {model_type.name} + {encoder}); "
-            "the other smp topologies are listed as next rows in SURVEY.md section 8f")
+            f"the MI355X engine implements U_NET over {sorted(VolSegUnet.ENCODERS)} (requested {model_type.name} + {encoder}); "
+            "the other smp topologies / encoders are listed as next rows in SURVEY.md section 8f")
     if int(struct.get("in_channels", 1)) != 1:
         raise NotImplementedError("the engine implements the reference's single-channel input (config.MODEL_INPUT_CHANNELS)")
-    model = VolSegUnet(int(struct["classes"]), device=_device(device_num), precision=struct.get("precision"))
+    model = VolSegUnet(int(struct["classes"]), device=_device(device_num), precision=struct.get("precision"), encoder=encoder)
     weights = struct.get("encoder_weights")
     if weights:
-        # smp downloads ImageNet weights here; there is no network, so an explicit local torchvision
-        # resnet34 state dict can be supplied instead (env VOLSEG_RESNET34_WEIGHTS)
-        path = os.environ.get("VOLSEG_RESNET34_WEIGHTS")
+        # smp downloads ImageNet weights here; there is no network, so an explicit local torchvision state dict of the
+        # same encoder can be supplied instead (env VOLSEG_ENCODER_WEIGHTS; VOLSEG_RESNET34_WEIGHTS for resnet34)
+        path = os.environ.get("VOLSEG_ENCODER_WEIGHTS") or (os.environ.get("VOLSEG_RESNET34_WEIGHTS") if encoder == "resnet34" else None)
         if path and Path(path).exists():
             load_torchvision_resnet34(model, torch.load(path, map_location="cpu"))
             logging.info(f"Loaded {weights} encoder weights from {path}")
         elif struct.get("allow_random_encoder"):
             logging.warning(f"encoder_weights={weights!r} requested but no local weights available "
-                            "(set VOLSEG_RESNET34_WEIGHTS); allow_random_encoder is set: smp's random initialisation")
+                            "(set VOLSEG_ENCODER_WEIGHTS); allow_random_encoder is set: smp's random initialisation")
         else:
             # smp would download the ImageNet encoder here; the LR finder and the frozen-encoder phase are built around a
             # pretrained encoder, so silently training from random weights would be a behaviour change
             raise FileNotFoundError(
-                f"encoder_weights={weights!r}: no network access and no local weights - point VOLSEG_RESNET34_WEIGHTS at a "
-                "torchvision resnet34 state dict, or set `allow_random_encoder: true` (or encoder_weights: null) in the "
+                f"encoder_weights={weights!r}: no network access and no local weights - point VOLSEG_ENCODER_WEIGHTS at a "
+                f"torchvision {encoder} state dict, or set `allow_random_encoder: true` (or encoder_weights: null) in the "
                 "model settings to train the encoder from random initialisation")
     logging.info(f"Sending the U-Net model to device {device_num}")
     return model
