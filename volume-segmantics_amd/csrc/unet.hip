@@ -29,7 +29,7 @@ struct TensorInfo {
     int64_t offset;
 };
 
-enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD };
+enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT };
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -49,6 +49,7 @@ struct Unit {
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
+    std::vector<int> members;                    // U_CONCAT: the activations whose channels `out` strings together, in order
 };
 
 struct Layout {
@@ -84,6 +85,7 @@ int add_bn(Layout& L, const std::string& prefix, int c) {
 
 struct vs_unet {
     int dtype, classes, max_batch, h, w;
+    int topology = 0;   // 0 = smp.Unet, 1 = smp.UnetPlusPlus (dense nested skips)
     int encoder = 34;   // torchvision ResNet depth behind smp's encoder_name: 18 / 34 (BasicBlock) or 50 (Bottleneck)
     Layout layout;
     std::vector<Act> acts;
@@ -188,6 +190,7 @@ int build(vs_unet* net) {
     const int dec[5] = {256, 128, 64, 32, 16};
     const int skipc[5] = {featc[4], featc[3], featc[2], featc[1], 0};
     int xin = feat[5], xc = featc[5];
+    if (net->topology == 0) {
     for (int i = 0; i < 5; ++i) {
         const std::string pre = "decoder.blocks." + std::to_string(i);
         const int oh = ch * 2, ow = cw * 2;
@@ -204,6 +207,68 @@ int build(vs_unet* net) {
         u2.out = new_act(dec[i], oh, ow, true);
         U.push_back(u1); U.push_back(u2);
         xin = u2.out; xc = dec[i]; ch = oh; cw = ow;
+    }
+    } else {
+        // smp.UnetPlusPlusDecoder (decoders/unetplusplus/decoder.py of segmentation-models-pytorch 0.2.1, restated):
+        // features reversed, deepest first: f[0] = layer4 .. f[4] = stem; in_channels = [C(f0), 256, 128, 64, 32],
+        // skip_channels = [C(f1), C(f2), C(f3), C(f4), 0], out_channels = dec.  Node x_d_l = DecoderBlock(up(x_d_(l-1) or f[d]),
+        // cat(x_(d+1)_l .. x_l_l, f[l+1])); all nodes x_*_l and f[l+1] share a resolution.  Parameters are REGISTERED in the
+        // constructor's order (x_0_0; x_0_1 x_1_1; x_0_2 x_1_2 x_2_2; ..; x_0_4) but EXECUTED in forward()'s order
+        // (x_0_0 x_1_1 x_2_2 x_3_3; x_0_1 x_1_2 x_2_3; x_0_2 x_1_3; x_0_3; x_0_4): tensors first, units second.
+        const int f_act[5] = {feat[5], feat[4], feat[3], feat[2], feat[1]};
+        const int f_c[5] = {featc[5], featc[4], featc[3], featc[2], featc[1]};
+        const int in_c[5] = {f_c[0], dec[0], dec[1], dec[2], dec[3]};
+        struct Node { int in_ch, skip_ch, out_ch, w1, bn1, w2, bn2, out_act; };
+        Node node[5][5] = {};
+        auto reg = [&](int d, int l, int in_ch, int skip_ch, int out_ch) {
+            const std::string pre = "decoder.blocks.x_" + std::to_string(d) + "_" + std::to_string(l);
+            Node& nd = node[d][l];
+            nd.in_ch = in_ch; nd.skip_ch = skip_ch; nd.out_ch = out_ch;
+            nd.w1 = (int)L.tensors.size(); add_tensor(L, pre + ".conv1.0.weight", {out_ch, in_ch + skip_ch, 3, 3}, 0);
+            nd.bn1 = add_bn(L, pre + ".conv1.1", out_ch);
+            nd.w2 = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.0.weight", {out_ch, out_ch, 3, 3}, 0);
+            nd.bn2 = add_bn(L, pre + ".conv2.1", out_ch);
+        };
+        for (int l = 0; l < 4; ++l)
+            for (int d = 0; d <= l; ++d) {
+                if (d == 0) reg(0, l, in_c[l], skipc[l] * (l + 1), dec[l]);
+                else reg(d, l, skipc[l - 1], skipc[l] * (l + 1 - d), skipc[l]);
+            }
+        reg(0, 4, in_c[4], 0, dec[4]);
+        auto run_node = [&](int d, int l, int x_act, int x_c, const std::vector<int>& skip_members) {
+            Node& nd = node[d][l];
+            const Act xa = A[x_act];
+            const int oh = xa.h * 2, ow = xa.w * 2;
+            int skip_act = -1;
+            if (!skip_members.empty()) {   // the concatenation is materialised (channel-slice copies): its gradient is split back
+                Unit cu; cu.kind = U_CONCAT; cu.members = skip_members; cu.cout = nd.skip_ch; cu.hout = oh; cu.wout = ow; cu.relu = 0;
+                cu.out = new_act(nd.skip_ch, oh, ow, false);
+                U.push_back(cu);
+                skip_act = cu.out;
+            }
+            Unit u1; u1.kind = U_CONV; u1.src0 = x_act; u1.up0 = 1; u1.cin0 = x_c; u1.cin1 = nd.skip_ch; u1.src1 = skip_act;
+            u1.cout = nd.out_ch; u1.hin = oh; u1.win = ow; u1.hout = oh; u1.wout = ow; u1.w_idx = nd.w1; u1.bn_idx = nd.bn1;
+            u1.out = new_act(nd.out_ch, oh, ow, true);
+            Unit u2; u2.kind = U_CONV; u2.src0 = u1.out; u2.cin0 = nd.out_ch; u2.cout = nd.out_ch;
+            u2.hin = oh; u2.win = ow; u2.hout = oh; u2.wout = ow; u2.w_idx = nd.w2; u2.bn_idx = nd.bn2;
+            u2.out = new_act(nd.out_ch, oh, ow, true);
+            U.push_back(u1); U.push_back(u2);
+            nd.out_act = u2.out;
+        };
+        for (int layer = 0; layer < 4; ++layer)
+            for (int d = 0; d < 4 - layer; ++d) {
+                const int l = d + layer;
+                if (layer == 0) {
+                    run_node(d, d, f_act[d], f_c[d], {f_act[d + 1]});
+                } else {
+                    std::vector<int> members;
+                    for (int idx = d + 1; idx <= l; ++idx) members.push_back(node[idx][l].out_act);
+                    members.push_back(f_act[l + 1]);
+                    run_node(d, l, node[d][l - 1].out_act, node[d][l - 1].out_ch, members);
+                }
+            }
+        run_node(0, 4, node[0][3].out_act, node[0][3].out_ch, {});
+        xin = node[0][4].out_act; xc = dec[4];
     }
     Unit head; head.kind = U_HEAD; head.src0 = xin; head.cin0 = 16; head.cout = net->classes; head.relu = 0;
     head.hin = H; head.win = W; head.hout = H; head.wout = W;
@@ -320,9 +385,12 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
 }  // namespace
 
 // ---- parameter table -------------------------------------------------------------------------------
-static int with_layout(int classes, int encoder, Layout& out) {
+static int with_layout(int classes, int encoder_code, Layout& out) {   // encoder_code = topology * 1000 + encoder
     vs_unet tmp{};
+    const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
+    tmp.topology = encoder_code / 1000;
+    VS_REQUIRE(tmp.topology == 0 || tmp.topology == 1, "topology must be 0 (U-Net) or 1 (U-Net++), got %d", tmp.topology);
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
     build(&tmp);
@@ -373,8 +441,10 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
     return vs_unet_create_ex(out, dtype, classes, max_batch, h, w, 34);
 }
 
-extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder) {
+extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
+    const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
+    VS_REQUIRE(topology == 0 || topology == 1, "unet_create: topology must be 0 (U-Net) or 1 (U-Net++), got %d", topology);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "unet_create: encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -383,6 +453,7 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     vs_unet* net = new vs_unet();
     net->dtype = dtype; net->classes = classes; net->max_batch = max_batch; net->h = h; net->w = w;
     net->encoder = encoder;
+    net->topology = topology;
     net->esz = dtype_size(dtype);
     build(net);
     plan_workspace(net);
@@ -404,6 +475,12 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
     {   // every conv layer's low-precision copy and flipped/transposed dgrad copy in one launch
         long w_off[64], wc_off[64], wt_off[64];
         int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+        auto flush = [&]() -> int {
+            if (!nl) return VS_OK;
+            const int rc = launch_weight_prepare_all(net->dtype, params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, c.s);
+            nl = 0;
+            return rc;
+        };
         for (auto& u : net->units) {
             if (u.kind != U_CONV && u.kind != U_HEAD) continue;
             const bool wc = net->dtype == VS_BF16, wt = training != 0;
@@ -412,10 +489,13 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
             wc_off[nl] = wc ? (long)Ctx::wc_off(u, net->wset) : -1;
             wt_off[nl] = wt ? (long)Ctx::wt_off(u, net->wset) : -1;
             cout[nl] = u.cout; taps[nl] = u.k * u.k; cin[nl] = u.cin0 + u.cin1; cpad[nl] = u.kind == U_HEAD ? 16 : u.cout;
-            ++nl;
+            if (++nl == 64) {   // the descriptor table of one launch holds 64 layers (U-Net++ / resnet50 has 83)
+                int rc = flush();
+                if (rc) return rc;
+            }
         }
-        if (nl) {
-            int rc = launch_weight_prepare_all(net->dtype, params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, c.s);
+        {
+            int rc = flush();
             if (rc) return rc;
         }
     }
@@ -523,6 +603,16 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * 64 * net->esz * 1.25, c.s);
             if ((rc = vs_maxpool_fwd(dt, c.a(u.src0), c.a(u.out), training ? (uint8_t*)(c.ws + net->off_idx) : nullptr, n,
                                      u.hin, u.win, u.cout, stream))) return rc;
+            continue;
+        }
+        case U_CONCAT: {   // torch.cat of U-Net++'s dense skips, materialised (one channel-slice copy per member)
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            int off = 0;
+            for (int m : u.members) {
+                const int mc = net->acts[m].c;
+                if ((rc = vs_channel_slice(dt, c.a(m), mc, 0, c.a(u.out), u.cout, off, mc, (int64_t)n * u.hout * u.wout, 0, stream))) return rc;
+                off += mc;
+            }
             continue;
         }
         case U_CONV: {
@@ -648,6 +738,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (v.out >= 0) net->producer[v.out] = k;
             for (int a : {v.src0, v.src1, v.res})
                 if (a >= 0 && k < net->first_consumer[a]) net->first_consumer[a] = k;
+            for (int a : v.members)
+                if (k < net->first_consumer[a]) net->first_consumer[a] = k;
         }
     }
     if (do_main && unit_hi == (int)net->units.size()) net->bwd_stat_rows.assign(net->acts.size(), 0);
@@ -692,7 +784,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     // the group's parameter slice and ONE launch deriving its weight copies for the next forward follow on the side stream.
     auto group_update = [&](int ui) -> int {
         if (net->group_first.empty()) {   // unit index -> does an optimiser group start here
-            static const char* const kCuts[] = {"decoder.blocks.0.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
+            static const char* const kCuts[] = {"decoder.blocks.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
             net->group_first.assign(net->units.size(), 0);
             net->group_first[0] = 1;
             std::string prev;
@@ -727,6 +819,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (v.bias_idx >= 0) push(v.bias_idx);
             VS_REQUIRE(r.n < 158, "unet_backward: too many parameter slices in one optimiser group");
             if (v.kind == U_CONV || v.kind == U_HEAD) {
+                VS_REQUIRE(nl < 64, "unet_backward: too many layers in one optimiser group");
                 w_off[nl] = c.t(v.w_idx).offset;
                 wc_off[nl] = dt == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
                 wt_off[nl] = (long)Ctx::wt_off(v, other);
@@ -786,6 +879,19 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
+        if (u.kind == U_CONCAT) {   // gradient of the concatenation: each slice is added onto its member's gradient
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: concat gradient missing");
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            int off = 0;
+            for (int m : u.members) {
+                const int mc = net->acts[m].c;
+                if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, off, c.da(m), mc, 0, mc, (int64_t)n * u.hout * u.wout, written[m], stream))) return rc;
+                written[m] = 1;
+                off += mc;
+            }
+            continue;
+        }
         if (u.kind == U_POOL) {
             if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
@@ -854,9 +960,12 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
         p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0 + u.cin1;
         if (u.up0) {
-            VS_REQUIRE(!written[u.src0] && (u.src1 < 0 || !written[u.src1]), "backward: decoder input gradient written twice");
+            // U-Net: every decoder input has this one consumer.  U-Net++: the upsampled input may already hold the contributions
+            // of the nodes that read it as a dense skip - then the 2x2 sum goes through the separate, accumulating kernel.
+            const bool acc0 = written[u.src0] != 0;
+            VS_REQUIRE(u.src1 < 0 || !written[u.src1], "backward: decoder skip gradient written twice");
             if (u.src1 >= 0) { p.out1 = c.da(u.src1); p.split_c = u.cin0; written[u.src1] = 1; }
-            if (conv_igemm_can_pool(p)) {  // 2x2 sum of the upsampled part inside the dgrad epilogue
+            if (!acc0 && conv_igemm_can_pool(p)) {  // 2x2 sum of the upsampled part inside the dgrad epilogue
                 p.pool0 = 1;
                 p.out = c.da(u.src0);
                 prof_set_variant(conv_igemm_variant(dt, p));
@@ -870,7 +979,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                     if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 }
                 ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cin0 * net->esz * 1.25, c.s);
-                if ((rc = vs_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, stream))) return rc;
+                if ((rc = launch_upsample2x_bwd(dt, p.out, c.da(u.src0), n, u.hin / 2, u.win / 2, u.cin0, acc0 ? 1 : 0, c.s))) return rc;
             }
             written[u.src0] = 1;
         } else {
@@ -962,7 +1071,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
-    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : "maxpool";
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : "maxpool");
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];

@@ -72,13 +72,17 @@ class _UnetFn(torch.autograd.Function):
 
 class VolSegUnet(nn.Module):
     ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50}
+    TOPOLOGIES = {"unet": 0, "unetplusplus": 1}     # smp.Unet, smp.UnetPlusPlus
 
     def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
-                 encoder: str = "resnet34"):
+                 encoder: str = "resnet34", topology: str = "unet"):
         super().__init__()
         if encoder not in self.ENCODERS:
             raise NotImplementedError(f"encoder {encoder!r}: the engine builds {sorted(self.ENCODERS)}")
-        self.encoder_name, self._enc = encoder, self.ENCODERS[encoder]
+        if topology not in self.TOPOLOGIES:
+            raise NotImplementedError(f"topology {topology!r}: the engine builds {sorted(self.TOPOLOGIES)}")
+        self.encoder_name, self.topology = encoder, topology
+        self._enc = self.TOPOLOGIES[topology] * 1000 + self.ENCODERS[encoder]     # the C ABI's encoder code
         precision = precision or default_precision()
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
@@ -503,7 +507,7 @@ class VolSegUnet(nn.Module):
         layer3, then stem + layer1 + layer2.  Backward fills the flat buffer from its end towards its start."""
         names = _lib.unit_names(handle)
         cuts = [len(names)]
-        for prefix in ("decoder.blocks.0.", "encoder.layer4.0.", "encoder.layer3.0."):
+        for prefix in ("decoder.blocks.", "encoder.layer4.0.", "encoder.layer3.0."):
             cuts.append(next(i for i, nm in enumerate(names) if nm.startswith(prefix)))
         cuts.append(0)
         plan = []

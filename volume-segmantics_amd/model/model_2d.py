@@ -27,13 +27,15 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
     struct = dict(model_struc_dict)
     model_type = utils.create_enum_from_setting(struct.pop("type"), utils.ModelType)
     encoder = struct.get("encoder_name", "resnet34")
-    if model_type != utils.ModelType.U_NET or encoder not in VolSegUnet.ENCODERS:
+    topologies = {utils.ModelType.U_NET: "unet", utils.ModelType.U_NET_PLUS_PLUS: "unetplusplus"}
+    if model_type not in topologies or encoder not in VolSegUnet.ENCODERS:
         raise NotImplementedError(
-            f"the MI355X engine implements U_NET over {sorted(VolSegUnet.ENCODERS)} (requested {model_type.name} + {encoder}); "
-            "the other smp topologies / encoders are listed as next rows in SURVEY.md section 8f")
+            f"the MI355X engine implements U_NET and U_NET_PLUS_PLUS over {sorted(VolSegUnet.ENCODERS)} (requested "
+            f"{model_type.name} + {encoder}); the other smp topologies / encoders are listed as next rows in SURVEY.md section 8f")
     if int(struct.get("in_channels", 1)) != 1:
         raise NotImplementedError("the engine implements the reference's single-channel input (config.MODEL_INPUT_CHANNELS)")
-    model = VolSegUnet(int(struct["classes"]), device=_device(device_num), precision=struct.get("precision"), encoder=encoder)
+    model = VolSegUnet(int(struct["classes"]), device=_device(device_num), precision=struct.get("precision"), encoder=encoder,
+                       topology=topologies[model_type])
     weights = struct.get("encoder_weights")
     if weights:
         # smp downloads ImageNet weights here; there is no network, so an explicit local torchvision state dict of the
