@@ -308,6 +308,12 @@ def main():
                          "during the untimed set-up and keep the faster one on this box")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
+    ap.add_argument("--encoder", default="resnet34", choices=["resnet18", "resnet34", "resnet50"])
+    ap.add_argument("--topology", default="unet", choices=["unet", "unetplusplus"],
+                    help="with --encoder / --size / --classes: other rows of the model matrix, e.g. BASELINE configs[3] = "
+                         "--topology unetplusplus --encoder resnet50 --size 512 --classes 4 (not the headline metric: no FLOP model)")
+    ap.add_argument("--size", type=int, default=256, help="slice height = width")
+    ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--per-unit", default="", help="write a per-layer kernel-time table (instrumented steps) to this file")
     args = ap.parse_args()
 
@@ -334,15 +340,18 @@ def main():
     from volume_segmantics_amd import _lib
     from volume_segmantics_amd.engine import VolSegUnet
 
-    model = VolSegUnet(2, device=dev, precision=args.precision, seed=0)
+    headline = (args.encoder, args.topology, args.size, args.classes, args.batch) == ("resnet34", "unet", 256, 2, 32)
+    if not headline:
+        args.no_predict = True      # the prediction legs are the headline configuration's
+    model = VolSegUnet(args.classes, device=dev, precision=args.precision, seed=0, encoder=args.encoder, topology=args.topology)
     if world > 1:
         dist.broadcast(model._flat, 0)
         dist.broadcast(model._bnstate, 0)
         model.dp_group = dist.group.WORLD
-    x, lab = synth_batch(args.batch, 256, 2, seed=1234 + rank)   # every rank: its own shard of the global batch
+    x, lab = synth_batch(args.batch, args.size, args.classes, seed=1234 + rank)   # every rank: its own shard of the global batch
     x = x.to(dev)
     # one-hot targets as prepare_training_batch hands them over (utilities/base_data_utils.py:150-158): NCHW uint8, contiguous
-    target = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8).contiguous()
+    target = torch.nn.functional.one_hot(lab, args.classes).permute(0, 3, 1, 2).to(dev, torch.uint8).contiguous()
     opt = model.fused_adamw(lr=1e-4, fuse_step_into_backward=True)   # single GPU: the step hides under the backward pass
     setup_steps = 3   # untimed, before the warm-up: lazy initialisation + recording the step's two hipGraphs (one per weight set)
     total = setup_steps + args.warmup + args.steps + 13 * 2 * (max(4, args.steps) + 1) + 64
@@ -461,7 +470,7 @@ def main():
     _lib.check(_lib.lib.vs_profile_enable(0))
     _lib.set_option("side_stream", side)
     if rank == 0 and args.per_unit:
-        names = _lib.unit_names(model._plans[(256, 256)]["handle"])
+        names = _lib.unit_names(model._plans[(args.size, args.size)]["handle"])
         agg = {}
         for kind, tag, ms, fl, by, _var in raw:
             a = agg.setdefault((kind, tag), [0.0, 0.0, 0.0])
@@ -511,15 +520,19 @@ def main():
                          **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] and v["ms"] else {})}
                      for k, v in prof.items()}
         out = {
-            "metric": "slices/sec fwd+bwd U-Net/ResNet-34 256x256 bf16 batch 32 (training step incl. loss, AdamW)",
+            "metric": ("slices/sec fwd+bwd U-Net/ResNet-34 256x256 bf16 batch 32 (training step incl. loss, AdamW)" if headline else
+                       f"slices/sec fwd+bwd {args.topology}/{args.encoder} {args.size}x{args.size} {args.precision} batch {args.batch} "
+                       f"{args.classes}-class (training step incl. loss, AdamW) - NOT the headline configuration"),
             "value": round(slices_per_s, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 256^3-style 1-ch slices, 2-class, U-Net/ResNet-34, batch 32 per GPU, "
-                                   "train step (fwd + DiceLoss + bwd + AdamW + OneCycleLR)",
-                       "global_batch": args.batch * world, "slice": "256x256", "parallelism": f"dp{world}",
+            "config": {"workload": ("configs[1]: synthetic 256^3-style 1-ch slices, 2-class, U-Net/ResNet-34, batch 32 per GPU, "
+                                    "train step (fwd + DiceLoss + bwd + AdamW + OneCycleLR)") if headline else
+                                   (f"synthetic 1-ch slices, {args.classes}-class, {args.topology}/{args.encoder}, batch {args.batch} per GPU, "
+                                    "train step (fwd + DiceLoss + bwd + AdamW + OneCycleLR)"),
+                       "global_batch": args.batch * world, "slice": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "master_weights": "fp32", "final_loss": round(final_loss, 5)},
-            "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
+            "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4) if headline else None,
             # where a step's wall time goes: a host- or gap-bound run shows ms_per_step well above the kernel sums
             "step_timing": {
                 "mode": "hipGraph replay (forward + DiceLoss + backward + AdamW recorded once per weight set as linear graphs "
