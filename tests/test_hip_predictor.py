@@ -291,3 +291,40 @@ def test_staged_key_scatter_for_slices_along_the_contiguous_axis(classes):
             assert (got != init).any() and (got == init).any()
     finally:
         L.set_option("conv_direct_min_px", old)
+
+
+def test_model_train_2d_flow_from_volumes_to_prediction(tmp_path):
+    """BASELINE configs[0]'s plumbing (scripts/train_2d_model.py:40-75, predict_2d_model.py) on a synthetic volume pair: slice
+    the volumes to PNGs (TrainingDataSlicer), train from the PNG directories (frozen epoch, then unfrozen), write the checkpoint,
+    clean up, and predict a volume with the saved model through VolSeg2DPredictionManager."""
+    from volume_segmantics_amd.data.slicers import TrainingDataSlicer
+    from volume_segmantics_amd.model.operations.vol_seg_2d_trainer import VolSeg2dTrainer
+    from volume_segmantics_amd.model.operations.vol_seg_prediction_manager import VolSeg2DPredictionManager
+    rng = np.random.default_rng(1)
+    field = rng.standard_normal((40, 40, 40)).astype(np.float32)
+    for ax in range(3):
+        field = (np.roll(field, 1, ax) + field + np.roll(field, -1, ax)) / 3
+    data = (field * 1000 + 3000).astype(np.float32)                      # a float volume: clip_data -> uint8 on the device
+    labels = (field > 0.05).astype(np.uint8) * 255                        # binary {0, 255} as in the reference's vessels labels
+    settings = SimpleNamespace(starting_lr=1e-6, end_lr=50, lr_find_epochs=1, lr_reduce_factor=500, cuda_device=0, patience=3,
+                               loss_criterion="BCEDiceLoss", alpha=0.75, beta=0.25, eval_metric="MeanIoU", pct_lr_inc=0.3,
+                               plot_lr_graph=False, image_size=64, training_set_proportion=0.8, training_axes="All",
+                               st_dev_factor=2.575, downsample=False, clip_data=True, data_hdf5_path="/data", seg_hdf5_path="/data",
+                               batch_size=8, num_workers=0, precision="bf16",
+                               model={"type": "U_Net", "encoder_name": "resnet34", "encoder_weights": None})
+    slicer = TrainingDataSlicer(data, labels, settings)
+    slicer.output_data_slices(tmp_path / "data", "data")
+    slicer.output_label_slices(tmp_path / "seg", "seg")
+    assert len(list((tmp_path / "data").glob("*.png"))) == 120 and slicer.num_seg_classes == 2
+    trainer = VolSeg2dTrainer(tmp_path / "data", tmp_path / "seg", slicer.num_seg_classes, settings)
+    out = tmp_path / "model.pytorch"
+    trainer.train_model(out, 1, 3, create=True, frozen=True)
+    trainer.train_model(out, 1, 3, create=False, frozen=False)
+    slicer.clean_up_slices()
+    assert out.exists() and len(trainer.avg_train_losses) == 2 and np.all(np.isfinite(trainer.avg_valid_losses))
+    d = torch.load(out, weights_only=False)
+    assert "precision" not in d["model_struc_dict"] and d["engine_settings"] == {"precision": "bf16"}
+    psettings = _settings(clip_data=True, quality="medium", output_probs=False)
+    mgr = VolSeg2DPredictionManager(str(out), data, psettings)
+    pred = mgr.predict_volume_to_path(tmp_path / "pred.npy")
+    assert pred.shape == data.shape and pred.dtype == np.uint8 and pred.max() <= 1 and mgr.predictor.model.precision == "bf16"

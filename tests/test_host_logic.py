@@ -225,3 +225,43 @@ def test_predictor_orchestration_with_cpu_standin_matches_reference_goldens(gold
     assert np.array_equal(l, g["three_labels"]) and np.array_equal(p, g["three_probs"])
     assert np.array_equal(pred._predict_3_ways_one_hot(vol), g["onehot_three"])
     assert np.array_equal(pred._predict_single_axis_to_one_hot(vol), g["onehot_z"])
+
+
+def test_training_data_slicer_follows_the_reference_tests(tmp_path):
+    """volume_segmantics/data/slicers.py through the reference's own test expectations (tests/test_slicers.py:33-160): label
+    classes made sequential from zero, one PNG per slice of every requested axis named <prefix>_<axis>_stack_<i>.png, binary
+    labels {0, 255} written as {0, 1}, clean-up removes the directories - plus known answers of skimage.img_as_ubyte (generated
+    with scikit-image 0.18.3's own function) for the restated conversion."""
+    from PIL import Image
+    from volume_segmantics_amd.data.slicers import TrainingDataSlicer, img_as_ubyte
+    settings = SimpleNamespace(st_dev_factor=2.575, downsample=False, clip_data=True, data_hdf5_path="/data", seg_hdf5_path="/data",
+                               training_axes="All", device_preprocess=False)
+    rng = np.random.default_rng(0)
+    vol = rng.integers(0, 256, (9, 14, 11))
+    labels = rng.integers(1, 5, (9, 14, 11)).astype(np.uint8)           # no zeros: 1..4 -> 0..3
+    s = TrainingDataSlicer(vol, labels.copy(), settings)
+    assert s.data_vol.dtype == np.uint8 and list(np.unique(s.seg_vol)) == [0, 1, 2, 3] and s.multilabel
+    assert s.codes == ["label_val_1", "label_val_2", "label_val_3", "label_val_4"]
+    s.output_data_slices(tmp_path / "im", "data")
+    s.output_label_slices(tmp_path / "seg", "seg")
+    assert len(list((tmp_path / "im").glob("*.png"))) == sum(vol.shape) == len(list((tmp_path / "seg").glob("*.png")))
+    assert np.array_equal(np.array(Image.open(tmp_path / "seg" / "seg_y_stack_3.png")), s.seg_vol[:, 3])
+    assert np.array_equal(np.array(Image.open(tmp_path / "im" / "data_x_stack_10.png")), s.data_vol[:, :, 10])
+    s.clean_up_slices()
+    assert not (tmp_path / "im").exists() and not (tmp_path / "seg").exists()
+    settings.training_axes = "x"
+    binary = (rng.integers(0, 2, (9, 14, 11)) * 255).astype(np.uint8)   # {0, 255}: two classes -> relabelled {0, 1}
+    b = TrainingDataSlicer(vol, binary, settings)
+    b.output_label_slices(tmp_path / "bin", "seg")
+    files = list((tmp_path / "bin").glob("*.png"))
+    assert len(files) == 11 and all(np.array_equal(np.unique(np.array(Image.open(f))), [0, 1]) for f in files)
+    # skimage.img_as_ubyte known answers (scikit-image 0.18.3): integers are rescaled by bit depth
+    src = [0, 1, 2, 3, 100, 255, 1000, 30000]
+    assert img_as_ubyte(np.array(src, np.int64)).tolist() == [0] * 8 == img_as_ubyte(np.array(src, np.uint32)).tolist()
+    assert img_as_ubyte(np.array(src, np.int16)).tolist() == [0, 0, 0, 0, 0, 1, 7, 234]
+    assert img_as_ubyte(np.array(src, np.uint16)).tolist() == [0, 0, 0, 0, 0, 0, 3, 117]
+    assert img_as_ubyte(np.array([0, 1, 2, 3, 100, -1, -24, 48], np.int8)).tolist() == [0, 2, 4, 6, 201, 0, 0, 96]
+    assert img_as_ubyte(np.array([-1.0, -0.5, 0.0, 0.25, 0.5, 0.999, 1.0])).tolist() == [0, 0, 0, 64, 128, 255, 255]
+    assert img_as_ubyte(np.array([True, False])).tolist() == [255, 0]
+    with pytest.raises(ValueError, match="between -1 and 1"):
+        img_as_ubyte(np.array([1.5]))

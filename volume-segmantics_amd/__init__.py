@@ -13,6 +13,7 @@ _LAZY = {
     "create_model_on_device": "volume_segmantics_amd.model.model_2d",
     "create_model_from_file": "volume_segmantics_amd.model.model_2d",
     "get_settings_data": "volume_segmantics_amd.data.settings_data",
+    "TrainingDataSlicer": "volume_segmantics_amd.data.slicers",
     "Quality": "volume_segmantics_amd.utilities.base_data_utils",
     "Axis": "volume_segmantics_amd.utilities.base_data_utils",
     "ModelType": "volume_segmantics_amd.utilities.base_data_utils",
