@@ -13,6 +13,7 @@ namespace {
 
 constexpr int kVec = 8;  // channels per thread (C is always a multiple of 8 in this network)
 constexpr int kMaxBlocks = 2048;
+constexpr int kU = 4;    // rows per trip of the streaming kernels (loads of a trip are issued together)
 static int g_bn_blocks = getenv("VS_BN_BLOCKS") ? atoi(getenv("VS_BN_BLOCKS")) : 1024;
 static int g_bn_iters = getenv("VS_BN_ITERS") ? atoi(getenv("VS_BN_ITERS")) : 4;
 
@@ -152,23 +153,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
-    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
-        const size_t o = (size_t)r * c + cvi * kVec;
-        float v[kVec];
-        ld8(x + o, v);
+    // kU rows per trip with every load issued before the first use: one 16-byte load in flight per thread left these sweeps
+    // latency-bound at ~2.5 TB/s (a trip per ~1 us memory round trip)
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
+        float v[kU][kVec], rv[kU][kVec];
+        size_t o[kU];
+        bool ok[kU];
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) v[k] = (v[k] - mu[k]) * a[k] + b[k];
+        for (int u = 0; u < kU; ++u) {
+            const int64_t r = rb + (int64_t)u * m.rpb;
+            ok[u] = r < r1;
+            o[u] = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
+            ld8(x + o[u], v[u]);
+        }
         if (res) {
-            float rv[kVec];
-            ld8(res + o, rv);
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) v[k] += rv[k];
+            for (int u = 0; u < kU; ++u) ld8(res + o[u], rv[u]);
         }
-        if (relu) {
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) v[k] = fmaxf(v[k], 0.f);
+        for (int u = 0; u < kU; ++u) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[u][k] = (v[u][k] - mu[k]) * a[k] + b[k];
+            if (res) {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[u][k] += rv[u][k];
+            }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[u][k] = fmaxf(v[u][k], 0.f);
+            }
+            if (ok[u]) st8(y + o[u], v[u]);
         }
-        st8(y + o, v);
     }
 }
 
@@ -221,23 +236,37 @@ __global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restric
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
-    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
-        const size_t o = (size_t)r * c + cvi * kVec;
-        float v[kVec];
-        ld8(x + o, v);
+    // kU rows per trip with every load issued before the first use: one 16-byte load in flight per thread left these sweeps
+    // latency-bound at ~2.5 TB/s (a trip per ~1 us memory round trip)
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
+        float v[kU][kVec], rv[kU][kVec];
+        size_t o[kU];
+        bool ok[kU];
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) v[k] = (v[k] - mu[k]) * a[k] + b[k];
+        for (int u = 0; u < kU; ++u) {
+            const int64_t r = rb + (int64_t)u * m.rpb;
+            ok[u] = r < r1;
+            o[u] = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
+            ld8(x + o[u], v[u]);
+        }
         if (res) {
-            float rv[kVec];
-            ld8(res + o, rv);
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) v[k] += rv[k];
+            for (int u = 0; u < kU; ++u) ld8(res + o[u], rv[u]);
         }
-        if (relu) {
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) v[k] = fmaxf(v[k], 0.f);
+        for (int u = 0; u < kU; ++u) {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[u][k] = (v[u][k] - mu[k]) * a[k] + b[k];
+            if (res) {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[u][k] += rv[u][k];
+            }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[u][k] = fmaxf(v[u][k], 0.f);
+            }
+            if (ok[u]) st8(y + o[u], v[u]);
         }
-        st8(y + o, v);
     }
 }
 
@@ -267,24 +296,35 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, 
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
     if (rl < m.rpb) {
-        for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
-            const size_t o = (size_t)r * c + cvi * kVec;
-            float g[kVec], xv[kVec];
-            ld8(dy + o, g);
-            ld8(x + o, xv);
-            if (relu) {
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
+            float g[kU][kVec], xv[kU][kVec], yv[RECOMPUTE ? 1 : kU][kVec];
+            bool ok[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {       // all loads of the trip first
+                const int64_t r = rb + (int64_t)u * m.rpb;
+                ok[u] = r < r1;
+                const size_t o = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
+                ld8(dy + o, g[u]);
+                ld8(x + o, xv[u]);
                 if constexpr (!RECOMPUTE) {
-                    float yv[kVec];
-                    ld8(y + o, yv);
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) g[k] = ((xv[k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+                    if (relu) ld8(y + o, yv[u]);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) { s[k] += g[k]; q[k] += g[k] * (xv[k] - mu[k]) * is[k]; }
+            for (int u = 0; u < kU; ++u) {       // rows in order: the sums are the ones the one-row-per-trip loop formed
+                if (!ok[u]) continue;
+                if (relu) {
+                    if constexpr (!RECOMPUTE) {
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) g[u][k] = yv[u][k] > 0.f ? g[u][k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) g[u][k] = ((xv[u][k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[u][k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) { s[k] += g[u][k]; q[k] += g[u][k] * (xv[u][k] - mu[k]) * is[k]; }
+            }
         }
     }
 #pragma unroll
@@ -329,27 +369,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
     }
     const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
     const int64_t r1 = min(rows, r0 + m.rows_per_block);
-    for (int64_t r = r0 + rl; r < r1; r += m.rpb) {
-        const size_t o = (size_t)r * c + cvi * kVec;
-        float g[kVec], xv[kVec];
-        ld8(dy + o, g);
-        ld8(x + o, xv);
-        if (relu) {
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
+        float g[kU][kVec], xv[kU][kVec], yv[RECOMPUTE ? 1 : kU][kVec];
+        size_t o[kU];
+        bool ok[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int64_t r = rb + (int64_t)u * m.rpb;
+            ok[u] = r < r1;
+            o[u] = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
+            ld8(dy + o[u], g[u]);
+            ld8(x + o[u], xv[u]);
             if constexpr (!RECOMPUTE) {
-                float yv[kVec];
-                ld8(y + o, yv);
-#pragma unroll
-                for (int k = 0; k < kVec; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kVec; ++k) g[k] = ((xv[k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
+                if (relu) ld8(y + o[u], yv[u]);
             }
         }
-        if (dres) st8(dres + o, g);
-        float o8[kVec];
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) o8[k] = gi[k] * (g[k] - db[k] - (xv[k] - mu[k]) * is[k] * dg[k]);
-        st8(dx + o, o8);
+        for (int u = 0; u < kU; ++u) {
+            if (!ok[u]) continue;
+            if (relu) {
+                if constexpr (!RECOMPUTE) {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) g[u][k] = yv[u][k] > 0.f ? g[u][k] : 0.f;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) g[u][k] = ((xv[u][k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[u][k] : 0.f;
+                }
+            }
+            if (dres) st8(dres + o[u], g[u]);
+            float o8[kVec];
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) o8[k] = gi[k] * (g[u][k] - db[k] - (xv[u][k] - mu[k]) * is[k] * dg[k]);
+            st8(dx + o[u], o8);
+        }
     }
 }
 
