@@ -25,6 +25,9 @@ cp $out/pred/p_kernel_stats.csv profiles/${tag}_predict_kernel_stats.csv
 echo "[recipe] predict FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pfetch -o f -- $PRED > /dev/null 2> $out/pfetch.err
 echo "[recipe] predict WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pwrite -o w -- $PRED > /dev/null 2> $out/pwrite.err
 python3 tools/pmc_traffic.py $out/pfetch/f_counter_collection.csv $out/pwrite/w_counter_collection.csv profiles/${tag}_pmc_traffic_predict.json > $out/ptraffic.txt 2>&1
+echo "[recipe] per-layer traffic"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/lf -o f -- python3 tools/per_layer_traffic.py run > $out/lf.txt 2> $out/lf.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/lw -o w -- python3 tools/per_layer_traffic.py run > $out/lw.txt 2> $out/lw.err
+python3 tools/per_layer_traffic.py merge $out/lf/f_counter_collection.csv $out/lw/w_counter_collection.csv gpurun_out/layer_seq.json profiles/${tag}_per_layer_traffic.md > $out/layer_merge.txt 2>&1
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_* gpurun_out/profiles_$tag/
 cp $out/*.txt $out/*.err gpurun_out/profiles_$tag/ 2>/dev/null
 rm -rf $out      # the raw traces / counter CSVs are hundreds of MB; gpurun merges at most 64 MiB back
