@@ -291,6 +291,30 @@ int vs_mean_iou(const float* input, const void* targets, int target_is_f32, int 
 int vs_onehot_u8(const uint8_t* labels, int n, int classes, int64_t hw, uint8_t* onehot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training augmentations on the device (get_train_augs, data/augmentations.py:68-101; applied per sample by the reference's
+ * DataLoader workers, data/datasets.py:42-60)
+ * ---------------------------------------------------------------------------------------- */
+/* One sample's draws, made by the host (every transform's coin and parameters; data/augmentations.py:sample_params). */
+typedef struct vs_aug_params {
+    int32_t crop, y1, x1, ch, cw;      /* RandomSizedCrop: window in the input image (crop = 0: off) */
+    int32_t flip_v, rot_k, transpose;  /* VerticalFlip, RandomRotate90 (k quarter turns, counter-clockwise), Transpose */
+    int32_t distort;                   /* OneOf: 0 none, 1 ElasticTransform, 2 GridDistortion, 3 OpticalDistortion */
+    float inv_affine[6];               /* elastic: the sampling (inverse) affine map, row major 2 x 3 */
+    float k, cx, cy;                   /* optical: distortion coefficient, principal point */
+    uint32_t noise_seed;               /* elastic: seed of the displacement noise */
+    float clahe_clip;                  /* CLAHE clip limit (0 = off) */
+    int32_t clahe_limit;               /* max(int(clip * tile_area / 256), 1) */
+} vs_aug_params;
+/* images / masks: n x size x size uint8 (resident); params_dev: n structs; luts_dev: n x 256 uint8 intensity maps
+ * (RandomBrightnessContrast / RandomGamma / identity); grid_tables_dev: n x 2 x size floats (GridDistortion's x / y coordinate
+ * tables).  out_x: (n, 1, size, size) fp32 normalised network input, out_masks: n x size x size uint8.  fields_out (optional,
+ * n x 2 x size x size floats): the elastic displacement fields that were used (tests).  size: a multiple of 8. */
+size_t vs_augment_workspace(int n, int size);
+int vs_augment_batch(const uint8_t* images, const uint8_t* masks, int n, int size, const vs_aug_params* params_dev,
+                     const uint8_t* luts_dev, const float* grid_tables_dev, float* out_x, uint8_t* out_masks,
+                     void* workspace, size_t workspace_bytes, float* fields_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Volume pre-processing (BaseDataManager._preprocess_data, data/base_data_manager.py:29-42;
  * clip_to_uint8, utilities/base_data_utils.py:243-287)
  * ---------------------------------------------------------------------------------------- */

@@ -44,6 +44,12 @@ class AdamwArgs(C.Structure):
                 ("hyper", C.c_void_p)]
 
 
+class AugParams(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("crop", "y1", "x1", "ch", "cw", "flip_v", "rot_k", "transpose", "distort")] +
+                [("inv_affine", C.c_float * 6), ("k", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("noise_seed", C.c_uint32),
+                 ("clahe_clip", C.c_float), ("clahe_limit", C.c_int32)])
+
+
 P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _SIGS = {
     "vs_last_error": (C.c_char_p, []),
@@ -123,6 +129,8 @@ _SIGS = {
     "vs_unet_forward_to_volume": (I, [P, P, P, P, I, P, P, C.POINTER(DirMap), I, I, I, P, P, P, P, I64]),
     "vs_merge_maxprob": (I, [P, P, P, P, I64, P]),
     "vs_keys_unpack": (I, [P, P, P, I64, P]),
+    "vs_augment_workspace": (SZ, [I, I]),
+    "vs_augment_batch": (I, [P, P, I, I, P, P, P, P, P, P, SZ, P, P]),
     "vs_volume_sum_workspace": (SZ, [I64]),
     "vs_volume_sum": (I, [I, P, I64, I, C.c_double, P, SZ, P, P]),
     "vs_clip_to_uint8": (I, [I, P, I64, C.c_double, C.c_double, C.c_double, P, P, P]),

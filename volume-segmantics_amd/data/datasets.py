@@ -1,8 +1,9 @@
 """Slice datasets feeding the trainer (reference: volume_segmantics/data/datasets.py:12-181, dataloaders.py:15-71,
-augmentations.py).  PNG slices are read with PIL.  The reference's stochastic albumentations pipeline (elastic / grid /
-optical distortion, CLAHE, brightness, gamma) is CPU-side data preparation outside the accelerated path (SURVEY.md
-section 2 row 5); the geometric subset that needs no third-party library is provided: random flips, 90-degree
-rotations and transposes."""
+augmentations.py).  PNG slices are read with PIL.  The reference's albumentations pipeline (RandomSizedCrop, flips / rotations /
+transposes, elastic / grid / optical distortion, CLAHE, brightness-contrast / gamma) is restated in data/augmentations.py; with
+``augment="device"`` (the default of get_2d_training_dataloaders when a GPU is present) the dataset hands out the raw uint8 pairs
+and the batch is augmented and normalised in HBM by csrc/augment.hip (prepare_training_batch), with ``augment="host"`` every
+sample goes through the NumPy form in the loader workers, as the reference does it."""
 from __future__ import annotations
 
 import re
@@ -55,7 +56,9 @@ def normalise(image: np.ndarray) -> np.ndarray:
 
 
 class VolSeg2dDataset(Dataset):
-    def __init__(self, images_dir: Path, masks_dir: Path, img_size: int, augment: bool, seed: int = 0):
+    def __init__(self, images_dir: Path, masks_dir: Path, img_size: int, augment, seed: int = 0):
+        """augment: False / None (validation), "host" or True (the NumPy pipeline per sample), "device" (raw uint8 pairs: the
+        trainer augments the batch on the GPU)."""
         self.images_fps = sorted(Path(images_dir).glob("*.png"), key=natsort_key)
         self.masks_fps = sorted(Path(masks_dir).glob("*.png"), key=natsort_key)
         if len(self.images_fps) != len(self.masks_fps):
@@ -79,14 +82,11 @@ class VolSeg2dDataset(Dataset):
 
     def __getitem__(self, i):
         image, mask = fit_to_square(_read_gray(self.images_fps[i]), _read_gray(self.masks_fps[i]), self.img_size)
+        if self.augment == "device":     # uint8 out: augmentation + normalisation happen on the GPU, batch-wise
+            return torch.from_numpy(np.ascontiguousarray(image)).unsqueeze(0), torch.from_numpy(np.ascontiguousarray(mask))
         if self.augment:
-            rng = self._worker_rng()
-            if rng.random() < 0.5:
-                image, mask = image[::-1], mask[::-1]
-            k = int(rng.integers(0, 4)) if rng.random() < 0.5 else 0
-            image, mask = np.rot90(image, k), np.rot90(mask, k)
-            if rng.random() < 0.5:
-                image, mask = image.T, mask.T
+            from .augmentations import train_augment
+            image, mask = train_augment(np.ascontiguousarray(image), np.ascontiguousarray(mask), self.img_size, self._worker_rng())
         image = normalise(np.ascontiguousarray(image)).astype(np.float32)
         return torch.from_numpy(image).unsqueeze(0), torch.from_numpy(np.ascontiguousarray(mask))
 
@@ -170,7 +170,8 @@ def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings, rank
     """80/20 random split, shuffled drop_last training loader (dataloaders.py:15-57).  With several ranks: the same split on
     every rank (one shared seed), disjoint shards of every global batch (batch_size is per rank)."""
     batch_size = utils.get_batch_size(settings)
-    train_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=True)
+    mode = getattr(settings, "augment", None) or ("device" if torch.cuda.is_available() and settings.image_size % 8 == 0 else "host")
+    train_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=mode)
     valid_full = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment=False)
     n = len(train_full)
     seed = shared_seed(rank, world)

@@ -172,7 +172,9 @@ class VolSeg2dTrainer:
         return dev if dev is not None else next(self.model.parameters()).device
 
     def _train_one_batch(self, lr_scheduler, batch):
-        inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no)
+        if self._aug_rng is None:     # draws of the device-side augmentation: one stream per rank
+            self._aug_rng = np.random.default_rng([int(getattr(self.settings, "augment_seed", 0)), self.rank])
+        inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no, augment_rng=self._aug_rng)
         fuse = getattr(self.model, "can_fuse_step", None)
         if fuse is not None and isinstance(self.loss_criterion, HipDiceLoss) and fuse(self.optimizer, inputs, targets):
             # the whole step (zero_grad .. optimizer.step) as one replayed hipGraph - same kernels, same order, same bits
@@ -267,6 +269,7 @@ class VolSeg2dTrainer:
             sampler.set_epoch(epoch)           # a new shared permutation (ShardedBatchSampler)
 
     _epochs_run = 0
+    _aug_rng = None
 
     def _lr_finder(self, lr_scheduler, smoothing=0.05):
         losses, lrs, iters = [], [], 0

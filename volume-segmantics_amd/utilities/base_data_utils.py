@@ -124,14 +124,21 @@ def one_hot_encode_array(input_array: np.ndarray, num_labels: int) -> np.ndarray
     return out.reshape((num_labels,) + input_array.shape)
 
 
-def prepare_training_batch(batch, device, num_labels: int):
-    """:150-158 - images to the device, masks to one-hot (B,K,H,W) uint8 (built on the device here)."""
+def prepare_training_batch(batch, device, num_labels: int, augment_rng=None):
+    """:150-158 - images to the device, masks to one-hot (B,K,H,W) uint8 (built on the device here).  A batch of raw uint8
+    images (datasets.VolSeg2dDataset(augment="device")) is augmented - with the reference pipeline's draws from ``augment_rng``,
+    or not at all when it is None - and normalised on the device (data/gpu_augment.py)."""
     if batch[1].numel() and not batch[1].is_cuda and int(batch[1].max()) >= num_labels:
         # torch.nn.functional.one_hot in the reference raises here (e.g. 0/255 PNG masks with 2 labels); the device kernel
         # would silently give such pixels an all-zero target
         raise RuntimeError("Class values must be smaller than num_classes.")
     inputs = batch[0].to(device, non_blocking=True)
     masks = batch[1].to(device, non_blocking=True)
+    if inputs.dtype == torch.uint8:
+        if not inputs.is_cuda:
+            raise RuntimeError("raw uint8 training batches are augmented / normalised on the GPU: use augment='host' without one")
+        from ..data.gpu_augment import augment_batch
+        inputs, masks = augment_batch(inputs.reshape(inputs.shape[0], inputs.shape[-2], inputs.shape[-1]), masks.to(torch.uint8), augment_rng)
     if masks.is_cuda and masks.dtype == torch.uint8 and num_labels <= 255:
         from .._lib import check, lib, ptr, stream_ptr   # one HIP sweep instead of int64 one_hot + permute + cast
         masks = masks.contiguous()
