@@ -373,7 +373,7 @@ def main():
     use_graph = args.step_mode != "eager"
 
     def step():
-        # the same step as replayed hipGraphs (VolSegUnet.fused_train_step) where it applies (single process)
+        # the same step as replayed hipGraphs (VolSegUnet.fused_train_step; N > 1: with the bucket all-reduces between them)
         if use_graph and model.can_fuse_step(opt, x, target):
             loss = model.fused_train_step(x, target, opt, eps=criterion.epsilon, clone_loss=False)
             sched.step()
@@ -414,7 +414,12 @@ def main():
             break
     autotune["bursts_ms"] = hist
     if graph_mode and args.step_mode == "auto":
-        use_graph = graph_mode = hist["graph"][-1] <= hist["eager"][-1]
+        last = [hist["graph"][-1], hist["eager"][-1]]
+        if world > 1:       # one decision for the whole job: the slowest rank's burst times
+            tt = torch.tensor(last, device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            last = tt.tolist()
+        use_graph = graph_mode = last[0] <= last[1]
         autotune["picked"] = "graph" if use_graph else "eager"
     log(f"setup done (replaying recorded step graphs: {graph_mode} {autotune}); warming up")
     for _ in range(args.warmup):

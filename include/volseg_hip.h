@@ -248,6 +248,15 @@ void vs_graph_destroy(vs_graph_t* g);
 int vs_unet_backward_adamw_part(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
                                 float* grads, void* workspace, void* stream, const vs_adamw_args* opt, int unit_lo,
                                 int unit_hi, int role);
+/* The data-parallel form of the two shares: vs_unet_backward_part = the shares without the optimiser (role 2 = weight
+ * gradients only); vs_unet_adamw_range = AdamW over the parameters of the units [unit_lo, unit_hi) from `grads` (after the
+ * caller's all-reduce of that slice, vs_unet_unit_param_offset) plus their next-forward weight copies, in order on
+ * `stream`.  Replaces the per-bucket hooks of a DistributedDataParallel wrap of the reference's loop
+ * (vol_seg_2d_trainer.py:419-432); neither flips the weight set. */
+int vs_unet_backward_part(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                          int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi, int role);
+int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const float* grads, void* workspace, void* stream,
+                        const vs_adamw_args* opt, int unit_lo, int unit_hi);
 /* the per-step scalars of a replayed optimiser step (see vs_adamw_args.hyper): one tiny launch on `stream` that also adds 1
  * to the n_bn BatchNorm num_batches_tracked counters (int64, may be NULL with n_bn = 0). */
 int vs_train_hyper_set(float* hyper, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -1,6 +1,7 @@
 """Worker of tests/test_hip_dp_rehearsal.py: two ranks on GPU 0 over gloo (a rehearsal of the RCCL run).  Trains the same
 data-parallel steps with the optimiser step (a) inside backward, bucket by bucket, and (b) as a separate step() after the
-all-reduce; the parameters, optimiser state and losses must agree bit for bit, and be identical on both ranks."""
+all-reduce and (c) as the recorded step (VolSegUnet.fused_train_step at world size 2: hipGraphs with the bucket all-reduces
+between them); the parameters, optimiser state and losses must agree bit for bit, and be identical on both ranks."""
 import os
 import sys
 from pathlib import Path
@@ -13,7 +14,7 @@ from volume_segmantics_amd.data.losses import HipDiceLoss  # noqa: E402
 from volume_segmantics_amd.engine import VolSegUnet  # noqa: E402
 
 
-def run(fuse: bool, frozen: bool, rank: int):
+def run(fuse: bool, frozen: bool, rank: int, graph: bool = False):
     dev = torch.device("cuda", 0)
     model = VolSegUnet(2, device=dev, precision="bf16", seed=11)
     dist.broadcast(model._flat, 0)
@@ -27,17 +28,25 @@ def run(fuse: bool, frozen: bool, rank: int):
     x = torch.randn(4, 1, 64, 64, generator=g).to(dev)
     t = torch.nn.functional.one_hot((torch.rand(4, 64, 64, generator=g) > 0.5).long(), 2).permute(0, 3, 1, 2).float().to(dev)
     opt = model.fused_adamw(lr=1e-3, fuse_step_into_backward=fuse)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=6, pct_start=0.3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=8, pct_start=0.3)
     crit = HipDiceLoss()
     model.train()
     losses = []
-    for _ in range(3):
-        opt.zero_grad()
-        loss = crit(model(x), t)
-        loss.backward()
-        opt.step()
+    for _ in range(5):
+        if graph:       # the recorded form: linear hipGraphs per unit range and stream, the bucket all-reduces between them
+            assert model.can_fuse_step(opt, x, t)
+            loss = model.fused_train_step(x, t, opt, eps=crit.epsilon)
+        else:
+            opt.zero_grad()
+            loss = crit(model(x), t)
+            loss.backward()
+            opt.step()
         sched.step()
         losses.append(loss.item())
+    if graph:
+        st = next(iter(model._steps.values()))
+        assert st["graphs"][0] is not None and st["graphs"][1] is not None
+        assert sum(1 for op, _ in st["graphs"][0] if op == "reduce") == 4
     model.eval()
     with torch.no_grad():
         ev = model(x)                                                   # reads the weight copies of the flipped set
@@ -53,9 +62,11 @@ def main():
     for frozen in (False, True):
         a = run(True, frozen, rank)
         b = run(False, frozen, rank)
-        assert a[0] == b[0], ("losses", frozen, a[0], b[0])
-        for u, v, nm in zip(a[1:], b[1:], ("params", "exp_avg", "exp_avg_sq", "eval logits")):
-            assert torch.equal(u, v), (nm, frozen, (u - v).abs().max().item())
+        c = run(True, frozen, rank, graph=True)
+        for o, what in ((b, "step() after the all-reduce"), (c, "recorded step")):
+            assert a[0] == o[0], ("losses", what, frozen, a[0], o[0])
+            for u, v, nm in zip(a[1:], o[1:], ("params", "exp_avg", "exp_avg_sq", "eval logits")):
+                assert torch.equal(u, v), (nm, what, frozen, (u - v).abs().max().item())
         mine = a[1].cpu()
         other = mine.clone()
         dist.broadcast(other, 0)

@@ -90,6 +90,8 @@ _SIGS = {
     "vs_unet_backward_range": (I, [P, P, P, P, I, I, P, P, P, I, I]),
     "vs_unet_backward_adamw": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs)]),
     "vs_unet_backward_adamw_part": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs), I, I, I]),
+    "vs_unet_backward_part": (I, [P, P, P, P, I, I, P, P, P, I, I, I]),
+    "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),
     "vs_unet_weight_set": (I, [P]),

@@ -720,6 +720,49 @@ extern "C" int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit) {
     return net->layout.n_params;
 }
 
+// AdamW over the parameter slices of the units [lo, hi) (everything, minus the frozen encoder convolutions when those are
+// not trained) and the derived weight copies of their convolutions for the NEXT forward (the other weight set), on `s`.
+static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, const float* grads, const vs_adamw_args& opt,
+                        hipStream_t s) {
+    vs_unet* net = c.net;
+    const int dt = net->dtype;
+    const int other = net->wset ^ 1;
+    AdamwRanges r{};
+    long w_off[64], wc_off[64], wt_off[64];
+    int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+    int rc;
+    auto flush = [&]() -> int {
+        int rc2;
+        if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
+        if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, s))) return rc2;
+        r.n = 0; nl = 0;
+        return VS_OK;
+    };
+    auto push = [&](int idx) {
+        const TensorInfo& t = c.t(idx);
+        int64_t len = 1;
+        for (int d = 0; d < t.ndim; ++d) len *= t.shape[d];
+        if (r.n > 0 && r.off[r.n - 1] + r.len[r.n - 1] == t.offset) { r.len[r.n - 1] += len; return; }
+        r.off[r.n] = t.offset; r.len[r.n] = len; ++r.n;
+    };
+    for (int k = lo; k < hi; ++k) {
+        const Unit& v = net->units[k];
+        if (v.w_idx < 0) continue;
+        if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
+        if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
+        if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
+        if (v.bias_idx >= 0) push(v.bias_idx);
+        if (v.kind == U_CONV || v.kind == U_HEAD) {
+            w_off[nl] = c.t(v.w_idx).offset;
+            wc_off[nl] = dt == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
+            wt_off[nl] = (long)Ctx::wt_off(v, other);
+            cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+            ++nl;
+        }
+    }
+    return flush();
+}
+
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
                                int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
                                const vs_adamw_args* opt, int role) {
@@ -799,38 +842,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (!net->group_first[ui]) return VS_OK;
         int hi = ui + 1;   // the group is [ui, hi): up to the next group's first unit (or the end of the network)
         while (hi < (int)net->units.size() && !net->group_first[hi]) ++hi;
-        // parameter slices of the group: everything, minus the frozen encoder convolutions when those are not trained
-        AdamwRanges r{};
-        auto push = [&](int idx) {
-            const TensorInfo& t = c.t(idx);
-            int64_t len = 1;
-            for (int d = 0; d < t.ndim; ++d) len *= t.shape[d];
-            if (r.n > 0 && r.off[r.n - 1] + r.len[r.n - 1] == t.offset) { r.len[r.n - 1] += len; return; }
-            r.off[r.n] = t.offset; r.len[r.n] = len; ++r.n;
-        };
-        long w_off[64], wc_off[64], wt_off[64];
-        int cout[64], taps[64], cin[64], cpad[64], nl = 0;
-        const int other = net->wset ^ 1;
-        for (int k = ui; k < hi; ++k) {
-            const Unit& v = net->units[k];
-            if (v.w_idx < 0) continue;
-            if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
-            if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
-            if (v.bias_idx >= 0) push(v.bias_idx);
-            VS_REQUIRE(r.n < 158, "unet_backward: too many parameter slices in one optimiser group");
-            if (v.kind == U_CONV || v.kind == U_HEAD) {
-                VS_REQUIRE(nl < 64, "unet_backward: too many layers in one optimiser group");
-                w_off[nl] = c.t(v.w_idx).offset;
-                wc_off[nl] = dt == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
-                wt_off[nl] = (long)Ctx::wt_off(v, other);
-                cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
-                ++nl;
-            }
-        }
-        int rc2;
-        if ((rc2 = launch_adamw_ranges(*opt, grads, r, ws_stream))) return rc2;
-        if (nl && (rc2 = launch_weight_prepare_all(dt, opt->params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, ws_stream))) return rc2;
-        return VS_OK;
+        return update_units(c, ui, hi, need_encoder_wgrad != 0, grads, *opt, ws_stream);
     };
     // Weight-gradient work of one unit, queued on the side stream (after a fork event that covers its dz).
     struct SideItem { int ui; const void* dzp; int dz_c; };
@@ -1063,6 +1075,28 @@ extern "C" int vs_unet_backward_adamw_part(vs_unet_t* net, const float* x, const
     VS_REQUIRE(unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_backward_adamw_part: bad unit range");
     VS_REQUIRE(role == ROLE_MAIN || role == ROLE_SIDE, "unet_backward_adamw_part: role must be 1 (caller's stream) or 2 (weight gradients)");
     return unet_backward_range(net, opt->params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi, opt, role);
+}
+
+// Data-parallel form of the split roles: the same two shares WITHOUT the optimiser (role 2 = weight gradients only, written to
+// `grads`), so the caller can all-reduce a range's gradient slice before vs_unet_adamw_range updates it.
+extern "C" int vs_unet_backward_part(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
+                                     int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo,
+                                     int unit_hi, int role) {
+    VS_REQUIRE(net && unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_backward_part: bad unit range");
+    VS_REQUIRE(role == ROLE_MAIN || role == ROLE_SIDE, "unet_backward_part: role must be 1 (caller's stream) or 2 (weight gradients)");
+    return unet_backward_range(net, params, x, dlogits, n, need_encoder_wgrad, grads, workspace, stream, unit_lo, unit_hi, nullptr, role);
+}
+
+// AdamW over the parameters of the units [unit_lo, unit_hi) from `grads` (e.g. an all-reduced slice) plus the weight copies
+// of those units for the next forward, in order on `stream`; no weight-set flip (vs_unet_flip_weight_set once every range
+// of the step is queued).  The optimiser step of vs_unet_backward_adamw, cut loose from the backward pass.
+extern "C" int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const float* grads, void* workspace, void* stream,
+                                   const vs_adamw_args* opt, int unit_lo, int unit_hi) {
+    VS_REQUIRE(net && grads && workspace && opt && opt->params && opt->exp_avg && opt->exp_avg_sq && opt->step >= 1,
+               "unet_adamw_range: bad arguments");
+    VS_REQUIRE(unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(), "unet_adamw_range: bad unit range");
+    Ctx c{net, (char*)workspace, opt->params, nullptr, (hipStream_t)stream, net->last_n};
+    return update_units(c, unit_lo, unit_hi, need_encoder_wgrad != 0, grads, *opt, (hipStream_t)stream);
 }
 
 // ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------

@@ -360,7 +360,7 @@ class VolSegUnet(nn.Module):
             return False
         if not isinstance(opt, FusedAdamW) or opt.model is not self or self._fused_optimizer is not opt:
             return False
-        if self.dp_group is not None and self._world() > 1:
+        if self.dp_group is not None and self._world() > 1 and self.dp_grad_dtype != torch.float32:
             return False
         if x.dim() != 4 or targets.dim() != 4 or targets.shape != (x.shape[0], self.classes, x.shape[2], x.shape[3]):
             return False
@@ -428,6 +428,14 @@ class VolSegUnet(nn.Module):
             check(lib.vs_unet_backward_adamw_part(hd, ptr(st["x"]), ptr(st["dlogits"]), n, 1 if need_enc else 0,
                                                   ptr(self._flat_grad), ptr(plan["ws"]), s, _lib.C.byref(args), lo, hi, role))
 
+        def enqueue_dp_part(s, lo, hi, role):      # data parallel: the two shares without the optimiser ...
+            check(lib.vs_unet_backward_part(hd, ptr(self._flat), ptr(st["x"]), ptr(st["dlogits"]), n, 1 if need_enc else 0,
+                                            ptr(self._flat_grad), ptr(plan["ws"]), s, lo, hi, role))
+
+        def enqueue_dp_opt(s, lo, hi):             # ... and a bucket's AdamW + weight copies, after its all-reduce
+            check(lib.vs_unet_adamw_range(hd, 1 if need_enc else 0, ptr(self._flat_grad), ptr(plan["ws"]), s,
+                                          _lib.C.byref(args), lo, hi))
+
         def record(fn):
             cs = lib.vs_capture_begin()
             if not cs:
@@ -442,17 +450,44 @@ class VolSegUnet(nn.Module):
             return gh
 
         mode = os.environ.get("VOLSEG_STEP_GRAPH", "seg")
+        dp = self.dp_group is not None and self._world() > 1
         if not st["eager_done"]:
             # the first step runs eagerly: lazy one-time work (side streams, events, kernel attributes) must not be recorded
             enqueue_head(stream)
-            enqueue_backward(stream)
+            if dp:
+                self._backward_bucketed(plan, st["x"], st["dlogits"], n, need_enc, fused=opt)
+            else:
+                enqueue_backward(stream)
             st["eager_done"] = True
         else:
             wset = lib.vs_unet_weight_set(hd)
             prog = st["graphs"][wset]
             if prog is None:
                 nu = lib.vs_unet_num_units(hd)
-                if mode == "branch":      # ONE graph with the side stream as parallel branches
+                seg = max(1, int(os.environ.get("VOLSEG_STEP_SEG", "4")))
+                if dp:
+                    # data parallel: the same linear graphs without the optimiser; at the end of every gradient bucket
+                    # (decoder + head, layer4, layer3, the rest) its slice is all-reduced behind the weight-gradient stream
+                    # and a third stream runs the bucket's AdamW + weight copies when the all-reduce has landed
+                    if "buckets" not in plan:
+                        plan["buckets"] = self._bucket_plan(hd)
+                    prog, first = [], True
+                    for blo, bhi, a, b in plan["buckets"]:
+                        cuts = list(range(bhi, blo, -seg)) + [blo]
+                        for hi_, lo_ in zip(cuts[:-1], cuts[1:]):
+                            if first:
+                                prog.append(("main", record(lambda cs: (enqueue_head(cs), enqueue_dp_part(cs, lo_, hi_, 1)))))
+                                first = False
+                            else:
+                                prog.append(("main", record(lambda cs: enqueue_dp_part(cs, lo_, hi_, 1))))
+                            prog.append(("fork", torch.cuda.Event()))
+                            prog.append(("side", record(lambda cs: enqueue_dp_part(cs, lo_, hi_, 2))))
+                        if b > a:
+                            prog.append(("reduce", (a, b)))
+                            prog.append(("opt", record(lambda cs: enqueue_dp_opt(cs, blo, bhi))))
+                    prog.append(("join", torch.cuda.Event()))
+                    prog.append(("join_opt", torch.cuda.Event()))
+                elif mode == "branch":      # ONE graph with the side stream as parallel branches
                     g0 = record(lambda cs: (enqueue_head(cs), enqueue_backward(cs)))
                     check(lib.vs_unet_flip_weight_set(hd))      # undo the capture's flip: the replay below flips
                     prog = [("main", g0)]
@@ -460,7 +495,6 @@ class VolSegUnet(nn.Module):
                     # LINEAR graphs (the runtime replays those as one batch of queue packets): per range of units one graph
                     # of the caller's-stream kernels and one of the weight-gradient / optimiser kernels, the second stream
                     # one range behind the first, ordinary events between them
-                    seg = max(1, int(os.environ.get("VOLSEG_STEP_SEG", "4")))
                     cuts = list(range(nu, 0, -seg)) + [0]
                     prog = []
                     for i, (hi_, lo_) in enumerate(zip(cuts[:-1], cuts[1:])):
@@ -483,6 +517,21 @@ class VolSegUnet(nn.Module):
                 elif op == "fork":
                     obj.record(cur)
                     self._step_side.wait_event(obj)
+                elif op == "reduce":
+                    import torch.distributed as dist
+                    if self._dp_side is None:
+                        self._dp_side = torch.cuda.Stream(device=self.device)
+                    a, b = obj
+                    with torch.cuda.stream(self._step_side):      # the collective is ordered behind the bucket's weight gradients
+                        h = dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True)
+                    with torch.cuda.stream(self._dp_side):
+                        h.wait()
+                        self._flat_grad[a:b].div_(self._world())
+                elif op == "opt":
+                    check(lib.vs_graph_launch(obj, self._dp_side.cuda_stream))
+                elif op == "join_opt":
+                    obj.record(self._dp_side)
+                    cur.wait_event(obj)
                 else:
                     obj.record(self._step_side)
                     cur.wait_event(obj)
