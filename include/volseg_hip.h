@@ -43,6 +43,8 @@ typedef struct vs_conv_desc {
     int32_t relu;              /* apply ReLU in the epilogue */
     int32_t out_f32;           /* store fp32 output regardless of dtype */
     int32_t split_c;           /* >0: output channels >= split_c go to y1 (dgrad through a concat) */
+    int32_t groups;            /* 0 / 1 = dense; > 1: grouped convolution (ResNeXt: nn.Conv2d(groups=32)) with c0 == cout and
+                                  4 / 8 / 16 / 32 channels per group; w from vs_weights_prepare_grouped, dw [cout][taps][c0/groups] */
 } vs_conv_desc;
 
 /* y = relu?( conv(x, w) * scale[c] + shift[c] + residual ).  w: [cout][kh*kw][c0+c1] in dtype.
@@ -63,6 +65,10 @@ int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const void* src1, c
  * [cin][taps reversed][cout] the data gradient reads through vs_conv2d_fwd (wt; may be NULL).  The reference's autograd
  * derives both from the one weight tensor (loss.backward(), vol_seg_2d_trainer.py:429). */
 int vs_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, void* stream);
+/* The same for a grouped convolution (cg = cin / groups channels per group, cin == cout): fp32 [cout][taps][cg] -> wc
+ * [cout][taps][32] and wt [cin][taps reversed][32].  The kernels work on 32-channel super-groups; a narrower group is its
+ * cg x cg block inside the super-group's 32 x 32 slab, zeros elsewhere (torchvision resnext50_32x4d: cg = 4, 8, 16, 32). */
+int vs_weights_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, void* stream);
 
 /* Stem: 7x7 stride-2 pad-3 conv with one input channel (encoder.conv1 after smp's
  * patch_first_conv).  x: [n][h][w] fp32 (the caller's (B,1,H,W) tensor); w: [64][49] fp32;
@@ -128,7 +134,8 @@ int64_t vs_unet_bnstate_elems(int classes);
 int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h, int w);
 /* Other members of the reference's model matrix (model/model_2d.py:15-38, README.md:57-76).  `encoder` = topology * 1000 + depth:
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
- *   1x1 projection shortcut);
+ *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
+ *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
  *   topology 0: smp.Unet; 1: smp.UnetPlusPlus - the dense nested decoder (node x_d_l = DecoderBlock(up(x_d_(l-1)),
  *   cat(x_(d+1)_l .. x_l_l, encoder feature)); the concatenations are materialised by vs_channel_slice copies and their
  *   gradients accumulated back onto the members).

@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure, never the product path): ``smp.Unet(encoder_name=E, in_channels=1, classes=K)`` for the other
-ResNet encoders of the reference's list (README.md:57-76, tests/test_model_2d.py:36-44) that the engine builds: resnet18 and
-resnet50 next to resnet34 (oracle/unet_resnet34_torch.py, whose blocks are reused here).
+ResNet encoders of the reference's list (README.md:57-76, tests/test_model_2d.py:36-44) that the engine builds: resnet18,
+resnet50 and resnext50_32x4d next to resnet34 (oracle/unet_resnet34_torch.py, whose blocks are reused here).
 
 Restated from the published architectures - segmentation-models-pytorch ^0.2.1 and torchvision are not installed here
 (oracle/unet_resnet34_torch.py explains the pinning situation; the same applies):
@@ -9,7 +9,7 @@ Restated from the published architectures - segmentation-models-pytorch ^0.2.1 a
   * smp encoder out_channels: resnet18 (3, 64, 64, 128, 256, 512), resnet50 (3, 64, 256, 512, 1024, 2048);
   * the U-Net decoder / head as for resnet34; the U-Net++ decoder (UnetPlusPlusDecoder below) from smp 0.2.1's published source.
 Structural pins (tests/test_oracle_topology.py): state-dict keys and shapes, and torchvision's published parameter counts -
-resnet18 11,689,512, resnet34 21,797,672, resnet50 25,557,032 with the 3-channel stem and the 1000-way fc layer added back."""
+resnet18 11,689,512, resnet34 21,797,672, resnet50 25,557,032, resnext50_32x4d 25,028,904 with the 3-channel stem and the 1000-way fc layer added back."""
 from __future__ import annotations
 
 import torch
@@ -17,23 +17,29 @@ import torch.nn as nn
 
 from .unet_resnet34_torch import DECODER_CHANNELS, BasicBlock, DecoderBlock
 
-LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3)}
-OUT_CHANNELS = {"resnet18": (1, 64, 64, 128, 256, 512), "resnet34": (1, 64, 64, 128, 256, 512), "resnet50": (1, 64, 256, 512, 1024, 2048)}
-FC_PARAMS = {"resnet18": 512 * 1000 + 1000, "resnet34": 512 * 1000 + 1000, "resnet50": 2048 * 1000 + 1000}
-TORCHVISION_PARAMS = {"resnet18": 11_689_512, "resnet34": 21_797_672, "resnet50": 25_557_032}
+LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnext50_32x4d": (3, 4, 6, 3)}
+OUT_CHANNELS = {"resnet18": (1, 64, 64, 128, 256, 512), "resnet34": (1, 64, 64, 128, 256, 512), "resnet50": (1, 64, 256, 512, 1024, 2048),
+                "resnext50_32x4d": (1, 64, 256, 512, 1024, 2048)}
+FC_PARAMS = {"resnet18": 512 * 1000 + 1000, "resnet34": 512 * 1000 + 1000, "resnet50": 2048 * 1000 + 1000,
+             "resnext50_32x4d": 2048 * 1000 + 1000}
+TORCHVISION_PARAMS = {"resnet18": 11_689_512, "resnet34": 21_797_672, "resnet50": 25_557_032, "resnext50_32x4d": 25_028_904}
+BOTTLENECK = ("resnet50", "resnext50_32x4d")
+GROUPS = {"resnext50_32x4d": (32, 4)}      # torchvision resnext50_32x4d: groups = 32, width_per_group = 4
 
 
 class Bottleneck(nn.Module):
-    """torchvision Bottleneck: relu(bn1(conv1x1)) -> relu(bn2(conv3x3, stride)) -> bn3(conv1x1 x4) -> + identity -> relu."""
+    """torchvision Bottleneck: relu(bn1(conv1x1)) -> relu(bn2(conv3x3, stride)) -> bn3(conv1x1 x4) -> + identity -> relu.
+    ResNeXt: the 3x3 convolution is grouped and the inner width is int(planes * base_width / 64) * groups."""
     expansion = 4
 
-    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, groups: int = 1, base_width: int = 64):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None
@@ -51,8 +57,12 @@ class Bottleneck(nn.Module):
 class ResNetEncoder(nn.Module):
     def __init__(self, name: str, in_channels: int = 1):
         super().__init__()
-        block = Bottleneck if name == "resnet50" else BasicBlock
-        exp = 4 if name == "resnet50" else 1
+        exp = 4 if name in BOTTLENECK else 1
+        if name in BOTTLENECK:
+            groups, base_width = GROUPS.get(name, (1, 64))
+            block = lambda i, p, s=1: Bottleneck(i, p, s, groups, base_width)   # noqa: E731
+        else:
+            block = BasicBlock
         self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)

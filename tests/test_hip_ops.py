@@ -272,6 +272,63 @@ def test_dgrad_and_wgrad_match_autograd(code, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 4, 1), (2, 16, 24, 64, 8, 1), (1, 8, 8, 64, 16, 2), (3, 8, 8, 96, 32, 1),
+                                   (2, 32, 32, 128, 4, 2), (1, 20, 12, 32, 8, 1)])
+def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
+    """nn.Conv2d(c, c, 3, stride, 1, groups=c/cg) - the 3x3 convolution of a ResNeXt bottleneck (torchvision resnext50_32x4d:
+    cg = 4 / 8 / 16 / 32 channels per group) - forward, data gradient and weight gradient against torch CPU.  The kernels
+    run on 32-channel super-groups with the groups as diagonal blocks (vs_weights_prepare_grouped)."""
+    L = lib()
+    n, h, w, c, cg, stride = shape
+    groups = c // cg
+    g = torch.Generator().manual_seed(11)
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(c, cg, 3, 3, generator=g) / (cg * 9) ** 0.5, code).requires_grad_()
+    y = F.conv2d(x, wt, stride=stride, padding=1, groups=groups)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    ho, wo = y.shape[2:]
+    w32 = wt.detach().permute(0, 2, 3, 1).contiguous().to(DEV)                # fp32 master layout [cout][taps][cg]
+    wc = torch.full((c, 9, 32), float("nan"), device=DEV, dtype=tdtype(code))
+    wtr = torch.full((c, 9, 32), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_weights_prepare_grouped(code, L.ptr(w32), L.ptr(wc), L.ptr(wtr), c, 9, cg, None))
+    sync()
+    # the expanded copy: the group's cg x cg block inside its super-group's 32 x 32 slab, zeros elsewhere
+    wcf = wc.float().cpu()
+    for o in (0, cg, c - 1):
+        sub = (o % 32) // cg
+        assert torch.equal(wcf[o, :, sub * cg:(sub + 1) * cg], wt.detach()[o].permute(1, 2, 0).reshape(9, cg))
+        rest = wcf[o].clone()
+        rest[:, sub * cg:(sub + 1) * cg] = 0
+        assert not rest.any()
+    d = conv_desc(L, code, n, h, w, c, c, 3, stride, 1, groups=groups)
+    xd = to_nhwc(x.detach(), code)
+    yd = torch.full((n, ho, wo, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wc), None, None, None, L.ptr(yd), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    # weight gradient, in the parameter's own [cout][taps][cg] layout
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((c, 3, 3, cg), float("nan"), device=DEV)
+    dyd = to_nhwc(dy, code)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(xd), None, L.ptr(dyd), L.ptr(dw), L.ptr(ws), ws_bytes, None))
+    sync()
+    ref_dw = wt.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    # data gradient: stride-1 grouped conv of the (zero-stuffed) dy with the flipped / transposed copy
+    if stride == 2:
+        zs = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+        L.check(L.lib.vs_zero_stuff2x(code, L.ptr(dyd), L.ptr(zs), n, ho, wo, c, None))
+        dyd = zs
+    dd = conv_desc(L, code, n, h, w, c, c, 3, 1, 1, groups=groups)
+    dx = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_wgrad_through_upsample_concat_and_split_dgrad(code):
     L = lib()
     g = torch.Generator().manual_seed(8)

@@ -359,7 +359,7 @@ def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
 
 # ---- other encoders of the reference's list behind the same decoder -------------------------------
 @pytest.mark.parametrize("encoder,topology", [("resnet18", "unet"), ("resnet50", "unet"), ("resnet34", "unetplusplus"),
-                                              ("resnet50", "unetplusplus")])
+                                              ("resnet50", "unetplusplus"), ("resnext50_32x4d", "unet")])
 def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
     """U_NET + resnet18 (BasicBlock x 2,2,2,2) and resnet50 (Bottleneck: 1x1 - 3x3(stride) - 1x1 x4, 1x1 shortcuts, features of
     256 .. 2048 channels) against oracle/unet_resnet_torch.py: eval logits within 1e-3 (fp32), train-mode forward / loss tight,

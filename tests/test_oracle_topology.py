@@ -51,7 +51,7 @@ def test_other_resnet_encoders_match_torchvision_published_parameter_counts():
     table of the engine's plan has the same keys / shapes in the same order, and resnet34 equals the original restatement."""
     from oracle.unet_resnet_torch import FC_PARAMS, TORCHVISION_PARAMS, OracleUnet
     from volume_segmantics_amd import _lib
-    for name, enc in (("resnet18", 18), ("resnet34", 34), ("resnet50", 50)):
+    for name, enc in (("resnet18", 18), ("resnet34", 34), ("resnet50", 50), ("resnext50_32x4d", 51)):
         net = OracleUnet(name, 3, 2)
         n_enc = sum(p.numel() for p in net.encoder.parameters())
         assert n_enc + FC_PARAMS[name] == TORCHVISION_PARAMS[name], (name, n_enc)
@@ -62,6 +62,8 @@ def test_other_resnet_encoders_match_torchvision_published_parameter_counts():
         assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
     assert OracleUnet("resnet50", 1, 2).state_dict()["decoder.blocks.0.conv1.0.weight"].shape == (256, 2048 + 1024, 3, 3)
     assert OracleUnet("resnet50", 1, 2).state_dict()["encoder.layer1.0.downsample.0.weight"].shape == (256, 64, 1, 1)
+    sd = OracleUnet("resnext50_32x4d", 1, 2).state_dict()     # groups = 32, width_per_group = 4: widths 128 .. 1024, 4 .. 32 per group
+    assert sd["encoder.layer1.0.conv2.weight"].shape == (128, 4, 3, 3) and sd["encoder.layer4.2.conv2.weight"].shape == (1024, 32, 3, 3)
     a, b = OracleUnet("resnet34", 1, 2).state_dict(), OracleUnetResnet34(1, 2).state_dict()
     assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
     net = OracleUnet("resnet50", 1, 3).eval()
@@ -77,7 +79,7 @@ def test_unetplusplus_matches_published_smp_parameter_counts():
     from volume_segmantics_amd import _lib
     assert sum(p.numel() for p in OracleUnet("resnet34", 3, 1, "unetplusplus").parameters()) == 26_078_609
     assert sum(p.numel() for p in OracleUnet("resnet50", 3, 1, "unetplusplus").parameters()) == 48_985_745
-    for name, code in (("resnet18", 1018), ("resnet34", 1034), ("resnet50", 1050)):
+    for name, code in (("resnet18", 1018), ("resnet34", 1034), ("resnet50", 1050), ("resnext50_32x4d", 1051)):
         sd = OracleUnet(name, 1, 3, "unetplusplus").state_dict()
         table = _lib.unet_tensor_table(3, code)
         assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name

@@ -30,7 +30,7 @@ lib = C.CDLL(str(LIB_PATH))
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c")]
+        "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c", "groups")]
 
 
 class DirMap(C.Structure):
@@ -58,6 +58,7 @@ _SIGS = {
     "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),
+    "vs_weights_prepare_grouped": (I, [I, P, P, P, I, I, I, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
     "vs_stem_wgrad": (I, [I, P, P, P, P, SZ, I, I, I, P]),
     "vs_stem_wgrad_workspace": (SZ, [I, I, I]),

@@ -25,6 +25,12 @@ static int desc_to_params(const vs_conv_desc* d, ConvParams& p) {
     p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
     p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
     p.Cout = d->cout; p.relu = d->relu; p.out_f32 = d->out_f32; p.split_c = d->split_c;
+    VS_REQUIRE(d->groups >= 0, "conv: bad group count");
+    if (d->groups > 1) {   // grouped: runs on 32-channel super-groups (weights from vs_weights_prepare_grouped)
+        VS_REQUIRE(d->c1 == 0 && d->c0 == d->cout && d->c0 % d->groups == 0 && 32 % (d->c0 / d->groups) == 0 && d->c0 % 32 == 0 &&
+                   d->c0 / d->groups >= 4, "conv: grouped convolutions need c0 == cout, 4 / 8 / 16 / 32 channels per group");
+        p.gc = 32;
+    }
     return VS_OK;
 }
 
@@ -49,6 +55,11 @@ static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
     p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
     p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
     p.Cout = d->cout;
+    if (d->groups > 1) {
+        VS_REQUIRE(d->c1 == 0 && d->c0 == d->cout && d->c0 % d->groups == 0 && 32 % (d->c0 / d->groups) == 0 && d->c0 % 32 == 0 &&
+                   d->c0 / d->groups >= 4, "conv: grouped convolutions need c0 == cout, 4 / 8 / 16 / 32 channels per group");
+        p.cg = d->c0 / d->groups;
+    }
     return VS_OK;
 }
 
@@ -74,4 +85,10 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
 extern "C" int vs_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, void* stream) {
     VS_REQUIRE(w && (wc || wt), "weights_prepare: null pointer");
     return launch_weight_prepare(dtype, w, wc, wt, cout, taps, cin, cout, (hipStream_t)stream);
+}
+/* grouped convolution with cg = cin / groups channels per group (cin == cout): fp32 [cout][taps][cg] -> wc [cout][taps][32]
+ * (the group's block inside its 32-channel super-group, zeros elsewhere) and wt [cin][taps reversed][32] for the data gradient */
+extern "C" int vs_weights_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, void* stream) {
+    VS_REQUIRE(w && (wc || wt), "weights_prepare_grouped: null pointer");
+    return launch_weight_prepare_grouped(dtype, w, wc, wt, cout, taps, cg, (hipStream_t)stream);
 }

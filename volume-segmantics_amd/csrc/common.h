@@ -130,7 +130,7 @@ struct ConvParams {
     int C0, C1, up0;
     int N, Hin, Win;                     // virtual input spatial dims
     int Hout, Wout, stride, pad, KH, KW;
-    const void* w;                       // [Cout][KH*KW][C0+C1]
+    const void* w;                       // [Cout][KH*KW][C0+C1]; grouped (gc = 32): [Cout][KH*KW][32], see vs_weights_prepare_grouped
     int Cout;
     void* out;                           // [N][Hout][Wout][Cout or split_c]
     void* out1; int split_c;             // optional: couts >= split_c go to out1 ([..][Cout-split_c])
@@ -149,6 +149,7 @@ struct ConvParams {
     const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta;
     float* bstats_partial;               // [tiles][2][Cout]
     int brelu;
+    int gc;                              // 0 = dense; 32 = grouped convolution on 32-channel super-groups (C0 == Cout, C1 == 0)
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
@@ -184,6 +185,8 @@ struct WgradParams {
     const void* dy; int Cout;             // [N][Hout][Wout][Cout]
     float* dw;                            // [Cout][KH*KW][Cin] fp32 (overwritten)
     float* partials; size_t partial_bytes;  // workspace
+    int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
+                                          // dw is [Cout][KH*KW][cg]
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
@@ -195,3 +198,6 @@ struct AdamwRanges { int n; long off[160]; long len[160]; };   // passed to the 
 int launch_adamw_slice(const vs_adamw_args& a, const float* grads, int64_t off, int64_t n, hipStream_t s);
 int launch_adamw_ranges(const vs_adamw_args& a, const float* grads, const AdamwRanges& r, hipStream_t s);
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
+// grouped convolution (cg channels per group, cin == cout): fp32 [cout][taps][cg] -> the block-expanded [cout][taps][32] copy
+// and its flipped / transposed twin [cin][taps reversed][32] (32-channel super-groups; zeros outside a group's own block)
+int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, hipStream_t s);

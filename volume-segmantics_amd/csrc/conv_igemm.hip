@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     // loads them where first used, a chain of four dependent ~0.3 us round trips at the head of every workgroup
     asm volatile("" ::"s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.out), "s"(p.C0), "s"(p.C1), "s"(p.up0), "s"(p.Hin), "s"(p.Win),
                  "s"(p.Hout), "s"(p.Wout), "s"(p.pad), "s"(p.Cout), "s"(g.tiles_w), "s"(g.tw_magic), "s"(g.pw_magic), "s"(g.PW),
-                 "s"(g.PH), "s"(g.tw_shift), "s"(g.probe));
+                 "s"(g.PH), "s"(g.tw_shift), "s"(g.probe), "s"(p.gc));
     unsigned long long tprobe[5];
     if (g.probe) tprobe[0] = wall_clock64();
 
@@ -122,7 +122,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         (void*)((const T*)p.src0 + (size_t)n * H0 * W0 * p.C0), 0, H0 * W0 * p.C0 * (int)sizeof(T), 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)p.src1 + (size_t)n * p.Hin * p.Win * p.C1), 0, p.src1 ? p.Hin * p.Win * p.C1 * (int)sizeof(T) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * NTAPS * Cin * (int)sizeof(T), 0x00020000);
+    // Grouped convolution (p.gc = 32, BN = 32): the cout tile IS one 32-channel super-group, whose outputs read only the
+    // super-group's own 32 input channels: the chunk loop covers [n0, n0 + 32) and the weight rows are 32 channels long
+    // (groups narrower than 32 channels are block-diagonal inside the super-group's 32 x 32 slab, zeros elsewhere).
+    const int kbeg = p.gc ? n0 : 0, kend = p.gc ? n0 + p.gc : Cin;
+    const int CinW = p.gc ? p.gc : Cin;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * NTAPS * CinW * (int)sizeof(T), 0x00020000);
     const int dummy = (P + NTAPS * BN) * kPS;    // 64 spare bytes behind the staged tiles: target of the stores of idle items
 
     // ---- chunk-invariant staging addresses (byte offsets; -1 = zero fill) ----
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int wrow0 = tid >> 2, wseg = tid & 3;
     const int wnr = wrow0 % BN, wtap0 = wrow0 / BN;
     const bool wok = n0 + wnr < p.Cout;
-    const int woff0 = (((n0 + wnr) * NTAPS + wtap0) * Cin + wseg * EPS) * (int)sizeof(T);
+    const int woff0 = (((n0 + wnr) * NTAPS + wtap0) * CinW + wseg * EPS) * (int)sizeof(T);
     const int wdst0 = swz(wrow0, wrow0, wseg);   // i*WROWS is a multiple of 16 rows: same swizzle in every pass
 
     // Prefetch depth: PF chunks are in flight (in registers) while one is being multiplied.  Kernels that run with one or
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         const int cs = from0 ? p.C0 : p.C1;
         const int cb = from0 ? c0 : c0 - p.C0;
         const int nseg = (cs - cb) / EPS;         // valid 16-byte segments of this chunk (< 4 only in a ragged channel tail)
-        const int nsegw = (Cin - c0) / EPS;
+        const int nsegw = (kend - c0) / EPS;
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i) {
             int off = from0 ? poff0[i] : poff1[i];
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         }
 #pragma unroll
         for (int i = 0; i < WITEMS; ++i) {
-            int off = woff0 + i * TS * Cin * (int)sizeof(T);
+            int off = woff0 + i * TS * CinW * (int)sizeof(T);
             if (!wok || wtap0 + i * TS >= NTAPS || wseg >= nsegw) off = -1;
-            wreg[i] = bload(rw, off, c0 * (int)sizeof(T));
+            wreg[i] = bload(rw, off, (c0 - kbeg) * (int)sizeof(T));
         }
     };
 
@@ -187,14 +192,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_chunk(0, pregs[0], wregs[0]);
-    if (PF == 2 && CK < Cin) load_chunk(CK, pregs[PF - 1], wregs[PF - 1]);
+    load_chunk(kbeg, pregs[0], wregs[0]);
+    if (PF == 2 && kbeg + CK < kend) load_chunk(kbeg + CK, pregs[PF - 1], wregs[PF - 1]);
     if (g.probe) tprobe[1] = wall_clock64();
-    for (int cbase = 0; cbase < Cin; cbase += PF * CK) {
+    for (int cbase = kbeg; cbase < kend; cbase += PF * CK) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const int c0 = cbase + s * CK;
-            if (c0 >= Cin) break;
+            if (c0 >= kend) break;
             __syncthreads();  // every wave is done reading the previous chunk
 #pragma unroll
             for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(patch + pdst[i]) = pregs[s][i];
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
                 *reinterpret_cast<uint4*>(smem + dst) = wregs[s][i];
             }
             __syncthreads();
-            if (g.probe && c0 == 0) tprobe[2] = wall_clock64();
-            if (c0 + PF * CK < Cin) load_chunk(c0 + PF * CK, pregs[s], wregs[s]);  // in flight while the MFMAs of PF chunks run
+            if (g.probe && c0 == kbeg) tprobe[2] = wall_clock64();
+            if (c0 + PF * CK < kend) load_chunk(c0 + PF * CK, pregs[s], wregs[s]);  // in flight while the MFMAs of PF chunks run
             // fragments of tap t+1 are read while the MFMAs of tap t run (two register sets)
             uint4 wf[2][NJ], xf[2][PT];
             auto read_frags = [&](int tap, uint4 (&w)[NJ], uint4 (&x)[PT]) {
@@ -583,7 +588,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && !p.bz && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.bz && !p.gc && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -693,6 +698,7 @@ Pick pick_cfg(const ConvParams& p) {
         return (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, bn);
     };
     int bn = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
+    if (p.gc) bn = 32;     // grouped: one 32-channel super-group per cout tile
     if (can8 && wgs(bn, 256) >= vs_option("conv_nw8_min_wgs")) { c.NW = 8; c.PT = 2; }
     if (bn == 64 && wgs(64, c.NW * c.PT * 16) < vs_option("conv_min_wgs")) bn = 32;
     c.BN = bn;
@@ -712,6 +718,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - p.KH) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - p.KW) / p.stride + 1,
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && (p.out || p.scatter), "conv_igemm: null pointer");
+    VS_REQUIRE(p.gc == 0 || (p.gc == 32 && p.C1 == 0 && p.C0 == p.Cout && p.Cout % 32 == 0 && !p.out1),
+               "conv_igemm: grouped convolutions run on 32-channel super-groups with as many inputs as outputs");
     VS_REQUIRE(!(out_nchw || (p.Cout & 3)) || (!p.out1), "conv_igemm: ragged / NCHW output cannot be split");
     const Pick cfg = pick_cfg(p);
     const int BN = cfg.BN, PT = cfg.PT, NW = cfg.NW;

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
     char* patch = smem;
     char* dyl = smem + P * kXS;
 
+    // grouped (p.cg: 32-channel super-groups, BNO = 32): the cout tile's own 32 input channels only, slab rows 32 long
     const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x % g.cchunks;
-    const int co0 = ct * BNO, c0 = cc * CK;
+    const int co0 = ct * BNO, c0 = p.cg ? co0 + cc * CK : cc * CK;
+    const int Cw = p.cg ? 32 : (p.C0 + p.C1), cwb = p.cg ? co0 : 0;
     const int split = blockIdx.y;
     const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
     const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
         if (wk != 0) return;
     }
     // partial slab of this split: [Cout][NTAPS][Cin] fp32
-    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cin;
+    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cw;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wo * 16 + lq * 4 + r;
-                if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cin + ci] = acc[t][c][r];
+                if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cw + ci - cwb] = acc[t][c][r];
             }
         }
 }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     // one batch of scalar loads for the kernel arguments instead of a chain of dependent ones (see conv_igemm_kernel)
     asm volatile("" ::"s"(p.src0), "s"(p.src1), "s"(p.dy), "s"(p.partials), "s"(p.C0), "s"(p.C1), "s"(p.up0), "s"(p.N), "s"(p.Hin),
                  "s"(p.Win), "s"(p.Hout), "s"(p.Wout), "s"(p.pad), "s"(p.Cout), "s"(g.cchunks), "s"(g.nsplit), "s"(g.total_tiles),
-                 "s"(g.tiles_w), "s"(g.tiles_h), "s"(g.tw_magic), "s"(g.th_magic), "s"(g.pw_magic), "s"(g.tw_shift));
+                 "s"(g.tiles_w), "s"(g.tiles_h), "s"(g.tw_magic), "s"(g.th_magic), "s"(g.pw_magic), "s"(g.tw_shift), "s"(p.cg));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int wc = wave & 1, wg2 = wave >> 1;
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     const int dummy = P * kXP + BM * DYP;                  // 16 spare bytes: target of the stores of idle staging items
 
     const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x - ct * g.cchunks;
-    const int co0 = ct * BNO, c0 = cc * 32;
+    const int co0 = ct * BNO, c0 = p.cg ? co0 : cc * 32;    // grouped (MO = 2): the cout tile's own super-group
+    const int Cw = p.cg ? 32 : (p.C0 + p.C1), cwb = p.cg ? co0 : 0;
     const int split = blockIdx.y;
     const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
     const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
         for (int m = 0; m < MO; ++m) acc[0][m] += red[(wc * MO + m) * 64 + lane];
     }
     // partial slab of this split: [Cout][NTAPS][Cin] fp32
-    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cin;
+    float* out = p.partials + (size_t)split * p.Cout * NTAPS * Cw;
     const int ci = c0 + wc * 16 + lr;
     if (ci < Cin) {
 #pragma unroll
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + m * 16 + lq * 4 + r;
-                    if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cin + ci] = acc[tt][m][r];
+                    if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cw + ci - cwb] = acc[tt][m][r];
                 }
         }
     }
@@ -431,6 +434,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (g == 0 && i < n) dw[i] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
+// grouped convolutions: dense[cout][taps][32] (super-group slabs) -> dw[cout][taps][cg], the group's own block
+__global__ __launch_bounds__(256) void wgrad_group_extract_kernel(const float* __restrict__ dense, float* __restrict__ dw, int n, int taps,
+                                                                int cg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // index into dw
+    if (i >= n) return;
+    const int row = i / cg, j = i - row * cg;           // row = cout * taps + tap
+    const int co = row / taps;
+    dw[i] = dense[(size_t)row * 32 + ((co & 31) / cg) * cg + j];
+}
+
 template <typename T>
 int geom(const WgradParams& p, WGeom& g, int& WO) {
     constexpr int CK = WT<T>::CK, EPS = WT<T>::EPS;
@@ -448,18 +461,21 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.tiles_w = cdiv(p.Wout, TW);
     g.PH = (g.TH - 1) * p.stride + p.KH;
     g.PW = (TW - 1) * p.stride + p.KW;
-    g.cchunks = cdiv(Cin, CK);
+    g.cchunks = p.cg ? 32 / CK : cdiv(Cin, CK);      // grouped: cin chunks per 32-channel cout tile
+    VS_REQUIRE(p.cg == 0 || (p.C1 == 0 && p.C0 == p.Cout && p.Cout % 32 == 0 && p.cg >= 4 && p.cg <= 32 && 32 % p.cg == 0 && !p.up0),
+               "conv_wgrad: grouped convolutions need c0 == cout in 32-channel super-groups, 4 / 8 / 16 / 32 channels per group");
     g.total_tiles = p.N * g.tiles_h * g.tiles_w;
     g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;   // unused when the divisor is 1
     g.th_magic = 0xffffffffu / (unsigned)g.tiles_h + 1u;
     const int target = vs_option("wgrad_target");
-    const double dw_bytes = (double)p.Cout * p.KH * p.KW * Cin * 4.0;
+    const double dw_bytes = (double)p.Cout * p.KH * p.KW * (p.cg ? 32 : Cin) * 4.0;
     // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
     g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
     if (g.fast) {
         WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);   // = MO
+        if (p.cg) WO = 2;
         g.ctiles = cdiv(p.Cout, 16 * WO);
         const int base = g.ctiles * g.cchunks;
         // K splits: `target` workgroups, and up to 4x that for layers whose slabs stay small (the wide, shallow decoder
@@ -475,11 +491,11 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     // bytes per split, written once and read once by the reduce; narrower cout tiles (WO = 2 / 1 waves of 16 couts, the
     // other waves split K inside the workgroup and meet in LDS) trade slabs for operand re-reads.
     static const double budget = (getenv("VS_WGRAD_SLAB_MB") ? atof(getenv("VS_WGRAD_SLAB_MB")) : 1.0e9) * 1048576.0;  // default: never trade tile width for slabs (measured slower)
-    const int wo_max = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);
+    const int wo_max = p.cg ? 2 : (p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1));
     const int BMt = g.TH << g.tw_shift;
     int best_wo = wo_max, best_ns = 1;
     double best_slab = 1e30;
-    for (int wo = wo_max; wo >= 1; wo >>= 1) {
+    for (int wo = wo_max; wo >= (p.cg ? 2 : 1); wo >>= 1) {
         if ((4 / wo) > BMt / WT<T>::KSTEP) continue;  // not enough K-steps in a tile to feed the K-waves
         const int base = cdiv(p.Cout, 16 * wo) * g.cchunks;
         int ns = cdiv(target, base);
@@ -513,7 +529,7 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
-    return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.C0 + p.C1), g.nsplit, s);
+    return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
 template <typename T, int WO, int NTAPS, int STRIDE, int PT>
@@ -533,7 +549,7 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
-    const size_t n = (size_t)p.Cout * NTAPS * (p.C0 + p.C1);
+    const size_t n = (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1);
     const int nparts = g.nsplit;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, p.partials, p.dw, n, nparts);
     VS_LAUNCH_CHECK();
@@ -545,9 +561,22 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     WGeom g; int WO;
     int rc = geom<T>(p, g, WO);
     if (rc) return rc;
-    const size_t need = (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+    const size_t slab = (size_t)p.Cout * p.KH * p.KW * (p.cg ? 32 : p.C0 + p.C1) * sizeof(float);
+    const bool extract = p.cg && p.cg < 32;          // the super-group slabs are denser than dw: one more slab, then the gather
+    const size_t need = ((size_t)g.nsplit + (extract ? 1 : 0)) * slab;
     VS_REQUIRE(p.partials && p.partial_bytes >= need, "conv_wgrad: workspace %zu < %zu", p.partial_bytes, need);
     const int nt = p.KH * p.KW;
+    if (extract) {
+        WgradParams q = p;
+        q.cg = 32;                                    // as a grouped layer whose groups ARE the super-groups ...
+        q.dw = p.partials + (size_t)g.nsplit * (slab / sizeof(float));
+        const int rc2 = dispatch<T>(q, s);
+        if (rc2) return rc2;
+        const int n = p.Cout * nt * p.cg;             // ... then every group's cg x cg block out of its 32 x 32 slab
+        hipLaunchKernelGGL(wgrad_group_extract_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, q.dw, p.dw, n, nt, p.cg);
+        VS_LAUNCH_CHECK();
+        return VS_OK;
+    }
     if constexpr (sizeof(T) == 2) {
         if (g.fast) {
 #define VS_WGF_CASE(mo, t)                                                                \
@@ -582,7 +611,7 @@ size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {
     WGeom g; int WO;
     if (dtype == VS_BF16) { if (geom<bf16_t>(p, g, WO)) return 0; }
     else { if (geom<float>(p, g, WO)) return 0; }
-    return (size_t)g.nsplit * p.Cout * p.KH * p.KW * (p.C0 + p.C1) * sizeof(float);
+    return ((size_t)g.nsplit + (p.cg && p.cg < 32 ? 1 : 0)) * p.Cout * p.KH * p.KW * (p.cg ? 32 : p.C0 + p.C1) * sizeof(float);
 }
 
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s) {

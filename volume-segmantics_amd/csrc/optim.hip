@@ -48,18 +48,22 @@ __global__ void adamw_ranges_kernel(float* __restrict__ p, const float* __restri
     }
 }
 
-// w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps flipped][cout_pad], optional)
+// One 32 x 32 (cout x cin) tile of one tap: w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps
+// flipped][cout_pad], optional).  cg > 0: grouped convolution with cg channels per group (cin == cout) - w is
+// [cout][taps][cg]; the tile is the super-group bx's diagonal 32 x 32 block, wc / wt rows are 32 long, and a weight lands in
+// its group's cg x cg sub-block (zeros elsewhere).  Threads: tx 0..31, ty 0..7.
 template <typename T>
-__global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout,
-                                      int taps, int cin, int cout_pad) {
-    __shared__ float tile[32][33];
-    const int tap = blockIdx.z;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+__device__ __forceinline__ void weight_prepare_tile(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout, int taps,
+                                                    int cin, int cout_pad, int cg, int bx, int by, int tap, int tx, int ty,
+                                                    float (&tile)[32][33]) {
+    const int ci0 = bx * 32, co0 = (cg ? bx : by) * 32;
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         float v = 0.f;
-        if (co < cout && ci < cin) {
+        if (cg) {
+            if (co / cg == ci / cg) v = w[((size_t)co * taps + tap) * cg + ci % cg];
+            if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * 32 + tx, v);
+        } else if (co < cout && ci < cin) {
             v = w[((size_t)co * taps + tap) * cin + ci];
             if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
         }
@@ -69,10 +73,18 @@ __global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict
     if (wt) {
         for (int r = ty; r < 32; r += 8) {
             const int ci = ci0 + r, co = co0 + tx;
-            if (ci < cin && co < cout_pad)
+            if (cg) Elem<T>::st(wt + ((size_t)ci * taps + (taps - 1 - tap)) * 32 + tx, tile[tx][r]);
+            else if (ci < cin && co < cout_pad)
                 Elem<T>::st(wt + ((size_t)ci * taps + (taps - 1 - tap)) * cout_pad + co, tile[tx][r]);
         }
     }
+}
+
+template <typename T>
+__global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout,
+                                      int taps, int cin, int cout_pad, int cg) {
+    __shared__ float tile[32][33];
+    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, threadIdx.y, tile);
 }
 
 // all layers in ONE launch: the descriptor table travels in the kernel arguments; a block finds its layer by a linear
@@ -82,7 +94,7 @@ struct PrepTable {
     int first_block[65];
     long w_off[64], wc_off[64], wt_off[64];  // element offset into params; BYTE offsets into the workspace (-1 = none)
     short cout[64], cin[64], cout_pad[64];
-    unsigned char taps[64];
+    unsigned char taps[64], cg[64];          // cg: channels per group of a grouped convolution (0 = dense)
 };
 
 template <typename T>
@@ -90,8 +102,8 @@ __global__ void weight_prepare_all_kernel(const float* __restrict__ params, char
     __shared__ float tile[32][33];
     int l = 0;
     while (l + 1 < t.n && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
-    const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l];
-    const int cib = (cin + 31) / 32, cob = ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
+    const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l], cg = t.cg[l];
+    const int cib = (cin + 31) / 32, cob = cg ? 1 : ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
     int b = blockIdx.x - t.first_block[l];
     const int bx = b % cib; b /= cib;
     const int by = b % cob;
@@ -99,25 +111,7 @@ __global__ void weight_prepare_all_kernel(const float* __restrict__ params, char
     const float* w = params + t.w_off[l];
     T* wc = t.wc_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wc_off[l]) : nullptr;
     T* wt = t.wt_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wt_off[l]) : nullptr;
-    const int ci0 = bx * 32, co0 = by * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int r = ty; r < 32; r += 8) {
-        const int co = co0 + r, ci = ci0 + tx;
-        float v = 0.f;
-        if (co < cout && ci < cin) {
-            v = w[((size_t)co * taps + tap) * cin + ci];
-            if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
-        }
-        tile[r][tx] = v;
-    }
-    __syncthreads();
-    if (wt) {
-        for (int r = ty; r < 32; r += 8) {
-            const int ci = ci0 + r, co = co0 + tx;
-            if (ci < cin && co < cout_pad)
-                Elem<T>::st(wt + ((size_t)ci * taps + (taps - 1 - tap)) * cout_pad + co, tile[tx][r]);
-        }
-    }
+    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile);
 }
 
 // dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels); the same sweep leaves per-class partial sums
@@ -233,17 +227,28 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
     dim3 grid(cdiv(cin, 32), cdiv(cout_pad > cout ? cout_pad : cout, 32), taps);
     if (dtype == VS_BF16)
         hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cout, taps,
-                           cin, cout_pad);
+                           cin, cout_pad, 0);
     else
         hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cin,
-                           cout_pad);
+                           cout_pad, 0);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, hipStream_t s) {
+    VS_REQUIRE(cout % 32 == 0 && cg >= 4 && cg <= 32 && 32 % cg == 0, "weight_prepare_grouped: %d channels in groups of %d", cout, cg);
+    dim3 grid(cout / 32, 1, taps);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cout, taps, cout, cout, cg);
+    else
+        hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cout, cout, cg);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
 
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
-                              hipStream_t s) {
+                              const int* cg, hipStream_t s) {
     VS_REQUIRE(n <= 64, "weight_prepare_all: too many layers (%d)", n);
     PrepTable t{};
     t.n = n;
@@ -252,7 +257,8 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
         t.first_block[i] = blocks;
         t.w_off[i] = w_off[i]; t.wc_off[i] = wc_off[i]; t.wt_off[i] = wt_off[i];
         t.cout[i] = (short)cout[i]; t.cin[i] = (short)cin[i]; t.cout_pad[i] = (short)cout_pad[i]; t.taps[i] = (unsigned char)taps[i];
-        blocks += cdiv(cin[i], 32) * cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32) * taps[i];
+        t.cg[i] = (unsigned char)(cg ? cg[i] : 0);
+        blocks += cdiv(cin[i], 32) * (t.cg[i] ? 1 : cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32)) * taps[i];
     }
     t.first_block[n] = blocks;
     if (dtype == VS_BF16)

@@ -18,7 +18,7 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, float* db, float* partial, hipStream_t s);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
-                              hipStream_t s);
+                              const int* cg, hipStream_t s);
 
 namespace {
 
@@ -46,6 +46,8 @@ struct Unit {
     int out = -1;   // output activation id
     int res = -1;   // residual activation id
     int relu = 1;
+    int cg = 0;     // grouped convolution (ResNeXt): channels per group, cin0 == cout; 0 = dense.  Weights [cout][k*k][cg]; the
+                    // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
@@ -142,7 +144,8 @@ int build(vs_unet* net) {
     const int planes[4] = {64, 128, 256, 512};
     const int blocks18[4] = {2, 2, 2, 2}, blocks34[4] = {3, 4, 6, 3};   // resnet50 uses the resnet34 block counts
     const int* blocks = net->encoder == 18 ? blocks18 : blocks34;
-    const bool bottleneck = net->encoder == 50;
+    const bool bottleneck = net->encoder == 50 || net->encoder == 51;   // 51 = resnext50_32x4d: Bottleneck with groups = 32,
+    const int groups = net->encoder == 51 ? 32 : 1;                     // width_per_group = 4 (torchvision): width = planes * 2
     const int expansion = bottleneck ? 4 : 1;
     int featc[6] = {0, 64, 0, 0, 0, 0};          // channels of the encoder features the decoder taps
     for (int l = 0; l < 4; ++l) {
@@ -151,10 +154,10 @@ int build(vs_unet* net) {
             const int stride = (b == 0 && l > 0) ? 2 : 1;
             const int oh = ch / stride, ow = cw / stride, pl = planes[l], outc = pl * expansion;
             auto conv_unit = [&](const std::string& name, const std::string& bn, int src, int cin, int cout, int k, int st, int hi, int wi,
-                                 bool frozen) {
+                                 bool frozen, int cg) {
                 Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.stride = st;
-                u.hin = hi; u.win = wi; u.hout = hi / st; u.wout = wi / st; u.frozen_candidate = frozen;
-                u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cin, k, k}, 0);
+                u.hin = hi; u.win = wi; u.hout = hi / st; u.wout = wi / st; u.frozen_candidate = frozen; u.cg = cg;
+                u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cg ? cg : cin, k, k}, 0);
                 u.bn_idx = add_bn(L, bn, cout);
                 u.out = new_act(cout, hi / st, wi / st, true);
                 return u;
@@ -163,17 +166,19 @@ int build(vs_unet* net) {
             // [downsample.0 downsample.1].  BasicBlock: 3x3 (stride) - 3x3; Bottleneck (v1.5): 1x1 - 3x3 (stride) - 1x1 (x4).
             std::vector<Unit> us;
             if (!bottleneck) {
-                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, pl, 3, stride, ch, cw, true));
-                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, pl, pl, 3, 1, oh, ow, true));
+                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, pl, 3, stride, ch, cw, true, 0));
+                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, pl, pl, 3, 1, oh, ow, true, 0));
             } else {
-                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, pl, 1, 1, ch, cw, true));
-                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, pl, pl, 3, stride, ch, cw, true));
-                us.push_back(conv_unit(pre + ".conv3.weight", pre + ".bn3", us[1].out, pl, outc, 1, 1, oh, ow, true));
+                const int width = groups > 1 ? pl * 2 : pl;
+                us.push_back(conv_unit(pre + ".conv1.weight", pre + ".bn1", cur, inpl, width, 1, 1, ch, cw, true, 0));
+                us.push_back(conv_unit(pre + ".conv2.weight", pre + ".bn2", us[0].out, width, width, 3, stride, ch, cw, true,
+                                       groups > 1 ? width / groups : 0));
+                us.push_back(conv_unit(pre + ".conv3.weight", pre + ".bn3", us[1].out, width, outc, 1, 1, oh, ow, true, 0));
             }
             Unit& last = us.back();
             for (size_t q = 0; q + 1 < us.size(); ++q) U.push_back(us[q]);
             if (stride != 1 || inpl != outc) {   // "downsample" lacks "conv" in its name: not frozen by the reference's predicate
-                Unit ud = conv_unit(pre + ".downsample.0.weight", pre + ".downsample.1", cur, inpl, outc, 1, stride, ch, cw, false);
+                Unit ud = conv_unit(pre + ".downsample.0.weight", pre + ".downsample.1", cur, inpl, outc, 1, stride, ch, cw, false, 0);
                 ud.relu = 0;
                 U.push_back(ud);
                 last.res = ud.out;
@@ -287,8 +292,8 @@ size_t plan_workspace(vs_unet* net) {
         if (u.kind == U_CONV || u.kind == U_HEAD) {
             const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
             const size_t cout_pad = u.kind == U_HEAD ? 16 : (size_t)u.cout;
-            u.off_wc = take((size_t)u.cout * taps * cin * esz);
-            u.off_wt = take(cin * taps * cout_pad * esz);
+            u.off_wc = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
+            u.off_wt = take(cin * taps * (u.cg ? 32 : cout_pad) * esz);
         }
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
@@ -306,8 +311,8 @@ size_t plan_workspace(vs_unet* net) {
     for (auto& u : net->units) {
         if (u.kind != U_CONV && u.kind != U_HEAD) continue;
         const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
-        u.off_wc2 = take((size_t)u.cout * taps * cin * esz);
-        u.off_wt2 = take(cin * taps * (u.kind == U_HEAD ? 16 : (size_t)u.cout) * esz);
+        u.off_wc2 = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
+        u.off_wt2 = take(cin * taps * (u.cg ? 32 : (u.kind == U_HEAD ? 16 : (size_t)u.cout)) * esz);
     }
     for (auto& a : net->acts) {
         const size_t bytes = N * a.c * a.h * a.w * esz;
@@ -322,6 +327,7 @@ size_t plan_workspace(vs_unet* net) {
         p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = (int)N; p.Hin = u.hin; p.Win = u.win;
         p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
         p.Cout = u.kind == U_HEAD ? 16 : u.cout;
+        p.cg = u.cg;
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
@@ -356,7 +362,7 @@ struct Ctx {
     const TensorInfo& t(int idx) const { return net->layout.tensors[idx]; }
     const float* P(int idx) const { return params + t(idx).offset; }
     const void* wfwd(const Unit& u) const {  // weights in the compute dtype
-        return net->dtype == VS_F32 ? (const void*)P(u.w_idx) : (const void*)(ws + wc_off(u, net->wset));
+        return (net->dtype == VS_F32 && !u.cg) ? (const void*)P(u.w_idx) : (const void*)(ws + wc_off(u, net->wset));
     }
     static size_t wc_off(const Unit& u, int set) { return set ? u.off_wc2 : u.off_wc; }
     static size_t wt_off(const Unit& u, int set) { return set ? u.off_wt2 : u.off_wt; }
@@ -365,7 +371,7 @@ struct Ctx {
 };
 
 double conv_flops(const Ctx& c, const Unit& u) {  // algorithmic: 2 * MACs of the (un-padded, un-stuffed) convolution
-    return 2.0 * c.n * u.hout * u.wout * (double)u.cout * u.k * u.k * (u.cin0 + u.cin1);
+    return 2.0 * c.n * u.hout * u.wout * (double)u.cout * u.k * u.k * (u.cg ? u.cg : u.cin0 + u.cin1);
 }
 double act_bytes(const Ctx& c, const Unit& u, int passes) {  // `passes` full sweeps over the unit's output tensor
     return (double)passes * c.n * u.hout * u.wout * u.cout * c.net->esz;
@@ -379,6 +385,7 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
     p.N = c.n; p.Hin = u.hin; p.Win = u.win; p.Hout = u.hout; p.Wout = u.wout;
     p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
     p.w = c.wfwd(u); p.Cout = u.cout;
+    p.gc = u.cg ? 32 : 0;
     return p;
 }
 
@@ -392,7 +399,7 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     tmp.topology = encoder_code / 1000;
     VS_REQUIRE(tmp.topology == 0 || tmp.topology == 1, "topology must be 0 (U-Net) or 1 (U-Net++), got %d", tmp.topology);
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -445,7 +452,7 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
     VS_REQUIRE(topology == 0 || topology == 1, "unet_create: topology must be 0 (U-Net) or 1 (U-Net++), got %d", topology);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50, "unet_create: encoder must be 18, 34 or 50 (resnet18 / resnet34 / resnet50), got %d", encoder);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
@@ -474,17 +481,18 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
     ProfScope prof(PK_PREPARE, 0, (double)net->layout.n_params * (4 + net->esz * (training ? 2 : 1)), c.s);
     {   // every conv layer's low-precision copy and flipped/transposed dgrad copy in one launch
         long w_off[64], wc_off[64], wt_off[64];
-        int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+        int cout[64], taps[64], cin[64], cpad[64], cgs[64], nl = 0;
         auto flush = [&]() -> int {
             if (!nl) return VS_OK;
-            const int rc = launch_weight_prepare_all(net->dtype, params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, c.s);
+            const int rc = launch_weight_prepare_all(net->dtype, params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, c.s);
             nl = 0;
             return rc;
         };
         for (auto& u : net->units) {
             if (u.kind != U_CONV && u.kind != U_HEAD) continue;
-            const bool wc = net->dtype == VS_BF16, wt = training != 0;
+            const bool wc = net->dtype == VS_BF16 || u.cg, wt = training != 0;
             if (!wc && !wt) continue;
+            cgs[nl] = u.cg;
             w_off[nl] = c.t(u.w_idx).offset;
             wc_off[nl] = wc ? (long)Ctx::wc_off(u, net->wset) : -1;
             wt_off[nl] = wt ? (long)Ctx::wt_off(u, net->wset) : -1;
@@ -517,20 +525,21 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
     VS_REQUIRE(net && params && workspace && unit_lo >= 0 && unit_lo < unit_hi && unit_hi <= (int)net->units.size(),
                "unet_prepare_range: bad arguments");
     long w_off[64], wc_off[64], wt_off[64];
-    int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+    int cout[64], taps[64], cin[64], cpad[64], cgs[64], nl = 0;
     const int other = net->wset ^ 1;
     for (int k = unit_lo; k < unit_hi; ++k) {
         const Unit& v = net->units[k];
         if (v.kind != U_CONV && v.kind != U_HEAD) continue;
         VS_REQUIRE(nl < 64, "unet_prepare_range: too many layers in one range");
         w_off[nl] = net->layout.tensors[v.w_idx].offset;
-        wc_off[nl] = net->dtype == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
+        wc_off[nl] = (net->dtype == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
         wt_off[nl] = (long)Ctx::wt_off(v, other);
         cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+        cgs[nl] = v.cg;
         ++nl;
     }
     if (!nl) return VS_OK;
-    return launch_weight_prepare_all(net->dtype, params, workspace, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, (hipStream_t)stream);
+    return launch_weight_prepare_all(net->dtype, params, workspace, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, (hipStream_t)stream);
 }
 extern "C" int vs_unet_weight_set(const vs_unet_t* net) { return net ? net->wset : VS_ERR_INVALID; }
 extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
@@ -729,12 +738,12 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     const int other = net->wset ^ 1;
     AdamwRanges r{};
     long w_off[64], wc_off[64], wt_off[64];
-    int cout[64], taps[64], cin[64], cpad[64], nl = 0;
+    int cout[64], taps[64], cin[64], cpad[64], cgs[64], nl = 0;
     int rc;
     auto flush = [&]() -> int {
         int rc2;
         if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
-        if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, s))) return rc2;
+        if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
         r.n = 0; nl = 0;
         return VS_OK;
     };
@@ -754,9 +763,10 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (v.bias_idx >= 0) push(v.bias_idx);
         if (v.kind == U_CONV || v.kind == U_HEAD) {
             w_off[nl] = c.t(v.w_idx).offset;
-            wc_off[nl] = dt == VS_BF16 ? (long)Ctx::wc_off(v, other) : -1;
+            wc_off[nl] = (dt == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
             wt_off[nl] = (long)Ctx::wt_off(v, other);
             cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+            cgs[nl] = v.cg;
             ++nl;
         }
     }
@@ -871,6 +881,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
             p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
             p.dy = dzp; p.Cout = dz_c;
+            p.cg = u.cg;
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
             if (u.kind == U_HEAD) {
                 p.dw = (float*)(c.ws + net->off_headdw);
@@ -971,6 +982,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (stuff_in_loader) p.up0 = 2;   // the patch loader reads dz at the even positions and zeros elsewhere
         p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
         p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0 + u.cin1;
+        p.gc = u.cg ? 32 : 0;
         if (u.up0) {
             // U-Net: every decoder input has this one consumer.  U-Net++: the upsampled input may already hold the contributions
             // of the nodes that read it as a dense skip - then the 2x2 sum goes through the separate, accumulating kernel.

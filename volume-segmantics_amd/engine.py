@@ -71,7 +71,7 @@ class _UnetFn(torch.autograd.Function):
 
 
 class VolSegUnet(nn.Module):
-    ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50}
+    ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51}
     TOPOLOGIES = {"unet": 0, "unetplusplus": 1}     # smp.Unet, smp.UnetPlusPlus
 
     def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
