@@ -421,3 +421,16 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
         sync()
         runs.append(m._flat.clone())
     assert torch.equal(runs[0], runs[1]), encoder
+    # the reference's frozen-encoder phase (vol_seg_2d_trainer.py:102-108): encoder conv weights get zero gradients, the
+    # BatchNorm parameters right behind them in the flat buffer keep theirs
+    m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
+    for name, p in m.named_parameters():
+        if "encoder" in name and "conv" in name:
+            p.requires_grad = False
+    m.train()
+    HipDiceLoss()(m(xt.to(DEV)), t.to(DEV).contiguous()).backward()
+    sync()
+    grads = {k: m._view_of(m._flat_grad, tt_[1], tt_[2], tt_[3]) for k, tt_ in ((q[0], q) for q in m._table) if tt_[2] <= 3}
+    assert not grads["encoder.layer1.0.conv2.weight"].any() and not grads["encoder.layer4.0.conv2.weight"].any()
+    for k in ("encoder.layer1.0.bn2.weight", "encoder.layer1.0.bn2.bias", "encoder.layer4.0.bn2.weight", "encoder.layer2.0.downsample.0.weight"):
+        assert grads[k].abs().sum().item() > 0, k

@@ -894,7 +894,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
         } else {
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
-                                        (size_t)u.cout * u.k * u.k * (u.cin0 + u.cin1) * sizeof(float), ws_stream));
+                                        (size_t)u.cout * u.k * u.k * (u.cg ? u.cg : u.cin0 + u.cin1) * sizeof(float), ws_stream));
         }
         return opt ? group_update(ui) : VS_OK;
     };
