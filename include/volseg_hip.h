@@ -136,6 +136,7 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   topology 2: smp.Linknet - 1x1 convolution / ConvTranspose2d(4, 2, 1) / 1x1 convolution blocks, encoder features added;
  *   topology 0: smp.Unet; 1: smp.UnetPlusPlus - the dense nested decoder (node x_d_l = DecoderBlock(up(x_d_(l-1)),
  *   cat(x_(d+1)_l .. x_l_l, encoder feature)); the concatenations are materialised by vs_channel_slice copies and their
  *   gradients accumulated back onto the members).
@@ -255,6 +256,21 @@ void vs_graph_destroy(vs_graph_t* g);
 int vs_unet_backward_adamw_part(vs_unet_t* net, const float* x, const float* dlogits, int n, int need_encoder_wgrad,
                                 float* grads, void* workspace, void* stream, const vs_adamw_args* opt, int unit_lo,
                                 int unit_hi, int role);
+/* Pixel shuffle with block 2 and its inverse (NHWC): y[n][2i+a][2j+b][k] = x[n][i][j][(2a+b) * c + k] (+ bias[k]) (* scale[k] +
+ * shift[k]) (ReLU), each part optional (NULL / 0).  nn.ConvTranspose2d(kernel 4, stride 2, padding 1) - smp Linknet's
+ * TransposeX2 (decoders/linknet/decoder.py) - is a 3x3 convolution onto 4 * c channels (vs_conv2d_fwd; parity (a, b) of the
+ * output reads taps kh = a + 3 - 2r, kw = b + 3 - 2q of the 4x4 kernel) followed by this shuffle.  vs_colsum: out[k] = sum over
+ * rows of x[rows][c] in fp32, fixed order (the bias gradient); workspace vs_colsum_workspace(c) bytes. */
+int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int h, int w, int c, const float* bias, const float* scale,
+                       const float* shift, int relu, void* stream);
+int vs_space_to_depth2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+/* the transposed convolution's weights in the 3x3 form: w fp32 [cin][cout][4][4] (torch's layout) -> wc [4 * cout][9][cin]
+ * (may be NULL) and the data-gradient copy wt [cin][9 reversed][4 * cout] (may be NULL); vs_convt_wgrad_gather maps the 3x3
+ * form's weight gradient (vs_conv2d_wgrad: [4 * cout][9][cin] fp32) back to dw [cin][cout][4][4] */
+int vs_convt_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, void* stream);
+int vs_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, void* stream);
+size_t vs_colsum_workspace(int c);
+int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream);
 /* The data-parallel form of the two shares: vs_unet_backward_part = the shares without the optimiser (role 2 = weight
  * gradients only); vs_unet_adamw_range = AdamW over the parameters of the units [unit_lo, unit_hi) from `grads` (after the
  * caller's all-reduce of that slice, vs_unet_unit_param_offset) plus their next-forward weight copies, in order on

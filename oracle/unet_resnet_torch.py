@@ -150,13 +150,53 @@ class UnetPlusPlusDecoder(nn.Module):
         return self.blocks[f"x_0_{self.depth}"](x[f"x_0_{self.depth - 1}"])
 
 
+class LinknetDecoder(nn.Module):
+    """smp.Linknet's decoder (segmentation-models-pytorch 0.2.1, decoders/linknet/decoder.py), restated.  channels = encoder
+    features without the input, deepest first, + [prefinal_channels = 32]; block i =
+      Sequential(Conv2dReLU(in, in // 4, 1), TransposeX2(in // 4, in // 4), Conv2dReLU(in // 4, out, 1))
+    with Conv2dReLU = Sequential(Conv2d(bias=False), BatchNorm2d, ReLU) and TransposeX2 = Sequential(ConvTranspose2d(kernel 4,
+    stride 2, padding 1 - with its bias), BatchNorm2d, ReLU); forward: x = block(x) (+ skip: the next-shallower feature) for
+    the first four blocks.  Keys: decoder.blocks.{i}.block.{0,1,2}.{0,1}.*."""
+
+    def __init__(self, encoder_channels, prefinal_channels: int = 32):
+        super().__init__()
+        ch = list(encoder_channels[1:][::-1]) + [prefinal_channels]
+
+        def conv_relu(i, o):
+            return nn.Sequential(nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU(inplace=True))
+
+        class Block(nn.Module):
+            def __init__(self, i, o):
+                super().__init__()
+                self.block = nn.Sequential(
+                    conv_relu(i, i // 4),
+                    nn.Sequential(nn.ConvTranspose2d(i // 4, i // 4, kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(i // 4), nn.ReLU(inplace=True)),
+                    conv_relu(i // 4, o))
+
+            def forward(self, x, skip=None):
+                x = self.block(x)
+                return x if skip is None else x + skip
+
+        self.blocks = nn.ModuleList(Block(ch[i], ch[i + 1]) for i in range(5))
+
+    def forward(self, feats):
+        f = feats[1:][::-1]
+        x, skips = f[0], f[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
-        self.decoder = (UnetDecoder if topology == "unet" else UnetPlusPlusDecoder)(OUT_CHANNELS[encoder_name])
-        self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
-        for m in self.decoder.modules():   # smp initialisation
+        self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder}[topology](OUT_CHANNELS[encoder_name])
+        if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
+            self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
+        else:
+            self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
+        for m in self.decoder.modules():   # smp initialisation (nn.ConvTranspose2d is not an nn.Conv2d: torch's default stays)
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
             elif isinstance(m, nn.BatchNorm2d):

@@ -273,7 +273,8 @@ def test_dgrad_and_wgrad_match_autograd(code, shape):
 
 @pytest.mark.parametrize("code", CODES)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 128, 4, 1), (2, 16, 24, 64, 8, 1), (1, 8, 8, 64, 16, 2), (3, 8, 8, 96, 32, 1),
-                                   (2, 32, 32, 128, 4, 2), (1, 20, 12, 32, 8, 1)])
+                                   (2, 32, 32, 128, 4, 2), (1, 20, 12, 32, 8, 1),
+                                   (32, 64, 64, 128, 4, 2)])      # a training batch: enough workgroups for the wide stride-2 tiles
 def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
     """nn.Conv2d(c, c, 3, stride, 1, groups=c/cg) - the 3x3 convolution of a ResNeXt bottleneck (torchvision resnext50_32x4d:
     cg = 4 / 8 / 16 / 32 channels per group) - forward, data gradient and weight gradient against torch CPU.  The kernels
@@ -326,6 +327,62 @@ def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
     L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
     sync()
     assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 128), (1, 16, 24, 16, 16), (2, 4, 4, 64, 32), (1, 32, 32, 32, 32)])
+def test_conv_transpose_4x4_stride2_as_conv3x3_plus_pixel_shuffle(code, shape):
+    """nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1) - smp Linknet's TransposeX2 - through the C ABI: weight
+    expansion (vs_convt_weights_prepare), 3x3 convolution onto 4 * cout channels, vs_depth_to_space2 (+ bias); backward:
+    vs_colsum (bias), vs_space_to_depth2, the 3x3 form's data and weight gradients, vs_convt_wgrad_gather - against autograd."""
+    L = lib()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(5)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5, code).requires_grad_()
+    bias = torch.randn(cout, generator=g).requires_grad_()
+    y = F.conv_transpose2d(x, wt, bias, stride=2, padding=1)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    wc = torch.full((4 * cout, 9, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    wtr = torch.full((cin, 9, 4 * cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_convt_weights_prepare(code, L.ptr(wt.detach().contiguous().to(DEV)), L.ptr(wc), L.ptr(wtr), cin, cout, None))
+    d = conv_desc(L, code, n, h, w, cin, 4 * cout, 3, 1, 1)
+    xd = to_nhwc(x.detach(), code)
+    zeff = torch.full((n, h, w, 4 * cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wc), None, None, None, L.ptr(zeff), None, None))
+    yd = torch.full((n, 2 * h, 2 * w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    bd = bias.detach().to(DEV)
+    L.check(L.lib.vs_depth_to_space2(code, L.ptr(zeff), L.ptr(yd), n, h, w, cout, L.ptr(bd), None, None, 0, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    # backward
+    dyd = to_nhwc(dy, code)
+    ws_b = L.lib.vs_colsum_workspace(cout)
+    wsb = torch.empty(ws_b, dtype=torch.uint8, device=DEV)
+    db = torch.full((cout,), float("nan"), device=DEV)
+    L.check(L.lib.vs_colsum(code, L.ptr(dyd), n * 4 * h * w, cout, L.ptr(db), L.ptr(wsb), ws_b, None))
+    dzeff = torch.full((n, h, w, 4 * cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_space_to_depth2(code, L.ptr(dyd), L.ptr(dzeff), n, h, w, cout, None))
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=DEV)
+    dense = torch.full((4 * cout, 9, cin), float("nan"), device=DEV)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(xd), None, L.ptr(dzeff), L.ptr(dense), L.ptr(ws), ws_bytes, None))
+    dw = torch.full((cin, cout, 4, 4), float("nan"), device=DEV)
+    L.check(L.lib.vs_convt_wgrad_gather(L.ptr(dense), L.ptr(dw), cin, cout, None))
+    dd = conv_desc(L, code, n, h, w, 4 * cout, cin, 3, 1, 1)
+    dx = torch.full((n, h, w, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dzeff), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
+    sync()
+    assert torch.allclose(db.cpu(), bias.grad, rtol=1e-4, atol=1e-4 * bias.grad.abs().max().item())
+    assert torch.allclose(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    # the shuffle and its inverse are exact permutations
+    back = torch.empty_like(zeff)
+    L.check(L.lib.vs_depth_to_space2(code, L.ptr(zeff), L.ptr(yd), n, h, w, cout, None, None, None, 0, None))
+    L.check(L.lib.vs_space_to_depth2(code, L.ptr(yd), L.ptr(back), n, h, w, cout, None))
+    sync()
+    assert torch.equal(back, zeff)
 
 
 @pytest.mark.parametrize("code", CODES)

@@ -220,10 +220,11 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("classes", [2, 4, 6])
-def test_head_scatter_epilogue_equals_forward_plus_logits_to_volume(precision, classes):
+@pytest.mark.parametrize("classes,topology", [(2, "unet"), (4, "unet"), (6, "unet"), (3, "linknet")])
+def test_head_scatter_epilogue_equals_forward_plus_logits_to_volume(precision, classes, topology):
     """vs_unet_forward_to_volume (head kernel writes labels / probabilities / keys itself) vs vs_unet_forward +
-    vs_logits_to_volume on the same slices: bit-identical volumes.  6 classes exercises the fall-back inside the call."""
+    vs_logits_to_volume on the same slices: bit-identical volumes.  6 classes exercises the fall-back inside the call, and so
+    does Linknet's 1x1 head (the fused epilogue belongs to the 3x3 direct kernel)."""
     import numpy as np
     from volume_segmantics_amd import _lib
     from volume_segmantics_amd.engine import VolSegUnet
@@ -232,7 +233,7 @@ def test_head_scatter_epilogue_equals_forward_plus_logits_to_volume(precision, c
     old = L.lib.vs_get_option(b"conv_direct_min_px")
     L.set_option("conv_direct_min_px", 1)          # small test slices still take the direct head kernel
     try:
-        model = VolSegUnet(classes, device=DEV, precision=precision, seed=3)
+        model = VolSegUnet(classes, device=DEV, precision=precision, seed=3, topology=topology)
         model.eval()
         vol = np.zeros((5, 61, 90), np.uint8)                       # padded to 64 x 96: crop offsets are exercised
         for view, direction in ((vol, 0), (np.swapaxes(vol, 0, 1)[:, :5], 4), (np.rot90(vol, 1, (1, 2)), 7)):

@@ -359,7 +359,8 @@ def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
 
 # ---- other encoders of the reference's list behind the same decoder -------------------------------
 @pytest.mark.parametrize("encoder,topology", [("resnet18", "unet"), ("resnet50", "unet"), ("resnet34", "unetplusplus"),
-                                              ("resnet50", "unetplusplus"), ("resnext50_32x4d", "unet")])
+                                              ("resnet50", "unetplusplus"), ("resnext50_32x4d", "unet"), ("resnet34", "linknet"),
+                                              ("resnet50", "linknet")])
 def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
     """U_NET + resnet18 (BasicBlock x 2,2,2,2) and resnet50 (Bottleneck: 1x1 - 3x3(stride) - 1x1 x4, 1x1 shortcuts, features of
     256 .. 2048 channels) against oracle/unet_resnet_torch.py: eval logits within 1e-3 (fp32), train-mode forward / loss tight,
@@ -398,10 +399,15 @@ def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
         assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
         for name, p in model.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2", "decoder.blocks.x_0_4.conv2")):
+            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2", "decoder.blocks.x_0_4.conv2", "decoder.blocks.4.block.2")):
                 r = refg[name].grad
                 err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
                 assert err < gtol, (encoder, precision, name, err)
+            elif name.endswith("block.1.0.bias"):
+                # the bias of a ConvTranspose2d that feeds a train-mode BatchNorm: its gradient is the per-channel sum of a
+                # batch-normalised gradient - zero in exact arithmetic, rounding noise here and in the oracle (1e-10)
+                # (bf16: dz is rounded to bf16 before the sum - 4e-6 measured)
+                assert p.grad.abs().max().item() < (1e-6 if precision == "fp32" else 1e-4) and refg[name].grad.abs().max().item() < 1e-6, name
             elif precision == "fp32":
                 assert _cos(p.grad.cpu(), refg[name].grad) > 0.98, (encoder, name)
     # the recorded step (graphs) runs for these plans too and equals the call-by-call step

@@ -94,3 +94,28 @@ def test_unetplusplus_matches_published_smp_parameter_counts():
     net = OracleUnet("resnet34", 1, 3, "unetplusplus").eval()
     with torch.no_grad():
         assert net(torch.zeros(1, 1, 96, 64)).shape == (1, 3, 96, 64)
+
+
+def test_linknet_restatement_and_engine_table_agree():
+    """smp.Linknet (oracle/unet_resnet_torch.py:LinknetDecoder): 1x1 convolution / ConvTranspose2d(4, 2, 1) / 1x1 convolution
+    blocks with the encoder features added, 32 channels into a 1x1 head.  No published per-architecture parameter count is
+    known here: the pins are the torchvision-pinned encoder, the decoder's arithmetic (487,232 parameters + a 33-parameter head
+    on resnet34, 3-channel input, 1 class: 21,771,937 in all), the module key names of smp's nn.Sequential nesting, and that
+    the engine's tensor table has the same keys / shapes in state_dict order for every encoder."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    net = OracleUnet("resnet34", 3, 1, "linknet")
+    assert sum(p.numel() for p in net.decoder.parameters()) == 487_232
+    assert sum(p.numel() for p in net.parameters()) == 21_771_937
+    for name, code in (("resnet18", 2018), ("resnet34", 2034), ("resnet50", 2050), ("resnext50_32x4d", 2051)):
+        sd = OracleUnet(name, 1, 3, "linknet").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet34", 1, 2, "linknet").state_dict()
+    assert sd["decoder.blocks.0.block.0.0.weight"].shape == (128, 512, 1, 1)
+    assert sd["decoder.blocks.0.block.1.0.weight"].shape == (128, 128, 4, 4) and sd["decoder.blocks.0.block.1.0.bias"].shape == (128,)
+    assert sd["decoder.blocks.4.block.2.0.weight"].shape == (32, 16, 1, 1)
+    assert sd["segmentation_head.0.weight"].shape == (2, 32, 1, 1)
+    with torch.no_grad():
+        assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)

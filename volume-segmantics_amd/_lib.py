@@ -59,6 +59,12 @@ _SIGS = {
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),
     "vs_weights_prepare_grouped": (I, [I, P, P, P, I, I, I, P]),
+    "vs_depth_to_space2": (I, [I, P, P, I, I, I, I, P, P, P, I, P]),
+    "vs_space_to_depth2": (I, [I, P, P, I, I, I, I, P]),
+    "vs_convt_weights_prepare": (I, [I, P, P, P, I, I, P]),
+    "vs_convt_wgrad_gather": (I, [P, P, I, I, P]),
+    "vs_colsum_workspace": (SZ, [I]),
+    "vs_colsum": (I, [I, P, C.c_int64, I, P, P, SZ, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
     "vs_stem_wgrad": (I, [I, P, P, P, P, SZ, I, I, I, P]),
     "vs_stem_wgrad_workspace": (SZ, [I, I, I]),

@@ -92,3 +92,15 @@ extern "C" int vs_weights_prepare_grouped(int dtype, const float* w, void* wc, v
     VS_REQUIRE(w && (wc || wt), "weights_prepare_grouped: null pointer");
     return launch_weight_prepare_grouped(dtype, w, wc, wt, cout, taps, cg, (hipStream_t)stream);
 }
+
+/* nn.ConvTranspose2d(kernel 4, stride 2, padding 1) as a 3x3 convolution onto 4 * cout channels + vs_depth_to_space2: w fp32
+ * [cin][cout][4][4] (torch's layout) -> wc [4 * cout][9][cin] (may be NULL) and the data-gradient copy wt [cin][9][4 * cout]
+ * (may be NULL); vs_convt_wgrad_gather maps the 3x3 form's weight gradient (vs_conv2d_wgrad, [4 * cout][9][cin] fp32) back. */
+extern "C" int vs_convt_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, void* stream) {
+    VS_REQUIRE(w && (wc || wt) && cin > 0 && cout > 0, "convt_weights_prepare: bad arguments");
+    return launch_convt_weight_prepare(dtype, w, wc, wt, cin, cout, (hipStream_t)stream);
+}
+extern "C" int vs_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, void* stream) {
+    VS_REQUIRE(dense && dw && cin > 0 && cout > 0, "convt_wgrad_gather: bad arguments");
+    return launch_convt_wgrad_gather(dense, dw, cin, cout, (hipStream_t)stream);
+}

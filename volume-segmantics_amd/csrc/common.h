@@ -201,3 +201,7 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
 // grouped convolution (cg channels per group, cin == cout): fp32 [cout][taps][cg] -> the block-expanded [cout][taps][32] copy
 // and its flipped / transposed twin [cin][taps reversed][32] (32-channel super-groups; zeros outside a group's own block)
 int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, hipStream_t s);
+// ConvTranspose2d(4, stride 2, padding 1) = 3x3 convolution onto 4 * cout channels + pixel shuffle (vs_depth_to_space2):
+// w fp32 [cin][cout][4][4] -> wc [4 * cout][9][cin] and wt [cin][9 reversed][4 * cout]; and the way back for the gradient
+int launch_convt_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, hipStream_t s);
+int launch_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, hipStream_t s);

@@ -690,7 +690,7 @@ Pick pick_cfg(const ConvParams& p) {
     Pick c;
     c.NW = 4;
     c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
-    if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && p.Wout >= 16 && p.Hout >= 8 && vs_option("conv_s2_pt2") &&
+    if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && !p.gc && p.Wout >= 16 && p.Hout >= 8 && vs_option("conv_s2_pt2") &&
         (long)p.N * cdiv(p.Hout, 8) * cdiv(p.Wout, 16) * cdiv(p.Cout, 64) >= vs_option("conv_min_wgs")) c.PT = 2;
     const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.Hout >= 16 && p.Wout >= 16;
     auto wgs = [&](int bn, int px) {

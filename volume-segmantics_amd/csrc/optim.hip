@@ -87,6 +87,34 @@ __global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict
     weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, threadIdx.y, tile);
 }
 
+// ConvTranspose2d(kernel 4, stride 2, padding 1) as a 3x3 convolution onto 4 * cout channels + pixel shuffle: output parity
+// (a, b) of the transposed convolution reads the 2 x 2 taps kh = a + 3 - 2r, kw = b + 3 - 2q (r, q = 3x3 tap row / column; the
+// other five taps are zero).  w fp32 [cin][cout][4][4] (torch's layout) -> wc [(2a+b) * cout + co][r * 3 + q][ci] and its
+// flipped / transposed twin wt [ci][8 - (r * 3 + q)][(2a+b) * cout + co] for the data gradient.
+template <typename T>
+__global__ void convt_weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cin, int cout) {
+    const int total = 4 * cout * 9 * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin, tap = (i / cin) % 9, row = i / (9 * cin);
+        const int sub = row / cout, co = row - sub * cout;
+        const int kh = (sub >> 1) + 3 - 2 * (tap / 3), kw = (sub & 1) + 3 - 2 * (tap % 3);
+        const float v = (kh >= 0 && kh < 4 && kw >= 0 && kw < 4) ? w[(((size_t)ci * cout + co) * 4 + kh) * 4 + kw] : 0.f;
+        if (wc) Elem<T>::st(wc + i, v);
+        if (wt) Elem<T>::st(wt + ((size_t)ci * 9 + (8 - tap)) * (4 * cout) + row, v);
+    }
+}
+
+// the weight gradient of that 3x3 convolution, dense[4 * cout][9][cin] fp32 -> dw[cin][cout][4][4]: every real tap once
+__global__ void convt_wgrad_gather_kernel(const float* __restrict__ dense, float* __restrict__ dw, int cin, int cout) {
+    const int total = cin * cout * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int kw = i & 3, kh = (i >> 2) & 3, co = (i >> 4) % cout, ci = (i >> 4) / cout;
+        const int a = (kh + 1) & 1, b = (kw + 1) & 1;
+        const int r = (a + 3 - kh) >> 1, q = (b + 3 - kw) >> 1;
+        dw[i] = dense[((size_t)((a * 2 + b) * cout + co) * 9 + r * 3 + q) * cin + ci];
+    }
+}
+
 // all layers in ONE launch: the descriptor table travels in the kernel arguments; a block finds its layer by a linear
 // scan over the (<= 64) cumulative block counts
 struct PrepTable {
@@ -231,6 +259,21 @@ int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cou
     else
         hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cin,
                            cout_pad, 0);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_convt_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, hipStream_t s) {
+    const int blocks = grid_for((int64_t)4 * cout * 9 * cin);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(convt_weight_prepare_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cin, cout);
+    else
+        hipLaunchKernelGGL(convt_weight_prepare_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wc, (float*)wt, cin, cout);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+int launch_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, hipStream_t s) {
+    hipLaunchKernelGGL(convt_wgrad_gather_kernel, dim3(grid_for((int64_t)cin * cout * 16)), dim3(256), 0, s, dense, dw, cin, cout);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

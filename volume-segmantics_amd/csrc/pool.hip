@@ -185,6 +185,87 @@ __global__ void zero_stuff2x_kernel(const T* __restrict__ x, T* __restrict__ y, 
     }
 }
 
+// Pixel shuffle with block 2 (NHWC): y[n][2i+a][2j+b][k] = f(x[n][i][j][(2a+b)*c + k]), f = (+ bias[k]) (* scale[k] + shift[k]) (ReLU),
+// each part optional.  A ConvTranspose2d(kernel 4, stride 2, padding 1) is a 3x3 convolution onto 4*c channels (one 2x2-tap
+// sub-kernel per output parity, embedded in the 3x3 taps) followed by this shuffle (smp Linknet's TransposeX2).
+template <typename T>
+__global__ void depth_to_space2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, const float* __restrict__ bias,
+                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * 2 * h * 2 * w * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int wo = t % (2 * w); t /= (2 * w);
+        const int ho = t % (2 * h);
+        const int b = t / (2 * h);
+        const int sub = (ho & 1) * 2 + (wo & 1);
+        float v[kVec];
+        ld8(x + (((size_t)b * h + (ho >> 1)) * w + (wo >> 1)) * 4 * c + sub * c + cg * kVec, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const int ch = cg * kVec + k;
+            if (bias) v[k] += bias[ch];
+            if (scale) v[k] = v[k] * scale[ch] + shift[ch];
+            if (relu) v[k] = fmaxf(v[k], 0.f);
+        }
+        st8(y + i * kVec, v);
+    }
+}
+
+// the inverse gather: y[n][i][j][(2a+b)*c + k] = x[n][2i+a][2j+b][k] (the shuffle's gradient)
+template <typename T>
+__global__ void space_to_depth2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * h * w * 4 * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cg = t % cv; t /= cv;
+        const int sub = t % 4; t /= 4;
+        const int wi = t % w; t /= w;
+        const int hi = t % h;
+        const int b = t / h;
+        float v[kVec];
+        ld8(x + (((size_t)b * 2 * h + 2 * hi + (sub >> 1)) * 2 * w + 2 * wi + (sub & 1)) * c + cg * kVec, v);
+        st8(y + i * kVec, v);
+    }
+}
+
+// column sums of x[rows][c] in two fixed-order stages (a bias gradient): partial[block][c], then out[c].  blockIdx.y = slab of
+// up to 256 channels (cs of them, starting at 256 * blockIdx.y)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t rows, int c, int cs, float* __restrict__ partial) {
+    // thread -> (row lane, 8-channel group): 256 / (cs / 8) rows per sweep
+    const int cv = cs / kVec, rl = 256 / cv, c0 = blockIdx.y * 256;
+    const int cg = threadIdx.x % cv, r0 = threadIdx.x / cv;
+    __shared__ float red[256 * kVec];
+    float s[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) s[k] = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * rl + r0; r < rows; r += (int64_t)gridDim.x * rl) {
+        float v[kVec];
+        ld8(x + (size_t)r * c + c0 + cg * kVec, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) red[threadIdx.x * kVec + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < cs) {
+        const int g = threadIdx.x / kVec, k = threadIdx.x % kVec;
+        float t = 0.f;
+        for (int r = 0; r < rl; ++r) t += red[(r * cv + g) * kVec + k];
+        partial[(size_t)blockIdx.x * c + c0 + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int c) {
+    const int ch = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * c + ch];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[ch] = s;
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -270,6 +351,54 @@ extern "C" int vs_zero_stuff2x(int dtype, const void* x, void* y, int n, int h, 
     else
         hipLaunchKernelGGL(zero_stuff2x_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (float*)y, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int h, int w, int c, const float* bias, const float* scale,
+                                  const float* shift, int relu, void* stream) {
+    VS_REQUIRE(x && y && c > 0 && c % kVec == 0 && (!scale == !shift), "depth_to_space2: channels must be a multiple of 8, scale and shift come together");
+    const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(depth_to_space2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (bf16_t*)y, n, h, w, c, bias, scale, shift, relu);
+    else
+        hipLaunchKernelGGL(depth_to_space2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (float*)y, n, h, w, c, bias, scale, shift, relu);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+extern "C" int vs_space_to_depth2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream) {
+    VS_REQUIRE(x && y && c > 0 && c % kVec == 0, "space_to_depth2: channels must be a multiple of 8");
+    const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(space_to_depth2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (bf16_t*)y, n, h, w, c);
+    else
+        hipLaunchKernelGGL(space_to_depth2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (float*)y, n, h, w, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// out[c] = sum over rows of x[rows][c] (fp32, fixed summation order); workspace: vs_colsum_workspace(c) bytes
+constexpr int kColsumBlocks = 512;
+extern "C" size_t vs_colsum_workspace(int c) { return (size_t)kColsumBlocks * c * sizeof(float); }
+extern "C" int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream) {
+    const int cs = c < 256 ? c : 256;
+    VS_REQUIRE(x && out && workspace && c >= kVec && c % kVec == 0 && 256 % (cs / kVec) == 0 && c % cs == 0,
+               "colsum: channels must be 8, 16, 32, 64, 128 or a multiple of 256 (got %d)", c);
+    VS_REQUIRE(workspace_bytes >= vs_colsum_workspace(c), "colsum: workspace too small");
+    const int rl = 256 / (cs / kVec);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kColsumBlocks, (rows + rl - 1) / rl));
+    const dim3 grid(blocks, c / cs);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, cs, workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, c, cs, workspace);
+    VS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, workspace, out, blocks, c);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

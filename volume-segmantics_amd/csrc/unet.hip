@@ -16,6 +16,10 @@
 
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, float* db, float* partial, hipStream_t s);
+extern "C" int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int h, int w, int c, const float* bias, const float* scale,
+                                  const float* shift, int relu, void* stream);
+extern "C" int vs_space_to_depth2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+extern "C" int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -29,7 +33,10 @@ struct TensorInfo {
     int64_t offset;
 };
 
-enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT };
+enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
+                U_CONVT,   // ConvTranspose2d(4, stride 2, padding 1) + BN + ReLU (smp Linknet's TransposeX2): a 3x3 convolution onto
+                           // 4 * cout channels (conv_igemm) + pixel shuffle; cin0 -> cout channels, hin x win -> hout x wout = 2x
+                U_ADD };   // out = a(src0) + a(src1) (Linknet's skip connection)
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -101,6 +108,7 @@ struct vs_unet {
     std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
+    size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
@@ -195,7 +203,9 @@ int build(vs_unet* net) {
     const int dec[5] = {256, 128, 64, 32, 16};
     const int skipc[5] = {featc[4], featc[3], featc[2], featc[1], 0};
     int xin = feat[5], xc = featc[5];
-    if (net->topology == 0) {
+    if (net->topology == 2) {
+        // (built below, next to the head)
+    } else if (net->topology == 0) {
     for (int i = 0; i < 5; ++i) {
         const std::string pre = "decoder.blocks." + std::to_string(i);
         const int oh = ch * 2, ow = cw * 2;
@@ -275,9 +285,51 @@ int build(vs_unet* net) {
         run_node(0, 4, node[0][3].out_act, node[0][3].out_ch, {});
         xin = node[0][4].out_act; xc = dec[4];
     }
-    Unit head; head.kind = U_HEAD; head.src0 = xin; head.cin0 = 16; head.cout = net->classes; head.relu = 0;
+    int head_k = 3;
+    if (net->topology == 2) {
+        // smp.Linknet (decoders/linknet/decoder.py of segmentation-models-pytorch 0.2.1, restated): channels = reversed encoder
+        // features (deepest first) + [32]; block i = Conv2dReLU(in, in/4, 1) -> TransposeX2(in/4, in/4) -> Conv2dReLU(in/4, out, 1),
+        // then + skip (the next-shallower encoder feature) for i < 4; head = Conv2d(32, classes, 1).
+        const int chans[6] = {featc[5], featc[4], featc[3], featc[2], featc[1], 32};
+        const int skips[5] = {feat[4], feat[3], feat[2], feat[1], -1};
+        int x_act = feat[5], xh = A[feat[5]].h, xw = A[feat[5]].w;
+        for (int i = 0; i < 5; ++i) {
+            const std::string pre = "decoder.blocks." + std::to_string(i) + ".block.";
+            const int cin = chans[i], mid = cin / 4, cout = chans[i + 1];
+            Unit u1; u1.kind = U_CONV; u1.src0 = x_act; u1.cin0 = cin; u1.cout = mid; u1.k = 1; u1.pad = 0;
+            u1.hin = xh; u1.win = xw; u1.hout = xh; u1.wout = xw;
+            u1.w_idx = (int)L.tensors.size(); add_tensor(L, pre + "0.0.weight", {mid, cin, 1, 1}, 0);
+            u1.bn_idx = add_bn(L, pre + "0.1", mid);
+            u1.out = new_act(mid, xh, xw, true);
+            U.push_back(u1);
+            Unit ut; ut.kind = U_CONVT; ut.src0 = u1.out; ut.cin0 = mid; ut.cout = mid; ut.k = 3; ut.pad = 1;
+            ut.hin = xh; ut.win = xw; ut.hout = 2 * xh; ut.wout = 2 * xw;
+            ut.w_idx = (int)L.tensors.size(); add_tensor(L, pre + "1.0.weight", {mid, mid, 4, 4}, 3);   // torch's [in][out][kh][kw], as is
+            ut.bias_idx = (int)L.tensors.size(); add_tensor(L, pre + "1.0.bias", {mid}, 3);
+            ut.bn_idx = add_bn(L, pre + "1.1", mid);
+            ut.out = new_act(mid, 2 * xh, 2 * xw, true);
+            U.push_back(ut);
+            xh *= 2; xw *= 2;
+            Unit u3; u3.kind = U_CONV; u3.src0 = ut.out; u3.cin0 = mid; u3.cout = cout; u3.k = 1; u3.pad = 0;
+            u3.hin = xh; u3.win = xw; u3.hout = xh; u3.wout = xw;
+            u3.w_idx = (int)L.tensors.size(); add_tensor(L, pre + "2.0.weight", {cout, mid, 1, 1}, 0);
+            u3.bn_idx = add_bn(L, pre + "2.1", cout);
+            u3.out = new_act(cout, xh, xw, true);
+            U.push_back(u3);
+            x_act = u3.out;
+            if (skips[i] >= 0) {
+                Unit ua; ua.kind = U_ADD; ua.src0 = u3.out; ua.src1 = skips[i]; ua.cout = cout; ua.hout = xh; ua.wout = xw; ua.relu = 0;
+                ua.out = new_act(cout, xh, xw, false);
+                U.push_back(ua);
+                x_act = ua.out;
+            }
+        }
+        xin = x_act; xc = 32; head_k = 1;
+    }
+    Unit head; head.kind = U_HEAD; head.src0 = xin; head.cin0 = xc; head.cout = net->classes; head.relu = 0;
+    head.k = head_k; head.pad = head_k / 2;
     head.hin = H; head.win = W; head.hout = H; head.wout = W;
-    head.w_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.weight", {net->classes, 16, 3, 3}, 0);
+    head.w_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.weight", {net->classes, xc, head_k, head_k}, 0);
     head.bias_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.bias", {net->classes}, 3);
     U.push_back(head);
     return VS_OK;
@@ -288,6 +340,7 @@ size_t plan_workspace(vs_unet* net) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // weight copies + BN constants
+    size_t ct = 0;
     for (auto& u : net->units) {
         if (u.kind == U_CONV || u.kind == U_HEAD) {
             const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
@@ -295,8 +348,14 @@ size_t plan_workspace(vs_unet* net) {
             u.off_wc = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
             u.off_wt = take(cin * taps * (u.cg ? 32 : cout_pad) * esz);
         }
+        if (u.kind == U_CONVT) {   // the equivalent 3x3 convolution onto 4 * cout channels
+            u.off_wc = take((size_t)4 * u.cout * 9 * u.cin0 * esz);
+            u.off_wt = take((size_t)u.cin0 * 9 * 4 * u.cout * esz);
+            ct = std::max(ct, N * u.hin * u.win * 4 * u.cout * esz);
+        }
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
+    net->off_ct = take(ct);    // the transposed convolutions' un-shuffled output
     int cmax = 512;
     for (auto& u : net->units) cmax = std::max(cmax, u.cout);
     net->bnws_bytes = 4 * vs_bn_workspace(0, cmax);  // also receives the conv epilogue's per-tile statistics
@@ -308,12 +367,20 @@ size_t plan_workspace(vs_unet* net) {
     }
     net->off_logits = take(N * net->classes * (size_t)net->h * net->w * sizeof(float));   // vs_unet_forward_to_volume's fallback path
     net->ws_eval = off;
+    size_t ctdw = 0;
     for (auto& u : net->units) {
+        if (u.kind == U_CONVT) {
+            u.off_wc2 = take((size_t)4 * u.cout * 9 * u.cin0 * esz);
+            u.off_wt2 = take((size_t)u.cin0 * 9 * 4 * u.cout * esz);
+            ctdw = std::max(ctdw, (size_t)4 * u.cout * 9 * u.cin0 * sizeof(float));
+        }
         if (u.kind != U_CONV && u.kind != U_HEAD) continue;
         const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
         u.off_wc2 = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
         u.off_wt2 = take(cin * taps * (u.cg ? 32 : (u.kind == U_HEAD ? 16 : (size_t)u.cout)) * esz);
     }
+    net->ctdw_bytes = ctdw;
+    net->off_ctdw = take(ctdw * vs_unet::kSide);   // dense weight gradient of a transposed convolution's 3x3 form, per side stream
     for (auto& a : net->acts) {
         const size_t bytes = N * a.c * a.h * a.w * esz;
         if (a.has_z) { a.off_z = take(bytes); a.off_dz = take(bytes); }
@@ -322,18 +389,22 @@ size_t plan_workspace(vs_unet* net) {
     // wgrad split-K slabs: worst case over layers
     size_t wg = vs_stem_wgrad_workspace((int)N, net->h, net->w);
     for (auto& u : net->units) {
-        if (u.kind != U_CONV && u.kind != U_HEAD) continue;
+        if (u.kind != U_CONV && u.kind != U_HEAD && u.kind != U_CONVT) continue;
         WgradParams p{};
         p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = (int)N; p.Hin = u.hin; p.Win = u.win;
         p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
         p.Cout = u.kind == U_HEAD ? 16 : u.cout;
+        if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
         p.cg = u.cg;
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
     net->wgws_bytes = wg;
     net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
-    net->off_headdw = take(16 * 9 * 16 * sizeof(float));
+    {
+        const Unit& hd = net->units.back();
+        net->off_headdw = take((size_t)16 * hd.k * hd.k * hd.cin0 * sizeof(float));
+    }
     net->off_dyh = take(N * net->h * net->w * 16 * esz);
     size_t dup = 0, zs = 0;
     for (auto& u : net->units) {
@@ -386,6 +457,10 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
     p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
     p.w = c.wfwd(u); p.Cout = u.cout;
     p.gc = u.cg ? 32 : 0;
+    if (u.kind == U_CONVT) {   // its 3x3 form: same-size output, 4 * cout channels, always from the prepared copy
+        p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout;
+        p.w = c.ws + Ctx::wc_off(u, c.net->wset);
+    }
     return p;
 }
 
@@ -397,7 +472,7 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology == 0 || tmp.topology == 1, "topology must be 0 (U-Net) or 1 (U-Net++), got %d", tmp.topology);
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 2, "topology must be 0 (U-Net), 1 (U-Net++) or 2 (Linknet), got %d", tmp.topology);
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -451,7 +526,7 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology == 0 || topology == 1, "unet_create: topology must be 0 (U-Net) or 1 (U-Net++), got %d", topology);
+    VS_REQUIRE(topology >= 0 && topology <= 2, "unet_create: topology must be 0 (U-Net), 1 (U-Net++) or 2 (Linknet), got %d", topology);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -506,6 +581,12 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
             int rc = flush();
             if (rc) return rc;
         }
+        for (auto& u : net->units) {
+            if (u.kind != U_CONVT) continue;
+            const int rc = launch_convt_weight_prepare(net->dtype, c.P(u.w_idx), c.ws + Ctx::wc_off(u, net->wset),
+                                                       training ? c.ws + Ctx::wt_off(u, net->wset) : nullptr, u.cin0, u.cout, c.s);
+            if (rc) return rc;
+        }
     }
     for (auto& u : net->units) {
         if (u.bn_idx >= 0 && !training) {  // eval-mode folding from the running statistics
@@ -529,6 +610,11 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
     const int other = net->wset ^ 1;
     for (int k = unit_lo; k < unit_hi; ++k) {
         const Unit& v = net->units[k];
+        if (v.kind == U_CONVT) {
+            const int rc = launch_convt_weight_prepare(net->dtype, params + net->layout.tensors[v.w_idx].offset, (char*)workspace + Ctx::wc_off(v, other),
+                                                       (char*)workspace + Ctx::wt_off(v, other), v.cin0, v.cout, (hipStream_t)stream);
+            if (rc) return rc;
+        }
         if (v.kind != U_CONV && v.kind != U_HEAD) continue;
         VS_REQUIRE(nl < 64, "unet_prepare_range: too many layers in one range");
         w_off[nl] = net->layout.tensors[v.w_idx].offset;
@@ -645,6 +731,28 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 p.relu = u.relu;
             }
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            break;
+        }
+        case U_ADD: {
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t rows = (int64_t)n * u.hout * u.wout;
+            if ((rc = vs_channel_slice(dt, c.a(u.src0), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, rows, 0, stream))) return rc;
+            if ((rc = vs_channel_slice(dt, c.a(u.src1), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, rows, 1, stream))) return rc;
+            continue;
+        }
+        case U_CONVT: {   // 3x3 convolution onto 4 * cout channels, then the pixel shuffle (+ bias; eval: + folded BN + ReLU)
+            ConvParams p = conv_params(c, u);
+            p.out = c.ws + net->off_ct;
+            {
+                ProfScope prof(PK_CONV_FWD, conv_flops(c, u) * 4, 0, c.s);
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            }
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if (training) {
+                if ((rc = vs_depth_to_space2(dt, p.out, c.z(u.out), n, u.hin, u.win, u.cout, c.P(u.bias_idx), nullptr, nullptr, 0, stream))) return rc;
+            } else {
+                if ((rc = vs_depth_to_space2(dt, p.out, c.a(u.out), n, u.hin, u.win, u.cout, c.P(u.bias_idx), c.bnc(u, 0), c.bnc(u, 1), u.relu, stream))) return rc;
+            }
             break;
         }
         case U_HEAD: {
@@ -770,7 +878,14 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
             ++nl;
         }
     }
-    return flush();
+    if ((rc = flush())) return rc;
+    for (int k = lo; k < hi; ++k) {   // transposed convolutions: their own expansion kernel, after every AdamW launch of the range
+        const Unit& v = net->units[k];
+        if (v.kind != U_CONVT) continue;
+        if ((rc = launch_convt_weight_prepare(dt, opt.params + c.t(v.w_idx).offset, c.ws + Ctx::wc_off(v, other), c.ws + Ctx::wt_off(v, other),
+                                              v.cin0, v.cout, s))) return rc;
+    }
+    return VS_OK;
 }
 
 static int unet_backward_range(vs_unet_t* net, const float* params, const float* x, const float* dlogits, int n,
@@ -883,10 +998,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.dy = dzp; p.Cout = dz_c;
             p.cg = u.cg;
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
-            if (u.kind == U_HEAD) {
+            if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
+                p.Hout = u.hin; p.Wout = u.win;
+                const size_t k = ((const char*)wgws - (c.ws + net->off_wgws)) / net->wgws_bytes;
+                p.dw = (float*)(c.ws + net->off_ctdw + k * net->ctdw_bytes);
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                if ((rc = launch_convt_wgrad_gather(p.dw, grads + c.t(u.w_idx).offset, u.cin0, u.cout, ws_stream))) return rc;
+            } else if (u.kind == U_HEAD) {
                 p.dw = (float*)(c.ws + net->off_headdw);
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * 9 * 16 * sizeof(float),
+                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * u.k * u.k * u.cin0 * sizeof(float),
                                             hipMemcpyDeviceToDevice, ws_stream));
             } else {
                 p.dw = grads + c.t(u.w_idx).offset;
@@ -915,6 +1036,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             continue;
         }
+        if (u.kind == U_ADD) {      // both addends receive the sum's gradient
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of a sum missing");
+            ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            for (int m : {u.src0, u.src1}) {
+                if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(m), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, written[m], stream))) return rc;
+                written[m] = 1;
+            }
+            continue;
+        }
         if (u.kind == U_POOL) {
             if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
@@ -936,6 +1067,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             dzp = dyh; dz_c = 16;
         } else if (!do_main) {
             dzp = c.dz(u.out); dz_c = u.cout;
+            if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
         } else {
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             void* dres = nullptr;
@@ -961,6 +1093,14 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                           (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             }
             dzp = c.dz(u.out); dz_c = u.cout;
+            if (u.kind == U_CONVT) {
+                // the bias gradient (column sums of dz), then dz back through the pixel shuffle: the gradient of the 3x3 form's
+                // output, kept in the (now dead) da buffer of this unit - the side stream's weight gradient reads it later
+                ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+                if ((rc = vs_colsum(dt, dzp, c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+                if ((rc = vs_space_to_depth2(dt, dzp, c.da(u.out), n, u.hin, u.win, u.cout, stream))) return rc;
+                dzp = c.da(u.out); dz_c = 4 * u.cout;
+            }
         }
         // ---- fork policy: one event (a barrier packet on the caller's stream, ~7 us of command-processor time) covers the
         // weight-gradient work of up to `fork_every` consecutive units ----
@@ -1033,7 +1173,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 }
             }
             prof_set_variant(conv_igemm_variant(dt, p));
-            ProfScope prof(PK_CONV_DGRAD, u.kind == U_HEAD ? 2.0 * n * u.hout * u.wout * net->classes * 9 * 16 : conv_flops(c, u), 0, c.s);
+            ProfScope prof(PK_CONV_DGRAD, u.kind == U_HEAD ? 2.0 * n * u.hout * u.wout * net->classes * u.k * u.k * u.cin0 : conv_flops(c, u), 0, c.s);
             prof_set_variant(0);
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             written[u.src0] = 1;
@@ -1117,7 +1257,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
-    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : "maxpool");
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : "maxpool"));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];

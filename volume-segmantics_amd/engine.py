@@ -72,7 +72,7 @@ class _UnetFn(torch.autograd.Function):
 
 class VolSegUnet(nn.Module):
     ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51}
-    TOPOLOGIES = {"unet": 0, "unetplusplus": 1}     # smp.Unet, smp.UnetPlusPlus
+    TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2}     # smp.Unet, smp.UnetPlusPlus, smp.Linknet
 
     def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
                  encoder: str = "resnet34", topology: str = "unet"):
@@ -152,6 +152,7 @@ class VolSegUnet(nn.Module):
         gen = None
         if seed is not None:
             gen = torch.Generator(device="cpu").manual_seed(seed)
+        convt_bound = None
         with torch.no_grad():
             for name, shape, kind, off in self._table:
                 v = self._views[name]
@@ -166,6 +167,16 @@ class VolSegUnet(nn.Module):
                     v.copy_(w)
                 elif kind in (KIND_GAMMA, KIND_RVAR):
                     v.fill_(1.0)
+                elif kind == KIND_BIAS and len(shape) == 4:
+                    # nn.ConvTranspose2d (Linknet's TransposeX2) is not an nn.Conv2d: smp's initialize_decoder leaves torch's
+                    # default initialisation in place - kaiming_uniform(a = sqrt(5)) and a uniform bias (the tensor after it)
+                    w = torch.empty(shape, dtype=torch.float32)
+                    nn.init.kaiming_uniform_(w, a=math.sqrt(5), generator=gen)
+                    v.copy_(w)
+                    convt_bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+                elif kind == KIND_BIAS and convt_bound is not None:
+                    v.copy_(torch.empty(shape, dtype=torch.float32).uniform_(-convt_bound, convt_bound, generator=gen))
+                    convt_bound = None
                 else:
                     v.zero_()
             self._nbt.zero_()
