@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
     ap.add_argument("--encoder", default="resnet34", choices=["resnet18", "resnet34", "resnet50", "resnext50_32x4d"])
-    ap.add_argument("--topology", default="unet", choices=["unet", "unetplusplus", "linknet"],
+    ap.add_argument("--topology", default="unet", choices=["unet", "unetplusplus", "linknet", "fpn"],
                     help="with --encoder / --size / --classes: other rows of the model matrix, e.g. BASELINE configs[3] = "
                          "--topology unetplusplus --encoder resnet50 --size 512 --classes 4 (not the headline metric: no FLOP model)")
     ap.add_argument("--size", type=int, default=256, help="slice height = width")
@@ -348,6 +348,7 @@ def main():
         dist.broadcast(model._flat, 0)
         dist.broadcast(model._bnstate, 0)
         model.dp_group = dist.group.WORLD
+        model.dropout_seed += 1000003 * rank
     x, lab = synth_batch(args.batch, args.size, args.classes, seed=1234 + rank)   # every rank: its own shard of the global batch
     x = x.to(dev)
     # one-hot targets as prepare_training_batch hands them over (utilities/base_data_utils.py:150-158): NCHW uint8, contiguous

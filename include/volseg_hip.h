@@ -136,6 +136,8 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   topology 3: smp.FPN - biased 1x1 laterals + nearest-x2 top-down sums, Conv3x3 + GroupNorm(32) + ReLU + bilinear x2
+ *   (align_corners) segmentation blocks, sum, Dropout2d(0.2), 1x1 head at 1/4 resolution + bilinear x4;
  *   topology 2: smp.Linknet - 1x1 convolution / ConvTranspose2d(4, 2, 1) / 1x1 convolution blocks, encoder features added;
  *   topology 0: smp.Unet; 1: smp.UnetPlusPlus - the dense nested decoder (node x_d_l = DecoderBlock(up(x_d_(l-1)),
  *   cat(x_(d+1)_l .. x_l_l, encoder feature)); the concatenations are materialised by vs_channel_slice copies and their
@@ -271,6 +273,32 @@ int vs_convt_weights_prepare(int dtype, const float* w, void* wc, void* wt, int 
 int vs_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, void* stream);
 size_t vs_colsum_workspace(int c);
 int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream);
+/* ---- streaming operators of smp.FPN's decoder (segmentation-models-pytorch 0.2.1, decoders/fpn/decoder.py; model/model_2d.py:22 of the
+ * reference builds smp.FPN(**model_struc_dict)); NHWC tensors in `dtype`, c a multiple of 8 ------------------------------------
+ * vs_upsample2x_add: y = F.interpolate(x, scale_factor=2, mode="nearest") + skip (FPNBlock); x [n][h][w][c], skip / y [n][2h][2w][c].
+ * vs_gn_fwd / vs_gn_bwd: nn.GroupNorm(groups, c) (+ ReLU) of Conv3x3GNReLU on x [n][hw][c]: stats [n][groups][2] = {mean,
+ *   1/sqrt(var + eps)} fp32 (written by fwd, read by bwd); bwd takes the gradient w.r.t. the (post-ReLU) output and masks it
+ *   itself (recomputed from x), writes dx, dgamma[c], dbeta[c].  c <= 256 with 256 % (c / 8) == 0.
+ * vs_bilinear_up(_bwd): F.interpolate(scale_factor=factor, mode="bilinear", align_corners=True) and its adjoint (accumulate = 1
+ *   adds to dx); vs_bilinear_up_planes(_bwd): the same on fp32 planes [planes][h][w] - nn.UpsamplingBilinear2d of the
+ *   SegmentationHead on NCHW logits.
+ * vs_dropout2d_mask + vs_channel_scale: nn.Dropout2d(p): mask [n][c] = 0 or 1/(1-p), drawn per (sample, channel) from a
+ *   counter-based generator keyed by (seed, *counter + bias) - counter is a device int64 (may be NULL) so that a replayed graph
+ *   draws a fresh mask per step; vs_channel_scale multiplies x [n][hw][c] by it (the forward, and the backward on the gradient). */
+int vs_upsample2x_add(int dtype, const void* x, const void* skip, void* y, int n, int h, int w, int c, void* stream);
+size_t vs_gn_workspace(int n, int c);
+size_t vs_gn_bwd_workspace(int n, int c, int groups);
+int vs_gn_fwd(int dtype, const void* x, const float* gamma, const float* beta, int relu, void* y, float* stats, int n, int64_t hw,
+              int c, int groups, float eps, float* workspace, size_t workspace_bytes, void* stream);
+int vs_gn_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const float* beta, int relu, void* dx,
+              float* dgamma, float* dbeta, int n, int64_t hw, int c, int groups, float* workspace, size_t workspace_bytes, void* stream);
+int vs_bilinear_up(int dtype, const void* x, void* y, int n, int h, int w, int c, int factor, void* stream);
+int vs_bilinear_up_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int factor, int accumulate, void* stream);
+int vs_bilinear_up_planes(const float* x, float* y, int planes, int h, int w, int factor, void* stream);
+int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int w, int factor, void* stream);
+int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
+int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
+
 /* The data-parallel form of the two shares: vs_unet_backward_part = the shares without the optimiser (role 2 = weight
  * gradients only); vs_unet_adamw_range = AdamW over the parameters of the units [unit_lo, unit_hi) from `grads` (after the
  * caller's all-reduce of that slice, vs_unet_unit_param_offset) plus their next-forward weight copies, in order on
@@ -280,6 +308,12 @@ int vs_unet_backward_part(vs_unet_t* net, const float* params, const float* x, c
                           int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi, int role);
 int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const float* grads, void* workspace, void* stream,
                         const vs_adamw_args* opt, int unit_lo, int unit_hi);
+/* Dropout2d draws of a training forward (smp.FPN's decoder): mask = f(seed, *counter), counter = a device int64 the training
+ * step advances (the engine passes encoder.bn1.num_batches_tracked), so a replayed graph draws a new mask every step.
+ * vs_unet_dropout_mask_offset: byte offset in the training workspace of the last forward's mask ([n][channels] fp32), -1 if the
+ * topology has no dropout (tests feed the mask to the oracle). */
+int vs_unet_set_rng(vs_unet_t* net, uint32_t seed, const int64_t* counter);
+int64_t vs_unet_dropout_mask_offset(const vs_unet_t* net);
 /* the per-step scalars of a replayed optimiser step (see vs_adamw_args.hyper): one tiny launch on `stream` that also adds 1
  * to the n_bn BatchNorm num_batches_tracked counters (int64, may be NULL with n_bn = 0). */
 int vs_train_hyper_set(float* hyper, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -187,13 +187,79 @@ class LinknetDecoder(nn.Module):
         return x
 
 
+class FPNDecoder(nn.Module):
+    """smp.FPN's decoder (segmentation-models-pytorch 0.2.1, decoders/fpn/decoder.py), restated: pyramid_channels 256,
+    segmentation_channels 128, merge_policy "add", dropout 0.2.
+      p5 = Conv2d(C5, 256, 1); p4 / p3 / p2 = FPNBlock: F.interpolate(x, scale_factor=2, mode="nearest") + skip_conv(skip)
+      (skip_conv = Conv2d(C_k, 256, 1), biased);
+      seg_blocks[i] (on p5, p4, p3, p2; n_upsamples 3, 2, 1, 0) = SegmentationBlock: Conv3x3GNReLU(256, 128, upsample = n > 0)
+      followed by n - 1 more Conv3x3GNReLU(128, 128, upsample=True); Conv3x3GNReLU = Conv2d(3x3, bias=False) +
+      GroupNorm(32, out) + ReLU (+ F.interpolate(scale_factor=2, mode="bilinear", align_corners=True));
+      x = sum of the four outputs; Dropout2d(p=0.2).
+    ``mask`` (tests): a fixed (N, 128) Dropout2d mask (0 or 1/(1-p)) instead of torch's own draw, so that the engine's draw can
+    be replayed here."""
+
+    class _GN(nn.Module):
+        def __init__(self, i, o, upsample):
+            super().__init__()
+            self.upsample = upsample
+            self.block = nn.Sequential(nn.Conv2d(i, o, 3, 1, 1, bias=False), nn.GroupNorm(32, o), nn.ReLU(inplace=True))
+
+        def forward(self, x):
+            x = self.block(x)
+            return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) if self.upsample else x
+
+    class _Seg(nn.Module):
+        def __init__(self, i, o, n_upsamples):
+            super().__init__()
+            blocks = [FPNDecoder._GN(i, o, bool(n_upsamples))]
+            blocks += [FPNDecoder._GN(o, o, True) for _ in range(1, n_upsamples)]
+            self.block = nn.Sequential(*blocks)
+
+        def forward(self, x):
+            return self.block(x)
+
+    class _Lat(nn.Module):
+        def __init__(self, pyramid, skip):
+            super().__init__()
+            self.skip_conv = nn.Conv2d(skip, pyramid, 1)
+
+        def forward(self, x, skip):
+            return torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest") + self.skip_conv(skip)
+
+    def __init__(self, encoder_channels, pyramid_channels: int = 256, segmentation_channels: int = 128, dropout: float = 0.2):
+        super().__init__()
+        ch = list(encoder_channels[::-1])            # deepest first
+        self.p5 = nn.Conv2d(ch[0], pyramid_channels, 1)
+        self.p4 = FPNDecoder._Lat(pyramid_channels, ch[1])
+        self.p3 = FPNDecoder._Lat(pyramid_channels, ch[2])
+        self.p2 = FPNDecoder._Lat(pyramid_channels, ch[3])
+        self.seg_blocks = nn.ModuleList(FPNDecoder._Seg(pyramid_channels, segmentation_channels, n) for n in (3, 2, 1, 0))
+        self.dropout = nn.Dropout2d(p=dropout, inplace=True)
+        self.mask = None
+
+    def forward(self, feats):
+        c2, c3, c4, c5 = feats[-4:]
+        p5 = self.p5(c5)
+        p4 = self.p4(p5, c4)
+        p3 = self.p3(p4, c3)
+        p2 = self.p2(p3, c2)
+        x = sum(blk(p) for blk, p in zip(self.seg_blocks, (p5, p4, p3, p2)))
+        if self.mask is not None and self.training:
+            return x * self.mask[:, :, None, None]
+        return self.dropout(x)
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
-        self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder}[topology](OUT_CHANNELS[encoder_name])
+        self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
+                        "fpn": FPNDecoder}[topology](OUT_CHANNELS[encoder_name])
         if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
             self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
+        elif topology == "fpn":       # SegmentationHead(in_channels=128, out_channels=classes, kernel_size=1, upsampling=4)
+            self.segmentation_head = nn.Sequential(nn.Conv2d(128, classes, 1), nn.UpsamplingBilinear2d(scale_factor=4))
         else:
             self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
         for m in self.decoder.modules():   # smp initialisation (nn.ConvTranspose2d is not an nn.Conv2d: torch's default stays)

@@ -639,3 +639,110 @@ def test_onehot_matches_reference_prepare_training_batch():
         ref = torch.nn.functional.one_hot(lab.long(), k).permute(0, 3, 1, 2).to(torch.uint8)
         x, t = prepare_training_batch((img, lab), DEV, k)
         assert t.is_cuda and t.dtype == torch.uint8 and torch.equal(t.cpu(), ref) and torch.equal(x.cpu(), img)
+
+
+# ---- smp.FPN's streaming operators (csrc/fpn.hip) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 32), (3, 8, 12, 64, 32), (1, 32, 32, 256, 32), (2, 5, 7, 32, 8)])
+def test_group_norm_relu_fwd_bwd(code, shape):
+    """nn.GroupNorm(groups, c) + ReLU (smp Conv3x3GNReLU) on NHWC tensors against torch CPU: output, input gradient (the ReLU
+    mask recomputed from x), dgamma, dbeta."""
+    L = lib()
+    n, h, w, c, G = shape
+    g = torch.Generator().manual_seed(3)
+    x = rounded(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, code).requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(c, generator=g) * 0.3).requires_grad_()
+    y = F.relu(F.group_norm(x, G, gamma, beta, eps=1e-5))
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), code)
+    yd = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    stats = torch.full((n, G, 2), float("nan"), device=DEV)
+    wsb = L.lib.vs_gn_bwd_workspace(n, c, G)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    L.check(L.lib.vs_gn_fwd(code, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1, L.ptr(yd), L.ptr(stats), n, h * w, c, G, 1e-5, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    xg = x.detach().view(n, G, -1)
+    assert torch.allclose(stats[..., 0].cpu(), xg.mean(-1), atol=1e-5)
+    assert torch.allclose(stats[..., 1].cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    dyd = to_nhwc(dy, code)
+    dx = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    dg, db = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+    L.check(L.lib.vs_gn_bwd(code, L.ptr(dyd), L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(bd), 1, L.ptr(dx), L.ptr(dg), L.ptr(db), n, h * w,
+                            c, G, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    assert torch.allclose(dg.cpu(), gamma.grad, rtol=1e-3, atol=1e-3 * gamma.grad.abs().max().item())
+    assert torch.allclose(db.cpu(), beta.grad, rtol=1e-3, atol=1e-3 * beta.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16, 2), (1, 5, 9, 8, 2), (2, 4, 6, 32, 4), (1, 1, 3, 8, 2)])
+def test_bilinear_upsampling_align_corners_fwd_bwd(code, shape):
+    """F.interpolate(scale_factor=f, mode="bilinear", align_corners=True) (Conv3x3GNReLU's upsampling; f = 4:
+    nn.UpsamplingBilinear2d of the head) and its adjoint, NHWC tensors and fp32 NCHW planes, against torch CPU."""
+    L = lib()
+    n, h, w, c, f = shape
+    g = torch.Generator().manual_seed(9)
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    y = F.interpolate(x, scale_factor=f, mode="bilinear", align_corners=True)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
+    yd = torch.full((n, h * f, w * f, c), float("nan"), device=DEV, dtype=tdtype(code))
+    dx = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_bilinear_up(code, L.ptr(xd), L.ptr(yd), n, h, w, c, f, None))
+    L.check(L.lib.vs_bilinear_up_bwd(code, L.ptr(dyd), L.ptr(dx), n, h, w, c, f, 0, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, 1.0))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    acc = dx.clone()
+    L.check(L.lib.vs_bilinear_up_bwd(code, L.ptr(dyd), L.ptr(acc), n, h, w, c, f, 1, None))     # accumulate: twice the gradient
+    sync()
+    assert torch.allclose(acc.float(), 2 * dx.float(), **tol(code, x.grad.abs().max().item()))
+    if code == 0:
+        xp, dyp = x.detach().contiguous().to(DEV), dy.contiguous().to(DEV)
+        yp = torch.full((n, c, h * f, w * f), float("nan"), device=DEV)
+        dxp = torch.full((n, c, h, w), float("nan"), device=DEV)
+        L.check(L.lib.vs_bilinear_up_planes(L.ptr(xp), L.ptr(yp), n * c, h, w, f, None))
+        L.check(L.lib.vs_bilinear_up_planes_bwd(L.ptr(dyp), L.ptr(dxp), n * c, h, w, f, None))
+        sync()
+        assert torch.allclose(yp.cpu(), y.detach(), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(dxp.cpu(), x.grad, rtol=1e-4, atol=1e-5 * x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_fpn_upsample_add_and_dropout2d(code):
+    """FPNBlock's F.interpolate(x, 2, "nearest") + skip, and nn.Dropout2d: whole (sample, channel) planes zeroed with
+    probability p, the rest scaled by 1 / (1 - p); a new mask per counter value, the same mask for the same (seed, counter)."""
+    L = lib()
+    n, h, w, c = 3, 6, 10, 32
+    g = torch.Generator().manual_seed(1)
+    x, s = rounded(torch.randn(n, c, h, w, generator=g), code), rounded(torch.randn(n, c, 2 * h, 2 * w, generator=g), code)
+    yd = torch.full((n, 2 * h, 2 * w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    xd, sd = to_nhwc(x, code), to_nhwc(s, code)
+    L.check(L.lib.vs_upsample2x_add(code, L.ptr(xd), L.ptr(sd), L.ptr(yd), n, h, w, c, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), F.interpolate(x, scale_factor=2, mode="nearest") + s, **tol(code, 4.0))
+    nn_, cc, p = 64, 128, 0.2
+    counter = torch.tensor([5], dtype=torch.int64, device=DEV)
+    masks = []
+    for bias in (0, 0, 1):
+        m = torch.full((nn_, cc), float("nan"), device=DEV)
+        L.check(L.lib.vs_dropout2d_mask(L.ptr(m), nn_, cc, p, 1234, L.ptr(counter), bias, None))
+        masks.append(m)
+    sync()
+    assert torch.equal(masks[0], masks[1]) and not torch.equal(masks[0], masks[2])
+    vals = set(masks[0].unique().tolist())
+    assert vals == {0.0, 1.25}
+    frac = (masks[0] == 0).float().mean().item()
+    assert abs(frac - p) < 0.02, frac                                    # 8192 draws: sigma = 0.0044
+    xs = rounded(torch.randn(nn_, cc, 3, 5, generator=g), code)
+    out = torch.full((nn_, 3, 5, cc), float("nan"), device=DEV, dtype=tdtype(code))
+    xsd = to_nhwc(xs, code)
+    L.check(L.lib.vs_channel_scale(code, L.ptr(xsd), L.ptr(masks[0]), L.ptr(out), nn_, 15, cc, None))
+    sync()
+    assert torch.allclose(from_nhwc(out), xs * masks[0].cpu()[:, :, None, None], **tol(code, 4.0))

@@ -119,3 +119,27 @@ def test_linknet_restatement_and_engine_table_agree():
     assert sd["segmentation_head.0.weight"].shape == (2, 32, 1, 1)
     with torch.no_grad():
         assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)
+
+
+def test_fpn_restatement_and_engine_table_agree():
+    """smp.FPN (oracle/unet_resnet_torch.py:FPNDecoder): 1,870,592 decoder parameters + a 129-parameter head on resnet34 (3-channel
+    input, 1 class: 23,155,393 in all), smp's key nesting (decoder.p5, decoder.p{4,3,2}.skip_conv,
+    decoder.seg_blocks.i.block.j.block.{0,1}), the engine's tensor table with the same keys / shapes in state_dict order for every
+    encoder, logits at the input's size through the head's x4 bilinear upsampling."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    net = OracleUnet("resnet34", 3, 1, "fpn")
+    assert sum(p.numel() for p in net.decoder.parameters()) == 1_870_592
+    assert sum(p.numel() for p in net.parameters()) == 23_155_393
+    for name, code in (("resnet18", 3018), ("resnet34", 3034), ("resnet50", 3050), ("resnext50_32x4d", 3051)):
+        sd = OracleUnet(name, 1, 3, "fpn").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet50", 1, 2, "fpn").state_dict()
+    assert sd["decoder.p5.weight"].shape == (256, 2048, 1, 1) and sd["decoder.p2.skip_conv.weight"].shape == (256, 256, 1, 1)
+    assert sd["decoder.seg_blocks.0.block.2.block.0.weight"].shape == (128, 128, 3, 3)
+    assert "decoder.seg_blocks.3.block.1.block.0.weight" not in sd and sd["decoder.seg_blocks.3.block.0.block.1.weight"].shape == (128,)
+    assert sd["segmentation_head.0.weight"].shape == (2, 128, 1, 1)
+    with torch.no_grad():
+        assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)

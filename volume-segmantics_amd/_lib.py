@@ -63,6 +63,17 @@ _SIGS = {
     "vs_space_to_depth2": (I, [I, P, P, I, I, I, I, P]),
     "vs_convt_weights_prepare": (I, [I, P, P, P, I, I, P]),
     "vs_convt_wgrad_gather": (I, [P, P, I, I, P]),
+    "vs_upsample2x_add": (I, [I, P, P, P, I, I, I, I, P]),
+    "vs_gn_workspace": (SZ, [I, I]),
+    "vs_gn_bwd_workspace": (SZ, [I, I, I]),
+    "vs_gn_fwd": (I, [I, P, P, P, I, P, P, I, C.c_int64, I, I, C.c_float, P, SZ, P]),
+    "vs_gn_bwd": (I, [I, P, P, P, P, P, I, P, P, P, I, C.c_int64, I, I, P, SZ, P]),
+    "vs_bilinear_up": (I, [I, P, P, I, I, I, I, I, P]),
+    "vs_bilinear_up_bwd": (I, [I, P, P, I, I, I, I, I, I, P]),
+    "vs_bilinear_up_planes": (I, [P, P, I, I, I, I, P]),
+    "vs_bilinear_up_planes_bwd": (I, [P, P, I, I, I, I, P]),
+    "vs_dropout2d_mask": (I, [P, I, I, C.c_float, C.c_uint32, P, C.c_int64, P]),
+    "vs_channel_scale": (I, [I, P, P, P, I, C.c_int64, I, P]),
     "vs_colsum_workspace": (SZ, [I]),
     "vs_colsum": (I, [I, P, C.c_int64, I, P, P, SZ, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
@@ -98,6 +109,8 @@ _SIGS = {
     "vs_unet_backward_adamw": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs)]),
     "vs_unet_backward_adamw_part": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs), I, I, I]),
     "vs_unet_backward_part": (I, [P, P, P, P, I, I, P, P, P, I, I, I]),
+    "vs_unet_set_rng": (I, [P, C.c_uint32, P]),
+    "vs_unet_dropout_mask_offset": (C.c_int64, [P]),
     "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),

@@ -20,6 +20,19 @@ extern "C" int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int 
                                   const float* shift, int relu, void* stream);
 extern "C" int vs_space_to_depth2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
 extern "C" int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream);
+extern "C" int vs_upsample2x_add(int dtype, const void* x, const void* skip, void* y, int n, int h, int w, int c, void* stream);
+extern "C" size_t vs_gn_bwd_workspace(int n, int c, int groups);
+extern "C" int vs_gn_fwd(int dtype, const void* x, const float* gamma, const float* beta, int relu, void* y, float* stats, int n, int64_t hw,
+                         int c, int groups, float eps, float* workspace, size_t workspace_bytes, void* stream);
+extern "C" int vs_gn_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const float* beta, int relu,
+                         void* dx, float* dgamma, float* dbeta, int n, int64_t hw, int c, int groups, float* workspace,
+                         size_t workspace_bytes, void* stream);
+extern "C" int vs_bilinear_up(int dtype, const void* x, void* y, int n, int h, int w, int c, int factor, void* stream);
+extern "C" int vs_bilinear_up_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int factor, int accumulate, void* stream);
+extern "C" int vs_bilinear_up_planes(const float* x, float* y, int planes, int h, int w, int factor, void* stream);
+extern "C" int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int w, int factor, void* stream);
+extern "C" int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
+extern "C" int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -36,7 +49,10 @@ struct TensorInfo {
 enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_CONVT,   // ConvTranspose2d(4, stride 2, padding 1) + BN + ReLU (smp Linknet's TransposeX2): a 3x3 convolution onto
                            // 4 * cout channels (conv_igemm) + pixel shuffle; cin0 -> cout channels, hin x win -> hout x wout = 2x
-                U_ADD };   // out = a(src0) + a(src1) (Linknet's skip connection)
+                U_ADD,     // out = a(src0) + a(src1) (Linknet's skip connection, FPN's merge)
+                U_UPADD,   // out = nearest-x2 upsampling of a(src0) + a(src1) (smp FPNBlock)
+                U_BILINEAR,  // out = bilinear x2 upsampling (align_corners) of a(src0) (smp Conv3x3GNReLU(upsample=True))
+                U_DROPOUT };  // nn.Dropout2d(0.2) in training, the identity in evaluation (smp FPNDecoder.dropout)
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -53,6 +69,8 @@ struct Unit {
     int out = -1;   // output activation id
     int res = -1;   // residual activation id
     int relu = 1;
+    int gn_idx = -1, gn_groups = 0;   // U_CONV followed by nn.GroupNorm(gn_groups, cout) + ReLU instead of BatchNorm (gamma at gn_idx)
+    size_t off_gn = 0;                // its statistics [n][groups][2] fp32
     int cg = 0;     // grouped convolution (ResNeXt): channels per group, cin0 == cout; 0 = dense.  Weights [cout][k*k][cg]; the
                     // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
@@ -108,6 +126,9 @@ struct vs_unet {
     std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
+    size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
+    int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
+    uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
@@ -203,7 +224,7 @@ int build(vs_unet* net) {
     const int dec[5] = {256, 128, 64, 32, 16};
     const int skipc[5] = {featc[4], featc[3], featc[2], featc[1], 0};
     int xin = feat[5], xc = featc[5];
-    if (net->topology == 2) {
+    if (net->topology >= 2) {
         // (built below, next to the head)
     } else if (net->topology == 0) {
     for (int i = 0; i < 5; ++i) {
@@ -285,7 +306,76 @@ int build(vs_unet* net) {
         run_node(0, 4, node[0][3].out_act, node[0][3].out_ch, {});
         xin = node[0][4].out_act; xc = dec[4];
     }
-    int head_k = 3;
+    int head_k = 3, head_h = H, head_w = W;
+    if (net->topology == 3) {
+        // smp.FPN (decoders/fpn/decoder.py of segmentation-models-pytorch 0.2.1, restated): p5 = Conv1x1(c5); p_k = nearest-x2(p_(k+1)) +
+        // Conv1x1(c_k) for k = 4, 3, 2 (pyramid_channels 256, biased, no norm); seg_blocks[i] on p5, p4, p3, p2 with 3, 2, 1, 0
+        // upsamplings: Conv3x3(256 -> 128, no bias) + GroupNorm(32) + ReLU (+ bilinear x2, align_corners) then (ups - 1) x
+        // [Conv3x3(128 -> 128) + GN + ReLU + bilinear x2]; merge = sum; Dropout2d(0.2); head = Conv1x1(128 -> classes) +
+        // UpsamplingBilinear2d(4).
+        const int pyr = 256, seg = 128;
+        auto lateral = [&](const std::string& name, int src, int cin) {
+            const Act sa = A[src];
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = pyr; u.k = 1; u.pad = 0; u.relu = 0;
+            u.hin = sa.h; u.win = sa.w; u.hout = sa.h; u.wout = sa.w;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, name + ".weight", {pyr, cin, 1, 1}, 0);
+            u.bias_idx = (int)L.tensors.size(); add_tensor(L, name + ".bias", {pyr}, 3);
+            u.out = new_act(pyr, sa.h, sa.w, false);
+            U.push_back(u);
+            return u.out;
+        };
+        int pyramid[4];
+        pyramid[0] = lateral("decoder.p5", feat[5], featc[5]);
+        for (int k = 0; k < 3; ++k) {   // p4, p3, p2
+            const int lat = lateral("decoder.p" + std::to_string(4 - k) + ".skip_conv", feat[4 - k], featc[4 - k]);
+            const Act la = A[lat];
+            Unit u; u.kind = U_UPADD; u.src0 = pyramid[k]; u.src1 = lat; u.cout = pyr; u.hout = la.h; u.wout = la.w; u.relu = 0;
+            u.hin = la.h / 2; u.win = la.w / 2;
+            u.out = new_act(pyr, la.h, la.w, false);
+            U.push_back(u);
+            pyramid[k + 1] = u.out;
+        }
+        int merged = -1;
+        for (int i = 0; i < 4; ++i) {
+            const int ups = 3 - i;
+            int x_act = pyramid[i], x_c = pyr;
+            for (int j = 0; j < std::max(1, ups); ++j) {
+                const std::string pre = "decoder.seg_blocks." + std::to_string(i) + ".block." + std::to_string(j) + ".block.";
+                const Act xa = A[x_act];
+                Unit u; u.kind = U_CONV; u.src0 = x_act; u.cin0 = x_c; u.cout = seg; u.k = 3; u.pad = 1;
+                u.hin = xa.h; u.win = xa.w; u.hout = xa.h; u.wout = xa.w;
+                u.w_idx = (int)L.tensors.size(); add_tensor(L, pre + "0.weight", {seg, x_c, 3, 3}, 0);
+                u.gn_idx = (int)L.tensors.size(); u.gn_groups = 32;
+                add_tensor(L, pre + "1.weight", {seg}, 1); add_tensor(L, pre + "1.bias", {seg}, 2);
+                u.out = new_act(seg, xa.h, xa.w, true);
+                U.push_back(u);
+                x_act = u.out; x_c = seg;
+                if (ups > 0) {
+                    Unit b; b.kind = U_BILINEAR; b.src0 = x_act; b.cout = seg; b.hin = xa.h; b.win = xa.w; b.hout = 2 * xa.h; b.wout = 2 * xa.w;
+                    b.relu = 0;
+                    b.out = new_act(seg, 2 * xa.h, 2 * xa.w, false);
+                    U.push_back(b);
+                    x_act = b.out;
+                }
+            }
+            if (merged < 0) merged = x_act;
+            else {
+                const Act ma = A[merged];
+                Unit ua; ua.kind = U_ADD; ua.src0 = merged; ua.src1 = x_act; ua.cout = seg; ua.hout = ma.h; ua.wout = ma.w; ua.relu = 0;
+                ua.out = new_act(seg, ma.h, ma.w, false);
+                U.push_back(ua);
+                merged = ua.out;
+            }
+        }
+        {
+            const Act ma = A[merged];
+            Unit d; d.kind = U_DROPOUT; d.src0 = merged; d.cout = seg; d.hout = ma.h; d.wout = ma.w; d.relu = 0;
+            d.out = new_act(seg, ma.h, ma.w, false);
+            U.push_back(d);
+            xin = d.out; xc = seg; head_k = 1; head_h = ma.h; head_w = ma.w;
+            net->head_up = 4;
+        }
+    }
     if (net->topology == 2) {
         // smp.Linknet (decoders/linknet/decoder.py of segmentation-models-pytorch 0.2.1, restated): channels = reversed encoder
         // features (deepest first) + [32]; block i = Conv2dReLU(in, in/4, 1) -> TransposeX2(in/4, in/4) -> Conv2dReLU(in/4, out, 1),
@@ -328,7 +418,7 @@ int build(vs_unet* net) {
     }
     Unit head; head.kind = U_HEAD; head.src0 = xin; head.cin0 = xc; head.cout = net->classes; head.relu = 0;
     head.k = head_k; head.pad = head_k / 2;
-    head.hin = H; head.win = W; head.hout = H; head.wout = W;
+    head.hin = head_h; head.win = head_w; head.hout = head_h; head.wout = head_w;
     head.w_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.weight", {net->classes, xc, head_k, head_k}, 0);
     head.bias_idx = (int)L.tensors.size(); add_tensor(L, "segmentation_head.0.bias", {net->classes}, 3);
     U.push_back(head);
@@ -356,6 +446,21 @@ size_t plan_workspace(vs_unet* net) {
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
     net->off_ct = take(ct);    // the transposed convolutions' un-shuffled output
+    {   // smp.FPN: GroupNorm statistics per unit, a scratch for the pre-norm convolution output in evaluation (training keeps z),
+        // the reduction workspace, the quarter-resolution logits in front of the head's bilinear upsampling
+        size_t gnz = 0, gnws = 0;
+        for (auto& u : net->units) {
+            if (u.kind != U_CONV || u.gn_idx < 0) continue;
+            u.off_gn = take((size_t)2 * N * u.gn_groups * sizeof(float));
+            gnz = std::max(gnz, N * u.hout * u.wout * u.cout * esz);
+            gnws = std::max(gnws, vs_gn_bwd_workspace((int)N, u.cout, u.gn_groups));
+        }
+        net->off_gnz = take(gnz);
+        net->gnws_bytes = gnws;
+        net->off_gnws = take(gnws);
+        const Unit& hd = net->units.back();
+        net->off_lsmall = take(net->head_up > 1 ? N * net->classes * (size_t)hd.hout * hd.wout * sizeof(float) : 0);
+    }
     int cmax = 512;
     for (auto& u : net->units) cmax = std::max(cmax, u.cout);
     net->bnws_bytes = 4 * vs_bn_workspace(0, cmax);  // also receives the conv epilogue's per-tile statistics
@@ -378,6 +483,14 @@ size_t plan_workspace(vs_unet* net) {
         const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
         u.off_wc2 = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
         u.off_wt2 = take(cin * taps * (u.cg ? 32 : (u.kind == U_HEAD ? 16 : (size_t)u.cout)) * esz);
+    }
+    {
+        const Unit& hd = net->units.back();
+        net->off_dlsmall = take(net->head_up > 1 ? N * net->classes * (size_t)hd.hout * hd.wout * sizeof(float) : 0);
+        size_t dm = 0;
+        for (auto& u : net->units)
+            if (u.kind == U_DROPOUT) dm = std::max(dm, N * u.cout * sizeof(float));
+        net->off_dropmask = take(dm);
     }
     net->ctdw_bytes = ctdw;
     net->off_ctdw = take(ctdw * vs_unet::kSide);   // dense weight gradient of a transposed convolution's 3x3 form, per side stream
@@ -472,7 +585,7 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 2, "topology must be 0 (U-Net), 1 (U-Net++) or 2 (Linknet), got %d", tmp.topology);
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 3, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet) or 3 (FPN), got %d", tmp.topology);
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -526,7 +639,7 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology >= 0 && topology <= 2, "unet_create: topology must be 0 (U-Net), 1 (U-Net++) or 2 (Linknet), got %d", topology);
+    VS_REQUIRE(topology >= 0 && topology <= 3, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet) or 3 (FPN), got %d", topology);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -628,6 +741,20 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
     return launch_weight_prepare_all(net->dtype, params, workspace, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, (hipStream_t)stream);
 }
 extern "C" int vs_unet_weight_set(const vs_unet_t* net) { return net ? net->wset : VS_ERR_INVALID; }
+// Dropout2d draws of a training forward (smp.FPN): mask = f(seed, *counter) with the counter in device memory (int64; the
+// engine passes a BatchNorm's num_batches_tracked, which the training step advances) - a replayed graph draws a new mask per step
+extern "C" int vs_unet_set_rng(vs_unet_t* net, uint32_t seed, const int64_t* counter) {
+    VS_REQUIRE(net, "unet_set_rng: null pointer");
+    net->rng_seed = seed; net->rng_counter = counter;
+    return VS_OK;
+}
+// byte offset inside the training workspace of the last training forward's Dropout2d mask ([n][128] fp32), -1 without dropout (tests)
+extern "C" int64_t vs_unet_dropout_mask_offset(const vs_unet_t* net) {
+    if (!net) return -1;
+    for (auto& u : net->units)
+        if (u.kind == U_DROPOUT) return (int64_t)net->off_dropmask;
+    return -1;
+}
 extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
     VS_REQUIRE(net, "unet_flip_weight_set: null pointer");
     net->wset ^= 1;
@@ -710,11 +837,45 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             }
             continue;
         }
+        case U_UPADD: {
+            ProfScope prof(PK_POOL_MISC, 0, 2.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_upsample2x_add(dt, c.a(u.src0), c.a(u.src1), c.a(u.out), n, u.hin, u.win, u.cout, stream))) return rc;
+            continue;
+        }
+        case U_BILINEAR: {
+            ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_bilinear_up(dt, c.a(u.src0), c.a(u.out), n, u.hin, u.win, u.cout, 2, stream))) return rc;
+            continue;
+        }
+        case U_DROPOUT: {
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t rows = (int64_t)n * u.hout * u.wout;
+            if (training) {
+                float* mask = (float*)(c.ws + net->off_dropmask);
+                if ((rc = vs_dropout2d_mask(mask, n, u.cout, 0.2f, net->rng_seed, net->rng_counter, 0, stream))) return rc;
+                if ((rc = vs_channel_scale(dt, c.a(u.src0), mask, c.a(u.out), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            } else {
+                if ((rc = vs_channel_slice(dt, c.a(u.src0), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, rows, 0, stream))) return rc;
+            }
+            continue;
+        }
         case U_CONV: {
             ConvParams p = conv_params(c, u);
             prof_set_variant(conv_igemm_variant(dt, p));
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
             prof_set_variant(0);
+            if (u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution (FPN's lateral 1x1s): no norm, no activation
+                p.out = c.a(u.out); p.shift = c.P(u.bias_idx);
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                continue;
+            }
+            if (u.gn_idx >= 0) {                  // convolution + GroupNorm + ReLU (per-sample statistics: nothing folds in evaluation)
+                p.out = training ? c.z(u.out) : (void*)(c.ws + net->off_gnz);
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                if ((rc = vs_gn_fwd(dt, p.out, c.P(u.gn_idx), c.P(u.gn_idx + 1), u.relu, c.a(u.out), (float*)(c.ws + u.off_gn), n,
+                                    (int64_t)u.hout * u.wout, u.cout, u.gn_groups, 1e-5f, (float*)(c.ws + net->off_gnws), net->gnws_bytes, stream))) return rc;
+                continue;
+            }
             if (training) {
                 p.out = c.z(u.out);
                 if (dt == VS_BF16 && vs_option("fuse_stats")) {  // batch statistics straight from the fp32 accumulators
@@ -759,6 +920,12 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             ConvParams p = conv_params(c, u);
             p.out = logits; p.shift = c.P(u.bias_idx); p.out_f32 = 3;  // fp32, NCHW
             ProfScope prof(PK_HEAD, conv_flops(c, u), 0, c.s);
+            if (net->head_up > 1) {   // SegmentationHead(upsampling=4): the convolution at 1/4 resolution, then nn.UpsamplingBilinear2d
+                p.out = c.ws + net->off_lsmall;
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                if ((rc = vs_bilinear_up_planes((const float*)p.out, logits, n * net->classes, u.hout, u.wout, net->head_up, stream))) return rc;
+                continue;
+            }
             if (scatter) {
                 p.scatter = scatter;
                 if (conv_head_scatter_ok(dt, p)) {
@@ -868,6 +1035,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
         if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
+        if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
         if (v.bias_idx >= 0) push(v.bias_idx);
         if (v.kind == U_CONV || v.kind == U_HEAD) {
             w_off[nl] = c.t(v.w_idx).offset;
@@ -952,7 +1120,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     // the group's parameter slice and ONE launch deriving its weight copies for the next forward follow on the side stream.
     auto group_update = [&](int ui) -> int {
         if (net->group_first.empty()) {   // unit index -> does an optimiser group start here
-            static const char* const kCuts[] = {"decoder.blocks.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
+            static const char* const kCuts[] = {"decoder.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
             net->group_first.assign(net->units.size(), 0);
             net->group_first[0] = 1;
             std::string prev;
@@ -1046,6 +1214,32 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             continue;
         }
+        if (u.kind == U_UPADD) {    // the lateral addend takes the gradient as is, the upsampled one its 2x2 sums
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of a pyramid level missing");
+            ProfScope prof(PK_POOL_MISC, 0, 3.5 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(u.src1), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, written[u.src1], stream))) return rc;
+            written[u.src1] = 1;
+            if ((rc = launch_upsample2x_bwd(dt, c.da(u.out), c.da(u.src0), n, u.hin, u.win, u.cout, written[u.src0] ? 1 : 0, c.s))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_BILINEAR) {
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of an upsampled tensor missing");
+            ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_bilinear_up_bwd(dt, c.da(u.out), c.da(u.src0), n, u.hin, u.win, u.cout, 2, written[u.src0] ? 1 : 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_DROPOUT) {
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: dropout gradient missing / its input's gradient already written");
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_scale(dt, c.da(u.out), (const float*)(c.ws + net->off_dropmask), c.da(u.src0), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
         if (u.kind == U_POOL) {
             if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: pool output gradient missing");
@@ -1061,13 +1255,32 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             void* dyh = c.ws + net->off_dyh;
             if (do_main) {
             ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
-            if ((rc = launch_dlogits_to_nhwc16(dt, dlogits, dyh, n, net->classes, (int64_t)net->h * net->w, grads + c.t(u.bias_idx).offset,
+            const float* dl = dlogits;
+            if (net->head_up > 1) {   // back through the head's bilinear upsampling first
+                float* ds = (float*)(c.ws + net->off_dlsmall);
+                if ((rc = vs_bilinear_up_planes_bwd(dlogits, ds, n * net->classes, u.hout, u.wout, net->head_up, stream))) return rc;
+                dl = ds;
+            }
+            if ((rc = launch_dlogits_to_nhwc16(dt, dl, dyh, n, net->classes, (int64_t)u.hout * u.wout, grads + c.t(u.bias_idx).offset,
                                                (float*)(c.ws + net->off_bnws), c.s))) return rc;   // + bias gradient, same sweep
             }
             dzp = dyh; dz_c = 16;
         } else if (!do_main) {
             dzp = c.dz(u.out); dz_c = u.cout;
             if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
+            if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) dzp = c.da(u.out);
+        } else if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution: dz IS the output's gradient
+            VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_colsum(dt, c.da(u.out), c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            dzp = c.da(u.out); dz_c = u.cout;
+        } else if (u.kind == U_CONV && u.gn_idx >= 0) {                  // GroupNorm + ReLU backward
+            VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
+            ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 5), c.s);
+            if ((rc = vs_gn_bwd(dt, c.da(u.out), c.z(u.out), (const float*)(c.ws + u.off_gn), c.P(u.gn_idx), c.P(u.gn_idx + 1), u.relu, c.dz(u.out),
+                                grads + c.t(u.gn_idx).offset, grads + c.t(u.gn_idx + 1).offset, n, (int64_t)u.hout * u.wout, u.cout, u.gn_groups,
+                                (float*)(c.ws + net->off_gnws), net->gnws_bytes, stream))) return rc;
+            dzp = c.dz(u.out); dz_c = u.cout;
         } else {
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             void* dres = nullptr;
@@ -1257,7 +1470,8 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
-    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : "maxpool"));
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
+                         : (u.kind == U_DROPOUT ? "dropout2d" : "maxpool")))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];

@@ -72,7 +72,7 @@ class _UnetFn(torch.autograd.Function):
 
 class VolSegUnet(nn.Module):
     ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51}
-    TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2}     # smp.Unet, smp.UnetPlusPlus, smp.Linknet
+    TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2, "fpn": 3}     # smp.Unet, smp.UnetPlusPlus, smp.Linknet, smp.FPN
 
     def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
                  encoder: str = "resnet34", topology: str = "unet"):
@@ -111,6 +111,7 @@ class VolSegUnet(nn.Module):
         self.dp_buckets = 4  # >1: bucketed, overlapped gradient all-reduce (decoder+head, layer4, layer3, rest)
         self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
         self._fused_optimizer = None   # FusedAdamW(fuse_step_into_backward=True) registers itself here
+        self.dropout_seed = 0 if seed is None else int(seed)   # Dropout2d draws (smp.FPN); give every data-parallel rank its own
         self._dp_side = None           # side stream of the data-parallel fused optimiser step
         self._bnver = 0  # bumped when a training forward moves the running statistics
         self._step_side = None         # second stream of a replayed step (weight gradients + optimiser)
@@ -232,8 +233,12 @@ class VolSegUnet(nn.Module):
             train_ws = training or (plan is not None and plan["training"])
             nbytes = lib.vs_unet_workspace_bytes(handle, 1 if train_ws else 0)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            plan = {"handle": handle, "max_batch": max_batch, "training": train_ws, "ws": ws, "prep": None}
+            plan = {"handle": handle, "max_batch": max_batch, "training": train_ws, "ws": ws, "prep": None, "rng": None}
             self._plans[key] = plan
+        if training and plan["rng"] != (self.dropout_seed, ptr(self._nbt)):
+            # Dropout2d draws (smp.FPN): mask = f(seed, encoder.bn1.num_batches_tracked) - the counter every training step advances
+            check(lib.vs_unet_set_rng(plan["handle"], self.dropout_seed & 0xFFFFFFFF, ptr(self._nbt)))
+            plan["rng"] = (self.dropout_seed, ptr(self._nbt))
         return plan
 
     def _drop_steps(self):
@@ -280,10 +285,11 @@ class VolSegUnet(nn.Module):
         plan = self._plan(n, h, w, training)
         self._prepare(plan, training)
         logits = torch.empty((n, self.classes, h, w), dtype=torch.float32, device=self.device)
+        if training:
+            self._nbt += 1      # before the forward: the dropout draw of this step reads the advanced counter, as a replayed step does
         check(lib.vs_unet_forward(plan["handle"], ptr(self._flat), ptr(self._bnstate), ptr(x), n, 1 if training else 0,
                                   ptr(logits), ptr(plan["ws"]), _lib.stream_ptr()))
         if training:
-            self._nbt += 1
             self._train_forward_token += 1
             self._bnver += 1
         return logits
@@ -567,7 +573,7 @@ class VolSegUnet(nn.Module):
         layer3, then stem + layer1 + layer2.  Backward fills the flat buffer from its end towards its start."""
         names = _lib.unit_names(handle)
         cuts = [len(names)]
-        for prefix in ("decoder.blocks.", "encoder.layer4.0.", "encoder.layer3.0."):
+        for prefix in ("decoder.", "encoder.layer4.0.", "encoder.layer3.0."):
             cuts.append(next(i for i, nm in enumerate(names) if nm.startswith(prefix)))
         cuts.append(0)
         plan = []

@@ -110,6 +110,7 @@ class VolSeg2dTrainer:
                 dist.broadcast(self.model._flat, 0)
                 dist.broadcast(self.model._bnstate, 0)
                 self.model.dp_group = dist.group.WORLD
+                self.model.dropout_seed += 1000003 * self.rank      # Dropout2d (FPN): every rank draws its own masks
             else:
                 vdist.broadcast_module(self.model)
         if frozen:
