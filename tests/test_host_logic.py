@@ -265,3 +265,23 @@ def test_training_data_slicer_follows_the_reference_tests(tmp_path):
     assert img_as_ubyte(np.array([True, False])).tolist() == [255, 0]
     with pytest.raises(ValueError, match="between -1 and 1"):
         img_as_ubyte(np.array([1.5]))
+
+
+def test_fit_to_square_downscales_without_antialiasing():
+    """LongestMaxSize + PadIfNeeded of the training dataset (reference data/augmentations.py:12-27 -> albumentations:
+    cv2.INTER_LINEAR for the image, INTER_NEAREST for the mask): a 2x down-scale of an 8-pixel checkerboard row samples at
+    (dst + 0.5) * 2 - 0.5 - the mean of TWO neighbours (a box-antialiased resize would average more and flatten it to grey
+    everywhere the same way), masks stay label-valued, and the short side is reflect-101 padded."""
+    import numpy as np
+    from volume_segmantics_amd.data.datasets import fit_to_square
+    img = np.zeros((4, 8), np.uint8)
+    img[:, 0::4] = 200; img[:, 1::4] = 200          # columns 200 200 0 0 200 200 0 0
+    mask = np.zeros((4, 8), np.uint8); mask[:, 4:] = 3
+    out, m = fit_to_square(img, mask, 4)
+    assert out.shape == (4, 4) and m.shape == (4, 4)
+    # rows: 2 real rows (4 * 0.5) centred, one reflected row above and below
+    assert np.array_equal(out[1], out[2]) and np.array_equal(out[0], out[1]) and np.array_equal(out[3], out[2])
+    assert out[1].tolist() == [200, 0, 200, 0]      # x = 0.5, 2.5, 4.5, 6.5: the mean of columns (0,1), (2,3), (4,5), (6,7)
+    assert set(np.unique(m).tolist()) <= {0, 3} and m[1].tolist() == [0, 0, 3, 3]
+    same, _ = fit_to_square(np.arange(16, dtype=np.uint8).reshape(4, 4), None, 4)
+    assert np.array_equal(same, np.arange(16, dtype=np.uint8).reshape(4, 4))

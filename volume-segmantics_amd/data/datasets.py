@@ -29,14 +29,14 @@ def _read_gray(path: Path) -> np.ndarray:
 
 def fit_to_square(image: np.ndarray, mask: np.ndarray | None, size: int):
     """LongestMaxSize(size) then centred PadIfNeeded(size, size) with reflect-101 borders (augmentations.py:12-27)."""
-    from PIL import Image
+    from .augmentations import resize      # cv2.INTER_LINEAR / INTER_NEAREST semantics: no antialiasing on down-scaling
     h, w = image.shape
     scale = size / max(h, w)
     if scale != 1.0:
         nh, nw = max(1, int(round(h * scale))), max(1, int(round(w * scale)))
-        image = np.array(Image.fromarray(image).resize((nw, nh), Image.BILINEAR))
+        image = resize(image, nh, nw)
         if mask is not None:
-            mask = np.array(Image.fromarray(mask).resize((nw, nh), Image.NEAREST))
+            mask = resize(mask, nh, nw, nearest=True)
         h, w = nh, nw
     top, left = (size - h) // 2, (size - w) // 2
     pads = ((top, size - h - top), (left, size - w - left))
