@@ -172,8 +172,17 @@ def gemm_crosscheck(dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
-    return {"what": "torch.matmul bf16 8192^3 (library GEMM, random operands)", "ms": round(ms, 3), "tflops": round(tf, 1),
-            "frac_of_vendor_peak": round(tf / MFMA_PEAK_BF16_TFLOPS, 4)}
+    out = {"what": "torch.matmul bf16 8192^3 (library GEMM, random operands)", "ms": round(ms, 3), "tflops": round(tf, 1),
+           "frac_of_vendor_peak": round(tf / MFMA_PEAK_BF16_TFLOPS, 4)}
+    # what a loop of nothing but v_mfma_f32_16x16x32_bf16 (register operands, every CU, 8 waves per SIMD) sustains on this box,
+    # with the clock the chip holds meanwhile (MI355X_MICROARCH.md "DVFS give-back"): the practical ceiling under the vendor peak
+    from volume_segmantics_amd import _lib
+    import ctypes
+    tfl, ghz = ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib.vs_debug_mfma_rate(20000, 8, ctypes.byref(tfl), ctypes.byref(ghz)))
+    out["mfma_only_loop"] = {"tflops": round(tfl.value, 1), "in_kernel_clock_ghz": round(ghz.value, 3),
+                             "frac_of_vendor_peak": round(tfl.value / MFMA_PEAK_BF16_TFLOPS, 4)}
+    return out
 
 
 def synth_volume(n: int, seed: int) -> np.ndarray:

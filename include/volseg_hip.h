@@ -299,6 +299,10 @@ int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int
 int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
 
+/* Diagnostics (bench.py's peak_crosscheck): TFLOP/s and mean in-kernel clock (GHz) of a register-only v_mfma_f32_16x16x32_bf16
+ * loop on every CU, waves_per_simd 4-wave workgroups per CU - what the matrix pipes sustain on this box under its power
+ * management, next to the 2.5 PFLOP/s of the data sheet. */
+int vs_debug_mfma_rate(int iters, int waves_per_simd, double* tflops, double* clock_ghz);
 /* The data-parallel form of the two shares: vs_unet_backward_part = the shares without the optimiser (role 2 = weight
  * gradients only); vs_unet_adamw_range = AdamW over the parameters of the units [unit_lo, unit_hi) from `grads` (after the
  * caller's all-reduce of that slice, vs_unet_unit_param_offset) plus their next-forward weight copies, in order on

@@ -110,6 +110,7 @@ _SIGS = {
     "vs_unet_backward_adamw_part": (I, [P, P, P, I, I, P, P, P, C.POINTER(AdamwArgs), I, I, I]),
     "vs_unet_backward_part": (I, [P, P, P, P, I, I, P, P, P, I, I, I]),
     "vs_unet_set_rng": (I, [P, C.c_uint32, P]),
+    "vs_debug_mfma_rate": (I, [I, I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vs_unet_dropout_mask_offset": (C.c_int64, [P]),
     "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),

@@ -105,3 +105,58 @@ extern "C" int vs_debug_probe(void* buf, size_t cap_wgs) {
     return VS_OK;
 }
 extern "C" int vs_get_option(const char* name) { return vs_option(name); }
+
+// ---- diagnostics: what the MFMA pipes sustain on this box (bench.py's peak_crosscheck; tools/mfma_probe.hip is the stand-alone
+// form).  Every wave issues iters x 8 v_mfma_f32_16x16x32_bf16 on register operands; 4-wave workgroups, waves_per_simd of them
+// per CU.  Returns the launch's TFLOP/s and the mean in-kernel clock (s_memtime ticks / wall time) in GHz.
+typedef __attribute__((ext_vector_type(4))) float dbg_f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 dbg_bf16x8;
+__global__ __launch_bounds__(256) void debug_mfma_loop(float* out, unsigned long long* clocks, int iters) {
+    dbg_f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = dbg_f32x4{0.f, 0.f, 0.f, 0.f};
+    dbg_bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)((threadIdx.x + i) & 3); b[i] = (__bf16)(0.5f + (float)(i & 1)); }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) clocks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+extern "C" int vs_debug_mfma_rate(int iters, int waves_per_simd, double* tflops, double* clock_ghz) {
+    VS_REQUIRE(iters > 0 && iters <= 1000000 && waves_per_simd >= 1 && waves_per_simd <= 8 && tflops && clock_ghz, "debug_mfma_rate: bad arguments");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    VS_CHECK_HIP(hipGetDevice(&dev));
+    VS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount * waves_per_simd, waves = blocks * 4;
+    float* out = nullptr; unsigned long long* clk = nullptr;
+    VS_CHECK_HIP(hipMalloc(&out, (size_t)blocks * 256 * sizeof(float)));
+    VS_CHECK_HIP(hipMalloc(&clk, (size_t)waves * sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    VS_CHECK_HIP(hipEventCreate(&e0)); VS_CHECK_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(debug_mfma_loop, dim3(blocks), dim3(256), 0, 0, out, clk, 64);
+    VS_CHECK_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(debug_mfma_loop, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+    VS_CHECK_HIP(hipEventRecord(e1, 0));
+    VS_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long* h = (unsigned long long*)malloc((size_t)waves * sizeof(unsigned long long));
+    VS_CHECK_HIP(hipMemcpy(h, clk, (size_t)waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean = 0.0;
+    for (int i = 0; i < waves; ++i) mean += (double)h[i];
+    mean /= waves;
+    free(h);
+    (void)hipFree(out); (void)hipFree(clk); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *tflops = (double)waves * iters * 8 * 2.0 * 16 * 16 * 32 / ((double)ms * 1e-3) * 1e-12;
+    *clock_ghz = mean / ((double)ms * 1e-3) * 1e-9;
+    return VS_OK;
+}
