@@ -183,9 +183,13 @@ def test_prediction_manager_qualities_and_outputs(tmp_path):
     assert mgr.predict_volume_to_path(None).shape == (4,) + vol.shape   # quality from settings ("low")... one_hot
 
 
-def test_trainer_end_to_end_on_synthetic_slices(tmp_path):
+@pytest.mark.parametrize("mtype,encoder", [("U_Net", "resnet34"), ("U_Net_Plus_Plus", "resnet34"), ("Linknet", "resnet34"), ("FPN", "resnet34"),
+                                           ("U_Net", "resnext50_32x4d")])
+def test_trainer_end_to_end_on_synthetic_slices(tmp_path, mtype, encoder):
     """1 frozen + 1 unfrozen epoch through LR finder, one-cycle schedule, early-stopping checkpoint and reload
-    (reference flow: scripts/train_2d_model.py:56-71, tests/test_vol_seg_2d_trainer.py:95-116)."""
+    (reference flow: scripts/train_2d_model.py:56-71, tests/test_vol_seg_2d_trainer.py:95-116), for every topology the engine
+    builds (settings `model: {type: ...}` as in the reference's 2d_model_train_settings.yaml) and a grouped-convolution encoder;
+    the checkpoint's model_struc_dict rebuilds the same network in the predictor."""
     from torch.utils.data import DataLoader
     from volume_segmantics_amd.data.datasets import ArraySliceDataset
     from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
@@ -201,7 +205,7 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path):
     settings = SimpleNamespace(starting_lr=1e-6, end_lr=50, lr_find_epochs=1, lr_reduce_factor=500, cuda_device=0, patience=3,
                                loss_criterion="DiceLoss", alpha=0.75, beta=0.25, eval_metric="MeanIoU", pct_lr_inc=0.3,
                                plot_lr_graph=False, image_size=64, training_set_proportion=0.8,
-                               model={"type": "U_Net", "encoder_name": "resnet34", "encoder_weights": None})
+                               model={"type": mtype, "encoder_name": encoder, "encoder_weights": None})
     tr = VolSeg2dTrainer(None, None, {"bg": 0, "fg": 1}, settings, loaders=loaders)
     out = tmp_path / "trained.pytorch"
     tr.train_model(out, 1, 3, create=True, frozen=True)
@@ -213,8 +217,10 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path):
     tr.output_prediction_figure(out)
     assert (tmp_path / "trained_train_stats.csv").exists()
     d = torch.load(out, weights_only=False)
-    assert d["model_struc_dict"]["type"].name == "U_NET" and d["label_codes"] == {"bg": 0, "fg": 1}
+    assert d["model_struc_dict"]["type"].name == mtype.upper() and d["label_codes"] == {"bg": 0, "fg": 1}
     pred = VolSeg2dPredictor(str(out), SimpleNamespace(cuda_device=0))
+    assert pred.model.topology == {"U_Net": "unet", "U_Net_Plus_Plus": "unetplusplus", "Linknet": "linknet", "FPN": "fpn"}[mtype]
+    assert torch.equal(pred.model._flat, tr.model._flat)
     labels, probs = pred._predict_single_axis(imgs[:8])
     assert labels.shape == (8, 64, 64) and labels.max() <= 1 and probs.dtype == np.float16
 
