@@ -299,6 +299,21 @@ int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int
 int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
 
+/* ---- RCCL behind the C ABI: the collectives of the two data-parallel splits on the caller's stream, one communicator per rank
+ * (one process per GPU).  The reference has no multi-GPU path; volume-segmantics_amd/dist.py uses
+ * torch.distributed by default and this transport with VOLSEG_COMM=rccl.  librccl is opened on first use (VS_ERR_UNSUPPORTED if it
+ * is absent).  id: 128 bytes from rank 0's vs_comm_unique_id, handed to the other ranks by the launcher. */
+typedef struct vs_comm vs_comm_t;
+int vs_comm_unique_id(char id[128]);
+int vs_comm_init(vs_comm_t** out, int nranks, int rank, const char id[128]);     /* on the current device */
+void vs_comm_destroy(vs_comm_t* c);
+int vs_comm_size(const vs_comm_t* c);
+int vs_comm_rank(const vs_comm_t* c);
+int vs_comm_allreduce_sum_f32(vs_comm_t* c, float* buf, int64_t n, void* stream);             /* gradients, in place */
+int vs_comm_allreduce_max_u32(vs_comm_t* c, uint32_t* buf, int64_t n, void* stream);          /* packed keys: max = the merge */
+int vs_comm_reduce_scatter_max_u32(vs_comm_t* c, const uint32_t* send, uint32_t* recv, int64_t n_per_rank, void* stream);
+int vs_comm_allgather(vs_comm_t* c, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int vs_comm_broadcast(vs_comm_t* c, void* buf, int64_t bytes, int root, void* stream);
 /* Diagnostics (bench.py's peak_crosscheck): TFLOP/s and mean in-kernel clock (GHz) of a register-only v_mfma_f32_16x16x32_bf16
  * loop on every CU, waves_per_simd 4-wave workgroups per CU - what the matrix pipes sustain on this box under its power
  * management, next to the 2.5 PFLOP/s of the data sheet. */

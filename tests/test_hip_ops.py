@@ -746,3 +746,29 @@ def test_fpn_upsample_add_and_dropout2d(code):
     L.check(L.lib.vs_channel_scale(code, L.ptr(xsd), L.ptr(masks[0]), L.ptr(out), nn_, 15, cc, None))
     sync()
     assert torch.allclose(from_nhwc(out), xs * masks[0].cpu()[:, :, None, None], **tol(code, 4.0))
+
+
+def test_rccl_communicator_through_the_c_abi_single_rank():
+    """vs_comm_* (csrc/comm.hip): RCCL opened lazily, a one-rank communicator on this GPU; with one rank every collective is
+    the identity - which pins the plumbing (unique id, init on the current device, datatypes, in-place calls on the caller's
+    stream, destroy).  N > 1 needs as many GPUs: the driver's multi-GPU run is the first time more than one rank exists."""
+    from volume_segmantics_amd.dist import VsComm
+    comm = VsComm(torch.device(DEV))
+    assert (comm.rank, comm.size) == (0, 1)
+    L = lib()
+    assert L.lib.vs_comm_size(comm.handle) == 1 and L.lib.vs_comm_rank(comm.handle) == 0
+    g = torch.randn(1 << 20, device=DEV)
+    ref = g.clone()
+    comm.allreduce_sum_(g)
+    keys = torch.randint(0, 2 ** 31 - 1, (1 << 20,), device=DEV, dtype=torch.int32)
+    kref = keys.clone()
+    comm.allreduce_max_keys_(keys)
+    out = torch.zeros_like(keys)
+    comm.reduce_scatter_max_keys(keys, out)
+    gathered = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    part = torch.arange(4096, device=DEV).to(torch.uint8)
+    comm.allgather(part, gathered)
+    comm.broadcast_(g)
+    sync()
+    assert torch.equal(g, ref) and torch.equal(keys, kref) and torch.equal(out, kref) and torch.equal(gathered, part)
+    comm.close()

@@ -111,6 +111,16 @@ _SIGS = {
     "vs_unet_backward_part": (I, [P, P, P, P, I, I, P, P, P, I, I, I]),
     "vs_unet_set_rng": (I, [P, C.c_uint32, P]),
     "vs_debug_mfma_rate": (I, [I, I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vs_comm_unique_id": (I, [P]),
+    "vs_comm_init": (I, [C.POINTER(P), I, I, P]),
+    "vs_comm_destroy": (None, [P]),
+    "vs_comm_size": (I, [P]),
+    "vs_comm_rank": (I, [P]),
+    "vs_comm_allreduce_sum_f32": (I, [P, P, C.c_int64, P]),
+    "vs_comm_allreduce_max_u32": (I, [P, P, C.c_int64, P]),
+    "vs_comm_reduce_scatter_max_u32": (I, [P, P, P, C.c_int64, P]),
+    "vs_comm_allgather": (I, [P, P, P, C.c_int64, P]),
+    "vs_comm_broadcast": (I, [P, P, C.c_int64, I, P]),
     "vs_unet_dropout_mask_offset": (C.c_int64, [P]),
     "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),

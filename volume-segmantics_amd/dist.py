@@ -46,10 +46,80 @@ def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class VsComm:
+    """This rank's RCCL communicator behind the C ABI (include/volseg_hip.h: vs_comm_*): the transport for callers without
+    torch.distributed, and - with VOLSEG_COMM=rccl in the environment - the one the key merge and the plain gradient
+    all-reduce of this package use.  Rank 0's unique id reaches the other ranks over the default process group (any
+    backend); without a process group the communicator has one rank."""
+
+    def __init__(self, device: torch.device | None = None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        rank, ws = world()
+        if device is not None:
+            torch.cuda.set_device(device)
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(_lib.lib.vs_comm_unique_id(ident))
+        if ws > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib.vs_comm_init(ctypes.byref(self.handle), ws, rank, ident))
+        self.rank, self.size = rank, ws
+
+    def allreduce_sum_(self, t: torch.Tensor) -> None:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        self._lib.check(self._lib.lib.vs_comm_allreduce_sum_f32(self.handle, self._lib.ptr(t), t.numel(), self._lib.stream_ptr()))
+
+    def allreduce_max_keys_(self, keys: torch.Tensor) -> None:
+        assert keys.element_size() == 4 and keys.is_contiguous() and keys.is_cuda
+        self._lib.check(self._lib.lib.vs_comm_allreduce_max_u32(self.handle, self._lib.ptr(keys), keys.numel(), self._lib.stream_ptr()))
+
+    def reduce_scatter_max_keys(self, keys: torch.Tensor, out: torch.Tensor) -> None:
+        assert keys.numel() == out.numel() * self.size and keys.is_contiguous() and out.is_contiguous()
+        self._lib.check(self._lib.lib.vs_comm_reduce_scatter_max_u32(self.handle, self._lib.ptr(keys), self._lib.ptr(out), out.numel(),
+                                                                    self._lib.stream_ptr()))
+
+    def allgather(self, part: torch.Tensor, out: torch.Tensor) -> None:
+        nbytes = part.numel() * part.element_size()
+        assert out.numel() * out.element_size() == nbytes * self.size and part.is_contiguous() and out.is_contiguous()
+        self._lib.check(self._lib.lib.vs_comm_allgather(self.handle, self._lib.ptr(part), self._lib.ptr(out), nbytes, self._lib.stream_ptr()))
+
+    def broadcast_(self, t: torch.Tensor, root: int = 0) -> None:
+        assert t.is_contiguous() and t.is_cuda
+        self._lib.check(self._lib.lib.vs_comm_broadcast(self.handle, self._lib.ptr(t), t.numel() * t.element_size(), root,
+                                                       self._lib.stream_ptr()))
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.lib.vs_comm_destroy(self.handle)
+            self.handle = None
+
+
+_vs_comm: VsComm | None = None
+
+
+def vs_comm(device: torch.device | None = None) -> VsComm | None:
+    """The process's C-ABI communicator when VOLSEG_COMM=rccl selects that transport (created on first use), else None."""
+    global _vs_comm
+    if os.environ.get("VOLSEG_COMM", "") != "rccl":
+        return None
+    if _vs_comm is None:
+        _vs_comm = VsComm(device)
+    return _vs_comm
+
+
 def allreduce_max_keys(keys: torch.Tensor, group=None) -> None:
     """In-place elementwise max of uint32 packed keys across ranks.  Keys are < 2**31 (fp16 bits of a probability
     <= 1.0 are <= 0x3C00), so they are reduced as int32 - the order is the same."""
     if world()[1] == 1:
+        return
+    comm = vs_comm(keys.device) if keys.is_cuda and group is None else None
+    if comm is not None:
+        comm.allreduce_max_keys_(keys)
         return
     dist.all_reduce(keys.view(torch.int32), op=dist.ReduceOp.MAX, group=group)
 

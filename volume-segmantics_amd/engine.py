@@ -539,11 +539,19 @@ class VolSegUnet(nn.Module):
                     if self._dp_side is None:
                         self._dp_side = torch.cuda.Stream(device=self.device)
                     a, b = obj
-                    with torch.cuda.stream(self._step_side):      # the collective is ordered behind the bucket's weight gradients
-                        h = dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True)
-                    with torch.cuda.stream(self._dp_side):
-                        h.wait()
-                        self._flat_grad[a:b].div_(self._world())
+                    from . import dist as vdist
+                    comm = vdist.vs_comm(self.device)
+                    if comm is not None:      # the C ABI's communicator: stream-ordered on the optimiser stream, behind the
+                        self._dp_side.wait_stream(self._step_side)       # bucket's weight gradients
+                        with torch.cuda.stream(self._dp_side):
+                            comm.allreduce_sum_(self._flat_grad[a:b])
+                            self._flat_grad[a:b].div_(self._world())
+                    else:
+                        with torch.cuda.stream(self._step_side):      # the collective is ordered behind the bucket's weight gradients
+                            h = dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True)
+                        with torch.cuda.stream(self._dp_side):
+                            h.wait()
+                            self._flat_grad[a:b].div_(self._world())
                 elif op == "opt":
                     check(lib.vs_graph_launch(obj, self._dp_side.cuda_stream))
                 elif op == "join_opt":
@@ -590,27 +598,38 @@ class VolSegUnet(nn.Module):
         import torch.distributed as dist
         if "buckets" not in plan:
             plan["buckets"] = self._bucket_plan(plan["handle"])
+        from . import dist as vdist
         world = self._world()
         handles = []
         main = torch.cuda.current_stream()
+        if self._dp_side is None:
+            self._dp_side = torch.cuda.Stream(device=self.device)
+        side = self._dp_side
+        comm = vdist.vs_comm(self.device)     # VOLSEG_COMM=rccl: the C ABI's communicator, stream-ordered on the side stream
         for lo, hi, a, b in plan["buckets"]:
             check(lib.vs_unet_backward_range(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
                                              ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr(), lo, hi))
             if b > a:
-                handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), lo, hi, a, b))
+                if comm is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        comm.allreduce_sum_(self._flat_grad[a:b])
+                    handles.append((None, lo, hi, a, b))
+                else:
+                    handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), lo, hi, a, b))
         if fused is None:
             for h, lo, hi, a, b in handles:
-                h.wait()
+                if h is not None:
+                    h.wait()
+            main.wait_stream(side)
             self._flat_grad.div_(world)
             return
-        if self._dp_side is None:
-            self._dp_side = torch.cuda.Stream(device=self.device)
-        side = self._dp_side
         g = fused.param_groups[0]
         mask = fused._grad_mask_for(self, need_enc)
         with torch.cuda.stream(side):
             for h, lo, hi, a, b in handles:
-                h.wait()                                   # this (side) stream waits for the bucket's all-reduce
+                if h is not None:
+                    h.wait()                               # this (side) stream waits for the bucket's all-reduce
                 self._flat_grad[a:b].div_(world)
                 check(lib.vs_adamw_step(ptr(self._flat) + 4 * a, ptr(self._flat_grad) + 4 * a, ptr(fused.exp_avg) + 4 * a,
                                         ptr(fused.exp_avg_sq) + 4 * a, (ptr(mask) + a) if mask is not None else None, b - a,
@@ -626,7 +645,12 @@ class VolSegUnet(nn.Module):
         world = dist.get_world_size(self.dp_group)
         if world == 1:
             return
-        if self.dp_grad_dtype == torch.float32:
+        from . import dist as vdist
+        comm = vdist.vs_comm(self.device)
+        if self.dp_grad_dtype == torch.float32 and comm is not None:
+            comm.allreduce_sum_(self._flat_grad)
+            self._flat_grad.div_(world)
+        elif self.dp_grad_dtype == torch.float32:
             dist.all_reduce(self._flat_grad, group=self.dp_group)
             self._flat_grad.div_(world)
         else:
