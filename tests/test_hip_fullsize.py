@@ -176,3 +176,31 @@ def test_odd_shaped_volume_twelve_way_equals_reference_formulation():
         pred._merge_vols_in_mem(prb, lab)
     assert np.array_equal(labels, lab[0])
     assert np.array_equal(probs.view(np.uint16), prb[0].view(np.uint16))
+
+
+def test_config5_sized_volume_1024_cube_three_axis_prediction_stays_resident_and_addresses_correctly():
+    """BASELINE configs[4]'s volume (1024^3, 2 classes, 3-axis prediction, everything HBM-resident: 1 GB volume, 4.3 GB of packed
+    keys, 3 GB of labels + probabilities) with the network this engine has for it (U-Net / ResNet-34): 2^30 voxels cross every
+    32-bit element-offset boundary of the volume-side kernels.  Properties: the result has the volume's shape, single-axis
+    slices of the big run equal the same slices predicted on their own (evaluation-mode BatchNorm: a slice's logits do not
+    depend on its batch), and the key-merged 3-axis result agrees with the single-axis one wherever that axis won."""
+    import time
+    from volume_segmantics_amd.utilities.base_data_utils import Axis
+    pred = _predictor(2, 16)
+    small = bench.synth_volume(256, seed=1234)
+    vol = np.tile(small, (4, 4, 4))
+    assert vol.shape == (1024, 1024, 1024)
+    t0 = time.perf_counter()
+    labels, probs = pred._predict_3_ways_max_probs(vol)
+    dt = time.perf_counter() - t0
+    print(f"1024^3 three-axis prediction (first call, incl. plans): {dt:.2f} s")
+    assert labels.shape == vol.shape and labels.dtype == np.uint8 and probs.shape == vol.shape and probs.dtype == np.float16
+    assert 0 < (labels[::8, ::8, ::8] == 1).mean() < 1
+    lz, pz = pred._predict_single_axis(vol, axis=Axis.Z)
+    for k in (0, 517, 1023):                       # slices of the full run vs the same slice as a one-slice volume
+        l1, p1 = pred._predict_single_axis(vol[k:k + 1], axis=Axis.Z)
+        assert np.array_equal(lz[k], l1[0]) and np.array_equal(pz[k].view(np.uint16), p1[0].view(np.uint16)), k
+    # the merge keeps the larger fp16 probability: wherever the merged probability equals the Z pass's, the Z label survived
+    won = probs[1000:1008] == pz[1000:1008]
+    assert won.mean() > 0.05 and np.array_equal(labels[1000:1008][won], lz[1000:1008][won])
+    assert (probs[1000:1008] >= pz[1000:1008]).all()
