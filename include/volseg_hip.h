@@ -45,6 +45,8 @@ typedef struct vs_conv_desc {
     int32_t split_c;           /* >0: output channels >= split_c go to y1 (dgrad through a concat) */
     int32_t groups;            /* 0 / 1 = dense; > 1: grouped convolution (ResNeXt: nn.Conv2d(groups=32)) with c0 == cout and
                                   4 / 8 / 16 / 32 channels per group; w from vs_weights_prepare_grouped, dw [cout][taps][c0/groups] */
+    int32_t dilation;          /* 0 / 1 = none; 2: a stride-1 3x3 convolution dilated by 2 (pad 2) - the stages torchvision / smp turn
+                                  from stride into dilation (smp utils.replace_strides_with_dilation, DeepLabV3+ at output stride 16) */
 } vs_conv_desc;
 
 /* y = relu?( conv(x, w) * scale[c] + shift[c] + residual ).  w: [cout][kh*kw][c0+c1] in dtype.

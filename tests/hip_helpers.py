@@ -42,9 +42,9 @@ def sync():
     torch.cuda.synchronize()
 
 
-def conv_desc(L, code, n, hin, win, c0, cout, k, stride, pad, c1=0, up0=0, relu=0, out_f32=0, split_c=0, groups=0):
+def conv_desc(L, code, n, hin, win, c0, cout, k, stride, pad, c1=0, up0=0, relu=0, out_f32=0, split_c=0, groups=0, dilation=0):
     return L.ConvDesc(dtype=code, n=n, hin=hin, win=win, c0=c0, c1=c1, up0=up0, cout=cout, kh=k, kw=k,
-                      stride=stride, pad=pad, relu=relu, out_f32=out_f32, split_c=split_c, groups=groups)
+                      stride=stride, pad=pad, relu=relu, out_f32=out_f32, split_c=split_c, groups=groups, dilation=dilation)
 
 
 def dirmap_from_view(L, vol, view):

@@ -386,6 +386,42 @@ def test_conv_transpose_4x4_stride2_as_conv3x3_plus_pixel_shuffle(code, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (2, 8, 8, 128, 256), (1, 16, 24, 32, 32), (3, 4, 4, 256, 64), (32, 16, 16, 256, 512)])
+def test_dilated_conv_fwd_dgrad_wgrad(code, shape):
+    """nn.Conv2d(cin, cout, 3, stride 1, padding 2, dilation 2): what smp's replace_strides_with_dilation makes of ResNet's
+    last stage for DeepLabV3+ (output stride 16) - forward, data gradient (the same kernel on the flipped / transposed copy)
+    and weight gradient against torch CPU."""
+    L = lib()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(13)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, code).requires_grad_()
+    y = F.conv2d(x, wt, stride=1, padding=2, dilation=2)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    d = conv_desc(L, code, n, h, w, cin, cout, 3, 1, 2, dilation=2)
+    xd, wd = to_nhwc(x.detach(), code), w_krsc(wt.detach(), code)
+    yd = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wd), None, None, None, L.ptr(yd), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((cout, 3, 3, cin), float("nan"), device=DEV)
+    dyd = to_nhwc(dy, code)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(xd), None, L.ptr(dyd), L.ptr(dw), L.ptr(ws), ws_bytes, None))
+    sync()
+    ref_dw = wt.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    _, wtr = _prep_weights(L, code, wt.detach())
+    dd = conv_desc(L, code, n, h, w, cout, cin, 3, 1, 2, dilation=2)
+    dx = torch.full((n, h, w, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(dd, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_wgrad_through_upsample_concat_and_split_dgrad(code):
     L = lib()
     g = torch.Generator().manual_seed(8)

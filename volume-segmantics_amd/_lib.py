@@ -30,7 +30,7 @@ lib = C.CDLL(str(LIB_PATH))
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c", "groups")]
+        "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c", "groups", "dilation")]
 
 
 class DirMap(C.Structure):

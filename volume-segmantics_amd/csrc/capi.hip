@@ -21,9 +21,11 @@ static int desc_to_params(const vs_conv_desc* d, ConvParams& p) {
     p.C0 = d->c0; p.C1 = d->c1; p.up0 = d->up0;
     p.N = d->n; p.Hin = d->hin; p.Win = d->win;
     p.stride = d->stride; p.pad = d->pad; p.KH = d->kh; p.KW = d->kw;
-    VS_REQUIRE(d->stride >= 1 && d->kh >= 1 && d->kw >= 1, "conv: bad geometry");
-    p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
-    p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
+    VS_REQUIRE(d->stride >= 1 && d->kh >= 1 && d->kw >= 1 && d->dilation >= 0, "conv: bad geometry");
+    const int dil = d->dilation > 1 ? d->dilation : 1;
+    p.dil = dil;
+    p.Hout = (d->hin + 2 * d->pad - (d->kh - 1) * dil - 1) / d->stride + 1;
+    p.Wout = (d->win + 2 * d->pad - (d->kw - 1) * dil - 1) / d->stride + 1;
     p.Cout = d->cout; p.relu = d->relu; p.out_f32 = d->out_f32; p.split_c = d->split_c;
     VS_REQUIRE(d->groups >= 0, "conv: bad group count");
     if (d->groups > 1) {   // grouped: runs on 32-channel super-groups (weights from vs_weights_prepare_grouped)
@@ -52,8 +54,10 @@ static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
     p = WgradParams{};
     p.C0 = d->c0; p.C1 = d->c1; p.up0 = d->up0; p.N = d->n; p.Hin = d->hin; p.Win = d->win;
     p.stride = d->stride; p.pad = d->pad; p.KH = d->kh; p.KW = d->kw;
-    p.Hout = (d->hin + 2 * d->pad - d->kh) / d->stride + 1;
-    p.Wout = (d->win + 2 * d->pad - d->kw) / d->stride + 1;
+    const int dil = d->dilation > 1 ? d->dilation : 1;
+    p.dil = dil;
+    p.Hout = (d->hin + 2 * d->pad - (d->kh - 1) * dil - 1) / d->stride + 1;
+    p.Wout = (d->win + 2 * d->pad - (d->kw - 1) * dil - 1) / d->stride + 1;
     p.Cout = d->cout;
     if (d->groups > 1) {
         VS_REQUIRE(d->c1 == 0 && d->c0 == d->cout && d->c0 % d->groups == 0 && 32 % (d->c0 / d->groups) == 0 && d->c0 % 32 == 0 &&

@@ -149,6 +149,7 @@ struct ConvParams {
     const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta;
     float* bstats_partial;               // [tiles][2][Cout]
     int brelu;
+    int dil;                             // 0 / 1 = none; 2 = dilation 2 of a stride-1 3x3 kernel (pad 2)
     int gc;                              // 0 = dense; 32 = grouped convolution on 32-channel super-groups (C0 == Cout, C1 == 0)
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
@@ -185,6 +186,7 @@ struct WgradParams {
     const void* dy; int Cout;             // [N][Hout][Wout][Cout]
     float* dw;                            // [Cout][KH*KW][Cin] fp32 (overwritten)
     float* partials; size_t partial_bytes;  // workspace
+    int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
 };

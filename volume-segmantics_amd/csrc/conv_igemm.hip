@@ -59,12 +59,14 @@ constexpr int patch_items(int pt, int stride, int nw = 4) {
     return nw == 8 ? 3 : (stride == 2 ? (pt == 2 ? 9 : 5) : (pt == 4 ? 6 : (pt == 2 ? 3 : 2)));
 }
 
-template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
+// DIL: dilation of a 3x3 kernel (1 or 2; torchvision / smp "replace stride with dilation" stages).  Dilated variants take their
+// tile geometry from the launch like the stride-2 ones and use the same staging budget (the patch is (tile + 2 DIL) wide).
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(ConvParams p, TileGeom g) {
     constexpr int NT = NW * 64;
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
     constexpr int NJ = BN / 16, KW = NTAPS == 9 ? 3 : 1;
-    constexpr int PITEMS = patch_items(PT, STRIDE, NW);
+    constexpr int PITEMS = patch_items(PT, DIL > 1 ? 2 : STRIDE, NW);
     constexpr int WROWS = NT / 4;                 // weight rows one pass of the workgroup stages
     constexpr int TS = WROWS / BN;                // taps per pass
     static_assert(WROWS % BN == 0, "cout tile must divide the rows of a staging pass");
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int lq = lane >> 4, lr = lane & 15;
     // stride-1 kernels have a compile-time tile (16 wide; 8 wide for the 64-pixel tiles of small images), so patch
     // row offsets are instruction immediates; stride-2 kernels take it from the launch
-    constexpr bool kStatic = STRIDE == 1;
+    constexpr bool kStatic = STRIDE == 1 && DIL == 1;
     constexpr int kTWS = PT == 1 ? 3 : 4, kTW = 1 << kTWS, kTH = NW * 16 * PT / kTW, kKH = NTAPS == 9 ? 3 : 1;
     const int tw_shift = kStatic ? kTWS : g.tw_shift;
     const int TW = 1 << tw_shift;
@@ -181,10 +183,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         const int pl = wave * (PT * 16) + i * 16 + lr;
         const int th = pl >> tw_shift, tw = pl & (TW - 1);
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) xb[i][kw] = swz((th * STRIDE) * PW + tw * STRIDE + kw, tw * STRIDE + kw, lq);
+        for (int kw = 0; kw < KW; ++kw) xb[i][kw] = swz((th * STRIDE) * PW + tw * STRIDE + kw * DIL, tw * STRIDE + kw * DIL, lq);
     }
     const int wbase_l = swz(lr, lr, lq);                  // (tap*BN + 16j) is a multiple of 16: it does not change the swizzle
-    const int khs = PW * kPS;
+    const int khs = DIL * PW * kPS;
 
     f32x4 acc[PT][NJ];
 #pragma unroll
@@ -588,7 +590,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && !p.bz && !p.gc && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.bz && !p.gc && p.dil <= 1 && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -637,15 +639,15 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     return VS_OK;
 }
 
-template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4>
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW>;
+    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW, DIL>;
     const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS + 64;
     VS_REQUIRE((double)p.Hin * p.Win * std::max(p.C0, p.C1) * sizeof(T) < 2.0e9 && (double)p.Cout * NTAPS * (p.C0 + p.C1) * sizeof(T) < 2.0e9,
                "conv_igemm: image or weight tensor exceeds the 32-bit staging offsets");
     VS_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS request %zu too large", lds);
-    VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, STRIDE, NW) * NW * 64, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
+    VS_REQUIRE(g.PH * g.PW * 4 <= patch_items(PT, DIL > 1 ? 2 : STRIDE, NW) * NW * 64, "conv_igemm: patch %dx%d exceeds the staging budget", g.PH, g.PW);
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -667,6 +669,9 @@ int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
 template <typename T, int BN, int PT>
 int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     const int nt = p.KH * p.KW;
+    if constexpr (BN >= 32) {
+        if (p.dil == 2) return launch_one<T, BN, PT, 9, 1, 4, 2>(p, g, s);
+    }
     if constexpr (PT == 1) {
         if (p.stride == 2) return nt == 9 ? launch_one<T, BN, 1, 9, 2>(p, g, s) : launch_one<T, BN, 1, 1, 2>(p, g, s);
     }
@@ -692,7 +697,7 @@ Pick pick_cfg(const ConvParams& p) {
     c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
     if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && !p.gc && p.Wout >= 16 && p.Hout >= 8 && vs_option("conv_s2_pt2") &&
         (long)p.N * cdiv(p.Hout, 8) * cdiv(p.Wout, 16) * cdiv(p.Cout, 64) >= vs_option("conv_min_wgs")) c.PT = 2;
-    const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.Hout >= 16 && p.Wout >= 16;
+    const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.dil <= 1 && p.Hout >= 16 && p.Wout >= 16;
     auto wgs = [&](int bn, int px) {
         const int tw = tile_tw(p, px == 64 ? 1 : 2), th = px / tw;
         return (long)p.N * cdiv(p.Hout, th) * cdiv(p.Wout, tw) * cdiv(p.Cout, bn);
@@ -715,7 +720,9 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(p.up0 != 2 || (p.C1 == 0 && !(p.Hin & 1) && !(p.Win & 1)), "conv_igemm: a zero-stuffed source has no concat partner and even dims");
     VS_REQUIRE(((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1)) && (p.stride == 1 || p.stride == 2),
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
-    VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - p.KH) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - p.KW) / p.stride + 1,
+    const int dil = p.dil > 1 ? p.dil : 1;
+    VS_REQUIRE(dil == 1 || (dil == 2 && p.KH == 3 && p.stride == 1 && p.Cout >= 32 && !p.gc && !p.pool0), "conv_igemm: dilation 2 is built for stride-1 3x3 layers of >= 32 channels");
+    VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - (p.KH - 1) * dil - 1) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - (p.KW - 1) * dil - 1) / p.stride + 1,
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && (p.out || p.scatter), "conv_igemm: null pointer");
     VS_REQUIRE(p.gc == 0 || (p.gc == 32 && p.C1 == 0 && p.C0 == p.Cout && p.Cout % 32 == 0 && !p.out1),
@@ -745,8 +752,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     g.TH = NW * 16 * PT / TW;
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
-    g.PH = (g.TH - 1) * p.stride + p.KH;
-    g.PW = (TW - 1) * p.stride + p.KW;
+    g.PH = (g.TH - 1) * p.stride + (p.KH - 1) * dil + 1;
+    g.PW = (TW - 1) * p.stride + (p.KW - 1) * dil + 1;
     g.out_nchw = out_nchw;
     g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;       // exact for x * PW < 2^32
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;

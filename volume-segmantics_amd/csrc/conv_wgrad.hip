@@ -39,12 +39,12 @@ __device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
 
 constexpr int wg_patch_items(int pt, int stride) { return stride == 2 ? 5 : (pt == 2 ? 3 : 2); }
 
-template <typename T, int WO, int NTAPS, int STRIDE, int PT>
+template <typename T, int WO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g) {
     constexpr int CK = WT<T>::CK, EPS = WT<T>::EPS, NCI = WT<T>::NCI, KSTEP = WT<T>::KSTEP;
     constexpr int WK = 4 / WO, BNO = 16 * WO, KW = NTAPS == 9 ? 3 : 1;
     constexpr int BM = 64 * PT, SEGS = BNO / EPS;      // SEGS: 16-byte segments per dy pixel row
-    constexpr int PITEMS = wg_patch_items(PT, STRIDE), DTOTAL = BM * SEGS, DITEMS = (DTOTAL + 255) / 256;
+    constexpr int PITEMS = wg_patch_items(PT, DIL > 1 ? 2 : STRIDE), DTOTAL = BM * SEGS, DITEMS = (DTOTAL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
                 const int xb = (((pb >> g.tw_shift) * STRIDE) * g.PW + (pb & (TW - 1)) * STRIDE) * kXS + coff;
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    const int toff = ((t / KW) * g.PW + (t % KW)) * kXS;
+                    const int toff = ((t / KW) * g.PW + (t % KW)) * DIL * kXS;
 #pragma unroll
                     for (int c = 0; c < NCI; ++c) {
                         const uint2 lo = ds_read_tr16(patch + xa + toff + c * 32);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
                 const int xo = (((pk >> g.tw_shift) * STRIDE) * g.PW + (pk & (TW - 1)) * STRIDE) * kXS + lr * 4;
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    const float bv = *reinterpret_cast<const float*>(patch + xo + ((t / KW) * g.PW + (t % KW)) * kXS);
+                    const float bv = *reinterpret_cast<const float*>(patch + xo + ((t / KW) * g.PW + (t % KW)) * DIL * kXS);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t][0], 0, 0, 0);
                 }
             }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
 // the next tile.
 constexpr int kXP = 64;
 
-template <int MO, int NTAPS, int STRIDE, int PT>
+template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, WGeom g) {
     constexpr int KW = NTAPS == 9 ? 3 : 1, KH = KW;
     constexpr int BM = 64 * PT, KS = BM / 32;             // pixels / k-steps per tile
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     constexpr int NSL = DYP / 32;
     constexpr int RPP = 256 / DSEG;                        // dy rows one staging pass of the workgroup covers
     constexpr int DITEMS = (BM + RPP - 1) / RPP;
-    constexpr bool kStatic = STRIDE == 1;
+    constexpr bool kStatic = STRIDE == 1 && DIL == 1;
     constexpr int kTWS = PT == 1 ? 3 : 4;
-    constexpr int PITEMS = wg_patch_items(PT, STRIDE);
+    constexpr int PITEMS = wg_patch_items(PT, DIL > 1 ? 2 : STRIDE);
     constexpr int TG = NTAPS == 9 ? 2 : 1, KG = 2 / TG;    // tap groups / K groups among the two waves of a cin slice
     constexpr int TPW = NTAPS == 9 ? 5 : 1;                // taps per wave (second group: 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     const int wt = TG == 2 ? wg2 : 0, wk = KG == 2 ? wg2 : 0;
     const int tw_shift = kStatic ? kTWS : g.tw_shift;
     const int TW = 1 << tw_shift, TH = BM >> tw_shift;
-    const int PW = (TW - 1) * STRIDE + KW, PH = (TH - 1) * STRIDE + KH;
+    const int PW = (TW - 1) * STRIDE + (KW - 1) * DIL + 1, PH = (TH - 1) * STRIDE + (KH - 1) * DIL + 1;
     const int P = PH * PW;
     const int Cin = p.C0 + p.C1;
     char* patch = smem;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
         const int row0 = ((px >> tw_shift) * STRIDE) * PW, col0 = (px & (TW - 1)) * STRIDE;
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw)
-            x_addr[h][kw] = (row0 + col0 + kw) * kXP + ((wc ^ ((col0 + kw) >> 3)) & 1) * 32 + (lr & 3) * 8;
+            x_addr[h][kw] = (row0 + col0 + kw * DIL) * kXP + ((wc ^ ((col0 + kw * DIL) >> 3)) & 1) * 32 + (lr & 3) * 8;
     }
     const int ks_rows = (32 >> tw_shift) * STRIDE * PW * kXP;            // patch bytes per k-step
 
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
                     const int t = g2 * TPW + tt;
                     if (t >= NTAPS) continue;
                     const int kh = t / KW, kw = t % KW;
-                    const uint2 lo = ds_read_tr16(patch + x_addr[0][kw] + kh * PW * kXP + ks * ks_rows);
-                    const uint2 hi = ds_read_tr16(patch + x_addr[1][kw] + kh * PW * kXP + ks * ks_rows);
+                    const uint2 lo = ds_read_tr16(patch + x_addr[0][kw] + kh * DIL * PW * kXP + ks * ks_rows);
+                    const uint2 hi = ds_read_tr16(patch + x_addr[1][kw] + kh * DIL * PW * kXP + ks * ks_rows);
                     const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
                     for (int m = 0; m < MO; ++m)
@@ -459,8 +459,10 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.PT = PT;
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
-    g.PH = (g.TH - 1) * p.stride + p.KH;
-    g.PW = (TW - 1) * p.stride + p.KW;
+    const int dil = p.dil > 1 ? p.dil : 1;
+    VS_REQUIRE(dil == 1 || (dil == 2 && p.KH == 3 && p.stride == 1 && !p.cg && !p.up0 && p.C1 == 0), "conv_wgrad: dilation 2 is built for plain stride-1 3x3 layers");
+    g.PH = (g.TH - 1) * p.stride + (p.KH - 1) * dil + 1;
+    g.PW = (TW - 1) * p.stride + (p.KW - 1) * dil + 1;
     g.cchunks = p.cg ? 32 / CK : cdiv(Cin, CK);      // grouped: cin chunks per 32-channel cout tile
     VS_REQUIRE(p.cg == 0 || (p.C1 == 0 && p.C0 == p.Cout && p.Cout % 32 == 0 && p.cg >= 4 && p.cg <= 32 && 32 % p.cg == 0 && !p.up0),
                "conv_wgrad: grouped convolutions need c0 == cout in 32-channel super-groups, 4 / 8 / 16 / 32 channels per group");
@@ -512,11 +514,11 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     return VS_OK;
 }
 
-template <int MO, int NTAPS, int STRIDE, int PT>
+template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_wgrad_bf16_kernel<MO, NTAPS, STRIDE, PT>;
-    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
+    auto kern = conv_wgrad_bf16_kernel<MO, NTAPS, STRIDE, PT, DIL>;
+    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, DIL > 1 ? 2 : STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
     constexpr int BM = 64 * PT, DYP = 32 * MO < 64 ? 64 : 32 * MO;
     size_t lds = (size_t)g.PH * g.PW * kXP + (size_t)BM * DYP + 16;
     if (NTAPS == 1) lds = std::max(lds, (size_t)2 * MO * 1024);   // K-group combine buffer
@@ -532,11 +534,11 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
-template <typename T, int WO, int NTAPS, int STRIDE, int PT>
+template <typename T, int WO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_wgrad_kernel<T, WO, NTAPS, STRIDE, PT>;
-    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
+    auto kern = conv_wgrad_kernel<T, WO, NTAPS, STRIDE, PT, DIL>;
+    VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, DIL > 1 ? 2 : STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
     const int BM = g.TH << g.tw_shift;
     size_t lds = (size_t)g.PH * g.PW * kXS + (size_t)BM * g.dys;
     if (WO < 4) lds = std::max(lds, (size_t)WO * NTAPS * WT<T>::NCI * 256 * sizeof(float));  // K-wave combine buffer
@@ -579,6 +581,11 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     }
     if constexpr (sizeof(T) == 2) {
         if (g.fast) {
+            if (p.dil == 2) {   // the dilated 3x3 layers (>= 32 channels): 64-pixel and 128-pixel tiles
+                if (WO == 4) return g.PT == 2 ? launch_fast<4, 9, 1, 2, 2>(p, g, s) : launch_fast<4, 9, 1, 1, 2>(p, g, s);
+                if (WO == 2) return g.PT == 2 ? launch_fast<2, 9, 1, 2, 2>(p, g, s) : launch_fast<2, 9, 1, 1, 2>(p, g, s);
+                return VS_ERR_UNSUPPORTED;
+            }
 #define VS_WGF_CASE(mo, t)                                                                \
     if (WO == mo && nt == t) {                                                            \
         if (p.stride == 2) return launch_fast<mo, t, 2, 1>(p, g, s);                      \
@@ -588,6 +595,11 @@ int dispatch(const WgradParams& p, hipStream_t s) {
 #undef VS_WGF_CASE
             return VS_ERR_UNSUPPORTED;
         }
+    }
+    if (p.dil == 2) {
+        if (WO == 4) return g.PT == 2 ? launch_one<T, 4, 9, 1, 2, 2>(p, g, s) : launch_one<T, 4, 9, 1, 1, 2>(p, g, s);
+        if (WO == 2) return g.PT == 2 ? launch_one<T, 2, 9, 1, 2, 2>(p, g, s) : launch_one<T, 2, 9, 1, 1, 2>(p, g, s);
+        return VS_ERR_UNSUPPORTED;
     }
 #define VS_WG_CASE(wo, t)                                                                  \
     if (WO == wo && nt == t) {                                                             \
