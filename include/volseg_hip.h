@@ -301,6 +301,20 @@ int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int
 int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
 
+/* ---- the non-dense operators of smp's DeepLabV3+ decoder (decoders/deeplabv3/decoder.py), NHWC, c a multiple of 8 --------------------
+ * vs_dwconv3x3: nn.Conv2d(c, c, 3, padding=d, dilation=d, groups=c, bias=False) - the depthwise half of SeparableConv2d; w fp32
+ *   [c][9]; flip = 1 gives the data gradient.  vs_dwconv3x3_wgrad: dw [c][9] (fp32).
+ * vs_spatial_sum / vs_broadcast_rows: nn.AdaptiveAvgPool2d(1) (scale 1 / hw) and F.interpolate of the 1x1 map back to the
+ *   feature's size in ASPPPooling - and each other's gradients.
+ * vs_dropout: element-wise nn.Dropout(p) of ASPP.project, mask = f(seed, *counter + bias, element) recomputed per call. */
+int vs_dwconv3x3(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int dilation, int flip, void* stream);
+size_t vs_dwconv3x3_wgrad_workspace(int c);
+int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int dilation, float* workspace,
+                       size_t workspace_bytes, void* stream);
+int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
+int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
+int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
+
 /* ---- RCCL behind the C ABI: the collectives of the two data-parallel splits on the caller's stream, one communicator per rank
  * (one process per GPU).  The reference has no multi-GPU path; volume-segmantics_amd/dist.py uses
  * torch.distributed by default and this transport with VOLSEG_COMM=rccl.  librccl is opened on first use (VS_ERR_UNSUPPORTED if it

@@ -808,3 +808,66 @@ def test_rccl_communicator_through_the_c_abi_single_rank():
     sync()
     assert torch.equal(g, ref) and torch.equal(keys, kref) and torch.equal(out, kref) and torch.equal(gathered, part)
     comm.close()
+
+
+# ---- the non-dense operators of smp's DeepLabV3+ decoder (csrc/dwconv.hip) ---------------------------------------------------
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1), (1, 16, 24, 304, 1), (2, 16, 16, 512, 12), (2, 8, 8, 256, 24), (1, 8, 8, 32, 36)])
+def test_depthwise_dilated_conv_fwd_dgrad_wgrad(code, shape):
+    """nn.Conv2d(c, c, 3, padding=d, dilation=d, groups=c, bias=False) - the depthwise half of smp's SeparableConv2d (ASPP rates 12 /
+    24 / 36, and rate 1 in the decoder; 304 = 256 + 48 channels after the concat) - against torch CPU."""
+    L = lib()
+    n, h, w, c, d = shape
+    g = torch.Generator().manual_seed(17)
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    wt = (torch.randn(c, 1, 3, 3, generator=g) / 3).requires_grad_()
+    y = F.conv2d(x, wt, padding=d, dilation=d, groups=c)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd, dyd, wd = to_nhwc(x.detach(), code), to_nhwc(dy, code), wt.detach().reshape(c, 9).contiguous().to(DEV)
+    yd = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    dx = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dwconv3x3(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, c, d, 0, None))
+    L.check(L.lib.vs_dwconv3x3(code, L.ptr(dyd), L.ptr(wd), L.ptr(dx), n, h, w, c, d, 1, None))
+    wsb = L.lib.vs_dwconv3x3_wgrad_workspace(c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((c, 9), float("nan"), device=DEV)
+    L.check(L.lib.vs_dwconv3x3_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, c, d, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    ref = wt.grad.reshape(c, 9)
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-3, atol=1e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_spatial_sum_broadcast_and_elementwise_dropout(code):
+    """nn.AdaptiveAvgPool2d(1) and the broadcast back over the map (ASPPPooling; each other's gradients), and element-wise
+    nn.Dropout(0.5) whose mask is a pure function of (seed, counter, element): the same call on the gradient is the backward."""
+    L = lib()
+    n, h, w, c = 3, 5, 7, 512
+    g = torch.Generator().manual_seed(2)
+    x = rounded(torch.randn(n, c, h, w, generator=g), code)
+    xd = to_nhwc(x, code)
+    pooled = torch.full((n, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_spatial_sum(code, L.ptr(xd), L.ptr(pooled), n, h * w, c, 1.0 / (h * w), None))
+    back = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_broadcast_rows(code, L.ptr(pooled), L.ptr(back), n, h * w, c, 1.0, 0, None))
+    acc = xd.clone()
+    L.check(L.lib.vs_broadcast_rows(code, L.ptr(pooled), L.ptr(acc), n, h * w, c, 2.0, 1, None))
+    sync()
+    ref = x.mean(dim=(2, 3))
+    assert torch.allclose(pooled.float().cpu(), ref, **tol(code, 1.0))
+    assert torch.allclose(from_nhwc(back), pooled.float().cpu()[:, :, None, None].expand(n, c, h, w), **tol(code, 1.0))
+    assert torch.allclose(from_nhwc(acc), x + 2 * pooled.float().cpu()[:, :, None, None], **tol(code, 4.0))
+    counter = torch.tensor([3], dtype=torch.int64, device=DEV)
+    big = torch.ones(1 << 20, device=DEV, dtype=tdtype(code))
+    outs = []
+    for bias in (0, 0, 1):
+        o = torch.empty_like(big)
+        L.check(L.lib.vs_dropout(code, L.ptr(big), L.ptr(o), big.numel(), 0.5, 77, L.ptr(counter), bias, None))
+        outs.append(o)
+    sync()
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    assert set(outs[0].float().unique().tolist()) == {0.0, 2.0}
+    assert abs((outs[0] == 0).float().mean().item() - 0.5) < 0.005

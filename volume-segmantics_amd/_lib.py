@@ -74,6 +74,12 @@ _SIGS = {
     "vs_bilinear_up_planes_bwd": (I, [P, P, I, I, I, I, P]),
     "vs_dropout2d_mask": (I, [P, I, I, C.c_float, C.c_uint32, P, C.c_int64, P]),
     "vs_channel_scale": (I, [I, P, P, P, I, C.c_int64, I, P]),
+    "vs_dwconv3x3": (I, [I, P, P, P, I, I, I, I, I, I, P]),
+    "vs_dwconv3x3_wgrad_workspace": (SZ, [I]),
+    "vs_dwconv3x3_wgrad": (I, [I, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "vs_spatial_sum": (I, [I, P, P, I, C.c_int64, I, C.c_float, P]),
+    "vs_broadcast_rows": (I, [I, P, P, I, C.c_int64, I, C.c_float, I, P]),
+    "vs_dropout": (I, [I, P, P, C.c_int64, C.c_float, C.c_uint32, P, C.c_int64, P]),
     "vs_colsum_workspace": (SZ, [I]),
     "vs_colsum": (I, [I, P, C.c_int64, I, P, P, SZ, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
