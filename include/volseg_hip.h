@@ -138,6 +138,9 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   topology 4: smp.DeepLabV3Plus (output stride 16: layer4 with dilation 2 instead of stride; ASPP with separable convolutions at
+ *   rates 12 / 24 / 36 + image pooling, Dropout(0.5), x4 bilinear, 48-channel low-level branch, separable 3x3, 1x1 head + x4
+ *   bilinear) - depths 18 / 34 / 50;
  *   topology 3: smp.FPN - biased 1x1 laterals + nearest-x2 top-down sums, Conv3x3 + GroupNorm(32) + ReLU + bilinear x2
  *   (align_corners) segmentation blocks, sum, Dropout2d(0.2), 1x1 head at 1/4 resolution + bilinear x4;
  *   topology 2: smp.Linknet - 1x1 convolution / ConvTranspose2d(4, 2, 1) / 1x1 convolution blocks, encoder features added;

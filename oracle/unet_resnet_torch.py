@@ -250,14 +250,88 @@ class FPNDecoder(nn.Module):
         return self.dropout(x)
 
 
+def replace_strides_with_dilation(module: nn.Module, dilation_rate: int) -> None:
+    """smp.encoders._utils.replace_strides_with_dilation (restated): every Conv2d of the stage gets stride 1, dilation =
+    padding-scale = dilation_rate ((k // 2) * rate of padding)."""
+    for mod in module.modules():
+        if isinstance(mod, nn.Conv2d):
+            mod.stride = (1, 1)
+            mod.dilation = (dilation_rate, dilation_rate)
+            kh, _ = mod.kernel_size
+            mod.padding = ((kh // 2) * dilation_rate, (kh // 2) * dilation_rate)
+
+
+class SeparableConv2d(nn.Sequential):
+    """smp.base.modules.SeparableConv2d: depthwise Conv2d(groups = in) then pointwise 1x1 Conv2d, no norm in between."""
+
+    def __init__(self, i, o, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__(nn.Conv2d(i, i, kernel_size, stride=stride, padding=padding, dilation=dilation, groups=i, bias=False),
+                         nn.Conv2d(i, o, 1, bias=bias))
+
+
+class DeepLabV3PlusDecoder(nn.Module):
+    """smp.DeepLabV3Plus's decoder (segmentation-models-pytorch 0.2.1, decoders/deeplabv3/decoder.py), restated: out_channels 256,
+    atrous_rates (12, 24, 36), output_stride 16.
+      aspp = Sequential(ASPP(C5, 256, rates, separable=True), SeparableConv2d(256, 256, 3, padding=1, bias=False), BatchNorm2d, ReLU)
+      ASPP.convs = [Conv1x1 + BN + ReLU, 3 x (SeparableConv2d(C5, 256, 3, padding=r, dilation=r, bias=False) + BN + ReLU),
+                    ASPPPooling = Sequential(AdaptiveAvgPool2d(1), Conv1x1, BN, ReLU) + F.interpolate(size, "bilinear",
+                    align_corners=False)]; ASPP.project = Conv1x1(5 * 256 -> 256) + BN + ReLU + Dropout(0.5)
+      up = UpsamplingBilinear2d(scale_factor=4); block1 = Conv1x1(C2 -> 48) + BN + ReLU; block2 = SeparableConv2d(304, 256, 3,
+      padding=1, bias=False) + BN + ReLU; forward: block2(cat(up(aspp(c5)), block1(c2))).
+    ``drop`` (tests): a callable replacing the Dropout(0.5) draw (the engine's mask, replayed)."""
+
+    class _Pool(nn.Sequential):
+        def __init__(self, i, o):
+            super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU())
+
+        def forward(self, x):
+            size = x.shape[-2:]
+            for mod in self:
+                x = mod(x)
+            return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+    class _ASPP(nn.Module):
+        def __init__(self, i, o, rates):
+            super().__init__()
+            mods = [nn.Sequential(nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU())]
+            mods += [nn.Sequential(SeparableConv2d(i, o, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(o), nn.ReLU()) for r in rates]
+            mods.append(DeepLabV3PlusDecoder._Pool(i, o))
+            self.convs = nn.ModuleList(mods)
+            self.project = nn.Sequential(nn.Conv2d(5 * o, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU(), nn.Dropout(0.5))
+            self.drop = None
+
+        def forward(self, x):
+            res = torch.cat([conv(x) for conv in self.convs], dim=1)
+            if self.drop is not None and self.training:
+                return self.drop(self.project[2](self.project[1](self.project[0](res))))
+            return self.project(res)
+
+    def __init__(self, encoder_channels, out_channels: int = 256, atrous_rates=(12, 24, 36)):
+        super().__init__()
+        self.aspp = nn.Sequential(DeepLabV3PlusDecoder._ASPP(encoder_channels[-1], out_channels, atrous_rates),
+                                  SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.up = nn.UpsamplingBilinear2d(scale_factor=4)
+        self.block1 = nn.Sequential(nn.Conv2d(encoder_channels[-4], 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU())
+        self.block2 = nn.Sequential(SeparableConv2d(48 + out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, feats):
+        a = self.up(self.aspp(feats[-1]))
+        h = self.block1(feats[-4])
+        return self.block2(torch.cat([a, h], dim=1))
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
-                        "fpn": FPNDecoder}[topology](OUT_CHANNELS[encoder_name])
+                        "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder}[topology](OUT_CHANNELS[encoder_name])
+        if topology == "deeplabv3plus":     # encoder_output_stride = 16: encoder.make_dilated(stage_list=[5], dilation_list=[2])
+            replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
             self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
+        elif topology == "deeplabv3plus":   # SegmentationHead(in_channels=256, out_channels=classes, kernel_size=1, upsampling=4)
+            self.segmentation_head = nn.Sequential(nn.Conv2d(256, classes, 1), nn.UpsamplingBilinear2d(scale_factor=4))
         elif topology == "fpn":       # SegmentationHead(in_channels=128, out_channels=classes, kernel_size=1, upsampling=4)
             self.segmentation_head = nn.Sequential(nn.Conv2d(128, classes, 1), nn.UpsamplingBilinear2d(scale_factor=4))
         else:

@@ -488,7 +488,8 @@ def test_stem_fwd_and_wgrad(code):
 
 
 @pytest.mark.parametrize("code", CODES)
-@pytest.mark.parametrize("c,rows_shape", [(64, (2, 16, 16)), (16, (2, 32, 32)), (512, (3, 2, 2)), (128, (1, 8, 8))])
+@pytest.mark.parametrize("c,rows_shape", [(64, (2, 16, 16)), (16, (2, 32, 32)), (512, (3, 2, 2)), (128, (1, 8, 8)),
+                                          (48, (2, 16, 16)), (304, (1, 8, 12))])      # channel counts that do not divide the block
 def test_batchnorm_train_fwd_bwd(code, c, rows_shape):
     L = lib()
     g = torch.Generator().manual_seed(10)

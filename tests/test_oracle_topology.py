@@ -143,3 +143,30 @@ def test_fpn_restatement_and_engine_table_agree():
     assert sd["segmentation_head.0.weight"].shape == (2, 128, 1, 1)
     with torch.no_grad():
         assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)
+
+
+def test_deeplabv3plus_restatement_and_engine_table_agree():
+    """smp.DeepLabV3Plus (oracle/unet_resnet_torch.py:DeepLabV3PlusDecoder, layer4 dilated by smp's replace_strides_with_dilation):
+    1,152,528 decoder parameters + a 257-parameter head on resnet34 (3-channel input, 1 class: 22,437,457 in all - the 22.4 M of
+    smp's model table), smp's key nesting (decoder.aspp.0.convs.{0..4}, .project, decoder.aspp.1 / .2, decoder.block1 / block2),
+    the engine's tensor table with the same keys / shapes in state_dict order, dilation = padding = 2 on every 3x3 of layer4."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    net = OracleUnet("resnet34", 3, 1, "deeplabv3plus")
+    assert sum(p.numel() for p in net.decoder.parameters()) == 1_152_528
+    assert sum(p.numel() for p in net.parameters()) == 22_437_457
+    convs = [m for m in net.encoder.layer4.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert all(m.stride == (1, 1) and m.dilation == (2, 2) for m in convs)
+    assert all(m.padding == ((2, 2) if m.kernel_size == (3, 3) else (0, 0)) for m in convs)
+    for name, code in (("resnet18", 4018), ("resnet34", 4034), ("resnet50", 4050)):
+        sd = OracleUnet(name, 1, 3, "deeplabv3plus").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet34", 1, 2, "deeplabv3plus").state_dict()
+    assert sd["decoder.aspp.0.convs.1.0.0.weight"].shape == (512, 1, 3, 3) and sd["decoder.aspp.0.convs.1.0.1.weight"].shape == (256, 512, 1, 1)
+    assert sd["decoder.aspp.0.convs.4.1.weight"].shape == (256, 512, 1, 1) and sd["decoder.aspp.0.project.0.weight"].shape == (256, 1280, 1, 1)
+    assert sd["decoder.block1.0.weight"].shape == (48, 64, 1, 1) and sd["decoder.block2.0.0.weight"].shape == (304, 1, 3, 3)
+    assert sd["segmentation_head.0.weight"].shape == (2, 256, 1, 1)
+    with torch.no_grad():
+        assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)

@@ -43,9 +43,15 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restric
             if (hi < 0 || hi >= h || wi < 0 || wi >= w) continue;
             float v[kVec];
             ld8(xb + ((size_t)hi * w + wi) * c, v);
-            const int tw = flip ? 8 - tap : tap;
+            const int tw = (flip & 1) ? 8 - tap : tap;
 #pragma unroll
             for (int k = 0; k < kVec; ++k) acc[k] += v[k] * wc[k * 9 + tw];
+        }
+        if (flip & 2) {       // accumulate onto y (a gradient that already holds other consumers' contributions)
+            float old[kVec];
+            ld8(y + i * kVec, old);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) acc[k] += old[k];
         }
         st8(y + i * kVec, acc);
     }
@@ -187,7 +193,7 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64
     } while (0)
 
 // nn.Conv2d(c, c, 3, padding=dilation, dilation=dilation, groups=c, bias=False) on x [n][h][w][c]; w: fp32 [c][9] (torch's [c][1][3][3]).
-// flip = 1: the data gradient (y = dx for x = dy).
+// flip: bit 0 = the data gradient (y = dx for x = dy: taps reversed), bit 1 = add to y instead of overwriting it.
 extern "C" int vs_dwconv3x3(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int dilation, int flip, void* stream) {
     VS_REQUIRE(x && w && y && c > 0 && c % kVec == 0 && dilation >= 1, "dwconv3x3: channels must be a multiple of 8, dilation >= 1");
     const int64_t total = (int64_t)n * h * wd * (c / kVec);

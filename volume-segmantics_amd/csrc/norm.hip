@@ -432,7 +432,7 @@ int stats_t(const void* x, int64_t rows, int c, float eps, float momentum, float
 int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial, int nparts, float eps, float momentum, float* mean,
                                   float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
                                   const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s) {
-    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_apply: unsupported channel count %d", c);
+    VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_apply: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     const size_t lds = 2 * (size_t)c * sizeof(float);
     if (dtype == VS_BF16)
@@ -458,7 +458,7 @@ int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t
 int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
                                 void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
                                 int nparts, hipStream_t s) {
-    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_bwd: unsupported channel count %d", c);
+    VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, partial, nparts, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
@@ -480,7 +480,7 @@ extern "C" size_t vs_bn_workspace(int64_t rows, int c) {
 extern "C" int vs_bn_stats(int dtype, const void* x, int64_t rows, int c, float eps, float momentum, float* mean,
                            float* invstd, float* running_mean, float* running_var, float* workspace,
                            size_t workspace_bytes, void* stream) {
-    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec > 256 ? 256 : c / kVec) == 0,
+    VS_REQUIRE(c % kVec == 0 && c <= 2048,
                "bn_stats: unsupported channel count %d", c);
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_stats: workspace too small");
     if (dtype == VS_BF16)
@@ -491,7 +491,7 @@ extern "C" int vs_bn_stats(int dtype, const void* x, int64_t rows, int c, float 
 extern "C" int vs_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, const void* residual, int relu, void* y, int64_t rows, int c,
                            void* stream) {
-    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_apply: unsupported channel count %d", c);
+    VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_apply: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VS_BF16)
@@ -516,7 +516,7 @@ extern "C" int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, con
                                    const float* invstd, const float* gamma, const float* beta, int relu, void* dx,
                                    void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
                                    size_t workspace_bytes, void* stream) {
-    VS_REQUIRE(c % kVec == 0 && c <= 2048 && 256 % (c / kVec) == 0, "bn_bwd: unsupported channel count %d", c);
+    VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     VS_REQUIRE(!relu || y || beta, "bn_bwd: need y or beta for the ReLU mask");
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_bwd: workspace too small");
     RowMap m = make_rowmap(rows, c);

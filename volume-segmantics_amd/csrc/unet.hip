@@ -33,6 +33,13 @@ extern "C" int vs_bilinear_up_planes(const float* x, float* y, int planes, int h
 extern "C" int vs_bilinear_up_planes_bwd(const float* dy, float* dx, int planes, int h, int w, int factor, void* stream);
 extern "C" int vs_dropout2d_mask(float* mask, int n, int c, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 extern "C" int vs_channel_scale(int dtype, const void* x, const float* mask, void* y, int n, int64_t hw, int c, void* stream);
+extern "C" int vs_dwconv3x3(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int dilation, int flip, void* stream);
+extern "C" size_t vs_dwconv3x3_wgrad_workspace(int c);
+extern "C" int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int dilation, float* workspace,
+                                  size_t workspace_bytes, void* stream);
+extern "C" int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
+extern "C" int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
+extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -52,7 +59,11 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_ADD,     // out = a(src0) + a(src1) (Linknet's skip connection, FPN's merge)
                 U_UPADD,   // out = nearest-x2 upsampling of a(src0) + a(src1) (smp FPNBlock)
                 U_BILINEAR,  // out = bilinear x2 upsampling (align_corners) of a(src0) (smp Conv3x3GNReLU(upsample=True))
-                U_DROPOUT };  // nn.Dropout2d(0.2) in training, the identity in evaluation (smp FPNDecoder.dropout)
+                U_DROPOUT,   // nn.Dropout2d(0.2) in training, the identity in evaluation (smp FPNDecoder.dropout)
+                U_DWCONV,    // depthwise 3x3 convolution, dilation = padding = dil (first half of smp's SeparableConv2d), no norm
+                U_GAP,       // nn.AdaptiveAvgPool2d(1): out [n][1][1][c]
+                U_BCAST,     // F.interpolate of a 1x1 map to hout x wout (ASPPPooling)
+                U_DROPOUT_E };  // element-wise nn.Dropout(0.5) (ASPP.project), the identity in evaluation
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -71,6 +82,8 @@ struct Unit {
     int relu = 1;
     int gn_idx = -1, gn_groups = 0;   // U_CONV followed by nn.GroupNorm(gn_groups, cout) + ReLU instead of BatchNorm (gamma at gn_idx)
     size_t off_gn = 0;                // its statistics [n][groups][2] fp32
+    int dil = 1;    // dilation of a stride-1 3x3 convolution (2: smp's replace_strides_with_dilation; any for U_DWCONV)
+    int factor = 2; // U_BILINEAR: integer scale factor
     int cg = 0;     // grouped convolution (ResNeXt): channels per group, cin0 == cout; 0 = dense.  Weights [cout][k*k][cg]; the
                     // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
@@ -180,12 +193,16 @@ int build(vs_unet* net) {
     for (int l = 0; l < 4; ++l) {
         for (int b = 0; b < blocks[l]; ++b) {
             const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(b);
-            const int stride = (b == 0 && l > 0) ? 2 : 1;
+            // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation turns layer4's stride into dilation 2 - every
+            // convolution of the stage gets stride 1, and the 3x3 ones dilation 2 / padding 2
+            const bool dilated = net->topology == 4 && l == 3;
+            const int stride = (b == 0 && l > 0 && !dilated) ? 2 : 1;
             const int oh = ch / stride, ow = cw / stride, pl = planes[l], outc = pl * expansion;
             auto conv_unit = [&](const std::string& name, const std::string& bn, int src, int cin, int cout, int k, int st, int hi, int wi,
                                  bool frozen, int cg) {
                 Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.stride = st;
                 u.hin = hi; u.win = wi; u.hout = hi / st; u.wout = wi / st; u.frozen_candidate = frozen; u.cg = cg;
+                if (dilated && k == 3) { u.dil = 2; u.pad = 2; }
                 u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cg ? cg : cin, k, k}, 0);
                 u.bn_idx = add_bn(L, bn, cout);
                 u.out = new_act(cout, hi / st, wi / st, true);
@@ -206,7 +223,7 @@ int build(vs_unet* net) {
             }
             Unit& last = us.back();
             for (size_t q = 0; q + 1 < us.size(); ++q) U.push_back(us[q]);
-            if (stride != 1 || inpl != outc) {   // "downsample" lacks "conv" in its name: not frozen by the reference's predicate
+            if (stride != 1 || inpl != outc || (dilated && b == 0)) {   // "downsample" lacks "conv" in its name: not frozen by the reference's predicate
                 Unit ud = conv_unit(pre + ".downsample.0.weight", pre + ".downsample.1", cur, inpl, outc, 1, stride, ch, cw, false, 0);
                 ud.relu = 0;
                 U.push_back(ud);
@@ -307,6 +324,75 @@ int build(vs_unet* net) {
         xin = node[0][4].out_act; xc = dec[4];
     }
     int head_k = 3, head_h = H, head_w = W;
+    if (net->topology == 4) {
+        // smp.DeepLabV3Plus (decoders/deeplabv3/decoder.py of segmentation-models-pytorch 0.2.1, restated; encoder_output_stride 16:
+        // layer4 dilated above).  aspp = Sequential(ASPP(C5, 256, rates (12, 24, 36), separable), SeparableConv2d(256, 256, 3), BN,
+        // ReLU); ASPP: convs = [1x1 conv + BN + ReLU, 3 x (SeparableConv2d(C5, 256, 3, dilation r) + BN + ReLU), AdaptiveAvgPool2d(1)
+        // + 1x1 conv + BN + ReLU + bilinear back to the map], concat, project = 1x1 conv (1280 -> 256) + BN + ReLU + Dropout(0.5);
+        // up = UpsamplingBilinear2d(4); block1 = 1x1 conv (C2 -> 48) + BN + ReLU on the stride-4 feature; concat; block2 =
+        // SeparableConv2d(304, 256, 3) + BN + ReLU; head = Conv2d(256, classes, 1) + UpsamplingBilinear2d(4).
+        // SeparableConv2d = depthwise 3x3 (dilation = padding) then pointwise 1x1, no norm in between, both without bias.
+        const int c5 = feat[5], c5c = featc[5], ah = A[feat[5]].h, aw = A[feat[5]].w;
+        auto conv_bn = [&](const std::string& wname, const std::string& bnname, int src, int cin, int cout, int hh, int ww) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = 1; u.pad = 0;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, wname, {cout, cin, 1, 1}, 0);
+            u.bn_idx = add_bn(L, bnname, cout);
+            u.out = new_act(cout, hh, ww, true);
+            U.push_back(u);
+            return u.out;
+        };
+        auto separable_bn = [&](const std::string& pre_conv, const std::string& bnname, int src, int cin, int cout, int hh, int ww, int dil) {
+            Unit d; d.kind = U_DWCONV; d.src0 = src; d.cin0 = cin; d.cout = cin; d.k = 3; d.dil = dil; d.pad = dil; d.relu = 0;
+            d.hin = hh; d.win = ww; d.hout = hh; d.wout = ww;
+            d.w_idx = (int)L.tensors.size(); add_tensor(L, pre_conv + ".0.weight", {cin, 1, 3, 3}, 0);
+            d.out = new_act(cin, hh, ww, false);
+            // the pointwise convolution's weight follows the depthwise one in the state dict, its BatchNorm after both
+            Unit u; u.kind = U_CONV; u.src0 = d.out; u.cin0 = cin; u.cout = cout; u.k = 1; u.pad = 0;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, pre_conv + ".1.weight", {cout, cin, 1, 1}, 0);
+            u.bn_idx = add_bn(L, bnname, cout);
+            u.out = new_act(cout, hh, ww, true);
+            U.push_back(d); U.push_back(u);
+            return u.out;
+        };
+        std::vector<int> branches;
+        branches.push_back(conv_bn("decoder.aspp.0.convs.0.0.weight", "decoder.aspp.0.convs.0.1", c5, c5c, 256, ah, aw));
+        const int rates[3] = {12, 24, 36};
+        for (int r = 0; r < 3; ++r) {
+            const std::string pre = "decoder.aspp.0.convs." + std::to_string(r + 1);
+            branches.push_back(separable_bn(pre + ".0", pre + ".1", c5, c5c, 256, ah, aw, rates[r]));
+        }
+        {   // ASPPPooling: Sequential(AdaptiveAvgPool2d(1), Conv2d, BatchNorm2d, ReLU) + F.interpolate(size, bilinear, align_corners=False)
+            Unit gp; gp.kind = U_GAP; gp.src0 = c5; gp.cout = c5c; gp.hin = ah; gp.win = aw; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+            gp.out = new_act(c5c, 1, 1, false);
+            U.push_back(gp);
+            const int pooled = conv_bn("decoder.aspp.0.convs.4.1.weight", "decoder.aspp.0.convs.4.2", gp.out, c5c, 256, 1, 1);
+            Unit bc; bc.kind = U_BCAST; bc.src0 = pooled; bc.cout = 256; bc.hin = 1; bc.win = 1; bc.hout = ah; bc.wout = aw; bc.relu = 0;
+            bc.out = new_act(256, ah, aw, false);
+            U.push_back(bc);
+            branches.push_back(bc.out);
+        }
+        Unit cat; cat.kind = U_CONCAT; cat.members = branches; cat.cout = 5 * 256; cat.hout = ah; cat.wout = aw; cat.relu = 0;
+        cat.out = new_act(5 * 256, ah, aw, false);
+        U.push_back(cat);
+        const int proj = conv_bn("decoder.aspp.0.project.0.weight", "decoder.aspp.0.project.1", cat.out, 5 * 256, 256, ah, aw);
+        Unit dr; dr.kind = U_DROPOUT_E; dr.src0 = proj; dr.cout = 256; dr.hout = ah; dr.wout = aw; dr.relu = 0;
+        dr.out = new_act(256, ah, aw, false);
+        U.push_back(dr);
+        const int aspp = separable_bn("decoder.aspp.1", "decoder.aspp.2", dr.out, 256, 256, ah, aw, 1);
+        Unit up; up.kind = U_BILINEAR; up.src0 = aspp; up.cout = 256; up.factor = 4; up.hin = ah; up.win = aw; up.hout = 4 * ah; up.wout = 4 * aw; up.relu = 0;
+        up.out = new_act(256, 4 * ah, 4 * aw, false);
+        U.push_back(up);
+        const Act hr = A[feat[2]];
+        const int high = conv_bn("decoder.block1.0.weight", "decoder.block1.1", feat[2], featc[2], 48, hr.h, hr.w);
+        Unit cat2; cat2.kind = U_CONCAT; cat2.members = {up.out, high}; cat2.cout = 256 + 48; cat2.hout = hr.h; cat2.wout = hr.w; cat2.relu = 0;
+        cat2.out = new_act(256 + 48, hr.h, hr.w, false);
+        U.push_back(cat2);
+        const int fused = separable_bn("decoder.block2.0", "decoder.block2.1", cat2.out, 256 + 48, 256, hr.h, hr.w, 1);
+        xin = fused; xc = 256; head_k = 1; head_h = hr.h; head_w = hr.w;
+        net->head_up = 4;
+    }
     if (net->topology == 3) {
         // smp.FPN (decoders/fpn/decoder.py of segmentation-models-pytorch 0.2.1, restated): p5 = Conv1x1(c5); p_k = nearest-x2(p_(k+1)) +
         // Conv1x1(c_k) for k = 4, 3, 2 (pyramid_channels 256, biased, no norm); seg_blocks[i] on p5, p4, p3, p2 with 3, 2, 1, 0
@@ -508,10 +594,12 @@ size_t plan_workspace(vs_unet* net) {
         p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
         p.Cout = u.kind == U_HEAD ? 16 : u.cout;
         if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
-        p.cg = u.cg;
+        p.cg = u.cg; p.dil = u.dil;
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
+    for (auto& u : net->units)
+        if (u.kind == U_DWCONV) wg = std::max(wg, vs_dwconv3x3_wgrad_workspace(u.cout));
     net->wgws_bytes = wg;
     net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
     {
@@ -570,6 +658,7 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
     p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
     p.w = c.wfwd(u); p.Cout = u.cout;
     p.gc = u.cg ? 32 : 0;
+    p.dil = u.dil;
     if (u.kind == U_CONVT) {   // its 3x3 form: same-size output, 4 * cout channels, always from the prepared copy
         p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout;
         p.w = c.ws + Ctx::wc_off(u, c.net->wset);
@@ -585,7 +674,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 3, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet) or 3 (FPN), got %d", tmp.topology);
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 4, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN) or 4 (DeepLabV3+), got %d", tmp.topology);
+    VS_REQUIRE(tmp.topology != 4 || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -639,7 +729,8 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology >= 0 && topology <= 3, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet) or 3 (FPN), got %d", topology);
+    VS_REQUIRE(topology >= 0 && topology <= 4, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN) or 4 (DeepLabV3+), got %d", topology);
+    VS_REQUIRE(topology != 4 || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -837,6 +928,31 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             }
             continue;
         }
+        case U_DWCONV: {
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_dwconv3x3(dt, c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.dil, 0, stream))) return rc;
+            continue;
+        }
+        case U_GAP: {
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cout * net->esz, c.s);
+            if ((rc = vs_spatial_sum(dt, c.a(u.src0), c.a(u.out), n, (int64_t)u.hin * u.win, u.cout, 1.f / (float)(u.hin * u.win), stream))) return rc;
+            continue;
+        }
+        case U_BCAST: {
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_broadcast_rows(dt, c.a(u.src0), c.a(u.out), n, (int64_t)u.hout * u.wout, u.cout, 1.f, 0, stream))) return rc;
+            continue;
+        }
+        case U_DROPOUT_E: {
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t elems = (int64_t)n * u.hout * u.wout * u.cout;
+            if (training) {
+                if ((rc = vs_dropout(dt, c.a(u.src0), c.a(u.out), elems, 0.5f, net->rng_seed ^ 0x5bd1e995u, net->rng_counter, 0, stream))) return rc;
+            } else {
+                if ((rc = vs_channel_slice(dt, c.a(u.src0), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, 0, stream))) return rc;
+            }
+            continue;
+        }
         case U_UPADD: {
             ProfScope prof(PK_POOL_MISC, 0, 2.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
             if ((rc = vs_upsample2x_add(dt, c.a(u.src0), c.a(u.src1), c.a(u.out), n, u.hin, u.win, u.cout, stream))) return rc;
@@ -844,7 +960,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_BILINEAR: {
             ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
-            if ((rc = vs_bilinear_up(dt, c.a(u.src0), c.a(u.out), n, u.hin, u.win, u.cout, 2, stream))) return rc;
+            if ((rc = vs_bilinear_up(dt, c.a(u.src0), c.a(u.out), n, u.hin, u.win, u.cout, u.factor, stream))) return rc;
             continue;
         }
         case U_DROPOUT: {
@@ -1157,6 +1273,12 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             return opt ? group_update(ui) : VS_OK;
         }
+        if (u.kind == U_DWCONV) {
+            ProfScope prof(PK_CONV_WGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, ws_stream);
+            if ((rc = vs_dwconv3x3_wgrad(dt, c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.dil, wgws, net->wgws_bytes,
+                                         (void*)ws_stream))) return rc;
+            return opt ? group_update(ui) : VS_OK;
+        }
         if (want_w) {
             ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
             WgradParams p{};
@@ -1164,7 +1286,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
             p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
             p.dy = dzp; p.Cout = dz_c;
-            p.cg = u.cg;
+            p.cg = u.cg; p.dil = u.dil;
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
             if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
                 p.Hout = u.hin; p.Wout = u.win;
@@ -1214,6 +1336,32 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             continue;
         }
+        if (u.kind == U_GAP) {      // every position receives the pooled gradient / hw
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of a pooled feature missing");
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hin * u.win * u.cout * net->esz, c.s);
+            if ((rc = vs_broadcast_rows(dt, c.da(u.out), c.da(u.src0), n, (int64_t)u.hin * u.win, u.cout, 1.f / (float)(u.hin * u.win),
+                                        written[u.src0] ? 1 : 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_BCAST) {    // the 1x1 map receives the sum over the positions it was copied to
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: broadcast gradient missing / its source written twice");
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_spatial_sum(dt, c.da(u.out), c.da(u.src0), n, (int64_t)u.hout * u.wout, u.cout, 1.f, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_DROPOUT_E) {
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: dropout gradient missing / its input's gradient already written");
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_dropout(dt, c.da(u.out), c.da(u.src0), (int64_t)n * u.hout * u.wout * u.cout, 0.5f, net->rng_seed ^ 0x5bd1e995u,
+                                 net->rng_counter, 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
         if (u.kind == U_UPADD) {    // the lateral addend takes the gradient as is, the upsampled one its 2x2 sums
             if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: gradient of a pyramid level missing");
@@ -1228,7 +1376,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (!do_main) continue;
             VS_REQUIRE(written[u.out], "backward: gradient of an upsampled tensor missing");
             ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
-            if ((rc = vs_bilinear_up_bwd(dt, c.da(u.out), c.da(u.src0), n, u.hin, u.win, u.cout, 2, written[u.src0] ? 1 : 0, stream))) return rc;
+            if ((rc = vs_bilinear_up_bwd(dt, c.da(u.out), c.da(u.src0), n, u.hin, u.win, u.cout, u.factor, written[u.src0] ? 1 : 0, stream))) return rc;
             written[u.src0] = 1;
             continue;
         }
@@ -1269,6 +1417,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             dzp = c.dz(u.out); dz_c = u.cout;
             if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
             if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) dzp = c.da(u.out);
+            if (u.kind == U_DWCONV) dzp = c.da(u.out);
+        } else if (u.kind == U_DWCONV) {      // no norm, no activation: dz IS the output's gradient
+            VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
+            dzp = c.da(u.out); dz_c = u.cout;
         } else if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution: dz IS the output's gradient
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hout * u.wout * u.cout * net->esz, c.s);
@@ -1320,7 +1472,11 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
         if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
-        if (u.kind != U_STEM && do_main) {
+        if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
+            ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, c.s);
+            if ((rc = vs_dwconv3x3(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.dil, 1 | (written[u.src0] ? 2 : 0), stream))) return rc;
+            written[u.src0] = 1;
+        } else if (u.kind != U_STEM && do_main) {
         // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
         ConvParams p{};
         const void* dsrc = dzp;
@@ -1336,6 +1492,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         p.stride = 1; p.pad = u.pad; p.KH = p.KW = u.k;
         p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0 + u.cin1;
         p.gc = u.cg ? 32 : 0;
+        p.dil = u.dil;
         if (u.up0) {
             // U-Net: every decoder input has this one consumer.  U-Net++: the upsampled input may already hold the contributions
             // of the nodes that read it as a dense skip - then the 2x2 sum goes through the separate, accumulating kernel.
@@ -1471,7 +1628,8 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
     const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
-                         : (u.kind == U_DROPOUT ? "dropout2d" : "maxpool")))));
+                         : (u.kind == U_DROPOUT ? "dropout2d" : (u.kind == U_GAP ? "avgpool" : (u.kind == U_BCAST ? "broadcast" : (u.kind == U_DROPOUT_E ? "dropout"
+                         : "maxpool"))))))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];
