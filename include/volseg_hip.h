@@ -138,6 +138,8 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   topology 5: smp.DeepLabV3 (output stride 8: layer3 / layer4 with dilation 2 / 4; dense dilated ASPP branches through
+ *   vs_space_to_batch; 3x3 conv; 1x1 head + x8 bilinear) - depths 18 / 34 / 50;
  *   topology 4: smp.DeepLabV3Plus (output stride 16: layer4 with dilation 2 instead of stride; ASPP with separable convolutions at
  *   rates 12 / 24 / 36 + image pooling, Dropout(0.5), x4 bilinear, 48-channel low-level branch, separable 3x3, 1x1 head + x4
  *   bilinear) - depths 18 / 34 / 50;
@@ -317,6 +319,9 @@ int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, int 
 int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
 int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
 int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
+/* space-to-batch with block r and back: y[(n r + a) r + b][i][j] = x[n][i r + a][j r + b] (zeros beyond the map) - a 3x3 convolution
+ * with dilation r / padding r on x is the plain padding-1 convolution on y (DeepLabV3's dense ASPP branches at rates 12 / 24 / 36) */
+int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 
 /* ---- RCCL behind the C ABI: the collectives of the two data-parallel splits on the caller's stream, one communicator per rank
  * (one process per GPU).  The reference has no multi-GPU path; volume-segmantics_amd/dist.py uses

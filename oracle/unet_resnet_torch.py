@@ -291,10 +291,13 @@ class DeepLabV3PlusDecoder(nn.Module):
             return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
     class _ASPP(nn.Module):
-        def __init__(self, i, o, rates):
+        def __init__(self, i, o, rates, separable=True):
             super().__init__()
             mods = [nn.Sequential(nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU())]
-            mods += [nn.Sequential(SeparableConv2d(i, o, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(o), nn.ReLU()) for r in rates]
+            if separable:      # ASPPSeparableConv
+                mods += [nn.Sequential(SeparableConv2d(i, o, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(o), nn.ReLU()) for r in rates]
+            else:              # ASPPConv: a dense dilated 3x3
+                mods += [nn.Sequential(nn.Conv2d(i, o, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(o), nn.ReLU()) for r in rates]
             mods.append(DeepLabV3PlusDecoder._Pool(i, o))
             self.convs = nn.ModuleList(mods)
             self.project = nn.Sequential(nn.Conv2d(5 * o, o, 1, bias=False), nn.BatchNorm2d(o), nn.ReLU(), nn.Dropout(0.5))
@@ -320,16 +323,33 @@ class DeepLabV3PlusDecoder(nn.Module):
         return self.block2(torch.cat([a, h], dim=1))
 
 
+class DeepLabV3Decoder(nn.Sequential):
+    """smp.DeepLabV3's decoder (decoders/deeplabv3/decoder.py, restated): Sequential(ASPP(C5, 256, (12, 24, 36)) with dense dilated 3x3
+    branches, Conv2d(256, 256, 3, padding=1, bias=False), BatchNorm2d, ReLU) on the last feature (encoder at output stride 8)."""
+
+    def __init__(self, encoder_channels, out_channels: int = 256, atrous_rates=(12, 24, 36)):
+        super().__init__(DeepLabV3PlusDecoder._ASPP(encoder_channels[-1], out_channels, atrous_rates, separable=False),
+                         nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, feats):
+        return super().forward(feats[-1])
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
-                        "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder}[topology](OUT_CHANNELS[encoder_name])
+                        "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder}[topology](OUT_CHANNELS[encoder_name])
+        if topology == "deeplabv3":         # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])
+            replace_strides_with_dilation(self.encoder.layer3, 2)
+            replace_strides_with_dilation(self.encoder.layer4, 4)
         if topology == "deeplabv3plus":     # encoder_output_stride = 16: encoder.make_dilated(stage_list=[5], dilation_list=[2])
             replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
             self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
+        elif topology == "deeplabv3":       # SegmentationHead(in_channels=256, out_channels=classes, kernel_size=1, upsampling=8)
+            self.segmentation_head = nn.Sequential(nn.Conv2d(256, classes, 1), nn.UpsamplingBilinear2d(scale_factor=8))
         elif topology == "deeplabv3plus":   # SegmentationHead(in_channels=256, out_channels=classes, kernel_size=1, upsampling=4)
             self.segmentation_head = nn.Sequential(nn.Conv2d(256, classes, 1), nn.UpsamplingBilinear2d(scale_factor=4))
         elif topology == "fpn":       # SegmentationHead(in_channels=128, out_channels=classes, kernel_size=1, upsampling=4)

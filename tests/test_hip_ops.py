@@ -872,3 +872,32 @@ def test_spatial_sum_broadcast_and_elementwise_dropout(code):
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
     assert set(outs[0].float().unique().tolist()) == {0.0, 2.0}
     assert abs((outs[0] == 0).float().mean().item() - 0.5) < 0.005
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 32, 12), (1, 32, 32, 32, 64, 24), (2, 8, 12, 64, 32, 36), (1, 20, 20, 32, 32, 3)])
+def test_dense_dilated_conv_through_space_to_batch(code, shape):
+    """nn.Conv2d(cin, cout, 3, padding=r, dilation=r) at a large rate r (DeepLabV3's ASPPConv, 12 / 24 / 36): vs_space_to_batch, the
+    plain padding-1 convolution on n r^2 small images, and the way back - against torch CPU; the round trip of the
+    rearrangement is exact."""
+    L = lib()
+    n, h, w, cin, cout, r = shape
+    g = torch.Generator().manual_seed(21)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code)
+    wt = rounded(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, code)
+    ref = F.conv2d(x, wt, padding=r, dilation=r)
+    hs, ws = -(-h // r), -(-w // r)
+    xd = to_nhwc(x, code)
+    xs = torch.full((n * r * r, hs, ws, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_space_to_batch(code, L.ptr(xd), L.ptr(xs), n, h, w, cin, r, 0, 0, None))
+    d = conv_desc(L, code, n * r * r, hs, ws, cin, cout, 3, 1, 1)
+    ys = torch.full((n * r * r, hs, ws, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    wd = w_krsc(wt, code)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xs), None, L.ptr(wd), None, None, None, L.ptr(ys), None, None))
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_space_to_batch(code, L.ptr(ys), L.ptr(y), n, h, w, cout, r, 1, 0, None))
+    back = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_space_to_batch(code, L.ptr(xs), L.ptr(back), n, h, w, cin, r, 1, 0, None))
+    sync()
+    assert torch.equal(back, xd)
+    assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))

@@ -533,17 +533,19 @@ def test_fpn_eval_and_train_vs_oracle(encoder):
     assert torch.equal(runs[0], runs[1]), encoder
 
 
-@pytest.mark.parametrize("encoder", ["resnet34", "resnet50"])
-def test_deeplabv3plus_eval_and_train_vs_oracle(encoder):
+@pytest.mark.parametrize("encoder,topo", [("resnet34", "deeplabv3plus"), ("resnet50", "deeplabv3plus"), ("resnet34", "deeplabv3"),
+                                          ("resnet50", "deeplabv3")])
+def test_deeplabv3plus_eval_and_train_vs_oracle(encoder, topo):
     """smp.DeepLabV3Plus (layer4 with dilation 2 instead of stride; ASPP = 1x1 + three separable 3x3 at rates 12 / 24 / 36 + image
     pooling, concat, 1x1 project + Dropout(0.5); separable 3x3; x4 bilinear; 48-channel 1x1 on the stride-4 feature; concat;
     separable 3x3; 1x1 head + x4 bilinear) against oracle/unet_resnet_torch.py:DeepLabV3PlusDecoder.  The element-wise dropout
-    mask is a pure function of (seed, counter, element): recomputed here with vs_dropout and replayed in the oracle."""
+    mask is a pure function of (seed, counter, element): recomputed here with vs_dropout and replayed in the oracle.
+    topo "deeplabv3" = smp.DeepLabV3: output stride 8 (layer3 dilation 2, layer4 dilation 4), DENSE dilated ASPP branches at rates
+    12 / 24 / 36 (run as plain convolutions on the space-to-batch form), 3x3 conv, 1x1 head + x8 bilinear."""
     from oracle.unet_resnet_torch import seeded_oracle_unet
     from volume_segmantics_amd import _lib as L
     from volume_segmantics_amd.data.losses import HipDiceLoss
     from volume_segmantics_amd.engine import VolSegUnet
-    topo = "deeplabv3plus"
     oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topo)
     model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topo)
     model.load_state_dict(oracle.state_dict())
@@ -554,7 +556,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder):
         ref, got = oracle(x), model(x.to(DEV)).cpu()
     assert (got - ref).abs().max().item() < 1e-3, (encoder, (got - ref).abs().max().item())
     # training: batch 4 of 128 x 128 (layer4 / ASPP at 8 x 8); dropout mask of the first training forward: counter 1
-    n, hh = 4, 128 // 16
+    n, hh = 4, 128 // (16 if topo == "deeplabv3plus" else 8)
     ones = torch.ones(n, hh, hh, 256, device=DEV)
     mask = torch.empty_like(ones)
     counter = torch.tensor([1], dtype=torch.int64, device=DEV)
@@ -563,7 +565,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder):
     mask_nchw = mask.permute(0, 3, 1, 2).contiguous().cpu()
     assert set(mask_nchw.unique().tolist()) == {0.0, 2.0}
     oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topo)
-    oracle.decoder.aspp[0].drop = lambda t_: t_ * mask_nchw
+    (oracle.decoder.aspp[0] if topo == "deeplabv3plus" else oracle.decoder[0]).drop = lambda t_: t_ * mask_nchw
     lab = (torch.rand(n, 128, 128, generator=g) > 0.6).to(torch.uint8)
     xt = torch.randn(n, 1, 128, 128, generator=g)
     _, t = P.prepare_training_batch(xt, lab, 2)
@@ -571,7 +573,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder):
     ref_loss = P.dice_loss_none(oracle(xt), t.float())
     ref_loss.backward()
     refg = dict(oracle.named_parameters())
-    for precision, ltol, gtol in (("fp32", 1e-5, 5e-3), ("bf16", 3e-2, 0.3)):      # (fp32: 3.1e-3 measured on resnet50 - BatchNorm mask flips)
+    for precision, ltol, gtol in (("fp32", 1e-5, 1e-2), ("bf16", 3e-2, 0.3)):      # (fp32: 3.1e-3 / 7.5e-3 measured on resnet50 - BatchNorm mask flips)
         model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder, topology=topo)
         model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topo).state_dict())
         model.train()
@@ -581,7 +583,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder):
         assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
         for name, p in model.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-            tight = ("segmentation_head", "decoder.block2") if precision == "fp32" else ("segmentation_head",)
+            tight = ("segmentation_head", "decoder.block2", "decoder.1.") if precision == "fp32" else ("segmentation_head",)
             if name.startswith(tight):
                 r = refg[name].grad
                 err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()

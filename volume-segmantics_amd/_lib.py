@@ -80,6 +80,7 @@ _SIGS = {
     "vs_spatial_sum": (I, [I, P, P, I, C.c_int64, I, C.c_float, P]),
     "vs_broadcast_rows": (I, [I, P, P, I, C.c_int64, I, C.c_float, I, P]),
     "vs_dropout": (I, [I, P, P, C.c_int64, C.c_float, C.c_uint32, P, C.c_int64, P]),
+    "vs_space_to_batch": (I, [I, P, P, I, I, I, I, I, I, I, P]),
     "vs_colsum_workspace": (SZ, [I]),
     "vs_colsum": (I, [I, P, C.c_int64, I, P, P, SZ, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),

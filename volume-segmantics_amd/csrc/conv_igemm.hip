@@ -671,6 +671,7 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     const int nt = p.KH * p.KW;
     if constexpr (BN >= 32) {
         if (p.dil == 2) return launch_one<T, BN, PT, 9, 1, 4, 2>(p, g, s);
+        if (p.dil == 4) return launch_one<T, BN, PT, 9, 1, 4, 4>(p, g, s);
     }
     if constexpr (PT == 1) {
         if (p.stride == 2) return nt == 9 ? launch_one<T, BN, 1, 9, 2>(p, g, s) : launch_one<T, BN, 1, 1, 2>(p, g, s);
@@ -721,7 +722,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1)) && (p.stride == 1 || p.stride == 2),
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
     const int dil = p.dil > 1 ? p.dil : 1;
-    VS_REQUIRE(dil == 1 || (dil == 2 && p.KH == 3 && p.stride == 1 && p.Cout >= 32 && !p.gc && !p.pool0), "conv_igemm: dilation 2 is built for stride-1 3x3 layers of >= 32 channels");
+    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && p.Cout >= 32 && !p.gc && !p.pool0),
+               "conv_igemm: dilation 2 / 4 is built for stride-1 3x3 layers of >= 32 channels");
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - (p.KH - 1) * dil - 1) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - (p.KW - 1) * dil - 1) / p.stride + 1,
                "conv_igemm: inconsistent output dims");
     VS_REQUIRE(p.src0 && p.w && (p.out || p.scatter), "conv_igemm: null pointer");

@@ -452,7 +452,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     VS_REQUIRE(p.C1 == 0 || p.C0 % CK == 0, "conv_wgrad: concat boundary must be a multiple of %d", CK);
     VS_REQUIRE((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1), "conv_wgrad: only 3x3 and 1x1 kernels");
     // tile: 16x8 pixels (PT = 2) for stride-1 layers at least 16 wide, else 64 pixels (8x8; stride 2: 16x4 when wide enough)
-    const int PT = (p.stride == 1 && p.Wout >= 16 && p.Hout * p.Wout >= 128) ? 2 : 1;
+    const int PT = (p.stride == 1 && p.Wout >= 16 && p.Hout * p.Wout >= 128 && p.dil < 4) ? 2 : 1;
     g.tw_shift = p.stride == 1 ? (PT == 2 ? 4 : 3) : (p.Wout >= 16 ? 4 : 3);
     const int TW = 1 << g.tw_shift;
     g.TH = 64 * PT / TW;
@@ -460,7 +460,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
     const int dil = p.dil > 1 ? p.dil : 1;
-    VS_REQUIRE(dil == 1 || (dil == 2 && p.KH == 3 && p.stride == 1 && !p.cg && !p.up0 && p.C1 == 0), "conv_wgrad: dilation 2 is built for plain stride-1 3x3 layers");
+    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && !p.cg && !p.up0 && p.C1 == 0), "conv_wgrad: dilation 2 / 4 is built for plain stride-1 3x3 layers");
     g.PH = (g.TH - 1) * p.stride + (p.KH - 1) * dil + 1;
     g.PW = (TW - 1) * p.stride + (p.KW - 1) * dil + 1;
     g.cchunks = p.cg ? 32 / CK : cdiv(Cin, CK);      // grouped: cin chunks per 32-channel cout tile
@@ -586,6 +586,11 @@ int dispatch(const WgradParams& p, hipStream_t s) {
                 if (WO == 2) return g.PT == 2 ? launch_fast<2, 9, 1, 2, 2>(p, g, s) : launch_fast<2, 9, 1, 1, 2>(p, g, s);
                 return VS_ERR_UNSUPPORTED;
             }
+            if (p.dil == 4) {   // (64-pixel tiles only: the 128-pixel tile's 24 x 16 patch exceeds the staging budget)
+                if (WO == 4) return launch_fast<4, 9, 1, 1, 4>(p, g, s);
+                if (WO == 2) return launch_fast<2, 9, 1, 1, 4>(p, g, s);
+                return VS_ERR_UNSUPPORTED;
+            }
 #define VS_WGF_CASE(mo, t)                                                                \
     if (WO == mo && nt == t) {                                                            \
         if (p.stride == 2) return launch_fast<mo, t, 2, 1>(p, g, s);                      \
@@ -599,6 +604,11 @@ int dispatch(const WgradParams& p, hipStream_t s) {
     if (p.dil == 2) {
         if (WO == 4) return g.PT == 2 ? launch_one<T, 4, 9, 1, 2, 2>(p, g, s) : launch_one<T, 4, 9, 1, 1, 2>(p, g, s);
         if (WO == 2) return g.PT == 2 ? launch_one<T, 2, 9, 1, 2, 2>(p, g, s) : launch_one<T, 2, 9, 1, 1, 2>(p, g, s);
+        return VS_ERR_UNSUPPORTED;
+    }
+    if (p.dil == 4) {
+        if (WO == 4) return launch_one<T, 4, 9, 1, 1, 4>(p, g, s);
+        if (WO == 2) return launch_one<T, 2, 9, 1, 1, 4>(p, g, s);
         return VS_ERR_UNSUPPORTED;
     }
 #define VS_WG_CASE(wo, t)                                                                  \

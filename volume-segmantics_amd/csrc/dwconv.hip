@@ -156,6 +156,52 @@ __global__ void broadcast_rows_kernel(const T* __restrict__ v, T* __restrict__ y
     }
 }
 
+// Space-to-batch with block r (the classic route to a dilated convolution through a dense one): phase (a, b) of every r x r block
+// becomes its own image, y[(n r + a) r + b][i][j][c] = x[n][i r + a][j r + b][c] (zero beyond the map: hs = ceil(h / r)); a 3x3
+// convolution with dilation r / padding r on x is the plain 3x3 / padding 1 convolution on y.  inverse = 1 gathers back (optionally
+// adding to the destination).
+template <typename T>
+__global__ void space_to_batch_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c, int r, int inverse, int accumulate) {
+    const int cv = c / kVec, hs = (h + r - 1) / r, ws = (w + r - 1) / r;
+    if (!inverse) {
+        const int64_t total = (int64_t)n * r * r * hs * ws * cv;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            int64_t t = i;
+            const int cg = t % cv; t /= cv;
+            const int j = t % ws; t /= ws;
+            const int ii = t % hs; t /= hs;
+            const int b = t % r; t /= r;
+            const int a = t % r;
+            const int64_t nb = t / r;
+            const int hh = ii * r + a, ww = j * r + b;
+            float v[kVec];
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = 0.f;
+            if (hh < h && ww < w) ld8(src + (((size_t)nb * h + hh) * w + ww) * c + cg * kVec, v);
+            st8(dst + i * kVec, v);
+        }
+    } else {
+        const int64_t total = (int64_t)n * h * w * cv;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            int64_t t = i;
+            const int cg = t % cv; t /= cv;
+            const int ww = t % w; t /= w;
+            const int hh = t % h;
+            const int64_t nb = t / h;
+            const int64_t img = (nb * r + hh % r) * r + ww % r;
+            float v[kVec];
+            ld8(src + ((img * hs + hh / r) * ws + ww / r) * c + cg * kVec, v);
+            if (accumulate) {
+                float old[kVec];
+                ld8(dst + i * kVec, old);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[k] += old[k];
+            }
+            st8(dst + i * kVec, v);
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t dmix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -243,5 +289,15 @@ extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, floa
                           void* stream) {
     VS_REQUIRE(x && y && elems >= 0 && elems % kVec == 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
     VS_LAUNCH_T(dropout_kernel, dim3(grid_for(elems / kVec)), 0, (hipStream_t)stream, (const T*)x, (T*)y, elems / kVec, p, seed, counter, bias);
+    return VS_OK;
+}
+
+// x [n][h][w][c] <-> y [n r r][ceil(h / r)][ceil(w / r)][c] (see space_to_batch_kernel); inverse = 1: src is the batch form, dst the
+// map (accumulate = 1 adds to it)
+extern "C" int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream) {
+    VS_REQUIRE(src && dst && c > 0 && c % kVec == 0 && r >= 1, "space_to_batch: channels must be a multiple of 8, block >= 1");
+    const int hs = (h + r - 1) / r, ws = (w + r - 1) / r;
+    const int64_t total = inverse ? (int64_t)n * h * w * (c / kVec) : (int64_t)n * r * r * hs * ws * (c / kVec);
+    VS_LAUNCH_T(space_to_batch_kernel, dim3(grid_for(total)), 0, (hipStream_t)stream, (const T*)src, (T*)dst, n, h, w, c, r, inverse, accumulate);
     return VS_OK;
 }

@@ -40,6 +40,7 @@ extern "C" int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, floa
 extern "C" int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
 extern "C" int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
 extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
+extern "C" int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -84,6 +85,9 @@ struct Unit {
     size_t off_gn = 0;                // its statistics [n][groups][2] fp32
     int dil = 1;    // dilation of a stride-1 3x3 convolution (2: smp's replace_strides_with_dilation; any for U_DWCONV)
     int factor = 2; // U_BILINEAR: integer scale factor
+    int s2b = 0;    // U_CONV: a 3x3 convolution with dilation = padding = s2b (DeepLabV3's dense ASPP rates 12 / 24 / 36), run as the
+                    // plain padding-1 convolution on the space-to-batch form of its input (vs_space_to_batch)
+    size_t off_xs = 0, off_dzs = 0;   // its input / output gradient in batch form (kept for the weight gradient)
     int cg = 0;     // grouped convolution (ResNeXt): channels per group, cin0 == cout; 0 = dense.  Weights [cout][k*k][cg]; the
                     // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
@@ -142,6 +146,7 @@ struct vs_unet {
     size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
     int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
+    size_t off_ys = 0;                 // scratch: a space-to-batch convolution's output (or input gradient) in batch form
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
@@ -195,14 +200,16 @@ int build(vs_unet* net) {
             const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(b);
             // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation turns layer4's stride into dilation 2 - every
             // convolution of the stage gets stride 1, and the 3x3 ones dilation 2 / padding 2
-            const bool dilated = net->topology == 4 && l == 3;
+            // DeepLabV3 (output stride 8): layer3 with dilation 2, layer4 with dilation 4
+            const int stage_dil = net->topology == 4 ? (l == 3 ? 2 : 1) : (net->topology == 5 ? (l == 2 ? 2 : (l == 3 ? 4 : 1)) : 1);
+            const bool dilated = stage_dil > 1;
             const int stride = (b == 0 && l > 0 && !dilated) ? 2 : 1;
             const int oh = ch / stride, ow = cw / stride, pl = planes[l], outc = pl * expansion;
             auto conv_unit = [&](const std::string& name, const std::string& bn, int src, int cin, int cout, int k, int st, int hi, int wi,
                                  bool frozen, int cg) {
                 Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.stride = st;
                 u.hin = hi; u.win = wi; u.hout = hi / st; u.wout = wi / st; u.frozen_candidate = frozen; u.cg = cg;
-                if (dilated && k == 3) { u.dil = 2; u.pad = 2; }
+                if (dilated && k == 3) { u.dil = stage_dil; u.pad = stage_dil; }
                 u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cg ? cg : cin, k, k}, 0);
                 u.bn_idx = add_bn(L, bn, cout);
                 u.out = new_act(cout, hi / st, wi / st, true);
@@ -324,6 +331,48 @@ int build(vs_unet* net) {
         xin = node[0][4].out_act; xc = dec[4];
     }
     int head_k = 3, head_h = H, head_w = W;
+    if (net->topology == 5) {
+        // smp.DeepLabV3 (decoders/deeplabv3/decoder.py, restated; encoder_output_stride 8): DeepLabV3Decoder = Sequential(ASPP(C5, 256,
+        // rates (12, 24, 36)), Conv2d(256, 256, 3, padding=1, bias=False), BatchNorm2d, ReLU); ASPP as in DeepLabV3+ but with DENSE
+        // dilated 3x3 branches (ASPPConv); head = Conv2d(256, classes, 1) + UpsamplingBilinear2d(8).
+        const int c5 = feat[5], c5c = featc[5], ah = A[feat[5]].h, aw = A[feat[5]].w;
+        auto conv_bn = [&](const std::string& wname, const std::string& bnname, int src, int cin, int cout, int hh, int ww, int k, int rate) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.s2b = rate;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, wname, {cout, cin, k, k}, 0);
+            u.bn_idx = add_bn(L, bnname, cout);
+            u.out = new_act(cout, hh, ww, true);
+            U.push_back(u);
+            return u.out;
+        };
+        std::vector<int> branches;
+        branches.push_back(conv_bn("decoder.0.convs.0.0.weight", "decoder.0.convs.0.1", c5, c5c, 256, ah, aw, 1, 0));
+        const int rates[3] = {12, 24, 36};
+        for (int r = 0; r < 3; ++r) {
+            const std::string pre = "decoder.0.convs." + std::to_string(r + 1);
+            branches.push_back(conv_bn(pre + ".0.weight", pre + ".1", c5, c5c, 256, ah, aw, 3, rates[r]));
+        }
+        {
+            Unit gp; gp.kind = U_GAP; gp.src0 = c5; gp.cout = c5c; gp.hin = ah; gp.win = aw; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+            gp.out = new_act(c5c, 1, 1, false);
+            U.push_back(gp);
+            const int pooled = conv_bn("decoder.0.convs.4.1.weight", "decoder.0.convs.4.2", gp.out, c5c, 256, 1, 1, 1, 0);
+            Unit bc; bc.kind = U_BCAST; bc.src0 = pooled; bc.cout = 256; bc.hin = 1; bc.win = 1; bc.hout = ah; bc.wout = aw; bc.relu = 0;
+            bc.out = new_act(256, ah, aw, false);
+            U.push_back(bc);
+            branches.push_back(bc.out);
+        }
+        Unit cat; cat.kind = U_CONCAT; cat.members = branches; cat.cout = 5 * 256; cat.hout = ah; cat.wout = aw; cat.relu = 0;
+        cat.out = new_act(5 * 256, ah, aw, false);
+        U.push_back(cat);
+        const int proj = conv_bn("decoder.0.project.0.weight", "decoder.0.project.1", cat.out, 5 * 256, 256, ah, aw, 1, 0);
+        Unit dr; dr.kind = U_DROPOUT_E; dr.src0 = proj; dr.cout = 256; dr.hout = ah; dr.wout = aw; dr.relu = 0;
+        dr.out = new_act(256, ah, aw, false);
+        U.push_back(dr);
+        const int fused = conv_bn("decoder.1.weight", "decoder.2", dr.out, 256, 256, ah, aw, 3, 0);
+        xin = fused; xc = 256; head_k = 1; head_h = ah; head_w = aw;
+        net->head_up = 8;
+    }
     if (net->topology == 4) {
         // smp.DeepLabV3Plus (decoders/deeplabv3/decoder.py of segmentation-models-pytorch 0.2.1, restated; encoder_output_stride 16:
         // layer4 dilated above).  aspp = Sequential(ASPP(C5, 256, rates (12, 24, 36), separable), SeparableConv2d(256, 256, 3), BN,
@@ -532,6 +581,16 @@ size_t plan_workspace(vs_unet* net) {
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
     net->off_ct = take(ct);    // the transposed convolutions' un-shuffled output
+    {
+        size_t ys = 0;
+        for (auto& u : net->units) {
+            if (u.kind != U_CONV || !u.s2b) continue;
+            const size_t r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
+            u.off_xs = take(N * r * r * hs * ws * u.cin0 * esz);
+            ys = std::max(ys, N * r * r * hs * ws * (size_t)std::max(u.cin0, u.cout) * esz);
+        }
+        net->off_ys = take(ys);
+    }
     {   // smp.FPN: GroupNorm statistics per unit, a scratch for the pre-norm convolution output in evaluation (training keeps z),
         // the reduction workspace, the quarter-resolution logits in front of the head's bilinear upsampling
         size_t gnz = 0, gnws = 0;
@@ -578,6 +637,11 @@ size_t plan_workspace(vs_unet* net) {
             if (u.kind == U_DROPOUT) dm = std::max(dm, N * u.cout * sizeof(float));
         net->off_dropmask = take(dm);
     }
+    for (auto& u : net->units) {
+        if (u.kind != U_CONV || !u.s2b) continue;
+        const size_t r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
+        u.off_dzs = take(N * r * r * hs * ws * u.cout * esz);
+    }
     net->ctdw_bytes = ctdw;
     net->off_ctdw = take(ctdw * vs_unet::kSide);   // dense weight gradient of a transposed convolution's 3x3 form, per side stream
     for (auto& a : net->acts) {
@@ -595,6 +659,10 @@ size_t plan_workspace(vs_unet* net) {
         p.Cout = u.kind == U_HEAD ? 16 : u.cout;
         if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
         p.cg = u.cg; p.dil = u.dil;
+        if (u.s2b) {
+            const int r = u.s2b;
+            p.N = (int)N * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
+        }
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
@@ -659,6 +727,11 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
     p.w = c.wfwd(u); p.Cout = u.cout;
     p.gc = u.cg ? 32 : 0;
     p.dil = u.dil;
+    if (u.s2b) {               // the batch form: n r^2 images of ceil(h / r) x ceil(w / r), plain padding-1 convolution
+        const int r = u.s2b;
+        p.src0 = c.ws + u.off_xs;
+        p.N = c.n * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
+    }
     if (u.kind == U_CONVT) {   // its 3x3 form: same-size output, 4 * cout channels, always from the prepared copy
         p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout;
         p.w = c.ws + Ctx::wc_off(u, c.net->wset);
@@ -674,8 +747,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 4, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN) or 4 (DeepLabV3+), got %d", tmp.topology);
-    VS_REQUIRE(tmp.topology != 4 || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 5, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+) or 5 (DeepLabV3), got %d", tmp.topology);
+    VS_REQUIRE(tmp.topology < 4 || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -729,8 +802,8 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology >= 0 && topology <= 4, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN) or 4 (DeepLabV3+), got %d", topology);
-    VS_REQUIRE(topology != 4 || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(topology >= 0 && topology <= 5, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+) or 5 (DeepLabV3), got %d", topology);
+    VS_REQUIRE(topology < 4 || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -984,6 +1057,15 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 p.out = c.a(u.out); p.shift = c.P(u.bias_idx);
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 continue;
+            }
+            if (u.s2b) {   // dense dilated convolution at a large rate: space-to-batch, plain convolution, batch-to-space
+                if ((rc = vs_space_to_batch(dt, c.a(u.src0), c.ws + u.off_xs, n, u.hin, u.win, u.cin0, u.s2b, 0, 0, stream))) return rc;
+                p.out = c.ws + net->off_ys;
+                if (!training) { p.scale = c.bnc(u, 0); p.shift = c.bnc(u, 1); p.relu = u.relu; }
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+                if ((rc = vs_space_to_batch(dt, p.out, training ? c.z(u.out) : c.a(u.out), n, u.hout, u.wout, u.cout, u.s2b, 1, 0, stream))) return rc;
+                if (!training) continue;
+                break;         // batch statistics + normalise on the map form (the batch form holds padded positions)
             }
             if (u.gn_idx >= 0) {                  // convolution + GroupNorm + ReLU (per-sample statistics: nothing folds in evaluation)
                 p.out = training ? c.z(u.out) : (void*)(c.ws + net->off_gnz);
@@ -1287,6 +1369,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
             p.dy = dzp; p.Cout = dz_c;
             p.cg = u.cg; p.dil = u.dil;
+            if (u.s2b) {
+                const int r = u.s2b;
+                p.src0 = c.ws + u.off_xs; p.N = n * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
+            }
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
             if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
                 p.Hout = u.hin; p.Wout = u.win;
@@ -1418,6 +1504,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
             if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) dzp = c.da(u.out);
             if (u.kind == U_DWCONV) dzp = c.da(u.out);
+            if (u.s2b) dzp = c.ws + u.off_dzs;
         } else if (u.kind == U_DWCONV) {      // no norm, no activation: dz IS the output's gradient
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             dzp = c.da(u.out); dz_c = u.cout;
@@ -1458,6 +1545,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                           (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             }
             dzp = c.dz(u.out); dz_c = u.cout;
+            if (u.s2b) {   // the gradient in batch form, kept for the side stream's weight gradient
+                if ((rc = vs_space_to_batch(dt, dzp, c.ws + u.off_dzs, n, u.hout, u.wout, u.cout, u.s2b, 0, 0, stream))) return rc;
+                dzp = c.ws + u.off_dzs;
+            }
             if (u.kind == U_CONVT) {
                 // the bias gradient (column sums of dz), then dz back through the pixel shuffle: the gradient of the 3x3 form's
                 // output, kept in the (now dead) da buffer of this unit - the side stream's weight gradient reads it later
@@ -1472,7 +1563,18 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
         if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
-        if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
+        if (u.s2b && do_main) {   // data gradient in batch form, then back to the map (adding to what other consumers left)
+            const int r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
+            ConvParams p{};
+            p.src0 = dzp; p.C0 = u.cout; p.N = n * r * r; p.Hin = p.Hout = hs; p.Win = p.Wout = ws; p.stride = 1; p.pad = 1; p.KH = p.KW = 3;
+            p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0; p.out = c.ws + net->off_ys;
+            {
+                ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
+                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
+            }
+            if ((rc = vs_space_to_batch(dt, p.out, c.da(u.src0), n, u.hin, u.win, u.cin0, r, 1, written[u.src0] ? 1 : 0, stream))) return rc;
+            written[u.src0] = 1;
+        } else if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
             ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, c.s);
             if ((rc = vs_dwconv3x3(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.dil, 1 | (written[u.src0] ? 2 : 0), stream))) return rc;
             written[u.src0] = 1;
