@@ -323,6 +323,26 @@ int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32
  * with dilation r / padding r on x is the plain padding-1 convolution on y (DeepLabV3's dense ASPP branches at rates 12 / 24 / 36) */
 int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 
+/* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
+ * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom
+ *   ([n][hw][C]), y = x + the product's memory reinterpreted as (n, C, h, w) exactly as smp's reshape does; sp fp32 [n][hw][hw] is
+ *   kept for bwd, which returns the gradients of the attention term w.r.t. top, center, bottom (the identity path is the caller's).
+ *   scratch: vs_pab_scratch_bytes(n, hw, C).
+ * vs_se_gate_fwd/bwd: MFAB's SE_ll / SE_hl after the average pool: a = sigmoid(W2 relu(W1 p + b1) + b2) on p [n][C]; W1 [R][C], W2
+ *   [C][R], b1, b2 fp32 (torch's 1x1 Conv2d weights); hid [n][R] fp32 carries the hidden layer to bwd (dp, dW1, db1, dW2, db2).
+ * vs_channel_gate / vs_channel_dot: x * g[n][c] over the map, and dg[n][c] = sum over positions of x * dy. */
+int vs_pab_attention_fwd(int dtype, const void* top, const void* center, const void* bottom, const void* x, void* y, float* sp, float* scratch,
+                         int n, int hw, int K, int C, void* stream);
+int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, const void* center, const void* bottom, const float* sp, void* dtop,
+                         void* dcenter, void* dbottom, float* scratch, int n, int hw, int K, int C, void* stream);
+size_t vs_pab_scratch_bytes(int n, int hw, int C);
+int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid, int n,
+                   int C, int R, void* stream);
+int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
+                   float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream);
+int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
+int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
+
 /* ---- RCCL behind the C ABI: the collectives of the two data-parallel splits on the caller's stream, one communicator per rank
  * (one process per GPU).  The reference has no multi-GPU path; volume-segmantics_amd/dist.py uses
  * torch.distributed by default and this transport with VOLSEG_COMM=rccl.  librccl is opened on first use (VS_ERR_UNSUPPORTED if it

@@ -901,3 +901,89 @@ def test_dense_dilated_conv_through_space_to_batch(code, shape):
     sync()
     assert torch.equal(back, xd)
     assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
+
+
+# ---- smp.MAnet's attention operators (csrc/manet.hip) --------------------------------------------------------------------------
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 4, 4, 64, 512), (1, 8, 8, 64, 64), (3, 2, 3, 16, 32)])
+def test_pab_attention_fwd_bwd(code, shape):
+    """smp's PAB (after its three convolutions): sp = softmax over ALL hw x hw entries of center^T top, out = sp bottom, then
+    `reshape(b, C, h, w)` of the [b][hw][C] product WITHOUT a transpose, added to x - restated in torch on NCHW tensors exactly
+    as decoders/manet/decoder.py writes it, forward and (through autograd) backward."""
+    L = lib()
+    n, h, w, K, C = shape
+    hw = h * w
+    g = torch.Generator().manual_seed(31)
+    top = rounded(torch.randn(n, K, h, w, generator=g) * 0.5, code).requires_grad_()
+    center = rounded(torch.randn(n, K, h, w, generator=g) * 0.5, code).requires_grad_()
+    bottom = rounded(torch.randn(n, C, h, w, generator=g), code).requires_grad_()
+    x = rounded(torch.randn(n, C, h, w, generator=g), code)
+    xt, xc, xb = top.flatten(2), center.flatten(2).transpose(1, 2), bottom.flatten(2).transpose(1, 2)
+    sp = torch.softmax(torch.matmul(xc, xt).view(n, -1), dim=1).view(n, hw, hw)
+    y = x + torch.matmul(sp, xb).reshape(n, C, h, w)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    td, cd, bd, xd, dyd = (to_nhwc(t_.detach(), code) for t_ in (top, center, bottom, x, dy))
+    yd = torch.full((n, h, w, C), float("nan"), device=DEV, dtype=tdtype(code))
+    spd = torch.full((n, hw, hw), float("nan"), device=DEV)
+    sb = L.lib.vs_pab_scratch_bytes(n, hw, C)
+    scr = torch.empty(sb, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.vs_pab_attention_fwd(code, L.ptr(td), L.ptr(cd), L.ptr(bd), L.ptr(xd), L.ptr(yd), L.ptr(spd), L.ptr(scr), n, hw, K, C, None))
+    dt_, dc_, db_ = (torch.full(t_.shape, float("nan"), device=DEV, dtype=tdtype(code)) for t_ in (td, cd, bd))
+    L.check(L.lib.vs_pab_attention_bwd(code, L.ptr(dyd), L.ptr(td), L.ptr(cd), L.ptr(bd), L.ptr(spd), L.ptr(dt_), L.ptr(dc_), L.ptr(db_), L.ptr(scr),
+                                       n, hw, K, C, None))
+    sync()
+    assert torch.allclose(spd.cpu(), sp.detach(), rtol=1e-3, atol=1e-6)
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    for got, ref in ((dt_, top.grad), (dc_, center.grad), (db_, bottom.grad)):
+        assert torch.allclose(from_nhwc(got), ref, **tol(code, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(4, 256, 16), (3, 64, 4), (2, 128, 8)])
+def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
+    """MFAB's squeeze-excitation: AdaptiveAvgPool2d(1) -> Conv1x1(C, C/16) -> ReLU -> Conv1x1(C/16, C) -> Sigmoid, the gate multiplied
+    onto the feature map - the pooled part (vs_spatial_sum is tested above) through vs_se_gate_*, the product and its two
+    gradients through vs_channel_gate / vs_channel_dot, against autograd."""
+    L = lib()
+    n, C, R = shape
+    h, w = 5, 6
+    g = torch.Generator().manual_seed(41)
+    x = rounded(torch.randn(n, C, h, w, generator=g), code).requires_grad_()
+    p = rounded(torch.randn(n, C, generator=g), code).requires_grad_()
+    w1 = (torch.randn(R, C, generator=g) / C ** 0.5).requires_grad_()
+    b1 = (torch.randn(R, generator=g) * 0.1).requires_grad_()
+    w2 = (torch.randn(C, R, generator=g) / R ** 0.5).requires_grad_()
+    b2 = (torch.randn(C, generator=g) * 0.1).requires_grad_()
+    a = torch.sigmoid(F.linear(F.relu(F.linear(p, w1, b1)), w2, b2))
+    y = x * a[:, :, None, None]
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    dev = lambda t_: t_.detach().contiguous().to(DEV)
+    pd = dev(p).to(tdtype(code))
+    ad = torch.full((n, C), float("nan"), device=DEV, dtype=tdtype(code))
+    hid = torch.full((n, R), float("nan"), device=DEV)
+    w1d, b1d, w2d, b2d = dev(w1), dev(b1), dev(w2), dev(b2)
+    L.check(L.lib.vs_se_gate_fwd(code, L.ptr(pd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(ad), L.ptr(hid), n, C, R, None))
+    xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
+    yd = torch.full((n, h, w, C), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_channel_gate(code, L.ptr(xd), L.ptr(ad), L.ptr(yd), n, h * w, C, None))
+    dx = torch.full_like(yd, float("nan"))
+    L.check(L.lib.vs_channel_gate(code, L.ptr(dyd), L.ptr(ad), L.ptr(dx), n, h * w, C, None))
+    da = torch.full((n, C), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_channel_dot(code, L.ptr(xd), L.ptr(dyd), L.ptr(da), n, h * w, C, None))
+    dp = torch.full((n, C), float("nan"), device=DEV, dtype=tdtype(code))
+    dw1, db1 = torch.full((R, C), float("nan"), device=DEV), torch.full((R,), float("nan"), device=DEV)
+    dw2, db2 = torch.full((C, R), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
+    L.check(L.lib.vs_se_gate_bwd(code, L.ptr(da), L.ptr(ad), L.ptr(pd), L.ptr(hid), L.ptr(w1d), L.ptr(w2d), L.ptr(dp), L.ptr(dw1), L.ptr(db1),
+                                 L.ptr(dw2), L.ptr(db2), n, C, R, None))
+    sync()
+    t = tol(code, 1.0)
+    assert torch.allclose(ad.float().cpu(), a.detach(), **t)
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    loose = dict(rtol=5e-2, atol=5e-2 * p.grad.abs().max().item()) if code else dict(rtol=1e-3, atol=1e-4 * p.grad.abs().max().item())
+    assert torch.allclose(dp.float().cpu(), p.grad, **loose)
+    for got, ref in ((dw1, w1.grad), (db1, b1.grad), (dw2, w2.grad), (db2, b2.grad)):
+        lim = (5e-2 if code else 1e-3) * ref.abs().max().item()
+        assert torch.allclose(got.cpu(), ref, rtol=5e-2 if code else 1e-3, atol=lim), (got.cpu() - ref).abs().max()

@@ -81,6 +81,13 @@ _SIGS = {
     "vs_broadcast_rows": (I, [I, P, P, I, C.c_int64, I, C.c_float, I, P]),
     "vs_dropout": (I, [I, P, P, C.c_int64, C.c_float, C.c_uint32, P, C.c_int64, P]),
     "vs_space_to_batch": (I, [I, P, P, I, I, I, I, I, I, I, P]),
+    "vs_pab_attention_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vs_pab_attention_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vs_pab_scratch_bytes": (SZ, [I, I, I]),
+    "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, P]),
+    "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vs_channel_gate": (I, [I, P, P, P, I, C.c_int64, I, P]),
+    "vs_channel_dot": (I, [I, P, P, P, I, C.c_int64, I, P]),
     "vs_colsum_workspace": (SZ, [I]),
     "vs_colsum": (I, [I, P, C.c_int64, I, P, P, SZ, P]),
     "vs_stem_fwd": (I, [I, P, P, P, P, I, P, I, I, I, P]),
