@@ -335,12 +335,83 @@ class DeepLabV3Decoder(nn.Sequential):
         return super().forward(feats[-1])
 
 
+class MAnetDecoder(nn.Module):
+    """smp.MAnet's decoder (segmentation-models-pytorch 0.2.1, decoders/manet/decoder.py), restated: decoder_channels (256, 128, 64,
+    32, 16), reduction 16, pab_channels 64.  center = PAB(C5); blocks[i] = MFAB(in, skip, out) where a skip exists, the U-Net
+    DecoderBlock for the last level.  PAB and MFAB follow smp line by line - including PAB's `reshape(b, C, h, w)` of the
+    (b, hw, C) attention product without a transpose, and the softmax over ALL hw * hw entries of a sample."""
+
+    class PAB(nn.Module):
+        def __init__(self, in_channels, pab_channels=64):
+            super().__init__()
+            self.in_channels = in_channels
+            self.top_conv = nn.Conv2d(in_channels, pab_channels, kernel_size=1)
+            self.center_conv = nn.Conv2d(in_channels, pab_channels, kernel_size=1)
+            self.bottom_conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1)
+            self.map_softmax = nn.Softmax(dim=1)
+            self.out_conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1)
+
+        def forward(self, x):
+            bsize, _, h, w = x.size()
+            x_top = self.top_conv(x).flatten(2)
+            x_center = self.center_conv(x).flatten(2).transpose(1, 2)
+            x_bottom = self.bottom_conv(x).flatten(2).transpose(1, 2)
+            sp_map = torch.matmul(x_center, x_top)
+            sp_map = self.map_softmax(sp_map.view(bsize, -1)).view(bsize, h * w, h * w)
+            sp_map = torch.matmul(sp_map, x_bottom)
+            sp_map = sp_map.reshape(bsize, self.in_channels, h, w)
+            return self.out_conv(x + sp_map)
+
+    class MFAB(nn.Module):
+        def __init__(self, in_channels, skip_channels, out_channels, reduction=16):
+            super().__init__()
+
+            def cbr(i, o, k):
+                return nn.Sequential(nn.Conv2d(i, o, k, padding=k // 2, bias=False), nn.BatchNorm2d(o), nn.ReLU(inplace=True))
+
+            def se(c):
+                r = max(1, c // reduction)
+                return nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(c, r, 1), nn.ReLU(inplace=True), nn.Conv2d(r, c, 1), nn.Sigmoid())
+
+            self.hl_conv = nn.Sequential(cbr(in_channels, in_channels, 3), cbr(in_channels, skip_channels, 1))
+            self.SE_ll = se(skip_channels)
+            self.SE_hl = se(skip_channels)
+            self.conv1 = cbr(skip_channels + skip_channels, out_channels, 3)
+            self.conv2 = cbr(out_channels, out_channels, 3)
+
+        def forward(self, x, skip=None):
+            x = self.hl_conv(x)
+            x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+            attention_hl = self.SE_hl(x)
+            if skip is not None:
+                attention_hl = attention_hl + self.SE_ll(skip)
+                x = x * attention_hl
+                x = torch.cat([x, skip], dim=1)
+            return self.conv2(self.conv1(x))
+
+    def __init__(self, encoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:][::-1])
+        ins = [enc[0]] + list(DECODER_CHANNELS[:-1])
+        skips = enc[1:] + [0]
+        self.center = MAnetDecoder.PAB(enc[0])
+        self.blocks = nn.ModuleList(MAnetDecoder.MFAB(i, s_, o) if s_ > 0 else DecoderBlock(i, s_, o) for i, s_, o in zip(ins, skips, DECODER_CHANNELS))
+
+    def forward(self, feats):
+        f = feats[1:][::-1]
+        x, skips = self.center(f[0]), f[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
-                        "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder}[topology](OUT_CHANNELS[encoder_name])
+                        "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder,
+                        "manet": MAnetDecoder}[topology](OUT_CHANNELS[encoder_name])
         if topology == "deeplabv3":         # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])
             replace_strides_with_dilation(self.encoder.layer3, 2)
             replace_strides_with_dilation(self.encoder.layer4, 4)

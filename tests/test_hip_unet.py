@@ -63,6 +63,8 @@ def _train_pair(precision, B=4, hw=64, seed=3):
 
 
 def _cos(a, b):
+    if not a.any() and not b.any():     # both exactly zero (e.g. a squeeze-excitation layer whose hidden ReLUs are all off): agreement
+        return 1.0
     return (torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-300)).item()
 
 
@@ -360,7 +362,7 @@ def test_ranged_backward_equals_one_shot_and_buckets_cover_the_flat_buffer():
 # ---- other encoders of the reference's list behind the same decoder -------------------------------
 @pytest.mark.parametrize("encoder,topology", [("resnet18", "unet"), ("resnet50", "unet"), ("resnet34", "unetplusplus"),
                                               ("resnet50", "unetplusplus"), ("resnext50_32x4d", "unet"), ("resnet34", "linknet"),
-                                              ("resnet50", "linknet")])
+                                              ("resnet50", "linknet"), ("resnet34", "manet"), ("resnet50", "manet")])
 def test_other_resnet_encoders_eval_and_train_vs_oracle(encoder, topology):
     """U_NET + resnet18 (BasicBlock x 2,2,2,2) and resnet50 (Bottleneck: 1x1 - 3x3(stride) - 1x1 x4, 1x1 shortcuts, features of
     256 .. 2048 channels) against oracle/unet_resnet_torch.py: eval logits within 1e-3 (fp32), train-mode forward / loss tight,

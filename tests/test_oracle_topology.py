@@ -192,3 +192,25 @@ def test_deeplabv3_restatement_and_engine_table_agree():
     assert sd["decoder.0.convs.1.0.weight"].shape == (256, 512, 3, 3) and sd["decoder.1.weight"].shape == (256, 256, 3, 3)
     with torch.no_grad():
         assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)
+
+
+def test_manet_restatement_and_engine_table_agree():
+    """smp.MAnet (oracle MAnetDecoder: PAB centre + four MFAB blocks + a U-Net DecoderBlock): 31,783,633 parameters on resnet34
+    (3-channel input, 1 class) = the 31.78 M of smp's model table; smp's key names (decoder.center.{top,center,bottom,out}_conv,
+    decoder.blocks.i.{hl_conv,SE_ll,SE_hl,conv1,conv2}); the engine's tensor table agrees for every encoder."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    net = OracleUnet("resnet34", 3, 1, "manet")
+    assert sum(p.numel() for p in net.parameters()) == 31_783_633
+    for name, code in (("resnet18", 6018), ("resnet34", 6034), ("resnet50", 6050), ("resnext50_32x4d", 6051)):
+        sd = OracleUnet(name, 1, 3, "manet").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet34", 1, 2, "manet").state_dict()
+    assert sd["decoder.center.top_conv.weight"].shape == (64, 512, 1, 1) and sd["decoder.center.bottom_conv.bias"].shape == (512,)
+    assert sd["decoder.blocks.0.hl_conv.1.0.weight"].shape == (256, 512, 1, 1) and sd["decoder.blocks.0.SE_ll.1.weight"].shape == (16, 256, 1, 1)
+    assert sd["decoder.blocks.3.SE_hl.3.weight"].shape == (64, 4, 1, 1) and sd["decoder.blocks.0.conv1.0.weight"].shape == (256, 512, 3, 3)
+    assert sd["decoder.blocks.4.conv1.0.weight"].shape == (16, 32, 3, 3)
+    with torch.no_grad():
+        assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)

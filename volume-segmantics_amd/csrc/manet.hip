@@ -173,7 +173,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
                                                     const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ a,
                                                     float* __restrict__ hid, int C, int R) {
-    __shared__ float ps[512], hs[64];
+    __shared__ float ps[2048], hs[128];
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += 256) ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
     __syncthreads();
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const T* __restrict__ 
                                                         const float* __restrict__ hid, const float* __restrict__ w1, const float* __restrict__ w2,
                                                         T* __restrict__ dp, float* __restrict__ dw1, float* __restrict__ db1,
                                                         float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int R) {
-    __shared__ float g2[512], ps[512], hs[64], g1[64];
+    __shared__ float g2[2048], ps[2048], hs[128], g1[128];
     const int tid = threadIdx.x;
     // this block owns every output: zero the weight gradients, then accumulate sample by sample
     for (int i = tid; i < R * C; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
@@ -316,16 +316,16 @@ extern "C" int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, 
 extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C) { return ((size_t)n * hw * C + (size_t)n * hw * hw) * sizeof(float); }
 
 // squeeze-excitation gate on pooled features (MFAB's SE_ll / SE_hl after the average pool): a = sigmoid(W2 relu(W1 p + b1) + b2);
-// hid [n][R] fp32 keeps the hidden activations for the backward pass.  C <= 512, R <= 64.
+// hid [n][R] fp32 keeps the hidden activations for the backward pass.  C <= 2048, R <= 128.
 extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
                               int n, int C, int R, void* stream) {
-    VS_REQUIRE(p && w1 && b1 && w2 && b2 && a && hid && C >= 1 && C <= 512 && R >= 1 && R <= 64, "se_gate_fwd: C <= 512, R <= 64");
+    VS_REQUIRE(p && w1 && b1 && w2 && b2 && a && hid && C >= 1 && C <= 2048 && R >= 1 && R <= 128, "se_gate_fwd: C <= 2048, R <= 128");
     VS_LAUNCH_T(se_gate_kernel, dim3(n), (hipStream_t)stream, (const T*)p, w1, b1, w2, b2, (T*)a, hid, C, R);
     return VS_OK;
 }
 extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
                               float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream) {
-    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && C <= 512 && R <= 64, "se_gate_bwd: bad arguments");
+    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && C <= 2048 && R <= 128, "se_gate_bwd: bad arguments");
     VS_LAUNCH_T(se_gate_bwd_kernel, dim3(1), (hipStream_t)stream, (const T*)da, (const T*)a, (const T*)p, hid, w1, w2, (T*)dp, dw1, db1, dw2, db2, n, C, R);
     return VS_OK;
 }

@@ -41,6 +41,17 @@ extern "C" int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t 
 extern "C" int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
 extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
 extern "C" int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
+extern "C" int vs_pab_attention_fwd(int dtype, const void* top, const void* center, const void* bottom, const void* x, void* y, float* sp,
+                                    float* scratch, int n, int hw, int K, int C, void* stream);
+extern "C" int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, const void* center, const void* bottom, const float* sp, void* dtop,
+                                    void* dcenter, void* dbottom, float* scratch, int n, int hw, int K, int C, void* stream);
+extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C);
+extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
+                              int n, int C, int R, void* stream);
+extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
+                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream);
+extern "C" int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
+extern "C" int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -64,7 +75,10 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_DWCONV,    // depthwise 3x3 convolution, dilation = padding = dil (first half of smp's SeparableConv2d), no norm
                 U_GAP,       // nn.AdaptiveAvgPool2d(1): out [n][1][1][c]
                 U_BCAST,     // F.interpolate of a 1x1 map to hout x wout (ASPPPooling)
-                U_DROPOUT_E };  // element-wise nn.Dropout(0.5) (ASPP.project), the identity in evaluation
+                U_DROPOUT_E,    // element-wise nn.Dropout(0.5) (ASPP.project), the identity in evaluation
+                U_PAB,          // smp MAnet's PAB attention: out = src0 + reinterpret(softmax_all(center top^T) bottom); members = {top, center, bottom}
+                U_SE,           // squeeze-excitation gate on a pooled [n][1][1][c] feature: tensors w_idx .. w_idx + 3 = W1, b1, W2, b2; cin1 = hidden width
+                U_CGATE };      // out = a(src0) * gate a(src1) ([n][1][1][c]) over the map
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -146,6 +160,7 @@ struct vs_unet {
     size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
     int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
+    size_t off_pab = 0, pab_bytes = 0; // scratch of the PAB attention (vs_pab_scratch_bytes)
     size_t off_ys = 0;                 // scratch: a space-to-batch convolution's output (or input gradient) in batch form
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
@@ -331,6 +346,89 @@ int build(vs_unet* net) {
         xin = node[0][4].out_act; xc = dec[4];
     }
     int head_k = 3, head_h = H, head_w = W;
+    if (net->topology == 6) {
+        // smp.MAnet (decoders/manet/decoder.py of segmentation-models-pytorch 0.2.1, restated): center = PAB(C5, pab_channels 64):
+        // top / center 1x1 convs (C5 -> 64), bottom 3x3 conv (C5 -> C5), all biased, attention (vs_pab_attention_*), out_conv 3x3
+        // (biased).  blocks[i] = MFAB(in, skip, out, reduction 16) for the four levels with a skip: hl_conv = Conv3x3(in, in) + BN +
+        // ReLU, Conv1x1(in, skip) + BN + ReLU; nearest x2; SE_hl on it, SE_ll on the skip (AdaptiveAvgPool2d(1), Conv1x1(skip,
+        // skip / 16), ReLU, Conv1x1(-> skip), Sigmoid); x * (SE_hl + SE_ll); cat skip; conv1, conv2 (3x3 + BN + ReLU);
+        // blocks[4] = U-Net's DecoderBlock(32, 0, 16).  The gate commutes with the nearest upsampling, so it is applied at the
+        // low resolution and conv1 reads up(x * gate) ++ skip through its loader, as the U-Net decoder does.
+        const int C5 = featc[5];
+        const Act fa = A[feat[5]];
+        auto plain = [&](const std::string& name, int src, int cin, int cout, int k) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.relu = 0;
+            u.hin = fa.h; u.win = fa.w; u.hout = fa.h; u.wout = fa.w;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, name + ".weight", {cout, cin, k, k}, 0);
+            u.bias_idx = (int)L.tensors.size(); add_tensor(L, name + ".bias", {cout}, 3);
+            u.out = new_act(cout, fa.h, fa.w, false);
+            U.push_back(u);
+            return u.out;
+        };
+        const int top = plain("decoder.center.top_conv", feat[5], C5, 64, 1);
+        const int cen = plain("decoder.center.center_conv", feat[5], C5, 64, 1);
+        const int bot = plain("decoder.center.bottom_conv", feat[5], C5, C5, 3);
+        Unit pab; pab.kind = U_PAB; pab.src0 = feat[5]; pab.members = {top, cen, bot}; pab.cout = C5; pab.cin0 = 64; pab.hout = fa.h; pab.wout = fa.w; pab.relu = 0;
+        pab.out = new_act(C5, fa.h, fa.w, false);
+        U.push_back(pab);
+        int x_act = plain("decoder.center.out_conv", pab.out, C5, C5, 3), x_c = C5, xh = fa.h, xw = fa.w;
+        const int decm[5] = {256, 128, 64, 32, 16};
+        const int skipa[5] = {feat[4], feat[3], feat[2], feat[1], -1};
+        const int skipcm[5] = {featc[4], featc[3], featc[2], featc[1], 0};
+        auto cbr = [&](const std::string& wname, const std::string& bnname, int src, int cin, int cout, int k, int hh, int ww) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, wname, {cout, cin, k, k}, 0);
+            u.bn_idx = add_bn(L, bnname, cout);
+            u.out = new_act(cout, hh, ww, true);
+            return u;
+        };
+        for (int i = 0; i < 5; ++i) {
+            const std::string pre = "decoder.blocks." + std::to_string(i) + ".";
+            const int S = skipcm[i], oc = decm[i];
+            int up_src = x_act, up_c = x_c;
+            if (S > 0) {
+                Unit h0 = cbr(pre + "hl_conv.0.0.weight", pre + "hl_conv.0.1", x_act, x_c, x_c, 3, xh, xw);
+                U.push_back(h0);
+                Unit h1 = cbr(pre + "hl_conv.1.0.weight", pre + "hl_conv.1.1", h0.out, x_c, S, 1, xh, xw);
+                U.push_back(h1);
+                const int R = std::max(1, S / 16);
+                auto se_tensors = [&](const std::string& nm) {
+                    const int w = (int)L.tensors.size();
+                    add_tensor(L, pre + nm + ".1.weight", {R, S, 1, 1}, 0); add_tensor(L, pre + nm + ".1.bias", {R}, 3);
+                    add_tensor(L, pre + nm + ".3.weight", {S, R, 1, 1}, 0); add_tensor(L, pre + nm + ".3.bias", {S}, 3);
+                    return w;
+                };
+                const int w_ll = se_tensors("SE_ll"), w_hl = se_tensors("SE_hl");      // registration order: ll, then hl
+                auto gate = [&](int src, int hh, int ww, int widx) {
+                    Unit gp; gp.kind = U_GAP; gp.src0 = src; gp.cout = S; gp.hin = hh; gp.win = ww; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+                    gp.out = new_act(S, 1, 1, false);
+                    U.push_back(gp);
+                    Unit se; se.kind = U_SE; se.src0 = gp.out; se.cout = S; se.cin0 = S; se.cin1 = R; se.w_idx = widx; se.hout = 1; se.wout = 1; se.relu = 0;
+                    se.out = new_act(S, 1, 1, false);
+                    U.push_back(se);
+                    return se.out;
+                };
+                const int a_hl = gate(h1.out, xh, xw, w_hl);
+                const int a_ll = gate(skipa[i], 2 * xh, 2 * xw, w_ll);
+                Unit ad; ad.kind = U_ADD; ad.src0 = a_hl; ad.src1 = a_ll; ad.cout = S; ad.hout = 1; ad.wout = 1; ad.relu = 0;
+                ad.out = new_act(S, 1, 1, false);
+                U.push_back(ad);
+                Unit cg; cg.kind = U_CGATE; cg.src0 = h1.out; cg.src1 = ad.out; cg.cout = S; cg.hout = xh; cg.wout = xw; cg.relu = 0;
+                cg.out = new_act(S, xh, xw, false);
+                U.push_back(cg);
+                up_src = cg.out; up_c = S;
+            }
+            xh *= 2; xw *= 2;
+            Unit c1 = cbr(pre + "conv1.0.weight", pre + "conv1.1", up_src, up_c + S, oc, 3, xh, xw);
+            c1.up0 = 1; c1.cin0 = up_c; c1.cin1 = S; c1.src1 = S > 0 ? skipa[i] : -1;
+            U.push_back(c1);
+            Unit c2 = cbr(pre + "conv2.0.weight", pre + "conv2.1", c1.out, oc, oc, 3, xh, xw);
+            U.push_back(c2);
+            x_act = c2.out; x_c = oc;
+        }
+        xin = x_act; xc = 16;
+    }
     if (net->topology == 5) {
         // smp.DeepLabV3 (decoders/deeplabv3/decoder.py, restated; encoder_output_stride 8): DeepLabV3Decoder = Sequential(ASPP(C5, 256,
         // rates (12, 24, 36)), Conv2d(256, 256, 3, padding=1, bias=False), BatchNorm2d, ReLU); ASPP as in DeepLabV3+ but with DENSE
@@ -582,6 +680,19 @@ size_t plan_workspace(vs_unet* net) {
     }
     net->off_ct = take(ct);    // the transposed convolutions' un-shuffled output
     {
+        size_t pab = 0;
+        for (auto& u : net->units) {
+            if (u.kind == U_PAB) {
+                const size_t hw = (size_t)u.hout * u.wout;
+                u.off_gn = take(N * hw * hw * sizeof(float));                       // the attention map, kept for the backward pass
+                pab = std::max(pab, vs_pab_scratch_bytes((int)N, (int)hw, u.cout));
+            }
+            if (u.kind == U_SE) u.off_gn = take(N * (size_t)u.cin1 * sizeof(float));   // hidden activations
+        }
+        net->pab_bytes = pab;
+        net->off_pab = take(pab);
+    }
+    {
         size_t ys = 0;
         for (auto& u : net->units) {
             if (u.kind != U_CONV || !u.s2b) continue;
@@ -747,8 +858,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 5, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+) or 5 (DeepLabV3), got %d", tmp.topology);
-    VS_REQUIRE(tmp.topology < 4 || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 6, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3) or 6 (MA-Net), got %d", tmp.topology);
+    VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -802,8 +913,8 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology >= 0 && topology <= 5, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+) or 5 (DeepLabV3), got %d", topology);
-    VS_REQUIRE(topology < 4 || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(topology >= 0 && topology <= 6, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3) or 6 (MA-Net), got %d", topology);
+    VS_REQUIRE((topology != 4 && topology != 5) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -1004,6 +1115,22 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         case U_DWCONV: {
             ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
             if ((rc = vs_dwconv3x3(dt, c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.dil, 0, stream))) return rc;
+            continue;
+        }
+        case U_PAB: {
+            ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_pab_attention_fwd(dt, c.a(u.members[0]), c.a(u.members[1]), c.a(u.members[2]), c.a(u.src0), c.a(u.out),
+                                           (float*)(c.ws + u.off_gn), (float*)(c.ws + net->off_pab), n, u.hout * u.wout, u.cin0, u.cout, stream))) return rc;
+            continue;
+        }
+        case U_SE: {
+            if ((rc = vs_se_gate_fwd(dt, c.a(u.src0), c.P(u.w_idx), c.P(u.w_idx + 1), c.P(u.w_idx + 2), c.P(u.w_idx + 3), c.a(u.out),
+                                     (float*)(c.ws + u.off_gn), n, u.cout, u.cin1, stream))) return rc;
+            continue;
+        }
+        case U_CGATE: {
+            ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_gate(dt, c.a(u.src0), c.a(u.src1), c.a(u.out), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
             continue;
         }
         case U_GAP: {
@@ -1231,6 +1358,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         const Unit& v = net->units[k];
         if (v.w_idx < 0) continue;
         if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
+        if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
@@ -1420,6 +1548,36 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(m), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, written[m], stream))) return rc;
                 written[m] = 1;
             }
+            continue;
+        }
+        if (u.kind == U_PAB) {      // identity path + the attention term's gradients w.r.t. its three convolution outputs
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.members[0]] && !written[u.members[1]] && !written[u.members[2]], "backward: PAB gradients out of order");
+            ProfScope prof(PK_POOL_MISC, 0, 6.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(u.src0), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, written[u.src0], stream))) return rc;
+            written[u.src0] = 1;
+            if ((rc = vs_pab_attention_bwd(dt, c.da(u.out), c.a(u.members[0]), c.a(u.members[1]), c.a(u.members[2]), (const float*)(c.ws + u.off_gn),
+                                           c.da(u.members[0]), c.da(u.members[1]), c.da(u.members[2]), (float*)(c.ws + net->off_pab), n,
+                                           u.hout * u.wout, u.cin0, u.cout, stream))) return rc;
+            for (int m : u.members) written[m] = 1;
+            continue;
+        }
+        if (u.kind == U_SE) {       // the gate's parameter gradients are produced here, on the caller's stream (a few hundred values)
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: SE gate gradients out of order");
+            if ((rc = vs_se_gate_bwd(dt, c.da(u.out), c.a(u.out), c.a(u.src0), (const float*)(c.ws + u.off_gn), c.P(u.w_idx), c.P(u.w_idx + 2),
+                                     c.da(u.src0), grads + c.t(u.w_idx).offset, grads + c.t(u.w_idx + 1).offset, grads + c.t(u.w_idx + 2).offset,
+                                     grads + c.t(u.w_idx + 3).offset, n, u.cout, u.cin1, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_CGATE) {    // d(input) = dy * gate, d(gate)[n][c] = sum over the map of dy * input
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0] && !written[u.src1], "backward: channel gate gradients out of order");
+            ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_dot(dt, c.a(u.src0), c.da(u.out), c.da(u.src1), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            if ((rc = vs_channel_gate(dt, c.da(u.out), c.a(u.src1), c.da(u.src0), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            written[u.src0] = 1; written[u.src1] = 1;
             continue;
         }
         if (u.kind == U_GAP) {      // every position receives the pooled gradient / hw
@@ -1731,7 +1889,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
     const Unit& u = net->units[unit];
     const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
                          : (u.kind == U_DROPOUT ? "dropout2d" : (u.kind == U_GAP ? "avgpool" : (u.kind == U_BCAST ? "broadcast" : (u.kind == U_DROPOUT_E ? "dropout"
-                         : "maxpool"))))))));
+                         : (u.kind == U_PAB ? "pab attention" : (u.kind == U_CGATE ? "channel gate" : "maxpool"))))))))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];
