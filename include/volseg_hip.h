@@ -345,6 +345,32 @@ int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, cons
 int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 
+/* ---- smp.PAN's Feature Pyramid Attention (decoders/pan/decoder.py: FPABlock) and the GAU gates, NHWC ----------------------------------
+ * vs_maxpool2x2(_bwd): nn.MaxPool2d(2, 2) on all channels (the gradient goes to the first maximum in scan order).
+ * vs_conv_to_plane(_bwd): a k x k convolution (padding k / 2, biased) from c channels to ONE: z fp32 [n][h][w]; w fp32 [k*k][c].
+ * vs_fpa_pyramid_fwd/_bwd: everything between down1's convolution output z1 [n][h/2][w/2] (the caller writes it at the start of the
+ *   arena) and the block's attention plane [n][h][w] - six single-channel ConvBnRelu layers (7x7, 5x5, 3x3), two max-pools, three
+ *   bilinear (align_corners) upsamplings, in ONE workgroup; the arena (vs_fpa_arena_floats) keeps every intermediate for bwd, which
+ *   leaves d z1 at arena[vs_fpa_dz1_offset] and the 6 x {dw, db, dgamma, dbeta} where `grads` points.  params / grads: HOST arrays
+ *   of device pointers, 6 x {conv weight, conv bias, gamma, beta, running mean, running var} / 6 x {dw, db, dgamma, dbeta}; layer 0
+ *   is the BatchNorm behind vs_conv_to_plane (its weight / bias slots are unused).
+ * vs_fpa_combine(_bwd): out = plane * mid + b1 (b1 [n][c] broadcast).  vs_sigmoid(_bwd): GAU's gate.  vs_bn_fold_bias: shift +=
+ *   scale * bias for a biased convolution in front of an evaluation-mode BatchNorm (smp's ConvBnRelu keeps the bias). */
+int vs_maxpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+int vs_maxpool2x2_bwd(int dtype, const void* x, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, void* stream);
+int vs_conv_to_plane(int dtype, const void* x, const float* w, const float* bias, float* z, int n, int h, int wd, int c, int k, void* stream);
+int vs_conv_to_plane_bwd(int dtype, const void* x, const float* w, const float* dz, void* dx, float* dw, float* db, int n, int h, int wd, int c,
+                         int k, void* stream);
+size_t vs_fpa_arena_floats(int n, int h, int w);
+size_t vs_fpa_dz1_offset(int n, int h, int w);
+int vs_fpa_pyramid_fwd(float* arena, float* plane, float* const* params, int n, int h, int w, int training, void* stream);
+int vs_fpa_pyramid_bwd(float* arena, const float* dplane, float* const* params, float* const* grads, int n, int h, int w, void* stream);
+int vs_fpa_combine(int dtype, const float* plane, const void* mid, const void* b1, void* out, int n, int64_t hw, int c, void* stream);
+int vs_fpa_combine_bwd(int dtype, const void* dy, const float* plane, const void* mid, void* dmid, float* dplane, int n, int64_t hw, int c, void* stream);
+int vs_sigmoid(int dtype, const void* x, void* y, int64_t elems, void* stream);
+int vs_sigmoid_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t elems, void* stream);
+int vs_bn_fold_bias(const float* scale, const float* bias, float* shift, int c, void* stream);
+
 /* ---- RCCL behind the C ABI: the collectives of the two data-parallel splits on the caller's stream, one communicator per rank
  * (one process per GPU).  The reference has no multi-GPU path; volume-segmantics_amd/dist.py uses
  * torch.distributed by default and this transport with VOLSEG_COMM=rccl.  librccl is opened on first use (VS_ERR_UNSUPPORTED if it

@@ -987,3 +987,96 @@ def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
     for got, ref in ((dw1, w1.grad), (db1, b1.grad), (dw2, w2.grad), (db2, b2.grad)):
         lim = (5e-2 if code else 1e-3) * ref.abs().max().item()
         assert torch.allclose(got.cpu(), ref, rtol=5e-2 if code else 1e-3, atol=lim), (got.cpu() - ref).abs().max()
+
+
+# ---- smp.PAN's Feature Pyramid Attention (csrc/pan.hip) -------------------------------------------------------------------------
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 16, 32)])
+def test_fpa_pyramid_fwd_bwd(code, shape):
+    """The single-channel pyramid of smp's FPABlock, restated in torch as decoders/pan/decoder.py writes it (MaxPool2d(2, 2), ConvBnRelu
+    with 7x7 / 5x5 / 3x3 kernels - biased convolution, train-mode BatchNorm, ReLU -, bilinear align_corners upsamplings, the two
+    additions), from the bottleneck feature to the attention plane and the final x * mid + b1: vs_maxpool2x2, vs_conv_to_plane,
+    vs_fpa_pyramid_fwd / _bwd (one workgroup), vs_fpa_combine - outputs, running statistics, every parameter gradient and the
+    input gradient against autograd."""
+    import ctypes
+    L = lib()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(51)
+    torch.manual_seed(51)
+
+    def cbr(i, o, k):
+        m = torch.nn.Sequential(torch.nn.Conv2d(i, o, k, padding=k // 2), torch.nn.BatchNorm2d(o), torch.nn.ReLU())
+        with torch.no_grad():
+            m[1].weight.copy_(torch.rand(o) + 0.5); m[1].bias.copy_(torch.randn(o) * 0.2)
+            if i == 1:
+                m[0].weight.mul_(3.0)
+        return m
+    down1, down2, d31, d32, conv2, conv1 = cbr(c, 1, 7), cbr(1, 1, 5), cbr(1, 1, 3), cbr(1, 1, 3), cbr(1, 1, 5), cbr(1, 1, 7)
+    layers = [down1, down2, d31, d32, conv2, conv1]
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    mid = rounded(torch.randn(n, 32, h, w, generator=g), code).requires_grad_()
+    b1 = rounded(torch.randn(n, 32, generator=g), code).requires_grad_()
+    up = lambda t_, s_: F.interpolate(t_, size=s_, mode="bilinear", align_corners=True)
+    pool = torch.nn.MaxPool2d(2, 2)
+    x1 = down1(pool(x)); x2 = down2(pool(x1)); x3 = d32(d31(pool(x2)))
+    s = conv2(x2) + up(x3, (h // 4, w // 4))
+    s = up(s, (h // 2, w // 2)) + conv1(x1)
+    plane = up(s, (h, w))
+    out = plane * mid + b1[:, :, None, None]
+    dy = rounded(torch.randn(out.shape, generator=g), code)
+    out.backward(dy)
+    # ---- device ----
+    xd, midd, dyd = to_nhwc(x.detach(), code), to_nhwc(mid.detach(), code), to_nhwc(dy, code)
+    b1d = b1.detach().to(DEV, tdtype(code)).contiguous()
+    pooled = torch.full((n, h // 2, w // 2, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_maxpool2x2(code, L.ptr(xd), L.ptr(pooled), n, h, w, c, None))
+    arena = torch.zeros(L.lib.vs_fpa_arena_floats(n, h, w), device=DEV)
+    w7 = down1[0].weight.detach().permute(0, 2, 3, 1).reshape(49, c).contiguous().to(DEV)
+    b7 = down1[0].bias.detach().to(DEV)
+    L.check(L.lib.vs_conv_to_plane(code, L.ptr(pooled), L.ptr(w7), L.ptr(b7), L.ptr(arena), n, h // 2, w // 2, c, 7, None))
+    keep, ptrs = [], []
+    for i, m in enumerate(layers):
+        ts = [m[0].weight.detach().reshape(-1) if i else torch.zeros(1), m[0].bias.detach() if i else torch.zeros(1), m[1].weight.detach(),
+              m[1].bias.detach(), torch.zeros(1), torch.ones(1)]
+        for t_ in ts:
+            d_ = t_.clone().contiguous().to(DEV); keep.append(d_); ptrs.append(L.ptr(d_))
+    params = (ctypes.c_void_p * 36)(*ptrs)
+    planed = torch.full((n, h, w), float("nan"), device=DEV)
+    L.check(L.lib.vs_fpa_pyramid_fwd(L.ptr(arena), L.ptr(planed), params, n, h, w, 1, None))
+    outd = torch.full((n, h, w, 32), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_fpa_combine(code, L.ptr(planed), L.ptr(midd), L.ptr(b1d), L.ptr(outd), n, h * w, 32, None))
+    dmid = torch.full_like(outd, float("nan"))
+    dplane = torch.full((n, h, w), float("nan"), device=DEV)
+    L.check(L.lib.vs_fpa_combine_bwd(code, L.ptr(dyd), L.ptr(planed), L.ptr(midd), L.ptr(dmid), L.ptr(dplane), n, h * w, 32, None))
+    gkeep, gptrs = [], []
+    for i, m in enumerate(layers):
+        for numel in (m[0].weight.numel() if i else 1, 1, 1, 1):
+            d_ = torch.full((numel,), float("nan"), device=DEV); gkeep.append(d_); gptrs.append(L.ptr(d_))
+    grads = (ctypes.c_void_p * 24)(*gptrs)
+    L.check(L.lib.vs_fpa_pyramid_bwd(L.ptr(arena), L.ptr(dplane), params, grads, n, h, w, None))
+    dz1 = arena[L.lib.vs_fpa_dz1_offset(n, h, w):][: n * (h // 2) * (w // 2)]
+    dpool = torch.full_like(pooled, float("nan"))
+    dw7, db7 = torch.full((49, c), float("nan"), device=DEV), torch.full((1,), float("nan"), device=DEV)
+    L.check(L.lib.vs_conv_to_plane_bwd(code, L.ptr(pooled), L.ptr(w7), L.ptr(dz1), L.ptr(dpool), L.ptr(dw7), L.ptr(db7), n, h // 2, w // 2, c, 7, None))
+    dx = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_maxpool2x2_bwd(code, L.ptr(xd), L.ptr(dpool), L.ptr(dx), n, h, w, c, 0, None))
+    sync()
+    tl = dict(rtol=2e-3, atol=2e-3) if code == 0 else dict(rtol=3e-2, atol=3e-2)
+    assert torch.allclose(planed.cpu(), plane.detach()[:, 0], **tl), (planed.cpu() - plane.detach()[:, 0]).abs().max()
+    assert torch.allclose(from_nhwc(outd), out.detach(), **tol(code, out.abs().max().item() * 4))
+    assert torch.allclose(from_nhwc(dmid), mid.grad, **tol(code, mid.grad.abs().max().item() * 4))
+    for i, m in enumerate(layers):        # running statistics and parameter gradients
+        assert torch.allclose(keep[6 * i + 4].cpu(), m[1].running_mean, rtol=1e-3, atol=1e-4), i
+        assert torch.allclose(keep[6 * i + 5].cpu(), m[1].running_var, rtol=1e-3, atol=1e-4), i
+        refs = [m[0].weight.grad.reshape(-1) if i else None, m[0].bias.grad if i else None, m[1].weight.grad, m[1].bias.grad]
+        for j, r in enumerate(refs):
+            if r is None:
+                continue
+            lim = (3e-3 if code == 0 else 6e-2) * max(r.abs().max().item(), 1e-3)
+            if j == 1:      # a bias in front of a train-mode BatchNorm: its gradient is zero in exact arithmetic, noise in fp32
+                lim = 1e-3
+            assert torch.allclose(gkeep[4 * i + j].cpu(), r, rtol=3e-3 if code == 0 else 6e-2, atol=lim), (i, j, gkeep[4 * i + j].cpu(), r)
+    r7 = down1[0].weight.grad.permute(0, 2, 3, 1).reshape(49, c)
+    lim = (3e-3 if code == 0 else 6e-2)
+    assert torch.allclose(dw7.cpu(), r7, rtol=lim, atol=lim * r7.abs().max().item())
+    assert torch.allclose(from_nhwc(dx), x.grad, rtol=lim, atol=lim * x.grad.abs().max().item())

@@ -81,6 +81,19 @@ _SIGS = {
     "vs_broadcast_rows": (I, [I, P, P, I, C.c_int64, I, C.c_float, I, P]),
     "vs_dropout": (I, [I, P, P, C.c_int64, C.c_float, C.c_uint32, P, C.c_int64, P]),
     "vs_space_to_batch": (I, [I, P, P, I, I, I, I, I, I, I, P]),
+    "vs_maxpool2x2": (I, [I, P, P, I, I, I, I, P]),
+    "vs_maxpool2x2_bwd": (I, [I, P, P, P, I, I, I, I, I, P]),
+    "vs_conv_to_plane": (I, [I, P, P, P, P, I, I, I, I, I, P]),
+    "vs_conv_to_plane_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "vs_fpa_arena_floats": (SZ, [I, I, I]),
+    "vs_fpa_dz1_offset": (SZ, [I, I, I]),
+    "vs_fpa_pyramid_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "vs_fpa_pyramid_bwd": (I, [P, P, P, P, I, I, I, P]),
+    "vs_fpa_combine": (I, [I, P, P, P, P, I, C.c_int64, I, P]),
+    "vs_fpa_combine_bwd": (I, [I, P, P, P, P, P, I, C.c_int64, I, P]),
+    "vs_sigmoid": (I, [I, P, P, C.c_int64, P]),
+    "vs_sigmoid_bwd": (I, [I, P, P, P, C.c_int64, P]),
+    "vs_bn_fold_bias": (I, [P, P, P, I, P]),
     "vs_pab_attention_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_pab_attention_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_pab_scratch_bytes": (SZ, [I, I, I]),
