@@ -138,6 +138,8 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   topology 7: smp.PAN (layer4 dilated; FPABlock with its single-channel 7x7 / 5x5 / 3x3 pyramid, three GAUBlocks, 3x3 head at 1/4
+ *   resolution + x4 bilinear; slices must be multiples of 128) - depths 18 / 34 / 50;
  *   topology 6: smp.MAnet (PAB position attention at the deepest level, four MFAB blocks with squeeze-excitation gates on skip and
  *   input, a U-Net decoder block, 3x3 head);
  *   topology 5: smp.DeepLabV3 (output stride 8: layer3 / layer4 with dilation 2 / 4; dense dilated ASPP branches through

@@ -405,13 +405,82 @@ class MAnetDecoder(nn.Module):
         return x
 
 
+class PANDecoder(nn.Module):
+    """smp.PAN's decoder (segmentation-models-pytorch 0.2.1, decoders/pan/decoder.py), restated: decoder_channels 32, upscale_mode
+    "bilinear" (align_corners=True).  ConvBnRelu = Conv2d (WITH bias) + BatchNorm2d (+ ReLU); FPABlock on the last feature, GAUBlock
+    on the three before it."""
+
+    class ConvBnRelu(nn.Module):
+        def __init__(self, i, o, k, padding=0, add_relu=True):
+            super().__init__()
+            self.conv = nn.Conv2d(i, o, k, padding=padding)
+            self.bn = nn.BatchNorm2d(o)
+            self.add_relu = add_relu
+
+        def forward(self, x):
+            x = self.bn(self.conv(x))
+            return torch.relu(x) if self.add_relu else x
+
+    class FPABlock(nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            C = PANDecoder.ConvBnRelu
+            self.branch1 = nn.Sequential(nn.AdaptiveAvgPool2d(1), C(i, o, 1))
+            self.mid = nn.Sequential(C(i, o, 1))
+            self.down1 = nn.Sequential(nn.MaxPool2d(2, 2), C(i, 1, 7, padding=3))
+            self.down2 = nn.Sequential(nn.MaxPool2d(2, 2), C(1, 1, 5, padding=2))
+            self.down3 = nn.Sequential(nn.MaxPool2d(2, 2), C(1, 1, 3, padding=1), C(1, 1, 3, padding=1))
+            self.conv2 = C(1, 1, 5, padding=2)
+            self.conv1 = C(1, 1, 7, padding=3)
+
+        def forward(self, x):
+            h, w = x.size(2), x.size(3)
+            up = dict(mode="bilinear", align_corners=True)
+            F_ = torch.nn.functional
+            b1 = F_.interpolate(self.branch1(x), size=(h, w), **up)
+            mid = self.mid(x)
+            x1 = self.down1(x); x2 = self.down2(x1); x3 = self.down3(x2)
+            x3 = F_.interpolate(x3, size=(h // 4, w // 4), **up)
+            x = self.conv2(x2) + x3
+            x = F_.interpolate(x, size=(h // 2, w // 2), **up)
+            x = x + self.conv1(x1)
+            x = F_.interpolate(x, size=(h, w), **up)
+            return torch.mul(x, mid) + b1
+
+    class GAUBlock(nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            C = PANDecoder.ConvBnRelu
+            self.conv1 = nn.Sequential(nn.AdaptiveAvgPool2d(1), C(o, o, 1, add_relu=False), nn.Sigmoid())
+            self.conv2 = C(i, o, 3, padding=1)
+
+        def forward(self, x, y):
+            y_up = torch.nn.functional.interpolate(y, size=(x.size(2), x.size(3)), mode="bilinear", align_corners=True)
+            return y_up + torch.mul(self.conv2(x), self.conv1(y))
+
+    def __init__(self, encoder_channels, decoder_channels: int = 32):
+        super().__init__()
+        self.fpa = PANDecoder.FPABlock(encoder_channels[-1], decoder_channels)
+        self.gau3 = PANDecoder.GAUBlock(encoder_channels[-2], decoder_channels)
+        self.gau2 = PANDecoder.GAUBlock(encoder_channels[-3], decoder_channels)
+        self.gau1 = PANDecoder.GAUBlock(encoder_channels[-4], decoder_channels)
+
+    def forward(self, feats):
+        x5 = self.fpa(feats[-1])
+        x4 = self.gau3(feats[-2], x5)
+        x3 = self.gau2(feats[-3], x4)
+        return self.gau1(feats[-4], x3)
+
+
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         self.encoder = ResNetEncoder(encoder_name, in_channels)
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
                         "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder,
-                        "manet": MAnetDecoder}[topology](OUT_CHANNELS[encoder_name])
+                        "manet": MAnetDecoder, "pan": PANDecoder}[topology](OUT_CHANNELS[encoder_name])
+        if topology == "pan":               # encoder_dilation=True: make_dilated(stage_list=[5], dilation_list=[2])
+            replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "deeplabv3":         # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])
             replace_strides_with_dilation(self.encoder.layer3, 2)
             replace_strides_with_dilation(self.encoder.layer4, 4)
@@ -419,6 +488,8 @@ class OracleUnet(nn.Module):
             replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
             self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
+        elif topology == "pan":             # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=3, upsampling=4)
+            self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 3, padding=1), nn.UpsamplingBilinear2d(scale_factor=4))
         elif topology == "deeplabv3":       # SegmentationHead(in_channels=256, out_channels=classes, kernel_size=1, upsampling=8)
             self.segmentation_head = nn.Sequential(nn.Conv2d(256, classes, 1), nn.UpsamplingBilinear2d(scale_factor=8))
         elif topology == "deeplabv3plus":   # SegmentationHead(in_channels=256, out_channels=classes, kernel_size=1, upsampling=4)

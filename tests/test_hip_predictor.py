@@ -184,6 +184,7 @@ def test_prediction_manager_qualities_and_outputs(tmp_path):
 
 
 @pytest.mark.parametrize("mtype,encoder", [("U_Net", "resnet34"), ("U_Net_Plus_Plus", "resnet34"), ("Linknet", "resnet34"), ("FPN", "resnet34"),
+                                           ("DeepLabV3", "resnet34"), ("DeepLabV3_Plus", "resnet34"), ("MA_Net", "resnet34"),
                                            ("U_Net", "resnext50_32x4d")])
 def test_trainer_end_to_end_on_synthetic_slices(tmp_path, mtype, encoder):
     """1 frozen + 1 unfrozen epoch through LR finder, one-cycle schedule, early-stopping checkpoint and reload
@@ -219,7 +220,8 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path, mtype, encoder):
     d = torch.load(out, weights_only=False)
     assert d["model_struc_dict"]["type"].name == mtype.upper() and d["label_codes"] == {"bg": 0, "fg": 1}
     pred = VolSeg2dPredictor(str(out), SimpleNamespace(cuda_device=0))
-    assert pred.model.topology == {"U_Net": "unet", "U_Net_Plus_Plus": "unetplusplus", "Linknet": "linknet", "FPN": "fpn"}[mtype]
+    assert pred.model.topology == {"U_Net": "unet", "U_Net_Plus_Plus": "unetplusplus", "Linknet": "linknet", "FPN": "fpn", "DeepLabV3": "deeplabv3",
+                                   "DeepLabV3_Plus": "deeplabv3plus", "MA_Net": "manet"}[mtype]
     assert torch.equal(pred.model._flat, tr.model._flat)
     labels, probs = pred._predict_single_axis(imgs[:8])
     assert labels.shape == (8, 64, 64) and labels.max() <= 1 and probs.dtype == np.float16

@@ -611,3 +611,69 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder, topo):
         sync()
         runs.append(m._flat.clone())
     assert torch.equal(runs[0], runs[1]), encoder
+
+
+@pytest.mark.parametrize("encoder", ["resnet34", "resnet50"])
+def test_pan_eval_and_train_vs_oracle(encoder):
+    """smp.PAN (layer4 dilated; FPABlock = pooled branch + mid branch + the single-channel 7x7 / 5x5 / 3x3 pyramid; three GAUBlocks;
+    3x3 head + x4 bilinear; every ConvBnRelu with its convolution bias) against oracle/unet_resnet_torch.py:PANDecoder.  Slices of
+    128 x 256 / 128 x 128: the pyramid kernel wants the stride-16 bottleneck to be a multiple of 8 (a documented limit)."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    topo = "pan"
+    oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topo)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topo)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 128, 256, generator=g)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    # (the untrained pyramid's evaluation-mode BatchNorms amplify: logits of magnitude ~2 000 here, hence the relative bound)
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), (encoder, (got - ref).abs().max().item(), ref.abs().max().item())
+    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topo)
+    lab = (torch.rand(4, 128, 128, generator=g) > 0.6).to(torch.uint8)
+    xt = torch.randn(4, 1, 128, 128, generator=g)
+    _, t = P.prepare_training_batch(xt, lab, 2)
+    oracle.train()
+    ref_loss = P.dice_loss_none(oracle(xt), t.float())
+    ref_loss.backward()
+    refg = dict(oracle.named_parameters())
+    for precision, ltol, gtol in (("fp32", 1e-5, 1e-2), ("bf16", 3e-2, 0.3)):
+        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder, topology=topo)
+        model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topo).state_dict())
+        model.train()
+        loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
+        loss.backward()
+        sync()
+        assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
+        for name, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            r = refg[name].grad
+            if name.endswith("conv.bias"):        # a bias in front of a train-mode BatchNorm: zero gradient up to rounding noise
+                assert p.grad.abs().max().item() < (1e-4 if precision == "fp32" else 1e-2) and r.abs().max().item() < 1e-4, name
+            elif name.startswith("segmentation_head") and precision == "fp32":
+                err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
+                assert err < gtol, (encoder, precision, name, err)
+            elif name.startswith("segmentation_head"):   # bf16: the single-channel BatchNorms amplify rounding (0.58 relative error
+                assert _cos(p.grad.cpu(), r) > 0.7, (encoder, name, _cos(p.grad.cpu(), r))      # measured on resnet50): direction
+            elif precision == "fp32":
+                assert _cos(p.grad.cpu(), r) > 0.98, (encoder, name, _cos(p.grad.cpu(), r))
+    # running statistics of the single-channel BatchNorms follow torch's momentum update
+    sd = dict(model.state_dict())
+    runs = []
+    xs, ts = xt.to(DEV), t.to(DEV).contiguous()
+    for graph in (True, False):
+        m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topo)
+        o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
+        m.train()
+        for _ in range(4):
+            if graph:
+                assert m.can_fuse_step(o, xs, ts)
+                m.fused_train_step(xs, ts, o)
+            else:
+                o.zero_grad(); l = HipDiceLoss()(m(xs), ts); l.backward(); o.step()
+        sync()
+        runs.append((m._flat.clone(), m._bnstate.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), encoder

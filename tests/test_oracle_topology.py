@@ -214,3 +214,24 @@ def test_manet_restatement_and_engine_table_agree():
     assert sd["decoder.blocks.4.conv1.0.weight"].shape == (16, 32, 3, 3)
     with torch.no_grad():
         assert net.eval()(torch.zeros(1, 3, 96, 64)).shape == (1, 1, 96, 64)
+
+
+def test_pan_restatement_and_engine_table_agree():
+    """smp.PAN (oracle PANDecoder; layer4 dilated 2): 21,475,816 parameters on resnet34 (3-channel input, 1 class) = the 21.5 M of
+    smp's model table; keys decoder.fpa.{branch1.1,mid.0,down1.1,down2.1,down3.1,down3.2,conv2,conv1}.{conv,bn}, decoder.gau{3,2,1}.
+    {conv1.1,conv2}.{conv,bn}; the engine's tensor table agrees; 7x7 / 5x5 / 3x3 single-channel kernels with biases."""
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    net = OracleUnet("resnet34", 3, 1, "pan")
+    assert sum(p.numel() for p in net.parameters()) == 21_475_816
+    for name, code in (("resnet18", 7018), ("resnet34", 7034), ("resnet50", 7050)):
+        sd = OracleUnet(name, 1, 3, "pan").state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+    sd = OracleUnet("resnet34", 1, 2, "pan").state_dict()
+    assert sd["decoder.fpa.down1.1.conv.weight"].shape == (1, 512, 7, 7) and sd["decoder.fpa.conv2.conv.weight"].shape == (1, 1, 5, 5)
+    assert sd["decoder.fpa.down3.2.bn.running_var"].shape == (1,) and sd["decoder.gau3.conv1.1.conv.bias"].shape == (32,)
+    assert sd["decoder.gau1.conv2.conv.weight"].shape == (32, 64, 3, 3) and sd["segmentation_head.0.weight"].shape == (2, 32, 3, 3)
+    with torch.no_grad():
+        assert net.eval()(torch.zeros(1, 3, 128, 128)).shape == (1, 1, 128, 128)

@@ -52,6 +52,21 @@ extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const vo
                               float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream);
 extern "C" int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 extern "C" int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
+extern "C" int vs_maxpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+extern "C" int vs_maxpool2x2_bwd(int dtype, const void* x, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, void* stream);
+extern "C" int vs_conv_to_plane(int dtype, const void* x, const float* w, const float* bias, float* z, int n, int h, int wd, int c, int k, void* stream);
+extern "C" int vs_conv_to_plane_bwd(int dtype, const void* x, const float* w, const float* dz, void* dx, float* dw, float* db, int n, int h, int wd,
+                                    int c, int k, void* stream);
+extern "C" size_t vs_fpa_arena_floats(int n, int h, int w);
+extern "C" size_t vs_fpa_dz1_offset(int n, int h, int w);
+extern "C" int vs_fpa_pyramid_fwd(float* arena, float* plane, float* const* params, int n, int h, int w, int training, void* stream);
+extern "C" int vs_fpa_pyramid_bwd(float* arena, const float* dplane, float* const* params, float* const* grads, int n, int h, int w, void* stream);
+extern "C" int vs_fpa_combine(int dtype, const float* plane, const void* mid, const void* b1, void* out, int n, int64_t hw, int c, void* stream);
+extern "C" int vs_fpa_combine_bwd(int dtype, const void* dy, const float* plane, const void* mid, void* dmid, float* dplane, int n, int64_t hw, int c,
+                                  void* stream);
+extern "C" int vs_sigmoid(int dtype, const void* x, void* y, int64_t elems, void* stream);
+extern "C" int vs_sigmoid_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t elems, void* stream);
+extern "C" int vs_bn_fold_bias(const float* scale, const float* bias, float* shift, int c, void* stream);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -78,7 +93,10 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_DROPOUT_E,    // element-wise nn.Dropout(0.5) (ASPP.project), the identity in evaluation
                 U_PAB,          // smp MAnet's PAB attention: out = src0 + reinterpret(softmax_all(center top^T) bottom); members = {top, center, bottom}
                 U_SE,           // squeeze-excitation gate on a pooled [n][1][1][c] feature: tensors w_idx .. w_idx + 3 = W1, b1, W2, b2; cin1 = hidden width
-                U_CGATE };      // out = a(src0) * gate a(src1) ([n][1][1][c]) over the map
+                U_CGATE,        // out = a(src0) * gate a(src1) ([n][1][1][c]) over the map
+                U_SIGMOID,      // element-wise sigmoid (smp PAN's GAU gate)
+                U_FPA };        // smp PAN's FPABlock pyramid + combination: out = plane(src0) * a(src1) + a(res) broadcast; tens = its 24
+                                // parameter tensors (6 x conv weight, conv bias, BN gamma, BN beta)
 
 struct Act {  // one activation tensor (per-sample element count = c*h*w)
     int c, h, w;
@@ -107,6 +125,8 @@ struct Unit {
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
+    std::vector<int> tens;                       // U_FPA: parameter tensor indices
+    size_t off_fpa_pool = 0, off_fpa_arena = 0, off_fpa_plane = 0;   // U_FPA: pooled input, pyramid arena (fp32), attention plane (fp32)
     std::vector<int> members;                    // U_CONCAT: the activations whose channels `out` strings together, in order
 };
 
@@ -216,7 +236,8 @@ int build(vs_unet* net) {
             // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation turns layer4's stride into dilation 2 - every
             // convolution of the stage gets stride 1, and the 3x3 ones dilation 2 / padding 2
             // DeepLabV3 (output stride 8): layer3 with dilation 2, layer4 with dilation 4
-            const int stage_dil = net->topology == 4 ? (l == 3 ? 2 : 1) : (net->topology == 5 ? (l == 2 ? 2 : (l == 3 ? 4 : 1)) : 1);
+            // PAN (encoder_dilation=True): layer4 with dilation 2, as DeepLabV3+
+            const int stage_dil = (net->topology == 4 || net->topology == 7) ? (l == 3 ? 2 : 1) : (net->topology == 5 ? (l == 2 ? 2 : (l == 3 ? 4 : 1)) : 1);
             const bool dilated = stage_dil > 1;
             const int stride = (b == 0 && l > 0 && !dilated) ? 2 : 1;
             const int oh = ch / stride, ow = cw / stride, pl = planes[l], outc = pl * expansion;
@@ -346,6 +367,79 @@ int build(vs_unet* net) {
         xin = node[0][4].out_act; xc = dec[4];
     }
     int head_k = 3, head_h = H, head_w = W;
+    if (net->topology == 7) {
+        // smp.PAN (decoders/pan/decoder.py of segmentation-models-pytorch 0.2.1, restated; decoder_channels 32, encoder_dilation).
+        // ConvBnRelu = biased Conv2d + BatchNorm2d (+ ReLU).  FPABlock(C5, 32): branch1 = AdaptiveAvgPool2d(1) + ConvBnRelu 1x1
+        // (broadcast back), mid = ConvBnRelu 1x1, the single-channel pyramid (down1 .. conv1, vs_fpa_pyramid_*), out = plane * mid +
+        // branch1.  GAUBlock(Ck, 32)(x, y): conv1 = AdaptiveAvgPool2d(1) + ConvBnRelu 1x1 without ReLU + Sigmoid on y, conv2 =
+        // ConvBnRelu 3x3 on x; out = bilinear(y -> x's size) + conv2(x) * conv1(y).  gau3 / gau2 / gau1 on the stride-16 / 8 / 4
+        // features; head = Conv2d(32, classes, 3, padding 1) + UpsamplingBilinear2d(4).
+        const int C5 = featc[5];
+        const Act fa = A[feat[5]];
+        auto cbr_bias = [&](const std::string& pre, int src, int cin, int cout, int k, int hh, int ww, int relu) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.relu = relu;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv.weight", {cout, cin, k, k}, 0);
+            u.bias_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv.bias", {cout}, 3);
+            u.bn_idx = add_bn(L, pre + ".bn", cout);
+            u.out = new_act(cout, hh, ww, true);
+            return u;
+        };
+        auto gap = [&](int src, int cch, int hh, int ww) {
+            Unit gp; gp.kind = U_GAP; gp.src0 = src; gp.cout = cch; gp.hin = hh; gp.win = ww; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+            gp.out = new_act(cch, 1, 1, false);
+            U.push_back(gp);
+            return gp.out;
+        };
+        // ---- FPA ----
+        Unit b1 = cbr_bias("decoder.fpa.branch1.1", -1, C5, 32, 1, 1, 1, 1);
+        Unit mid = cbr_bias("decoder.fpa.mid.0", feat[5], C5, 32, 1, fa.h, fa.w, 1);
+        Unit fpa; fpa.kind = U_FPA; fpa.src0 = feat[5]; fpa.cin0 = C5; fpa.cout = 32; fpa.hin = fa.h; fpa.win = fa.w; fpa.hout = fa.h; fpa.wout = fa.w; fpa.relu = 0;
+        {
+            const char* names[6] = {"decoder.fpa.down1.1", "decoder.fpa.down2.1", "decoder.fpa.down3.1", "decoder.fpa.down3.2", "decoder.fpa.conv2", "decoder.fpa.conv1"};
+            const int ks[6] = {7, 5, 3, 3, 5, 7};
+            for (int i = 0; i < 6; ++i) {
+                fpa.tens.push_back((int)L.tensors.size()); add_tensor(L, std::string(names[i]) + ".conv.weight", {1, i == 0 ? C5 : 1, ks[i], ks[i]}, 0);
+                fpa.tens.push_back((int)L.tensors.size()); add_tensor(L, std::string(names[i]) + ".conv.bias", {1}, 3);
+                const int g = add_bn(L, std::string(names[i]) + ".bn", 1);
+                fpa.tens.push_back(g); fpa.tens.push_back(g + 1);
+            }
+            fpa.w_idx = fpa.tens[0];
+        }
+        b1.src0 = gap(feat[5], C5, fa.h, fa.w);
+        U.push_back(b1); U.push_back(mid);
+        fpa.src1 = mid.out; fpa.res = b1.out;
+        fpa.out = new_act(32, fa.h, fa.w, false);
+        U.push_back(fpa);
+        // ---- GAU x 3 ----
+        int y_act = fpa.out;
+        const int gx[3] = {feat[4], feat[3], feat[2]};
+        const int gc[3] = {featc[4], featc[3], featc[2]};
+        for (int i = 0; i < 3; ++i) {
+            const std::string pre = "decoder.gau" + std::to_string(3 - i);
+            const Act xa = A[gx[i]], ya = A[y_act];
+            Unit c1 = cbr_bias(pre + ".conv1.1", -1, 32, 32, 1, 1, 1, 0);      // registered first, as in smp's constructor
+            Unit c2 = cbr_bias(pre + ".conv2", gx[i], gc[i], 32, 3, xa.h, xa.w, 1);
+            c1.src0 = gap(y_act, 32, ya.h, ya.w);
+            U.push_back(c1);
+            Unit sg; sg.kind = U_SIGMOID; sg.src0 = c1.out; sg.cout = 32; sg.hout = 1; sg.wout = 1; sg.relu = 0;
+            sg.out = new_act(32, 1, 1, false);
+            U.push_back(sg);
+            U.push_back(c2);
+            Unit cg; cg.kind = U_CGATE; cg.src0 = c2.out; cg.src1 = sg.out; cg.cout = 32; cg.hout = xa.h; cg.wout = xa.w; cg.relu = 0;
+            cg.out = new_act(32, xa.h, xa.w, false);
+            U.push_back(cg);
+            Unit up; up.kind = U_BILINEAR; up.src0 = y_act; up.cout = 32; up.factor = xa.h / ya.h; up.hin = ya.h; up.win = ya.w; up.hout = xa.h; up.wout = xa.w; up.relu = 0;
+            up.out = new_act(32, xa.h, xa.w, false);
+            U.push_back(up);
+            Unit ad; ad.kind = U_ADD; ad.src0 = up.out; ad.src1 = cg.out; ad.cout = 32; ad.hout = xa.h; ad.wout = xa.w; ad.relu = 0;
+            ad.out = new_act(32, xa.h, xa.w, false);
+            U.push_back(ad);
+            y_act = ad.out;
+        }
+        xin = y_act; xc = 32; head_k = 3; head_h = A[y_act].h; head_w = A[y_act].w;
+        net->head_up = 4;
+    }
     if (net->topology == 6) {
         // smp.MAnet (decoders/manet/decoder.py of segmentation-models-pytorch 0.2.1, restated): center = PAB(C5, pab_channels 64):
         // top / center 1x1 convs (C5 -> 64), bottom 3x3 conv (C5 -> C5), all biased, attention (vs_pab_attention_*), out_conv 3x3
@@ -679,6 +773,12 @@ size_t plan_workspace(vs_unet* net) {
         if (u.bn_idx >= 0) u.off_bn = take(4 * (size_t)u.cout * sizeof(float));
     }
     net->off_ct = take(ct);    // the transposed convolutions' un-shuffled output
+    for (auto& u : net->units) {
+        if (u.kind != U_FPA) continue;
+        u.off_fpa_pool = take(2 * N * (u.hin / 2) * (u.win / 2) * u.cin0 * esz);     // the pooled input and (backward) its gradient
+        u.off_fpa_arena = take(vs_fpa_arena_floats((int)N, u.hin, u.win) * sizeof(float));
+        u.off_fpa_plane = take(2 * N * u.hin * u.win * sizeof(float));     // the plane and (backward) its gradient
+    }
     {
         size_t pab = 0;
         for (auto& u : net->units) {
@@ -858,8 +958,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     const int encoder = encoder_code % 1000;
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
-    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 6, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3) or 6 (MA-Net), got %d", tmp.topology);
-    VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
+    VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     build(&tmp);
@@ -913,8 +1013,8 @@ extern "C" int vs_unet_create(vs_unet_t** out, int dtype, int classes, int max_b
 extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int max_batch, int h, int w, int encoder_code) {
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
-    VS_REQUIRE(topology >= 0 && topology <= 6, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3) or 6 (MA-Net), got %d", topology);
-    VS_REQUIRE((topology != 4 && topology != 5) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
+    VS_REQUIRE(topology >= 0 && topology <= 7, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", topology);
+    VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
@@ -982,6 +1082,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
             const float* rv = bnstate + c.t(u.bn_idx + 3).offset;
             int rc = vs_bn_fold(c.P(u.bn_idx), c.P(u.bn_idx + 1), rm, rv, 1e-5f, c.bnc(u, 0), c.bnc(u, 1), u.cout, stream);
             if (rc) return rc;
+            if (u.kind == U_CONV && u.bias_idx >= 0 && (rc = vs_bn_fold_bias(c.bnc(u, 0), c.P(u.bias_idx), c.bnc(u, 1), u.cout, stream))) return rc;
         }
     }
     return VS_OK;
@@ -1117,6 +1218,26 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             if ((rc = vs_dwconv3x3(dt, c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.dil, 0, stream))) return rc;
             continue;
         }
+        case U_SIGMOID: {
+            if ((rc = vs_sigmoid(dt, c.a(u.src0), c.a(u.out), (int64_t)n * u.hout * u.wout * u.cout, stream))) return rc;
+            continue;
+        }
+        case U_FPA: {   // max-pool, 7x7 convolution to the first single-channel map, the pyramid (one workgroup), the combination
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hin * u.win * u.cin0 * net->esz, c.s);
+            float* arena = (float*)(c.ws + u.off_fpa_arena);
+            float* plane = (float*)(c.ws + u.off_fpa_plane);
+            if ((rc = vs_maxpool2x2(dt, c.a(u.src0), c.ws + u.off_fpa_pool, n, u.hin, u.win, u.cin0, stream))) return rc;
+            if ((rc = vs_conv_to_plane(dt, c.ws + u.off_fpa_pool, c.P(u.tens[0]), c.P(u.tens[1]), arena, n, u.hin / 2, u.win / 2, u.cin0, 7, stream))) return rc;
+            float* pp[36];
+            for (int i = 0; i < 6; ++i) {
+                pp[6 * i + 0] = const_cast<float*>(c.P(u.tens[4 * i + 0])); pp[6 * i + 1] = const_cast<float*>(c.P(u.tens[4 * i + 1]));
+                pp[6 * i + 2] = const_cast<float*>(c.P(u.tens[4 * i + 2])); pp[6 * i + 3] = const_cast<float*>(c.P(u.tens[4 * i + 3]));
+                pp[6 * i + 4] = bnstate + c.t(u.tens[4 * i + 2] + 2).offset; pp[6 * i + 5] = bnstate + c.t(u.tens[4 * i + 2] + 3).offset;
+            }
+            if ((rc = vs_fpa_pyramid_fwd(arena, plane, pp, n, u.hin, u.win, training ? 1 : 0, stream))) return rc;
+            if ((rc = vs_fpa_combine(dt, plane, c.a(u.src1), c.a(u.res), c.a(u.out), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            continue;
+        }
         case U_PAB: {
             ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
             if ((rc = vs_pab_attention_fwd(dt, c.a(u.members[0]), c.a(u.members[1]), c.a(u.members[2]), c.a(u.src0), c.a(u.out),
@@ -1203,7 +1324,8 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             }
             if (training) {
                 p.out = c.z(u.out);
-                if (dt == VS_BF16 && vs_option("fuse_stats")) {  // batch statistics straight from the fp32 accumulators
+                if (u.bias_idx >= 0) p.shift = c.P(u.bias_idx);   // smp's ConvBnRelu keeps the convolution's bias: z includes it
+                if (dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
@@ -1359,6 +1481,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (v.w_idx < 0) continue;
         if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
+        if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
         if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
@@ -1550,6 +1673,37 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             continue;
         }
+        if (u.kind == U_SIGMOID) {
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: sigmoid gradients out of order");
+            if ((rc = vs_sigmoid_bwd(dt, c.da(u.out), c.a(u.out), c.da(u.src0), (int64_t)n * u.hout * u.wout * u.cout, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_FPA) {      // everything on the caller's stream (tiny): combination, pooled branch, pyramid, 7x7 convolution, max-pool
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src1] && !written[u.res], "backward: FPA gradients out of order");
+            ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hin * u.win * u.cin0 * net->esz, c.s);
+            float* arena = (float*)(c.ws + u.off_fpa_arena);
+            float* plane = (float*)(c.ws + u.off_fpa_plane);
+            float* dplane = plane + (size_t)n * u.hin * u.win;
+            if ((rc = vs_fpa_combine_bwd(dt, c.da(u.out), plane, c.a(u.src1), c.da(u.src1), dplane, n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            if ((rc = vs_spatial_sum(dt, c.da(u.out), c.da(u.res), n, (int64_t)u.hout * u.wout, u.cout, 1.f, stream))) return rc;
+            written[u.src1] = 1; written[u.res] = 1;
+            float* pp[36]; float* gp[24];
+            for (int i = 0; i < 6; ++i) {
+                for (int j = 0; j < 4; ++j) { pp[6 * i + j] = const_cast<float*>(c.P(u.tens[4 * i + j])); gp[4 * i + j] = grads + c.t(u.tens[4 * i + j]).offset; }
+                pp[6 * i + 4] = nullptr; pp[6 * i + 5] = nullptr;       // running statistics are not touched by the backward pass
+            }
+            if ((rc = vs_fpa_pyramid_bwd(arena, dplane, pp, gp, n, u.hin, u.win, stream))) return rc;
+            // down1's convolution: its weight / bias gradients overwrite slots 0 / 1 (the pyramid kernel leaves them alone)
+            char* dpool = c.ws + u.off_fpa_pool + (size_t)n * (u.hin / 2) * (u.win / 2) * u.cin0 * net->esz;
+            if ((rc = vs_conv_to_plane_bwd(dt, c.ws + u.off_fpa_pool, c.P(u.tens[0]), arena + vs_fpa_dz1_offset(n, u.hin, u.win), dpool,
+                                           grads + c.t(u.tens[0]).offset, grads + c.t(u.tens[1]).offset, n, u.hin / 2, u.win / 2, u.cin0, 7, stream))) return rc;
+            if ((rc = vs_maxpool2x2_bwd(dt, c.a(u.src0), dpool, c.da(u.src0), n, u.hin, u.win, u.cin0, written[u.src0] ? 1 : 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
         if (u.kind == U_PAB) {      // identity path + the attention term's gradients w.r.t. its three convolution outputs
             if (!do_main) continue;
             VS_REQUIRE(written[u.out] && !written[u.members[0]] && !written[u.members[1]] && !written[u.members[2]], "backward: PAB gradients out of order");
@@ -1703,6 +1857,9 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                           (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             }
             dzp = c.dz(u.out); dz_c = u.cout;
+            if (u.kind == U_CONV && u.bias_idx >= 0) {   // a biased convolution in front of BatchNorm (smp's ConvBnRelu): column sums of dz
+                if ((rc = vs_colsum(dt, dzp, c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            }
             if (u.s2b) {   // the gradient in batch form, kept for the side stream's weight gradient
                 if ((rc = vs_space_to_batch(dt, dzp, c.ws + u.off_dzs, n, u.hout, u.wout, u.cout, u.s2b, 0, 0, stream))) return rc;
                 dzp = c.ws + u.off_dzs;
@@ -1889,7 +2046,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
     const Unit& u = net->units[unit];
     const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
                          : (u.kind == U_DROPOUT ? "dropout2d" : (u.kind == U_GAP ? "avgpool" : (u.kind == U_BCAST ? "broadcast" : (u.kind == U_DROPOUT_E ? "dropout"
-                         : (u.kind == U_PAB ? "pab attention" : (u.kind == U_CGATE ? "channel gate" : "maxpool"))))))))));
+                         : (u.kind == U_PAB ? "pab attention" : (u.kind == U_CGATE ? "channel gate" : (u.kind == U_SIGMOID ? "sigmoid" : "maxpool")))))))))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
     if (u.out < 0) { *c = *h = *w = 0; *off_a = *off_z = *off_da = *off_dz = 0; return VS_OK; }
     const Act& a = net->acts[u.out];

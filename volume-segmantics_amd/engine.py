@@ -73,7 +73,8 @@ class _UnetFn(torch.autograd.Function):
 class VolSegUnet(nn.Module):
     ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51}
     TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2, "fpn": 3,
-                  "deeplabv3plus": 4, "deeplabv3": 5, "manet": 6}     # smp.Unet, UnetPlusPlus, Linknet, FPN, DeepLabV3Plus, DeepLabV3, MAnet
+                  "deeplabv3plus": 4, "deeplabv3": 5, "manet": 6,
+                  "pan": 7}     # smp.Unet, UnetPlusPlus, Linknet, FPN, DeepLabV3Plus, DeepLabV3, MAnet, PAN
 
     def __init__(self, classes: int, device=None, precision: str | None = None, init: str = "smp", seed: int | None = None,
                  encoder: str = "resnet34", topology: str = "unet"):

@@ -1,5 +1,5 @@
 """The drop-in seam: ``create_model_on_device`` / ``create_model_from_file``
-(volume_segmantics/model/model_2d.py:10-57).  For U_NET / U_NET_PLUS_PLUS / LINKNET / FPN / DEEPLABV3 / DEEPLABV3_PLUS / MA_NET over the ResNet-family encoders the
+(volume_segmantics/model/model_2d.py:10-57).  For U_NET / U_NET_PLUS_PLUS / LINKNET / FPN / DEEPLABV3 / DEEPLABV3_PLUS / MA_NET / PAN over the ResNet-family encoders the
 returned ``nn.Module`` is the HIP engine (engine.VolSegUnet); the other smp topologies / encoders of the reference are rows of
 SURVEY.md section 8f ("next") and are refused loudly rather than routed through a fallback."""
 from __future__ import annotations
@@ -29,10 +29,11 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
     encoder = struct.get("encoder_name", "resnet34")
     topologies = {utils.ModelType.U_NET: "unet", utils.ModelType.U_NET_PLUS_PLUS: "unetplusplus", utils.ModelType.LINKNET: "linknet",
                   utils.ModelType.FPN: "fpn", utils.ModelType.DEEPLABV3_PLUS: "deeplabv3plus",
-                  utils.ModelType.DEEPLABV3: "deeplabv3", utils.ModelType.MA_NET: "manet"}
+                  utils.ModelType.DEEPLABV3: "deeplabv3", utils.ModelType.MA_NET: "manet",
+                  utils.ModelType.PAN: "pan"}
     if model_type not in topologies or encoder not in VolSegUnet.ENCODERS:
         raise NotImplementedError(
-            f"the MI355X engine implements U_NET, U_NET_PLUS_PLUS, LINKNET, FPN, DEEPLABV3, DEEPLABV3_PLUS and MA_NET over {sorted(VolSegUnet.ENCODERS)} (requested "
+            f"the MI355X engine implements U_NET, U_NET_PLUS_PLUS, LINKNET, FPN, DEEPLABV3, DEEPLABV3_PLUS, MA_NET and PAN over {sorted(VolSegUnet.ENCODERS)} (requested "
             f"{model_type.name} + {encoder}); the other smp topologies / encoders are listed as next rows in SURVEY.md section 8f")
     if int(struct.get("in_channels", 1)) != 1:
         raise NotImplementedError("the engine implements the reference's single-channel input (config.MODEL_INPUT_CHANNELS)")
