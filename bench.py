@@ -258,9 +258,9 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
             dms, dfl, dn = byvar[dv]
             tname = "unsigned short" if precision == "bf16" else "float"
             code = dv % 10
-            name = (f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, 1, 8>" if code == 8 else
+            name = (f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, 1, 8, 1>" if code == 8 else
                     f"conv_direct_kernel<{tname}, 16, 0>" if code == 4 else
-                    f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, {code}, 4>")
+                    f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, {code}, 4, 1>")
             ach = dfl / (dms * 1e-3) / 1e12
             tr = load_traffic(name, "predict")
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -524,8 +524,8 @@ def main():
         dvar = max(byvar, key=lambda k: byvar[k][0])
         tname = "unsigned short" if args.precision == "bf16" else "float"
         code = dvar % 10
-        dom_name = (f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, 1, 8>" if code == 8 else
-                    f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {code}, 4>")
+        dom_name = (f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, 1, 8, 1>" if code == 8 else
+                    f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {code}, 4, 1>")
         dom_ms, dom_fl, dom_calls = byvar[dvar]
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         conv_ms = sum(prof[k]["ms"] for k in mfma_kinds) / prof_steps
