@@ -143,7 +143,7 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   topology 6: smp.MAnet (PAB position attention at the deepest level, four MFAB blocks with squeeze-excitation gates on skip and
  *   input, a U-Net decoder block, 3x3 head);
  *   topology 5: smp.DeepLabV3 (output stride 8: layer3 / layer4 with dilation 2 / 4; dense dilated ASPP branches through
- *   vs_space_to_batch; 3x3 conv; 1x1 head + x8 bilinear) - depths 18 / 34 / 50;
+ *   vs_dilated_im2col; 3x3 conv; 1x1 head + x8 bilinear) - depths 18 / 34 / 50;
  *   topology 4: smp.DeepLabV3Plus (output stride 16: layer4 with dilation 2 instead of stride; ASPP with separable convolutions at
  *   rates 12 / 24 / 36 + image pooling, Dropout(0.5), x4 bilinear, 48-channel low-level branch, separable 3x3, 1x1 head + x4
  *   bilinear) - depths 18 / 34 / 50;
@@ -323,9 +323,11 @@ int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, int 
 int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
 int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
 int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
-/* space-to-batch with block r and back: y[(n r + a) r + b][i][j] = x[n][i r + a][j r + b] (zeros beyond the map) - a 3x3 convolution
- * with dilation r / padding r on x is the plain padding-1 convolution on y (DeepLabV3's dense ASPP branches at rates 12 / 24 / 36) */
-int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
+/* a 3x3 convolution at a large dilation r (padding r) as ONE 1x1 convolution over 9 c channels: col[n][i][j][tap][c] =
+ * x[n][i + (kh - 1) r][j + (kw - 1) r][c] (zero beyond the map; the weights [cout][tap][c] are that 1x1 convolution's matrix as they
+ * lie); inverse = 1 is the adjoint, dst[n][i][j][c] (+)= the sum over taps of src's shifted entries (DeepLabV3's dense ASPP branches
+ * at rates 12 / 24 / 36, where most taps of a 32 x 32 map look at padding) */
+int vs_dilated_im2col(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 
 /* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
  * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom

@@ -876,31 +876,48 @@ def test_spatial_sum_broadcast_and_elementwise_dropout(code):
 
 @pytest.mark.parametrize("code", CODES)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 32, 12), (1, 32, 32, 32, 64, 24), (2, 8, 12, 64, 32, 36), (1, 20, 20, 32, 32, 3)])
-def test_dense_dilated_conv_through_space_to_batch(code, shape):
-    """nn.Conv2d(cin, cout, 3, padding=r, dilation=r) at a large rate r (DeepLabV3's ASPPConv, 12 / 24 / 36): vs_space_to_batch, the
-    plain padding-1 convolution on n r^2 small images, and the way back - against torch CPU; the round trip of the
-    rearrangement is exact."""
+def test_dense_dilated_conv_through_column_form(code, shape):
+    """nn.Conv2d(cin, cout, 3, padding=r, dilation=r) at a large rate r (DeepLabV3's ASPPConv, 12 / 24 / 36): vs_dilated_im2col and
+    the 1x1 convolution over 9 cin channels with the SAME weight memory ([cout][tap][cin]) - against torch CPU; the column form
+    itself is exact, and its adjoint (inverse = 1, with and without accumulation) reproduces autograd's input gradient."""
     L = lib()
     n, h, w, cin, cout, r = shape
     g = torch.Generator().manual_seed(21)
-    x = rounded(torch.randn(n, cin, h, w, generator=g), code)
+    x = rounded(torch.randn(n, cin, h, w, generator=g), code).requires_grad_()
     wt = rounded(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, code)
     ref = F.conv2d(x, wt, padding=r, dilation=r)
-    hs, ws = -(-h // r), -(-w // r)
-    xd = to_nhwc(x, code)
-    xs = torch.full((n * r * r, hs, ws, cin), float("nan"), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_space_to_batch(code, L.ptr(xd), L.ptr(xs), n, h, w, cin, r, 0, 0, None))
-    d = conv_desc(L, code, n * r * r, hs, ws, cin, cout, 3, 1, 1)
-    ys = torch.full((n * r * r, hs, ws, cout), float("nan"), device=DEV, dtype=tdtype(code))
-    wd = w_krsc(wt, code)
-    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xs), None, L.ptr(wd), None, None, None, L.ptr(ys), None, None))
+    dy = rounded(torch.randn(ref.shape, generator=g), code)
+    ref.backward(dy)
+    xd = to_nhwc(x.detach(), code)
+    col = torch.full((n, h, w, 9, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dilated_im2col(code, L.ptr(xd), L.ptr(col), n, h, w, cin, r, 0, 0, None))
+    d = conv_desc(L, code, n, h, w, 9 * cin, cout, 1, 1, 0)
     y = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_space_to_batch(code, L.ptr(ys), L.ptr(y), n, h, w, cout, r, 1, 0, None))
-    back = torch.full_like(xd, float("nan"))
-    L.check(L.lib.vs_space_to_batch(code, L.ptr(xs), L.ptr(back), n, h, w, cin, r, 1, 0, None))
+    wd = w_krsc(wt, code)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(col), None, L.ptr(wd), None, None, None, L.ptr(y), None, None))
     sync()
-    assert torch.equal(back, xd)
-    assert torch.allclose(from_nhwc(y), ref, **tol(code, ref.abs().max().item()))
+    xp = F.pad(x.detach(), (r, r, r, r))
+    want = torch.stack([xp[:, :, kh * r:kh * r + h, kw * r:kw * r + w] for kh in range(3) for kw in range(3)], 1)   # [n][9][c][h][w]
+    assert torch.equal(col.float().cpu(), want.permute(0, 3, 4, 1, 2))
+    assert torch.allclose(from_nhwc(y), ref.detach(), **tol(code, ref.abs().max().item()))
+    # the adjoint: the column form of the input gradient (dy through the [cout][9 cin] matrix, on the host) scattered back
+    dcol = rounded(torch.einsum("nohw,ockl->nhwklc", dy, wt).reshape(n, h, w, 9, cin), code)
+    want_dx = torch.zeros(n, cin, h, w)
+    dpad = torch.zeros(n, cin, h + 2 * r, w + 2 * r)
+    for kh in range(3):
+        for kw in range(3):
+            dpad[:, :, kh * r:kh * r + h, kw * r:kw * r + w] += dcol[:, :, :, kh * 3 + kw, :].permute(0, 3, 1, 2)
+    want_dx = dpad[:, :, r:r + h, r:r + w]
+    dcd = dcol.to(DEV, tdtype(code)).contiguous()
+    dx = torch.full((n, h, w, cin), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dilated_im2col(code, L.ptr(dcd), L.ptr(dx), n, h, w, cin, r, 1, 0, None))
+    twice = dx.clone()
+    L.check(L.lib.vs_dilated_im2col(code, L.ptr(dcd), L.ptr(twice), n, h, w, cin, r, 1, 1, None))
+    sync()
+    t = tol(code, want_dx.abs().max().item())
+    assert torch.allclose(from_nhwc(dx), want_dx, **t)
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item() * 2))
+    assert torch.allclose(from_nhwc(twice), 2 * want_dx, **tol(code, 2 * want_dx.abs().max().item()))
 
 
 # ---- smp.MAnet's attention operators (csrc/manet.hip) --------------------------------------------------------------------------

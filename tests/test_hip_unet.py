@@ -543,7 +543,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder, topo):
     separable 3x3; 1x1 head + x4 bilinear) against oracle/unet_resnet_torch.py:DeepLabV3PlusDecoder.  The element-wise dropout
     mask is a pure function of (seed, counter, element): recomputed here with vs_dropout and replayed in the oracle.
     topo "deeplabv3" = smp.DeepLabV3: output stride 8 (layer3 dilation 2, layer4 dilation 4), DENSE dilated ASPP branches at rates
-    12 / 24 / 36 (run as plain convolutions on the space-to-batch form), 3x3 conv, 1x1 head + x8 bilinear."""
+    12 / 24 / 36 (run as 1x1 convolutions over the column form, vs_dilated_im2col), 3x3 conv, 1x1 head + x8 bilinear."""
     from oracle.unet_resnet_torch import seeded_oracle_unet
     from volume_segmantics_amd import _lib as L
     from volume_segmantics_amd.data.losses import HipDiceLoss

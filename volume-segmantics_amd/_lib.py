@@ -80,7 +80,7 @@ _SIGS = {
     "vs_spatial_sum": (I, [I, P, P, I, C.c_int64, I, C.c_float, P]),
     "vs_broadcast_rows": (I, [I, P, P, I, C.c_int64, I, C.c_float, I, P]),
     "vs_dropout": (I, [I, P, P, C.c_int64, C.c_float, C.c_uint32, P, C.c_int64, P]),
-    "vs_space_to_batch": (I, [I, P, P, I, I, I, I, I, I, I, P]),
+    "vs_dilated_im2col": (I, [I, P, P, I, I, I, I, I, I, I, P]),
     "vs_maxpool2x2": (I, [I, P, P, I, I, I, I, P]),
     "vs_maxpool2x2_bwd": (I, [I, P, P, P, I, I, I, I, I, P]),
     "vs_conv_to_plane": (I, [I, P, P, P, P, I, I, I, I, I, P]),

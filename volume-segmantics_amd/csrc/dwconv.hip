@@ -156,28 +156,27 @@ __global__ void broadcast_rows_kernel(const T* __restrict__ v, T* __restrict__ y
     }
 }
 
-// Space-to-batch with block r (the classic route to a dilated convolution through a dense one): phase (a, b) of every r x r block
-// becomes its own image, y[(n r + a) r + b][i][j][c] = x[n][i r + a][j r + b][c] (zero beyond the map: hs = ceil(h / r)); a 3x3
-// convolution with dilation r / padding r on x is the plain 3x3 / padding 1 convolution on y.  inverse = 1 gathers back (optionally
-// adding to the destination).
+// A 3x3 convolution at a LARGE dilation r (padding r: DeepLabV3's dense ASPP rates 12 / 24 / 36 on a 32 x 32 map, where most taps
+// look at padding) as one 1x1 convolution over 9 c channels: col[n][i][j][tap][c] = x[n][i + (kh - 1) r][j + (kw - 1) r][c] (zero
+// beyond the map).  The weights [cout][tap][c] ARE that 1x1 convolution's [cout][9 c] matrix.  inverse = 1: the adjoint,
+// dst[n][i][j][c] (+)= sum over taps of src[n][i - (kh - 1) r][j - (kw - 1) r][tap][c] (fp32 sum of <= 9 terms).
 template <typename T>
-__global__ void space_to_batch_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c, int r, int inverse, int accumulate) {
-    const int cv = c / kVec, hs = (h + r - 1) / r, ws = (w + r - 1) / r;
+__global__ void dilated_im2col_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c, int r, int inverse, int accumulate) {
+    const int cv = c / kVec;
     if (!inverse) {
-        const int64_t total = (int64_t)n * r * r * hs * ws * cv;
+        const int64_t total = (int64_t)n * h * w * 9 * cv;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             int64_t t = i;
             const int cg = t % cv; t /= cv;
-            const int j = t % ws; t /= ws;
-            const int ii = t % hs; t /= hs;
-            const int b = t % r; t /= r;
-            const int a = t % r;
-            const int64_t nb = t / r;
-            const int hh = ii * r + a, ww = j * r + b;
+            const int tap = t % 9; t /= 9;
+            const int ww = t % w; t /= w;
+            const int hh = t % h;
+            const int64_t nb = t / h;
+            const int sh = hh + (tap / 3 - 1) * r, sw = ww + (tap % 3 - 1) * r;
             float v[kVec];
 #pragma unroll
             for (int k = 0; k < kVec; ++k) v[k] = 0.f;
-            if (hh < h && ww < w) ld8(src + (((size_t)nb * h + hh) * w + ww) * c + cg * kVec, v);
+            if (sh >= 0 && sh < h && sw >= 0 && sw < w) ld8(src + ((nb * h + sh) * w + sw) * c + cg * kVec, v);
             st8(dst + i * kVec, v);
         }
     } else {
@@ -188,9 +187,17 @@ __global__ void space_to_batch_kernel(const T* __restrict__ src, T* __restrict__
             const int ww = t % w; t /= w;
             const int hh = t % h;
             const int64_t nb = t / h;
-            const int64_t img = (nb * r + hh % r) * r + ww % r;
             float v[kVec];
-            ld8(src + ((img * hs + hh / r) * ws + ww / r) * c + cg * kVec, v);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sh = hh - (tap / 3 - 1) * r, sw = ww - (tap % 3 - 1) * r;
+                if (sh < 0 || sh >= h || sw < 0 || sw >= w) continue;
+                float g[kVec];
+                ld8(src + (((nb * h + sh) * w + sw) * 9 + tap) * c + cg * kVec, g);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) v[k] += g[k];
+            }
             if (accumulate) {
                 float old[kVec];
                 ld8(dst + i * kVec, old);
@@ -292,12 +299,11 @@ extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, floa
     return VS_OK;
 }
 
-// x [n][h][w][c] <-> y [n r r][ceil(h / r)][ceil(w / r)][c] (see space_to_batch_kernel); inverse = 1: src is the batch form, dst the
-// map (accumulate = 1 adds to it)
-extern "C" int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream) {
-    VS_REQUIRE(src && dst && c > 0 && c % kVec == 0 && r >= 1, "space_to_batch: channels must be a multiple of 8, block >= 1");
-    const int hs = (h + r - 1) / r, ws = (w + r - 1) / r;
-    const int64_t total = inverse ? (int64_t)n * h * w * (c / kVec) : (int64_t)n * r * r * hs * ws * (c / kVec);
-    VS_LAUNCH_T(space_to_batch_kernel, dim3(grid_for(total)), 0, (hipStream_t)stream, (const T*)src, (T*)dst, n, h, w, c, r, inverse, accumulate);
+// x [n][h][w][c] -> col [n][h][w][9][c] (see dilated_im2col_kernel); inverse = 1: src is the column form (a gradient), dst the map
+// (accumulate = 1 adds to it)
+extern "C" int vs_dilated_im2col(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream) {
+    VS_REQUIRE(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && c % kVec == 0 && r >= 1, "dilated_im2col: channels must be a multiple of 8, rate >= 1");
+    const int64_t total = (int64_t)n * h * w * (c / kVec) * (inverse ? 1 : 9);
+    VS_LAUNCH_T(dilated_im2col_kernel, dim3(grid_for(total)), 0, (hipStream_t)stream, (const T*)src, (T*)dst, n, h, w, c, r, inverse, accumulate);
     return VS_OK;
 }

@@ -40,7 +40,7 @@ extern "C" int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, floa
 extern "C" int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream);
 extern "C" int vs_broadcast_rows(int dtype, const void* v, void* y, int n, int64_t hw, int c, float scale, int accumulate, void* stream);
 extern "C" int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32_t seed, const int64_t* counter, int64_t bias, void* stream);
-extern "C" int vs_space_to_batch(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
+extern "C" int vs_dilated_im2col(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 extern "C" int vs_pab_attention_fwd(int dtype, const void* top, const void* center, const void* bottom, const void* x, void* y, float* sp,
                                     float* scratch, int n, int hw, int K, int C, void* stream);
 extern "C" int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, const void* center, const void* bottom, const float* sp, void* dtop,
@@ -117,9 +117,9 @@ struct Unit {
     size_t off_gn = 0;                // its statistics [n][groups][2] fp32
     int dil = 1;    // dilation of a stride-1 3x3 convolution (2: smp's replace_strides_with_dilation; any for U_DWCONV)
     int factor = 2; // U_BILINEAR: integer scale factor
-    int s2b = 0;    // U_CONV: a 3x3 convolution with dilation = padding = s2b (DeepLabV3's dense ASPP rates 12 / 24 / 36), run as the
-                    // plain padding-1 convolution on the space-to-batch form of its input (vs_space_to_batch)
-    size_t off_xs = 0, off_dzs = 0;   // its input / output gradient in batch form (kept for the weight gradient)
+    int colr = 0;   // U_CONV: a 3x3 convolution with dilation = padding = colr (DeepLabV3's dense ASPP rates 12 / 24 / 36), run as the
+                    // 1x1 convolution over the 9 * cin channels of its input's column form (vs_dilated_im2col)
+    size_t off_xs = 0;   // that column form (kept for the weight gradient)
     int cg = 0;     // grouped convolution (ResNeXt): channels per group, cin0 == cout; 0 = dense.  Weights [cout][k*k][cg]; the
                     // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
@@ -181,7 +181,7 @@ struct vs_unet {
     int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
     size_t off_pab = 0, pab_bytes = 0; // scratch of the PAB attention (vs_pab_scratch_bytes)
-    size_t off_ys = 0;                 // scratch: a space-to-batch convolution's output (or input gradient) in batch form
+    size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
@@ -529,7 +529,7 @@ int build(vs_unet* net) {
         // dilated 3x3 branches (ASPPConv); head = Conv2d(256, classes, 1) + UpsamplingBilinear2d(8).
         const int c5 = feat[5], c5c = featc[5], ah = A[feat[5]].h, aw = A[feat[5]].w;
         auto conv_bn = [&](const std::string& wname, const std::string& bnname, int src, int cin, int cout, int hh, int ww, int k, int rate) {
-            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.s2b = rate;
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.colr = rate;
             u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww;
             u.w_idx = (int)L.tensors.size(); add_tensor(L, wname, {cout, cin, k, k}, 0);
             u.bn_idx = add_bn(L, bnname, cout);
@@ -795,10 +795,10 @@ size_t plan_workspace(vs_unet* net) {
     {
         size_t ys = 0;
         for (auto& u : net->units) {
-            if (u.kind != U_CONV || !u.s2b) continue;
-            const size_t r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
-            u.off_xs = take(N * r * r * hs * ws * u.cin0 * esz);
-            ys = std::max(ys, N * r * r * hs * ws * (size_t)std::max(u.cin0, u.cout) * esz);
+            if (u.kind != U_CONV || !u.colr) continue;
+            const size_t col = N * u.hin * u.win * 9 * u.cin0 * esz;
+            u.off_xs = take(col);
+            ys = std::max(ys, col);
         }
         net->off_ys = take(ys);
     }
@@ -848,11 +848,6 @@ size_t plan_workspace(vs_unet* net) {
             if (u.kind == U_DROPOUT) dm = std::max(dm, N * u.cout * sizeof(float));
         net->off_dropmask = take(dm);
     }
-    for (auto& u : net->units) {
-        if (u.kind != U_CONV || !u.s2b) continue;
-        const size_t r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
-        u.off_dzs = take(N * r * r * hs * ws * u.cout * esz);
-    }
     net->ctdw_bytes = ctdw;
     net->off_ctdw = take(ctdw * vs_unet::kSide);   // dense weight gradient of a transposed convolution's 3x3 form, per side stream
     for (auto& a : net->acts) {
@@ -870,10 +865,7 @@ size_t plan_workspace(vs_unet* net) {
         p.Cout = u.kind == U_HEAD ? 16 : u.cout;
         if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
         p.cg = u.cg; p.dil = u.dil;
-        if (u.s2b) {
-            const int r = u.s2b;
-            p.N = (int)N * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
-        }
+        if (u.colr) { p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
@@ -938,11 +930,7 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
     p.w = c.wfwd(u); p.Cout = u.cout;
     p.gc = u.cg ? 32 : 0;
     p.dil = u.dil;
-    if (u.s2b) {               // the batch form: n r^2 images of ceil(h / r) x ceil(w / r), plain padding-1 convolution
-        const int r = u.s2b;
-        p.src0 = c.ws + u.off_xs;
-        p.N = c.n * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
-    }
+    if (u.colr) { p.src0 = c.ws + u.off_xs; p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }   // the 1x1 form over the column form
     if (u.kind == U_CONVT) {   // its 3x3 form: same-size output, 4 * cout channels, always from the prepared copy
         p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout;
         p.w = c.ws + Ctx::wc_off(u, c.net->wset);
@@ -1059,7 +1047,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
             w_off[nl] = c.t(u.w_idx).offset;
             wc_off[nl] = wc ? (long)Ctx::wc_off(u, net->wset) : -1;
             wt_off[nl] = wt ? (long)Ctx::wt_off(u, net->wset) : -1;
-            cout[nl] = u.cout; taps[nl] = u.k * u.k; cin[nl] = u.cin0 + u.cin1; cpad[nl] = u.kind == U_HEAD ? 16 : u.cout;
+            cout[nl] = u.cout; taps[nl] = u.colr ? 1 : u.k * u.k; cin[nl] = u.colr ? 9 * u.cin0 : u.cin0 + u.cin1; cpad[nl] = u.kind == U_HEAD ? 16 : u.cout;
             if (++nl == 64) {   // the descriptor table of one launch holds 64 layers (U-Net++ / resnet50 has 83)
                 int rc = flush();
                 if (rc) return rc;
@@ -1109,7 +1097,7 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
         w_off[nl] = net->layout.tensors[v.w_idx].offset;
         wc_off[nl] = (net->dtype == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
         wt_off[nl] = (long)Ctx::wt_off(v, other);
-        cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+        cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
         cgs[nl] = v.cg;
         ++nl;
     }
@@ -1306,15 +1294,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 continue;
             }
-            if (u.s2b) {   // dense dilated convolution at a large rate: space-to-batch, plain convolution, batch-to-space
-                if ((rc = vs_space_to_batch(dt, c.a(u.src0), c.ws + u.off_xs, n, u.hin, u.win, u.cin0, u.s2b, 0, 0, stream))) return rc;
-                p.out = c.ws + net->off_ys;
-                if (!training) { p.scale = c.bnc(u, 0); p.shift = c.bnc(u, 1); p.relu = u.relu; }
-                if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
-                if ((rc = vs_space_to_batch(dt, p.out, training ? c.z(u.out) : c.a(u.out), n, u.hout, u.wout, u.cout, u.s2b, 1, 0, stream))) return rc;
-                if (!training) continue;
-                break;         // batch statistics + normalise on the map form (the batch form holds padded positions)
-            }
+            if (u.colr && (rc = vs_dilated_im2col(dt, c.a(u.src0), c.ws + u.off_xs, n, u.hin, u.win, u.cin0, u.colr, 0, 0, stream))) return rc;
             if (u.gn_idx >= 0) {                  // convolution + GroupNorm + ReLU (per-sample statistics: nothing folds in evaluation)
                 p.out = training ? c.z(u.out) : (void*)(c.ws + net->off_gnz);
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
@@ -1490,7 +1470,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
             w_off[nl] = c.t(v.w_idx).offset;
             wc_off[nl] = (dt == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
             wt_off[nl] = (long)Ctx::wt_off(v, other);
-            cout[nl] = v.cout; taps[nl] = v.k * v.k; cin[nl] = v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
+            cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
             cgs[nl] = v.cg;
             ++nl;
         }
@@ -1620,10 +1600,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
             p.dy = dzp; p.Cout = dz_c;
             p.cg = u.cg; p.dil = u.dil;
-            if (u.s2b) {
-                const int r = u.s2b;
-                p.src0 = c.ws + u.off_xs; p.N = n * r * r; p.Hin = p.Hout = (u.hin + r - 1) / r; p.Win = p.Wout = (u.win + r - 1) / r; p.pad = 1; p.dil = 1;
-            }
+            if (u.colr) { p.src0 = c.ws + u.off_xs; p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
             if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
                 p.Hout = u.hin; p.Wout = u.win;
@@ -1816,7 +1793,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
             if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) dzp = c.da(u.out);
             if (u.kind == U_DWCONV) dzp = c.da(u.out);
-            if (u.s2b) dzp = c.ws + u.off_dzs;
         } else if (u.kind == U_DWCONV) {      // no norm, no activation: dz IS the output's gradient
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             dzp = c.da(u.out); dz_c = u.cout;
@@ -1860,10 +1836,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (u.kind == U_CONV && u.bias_idx >= 0) {   // a biased convolution in front of BatchNorm (smp's ConvBnRelu): column sums of dz
                 if ((rc = vs_colsum(dt, dzp, c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             }
-            if (u.s2b) {   // the gradient in batch form, kept for the side stream's weight gradient
-                if ((rc = vs_space_to_batch(dt, dzp, c.ws + u.off_dzs, n, u.hout, u.wout, u.cout, u.s2b, 0, 0, stream))) return rc;
-                dzp = c.ws + u.off_dzs;
-            }
             if (u.kind == U_CONVT) {
                 // the bias gradient (column sums of dz), then dz back through the pixel shuffle: the gradient of the 3x3 form's
                 // output, kept in the (now dead) da buffer of this unit - the side stream's weight gradient reads it later
@@ -1878,16 +1850,15 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
         if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
-        if (u.s2b && do_main) {   // data gradient in batch form, then back to the map (adding to what other consumers left)
-            const int r = u.s2b, hs = (u.hin + r - 1) / r, ws = (u.win + r - 1) / r;
+        if (u.colr && do_main) {   // data gradient of the 1x1 form = the input gradient's column form; its adjoint scatter onto the map
             ConvParams p{};
-            p.src0 = dzp; p.C0 = u.cout; p.N = n * r * r; p.Hin = p.Hout = hs; p.Win = p.Wout = ws; p.stride = 1; p.pad = 1; p.KH = p.KW = 3;
-            p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = u.cin0; p.out = c.ws + net->off_ys;
+            p.src0 = dzp; p.C0 = u.cout; p.N = n; p.Hin = p.Hout = u.hin; p.Win = p.Wout = u.win; p.stride = 1; p.pad = 0; p.KH = p.KW = 1;
+            p.w = c.ws + Ctx::wt_off(u, net->wset); p.Cout = 9 * u.cin0; p.out = c.ws + net->off_ys;
             {
                 ProfScope prof(PK_CONV_DGRAD, conv_flops(c, u), 0, c.s);
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             }
-            if ((rc = vs_space_to_batch(dt, p.out, c.da(u.src0), n, u.hin, u.win, u.cin0, r, 1, written[u.src0] ? 1 : 0, stream))) return rc;
+            if ((rc = vs_dilated_im2col(dt, p.out, c.da(u.src0), n, u.hin, u.win, u.cin0, u.colr, 1, written[u.src0] ? 1 : 0, stream))) return rc;
             written[u.src0] = 1;
         } else if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
             ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, c.s);
