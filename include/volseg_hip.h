@@ -329,13 +329,41 @@ int vs_dropout(int dtype, const void* x, void* y, int64_t elems, float p, uint32
  * at rates 12 / 24 / 36, where most taps of a 32 x 32 map look at padding) */
 int vs_dilated_im2col(int dtype, const void* src, void* dst, int n, int h, int w, int c, int r, int inverse, int accumulate, void* stream);
 
+/* ---- what smp's EfficientNet encoders add (encoders/efficientnet.py over efficientnet-pytorch 0.6.3: model.py MBConvBlock, utils.py
+ * Conv2dStaticSamePadding / drop_connect), NHWC (csrc/effnet.hip) -------------------------------------------------------------------------
+ * vs_bn2_*: nn.BatchNorm2d(c, eps, momentum) for ANY c that is a multiple of 8 (the expanded widths reach 2688), followed by nothing
+ *   (act 0), ReLU (1) or swish x * sigmoid(x) (2); bwd recomputes the activation's derivative from x.  vs_bn2_apply with var_eps >= 0
+ *   reads VARIANCES in place of invstd (evaluation straight from the running statistics).  workspace: vs_bn2_workspace(c) bytes.
+ * vs_dwconv2d*: nn.Conv2d(c, c, k, stride, groups=c, bias=False), k 3 / 5, stride 1 / 2, pad_lo zero rows / columns in front (TF "same"
+ *   static padding: (0, 1) for k = 3 and (1, 2) for k = 5 at stride 2); w fp32 [c][k * k].  x_single_channel = 1: x is an fp32 [n][h][w]
+ *   map broadcast over the channels = nn.Conv2d(1, c, k, stride, bias=False), the stem on greyscale slices.
+ * vs_sample_scale_add: y = x * mask[n] + skip - drop_connect (mask from vs_dropout2d_mask with c = 1) and the residual sum in one sweep;
+ *   on the gradient (skip NULL) its backward.  vs_sample_rowsum: out[n][c] = scale * sum over hw of a (* b) for any c % 8 == 0. */
+size_t vs_bn2_workspace(int c);
+int vs_bn2_stats(int dtype, const void* x, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                 float* running_var, float* workspace, size_t workspace_bytes, void* stream);
+int vs_bn2_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int act, float var_eps,
+                 void* y, int64_t rows, int c, void* stream);
+int vs_bn2_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+               void* dx, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream);
+int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+                int x_single_channel, void* stream);
+int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho,
+                         int wo, int accumulate, void* stream);
+size_t vs_dwconv2d_wgrad_workspace(int c, int k);
+int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+                      int x_single_channel, float* workspace, size_t workspace_bytes, void* stream);
+int vs_sample_scale_add(int dtype, const void* x, const float* mask, const void* skip, void* y, int n, int64_t per_sample, void* stream);
+int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream);
+
 /* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
  * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom
  *   ([n][hw][C]), y = x + the product's memory reinterpreted as (n, C, h, w) exactly as smp's reshape does; sp fp32 [n][hw][hw] is
  *   kept for bwd, which returns the gradients of the attention term w.r.t. top, center, bottom (the identity path is the caller's).
  *   scratch: vs_pab_scratch_bytes(n, hw, C).
  * vs_se_gate_fwd/bwd: MFAB's SE_ll / SE_hl after the average pool: a = sigmoid(W2 relu(W1 p + b1) + b2) on p [n][C]; W1 [R][C], W2
- *   [C][R], b1, b2 fp32 (torch's 1x1 Conv2d weights); hid [n][R] fp32 carries the hidden layer to bwd (dp, dW1, db1, dW2, db2).
+ *   [C][R], b1, b2 fp32 (torch's 1x1 Conv2d weights); hid [n][R] fp32 carries the hidden layer to bwd (dp, dW1, db1, dW2, db2);
+ *   swish = 1: x * sigmoid(x) instead of the ReLU (efficientnet-pytorch's MBConvBlock); C <= 4096, R <= 128.
  * vs_channel_gate / vs_channel_dot: x * g[n][c] over the map, and dg[n][c] = sum over positions of x * dy. */
 int vs_pab_attention_fwd(int dtype, const void* top, const void* center, const void* bottom, const void* x, void* y, float* sp, float* scratch,
                          int n, int hw, int K, int C, void* stream);
@@ -343,9 +371,9 @@ int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, const void*
                          void* dcenter, void* dbottom, float* scratch, int n, int hw, int K, int C, void* stream);
 size_t vs_pab_scratch_bytes(int n, int hw, int C);
 int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid, int n,
-                   int C, int R, void* stream);
+                   int C, int R, int swish, void* stream);
 int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                   float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream);
+                   float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream);
 int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 

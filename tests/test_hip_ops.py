@@ -957,8 +957,9 @@ def test_pab_attention_fwd_bwd(code, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
-@pytest.mark.parametrize("shape", [(4, 256, 16), (3, 64, 4), (2, 128, 8)])
-def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
+@pytest.mark.parametrize("swish", [0, 1])
+@pytest.mark.parametrize("shape", [(4, 256, 16), (3, 64, 4), (2, 128, 8), (2, 2688, 112)])
+def test_se_gate_and_channel_gate_fwd_bwd(code, shape, swish):
     """MFAB's squeeze-excitation: AdaptiveAvgPool2d(1) -> Conv1x1(C, C/16) -> ReLU -> Conv1x1(C/16, C) -> Sigmoid, the gate multiplied
     onto the feature map - the pooled part (vs_spatial_sum is tested above) through vs_se_gate_*, the product and its two
     gradients through vs_channel_gate / vs_channel_dot, against autograd."""
@@ -972,7 +973,8 @@ def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
     b1 = (torch.randn(R, generator=g) * 0.1).requires_grad_()
     w2 = (torch.randn(C, R, generator=g) / R ** 0.5).requires_grad_()
     b2 = (torch.randn(C, generator=g) * 0.1).requires_grad_()
-    a = torch.sigmoid(F.linear(F.relu(F.linear(p, w1, b1)), w2, b2))
+    hidden = F.linear(p, w1, b1)      # swish: efficientnet-pytorch's MBConvBlock (_se_reduce, swish, _se_expand, sigmoid)
+    a = torch.sigmoid(F.linear(hidden * torch.sigmoid(hidden) if swish else F.relu(hidden), w2, b2))
     y = x * a[:, :, None, None]
     dy = rounded(torch.randn(y.shape, generator=g), code)
     y.backward(dy)
@@ -981,7 +983,7 @@ def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
     ad = torch.full((n, C), float("nan"), device=DEV, dtype=tdtype(code))
     hid = torch.full((n, R), float("nan"), device=DEV)
     w1d, b1d, w2d, b2d = dev(w1), dev(b1), dev(w2), dev(b2)
-    L.check(L.lib.vs_se_gate_fwd(code, L.ptr(pd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(ad), L.ptr(hid), n, C, R, None))
+    L.check(L.lib.vs_se_gate_fwd(code, L.ptr(pd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(ad), L.ptr(hid), n, C, R, swish, None))
     xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
     yd = torch.full((n, h, w, C), float("nan"), device=DEV, dtype=tdtype(code))
     L.check(L.lib.vs_channel_gate(code, L.ptr(xd), L.ptr(ad), L.ptr(yd), n, h * w, C, None))
@@ -993,7 +995,7 @@ def test_se_gate_and_channel_gate_fwd_bwd(code, shape):
     dw1, db1 = torch.full((R, C), float("nan"), device=DEV), torch.full((R,), float("nan"), device=DEV)
     dw2, db2 = torch.full((C, R), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
     L.check(L.lib.vs_se_gate_bwd(code, L.ptr(da), L.ptr(ad), L.ptr(pd), L.ptr(hid), L.ptr(w1d), L.ptr(w2d), L.ptr(dp), L.ptr(dw1), L.ptr(db1),
-                                 L.ptr(dw2), L.ptr(db2), n, C, R, None))
+                                 L.ptr(dw2), L.ptr(db2), n, C, R, swish, None))
     sync()
     t = tol(code, 1.0)
     assert torch.allclose(ad.float().cpu(), a.detach(), **t)
@@ -1097,3 +1099,147 @@ def test_fpa_pyramid_fwd_bwd(code, shape):
     lim = (3e-3 if code == 0 else 6e-2)
     assert torch.allclose(dw7.cpu(), r7, rtol=lim, atol=lim * r7.abs().max().item())
     assert torch.allclose(from_nhwc(dx), x.grad, rtol=lim, atol=lim * x.grad.abs().max().item())
+
+
+# ---- smp's EfficientNet encoders (csrc/effnet.hip) -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 6, 5, 48), (3, 4, 4, 144), (2, 3, 3, 2688)])
+def test_bn2_any_channel_count_swish(code, act, shape):
+    """nn.BatchNorm2d(c, eps=1e-3, momentum=0.01) + nothing / ReLU / swish for channel counts the ResNet kernels do not take (48, 144,
+    2688 = EfficientNet-b4's widest expansion): batch statistics, running statistics, output, evaluation from the running statistics,
+    and the backward pass (dx, dgamma, dbeta) against autograd."""
+    L = lib()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(51)
+    x = rounded(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, code).requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).requires_grad_()
+    beta = (0.2 * torch.randn(c, generator=g)).requires_grad_()
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, 1 + 0.1 * torch.rand(c, generator=g)
+    rm, rv = rm0.clone(), rv0.clone()
+    f = {0: lambda v: v, 1: F.relu, 2: lambda v: v * torch.sigmoid(v)}[act]
+    y = f(F.batch_norm(x, rm, rv, gamma, beta, True, 0.01, 1e-3))
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    y_eval = f(F.batch_norm(x.detach(), rm0, rv0, gamma.detach(), beta.detach(), False, 0.01, 1e-3))
+    rows = n * h * w
+    xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
+    dev = lambda t_: t_.detach().contiguous().to(DEV)
+    gd, bd, rmd, rvd = dev(gamma), dev(beta), dev(rm0), dev(rv0)
+    rme, rve = dev(rm0), dev(rv0)
+    mean, invstd = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+    wsb = L.lib.vs_bn2_workspace(c)
+    ws = torch.empty(wsb // 4, device=DEV)
+    L.check(L.lib.vs_bn2_stats(code, L.ptr(xd), rows, c, 1e-3, 0.01, L.ptr(mean), L.ptr(invstd), L.ptr(rmd), L.ptr(rvd), L.ptr(ws), wsb, None))
+    yd = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_bn2_apply(code, L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), L.ptr(bd), act, -1.0, L.ptr(yd), rows, c, None))
+    ye = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_bn2_apply(code, L.ptr(xd), L.ptr(rme), L.ptr(rve), L.ptr(gd), L.ptr(bd), act, 1e-3, L.ptr(ye), rows, c, None))
+    dx = torch.full_like(xd, float("nan"))
+    dg, db = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+    L.check(L.lib.vs_bn2_bwd(code, L.ptr(dyd), L.ptr(xd), L.ptr(mean), L.ptr(invstd), L.ptr(gd), L.ptr(bd), act, L.ptr(dx), L.ptr(dg), L.ptr(db),
+                             rows, c, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(rmd.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    assert torch.allclose(from_nhwc(ye), y_eval, **tol(code, y_eval.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item() * (4 if code else 1)))
+    lim = (3e-2 if code else 1e-4)
+    assert torch.allclose(dg.cpu(), gamma.grad, rtol=lim, atol=lim * gamma.grad.abs().max().item())
+    assert torch.allclose(db.cpu(), beta.grad, rtol=lim, atol=lim * beta.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 0), (5, 1, 2), (5, 2, 1)])      # kernel, stride, zero rows / columns in front
+@pytest.mark.parametrize("shape", [(2, 12, 16, 48), (1, 8, 8, 528), (2, 7, 9, 144)])
+def test_dwconv2d_static_same_padding(code, geom, shape):
+    """efficientnet-pytorch's depthwise Conv2dStaticSamePadding (kernel 3 / 5, stride 1 / 2; at stride 2 the padding is (0, 1) resp.
+    (1, 2): TF's "same" for an even nominal image size) - forward, data gradient (with and without accumulation) and weight gradient
+    against F.conv2d on the explicitly padded input + autograd; 528 channels = two slabs (64 + 2 vectors)."""
+    L = lib()
+    k, s, lo = geom
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(61)
+    ho, wo = -(-h // s), -(-w // s)
+    hi_h, hi_w = max((ho - 1) * s + k - h, 0) - lo, max((wo - 1) * s + k - w, 0) - lo
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    wt = (torch.randn(c, 1, k, k, generator=g) / k).requires_grad_()
+    y = F.conv2d(F.pad(x, (lo, hi_w, lo, hi_h)), wt, stride=s, groups=c)
+    assert y.shape[2:] == (ho, wo)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
+    wd = wt.detach().reshape(c, k * k).contiguous().to(DEV)
+    yd = torch.full((n, ho, wo, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, c, k, s, lo, ho, wo, 0, None))
+    dx = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(dx), n, h, w, c, k, s, lo, ho, wo, 0, None))
+    twice = dx.clone()
+    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(twice), n, h, w, c, k, s, lo, ho, wo, 1, None))
+    wsb = L.lib.vs_dwconv2d_wgrad_workspace(c, k)
+    ws = torch.empty(wsb // 4, device=DEV)
+    dw = torch.full((c, k * k), float("nan"), device=DEV)
+    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, c, k, s, lo, ho, wo, 0, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    assert torch.allclose(from_nhwc(twice), 2 * x.grad, **tol(code, 2 * x.grad.abs().max().item()))
+    ref = wt.grad.reshape(c, k * k)
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("cout", [40, 48])
+def test_efficientnet_stem_on_a_single_channel(code, cout):
+    """smp's EfficientNet stem on greyscale slices: nn.Conv2d(1, cout, 3, stride=2, bias=False) behind static same padding (0, 1), the fp32
+    slices broadcast over the output channels (vs_dwconv2d with x_single_channel = 1) - forward and weight gradient."""
+    L = lib()
+    n, h, w = 2, 16, 24
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(n, 1, h, w, generator=g)
+    wt = (torch.randn(cout, 1, 3, 3, generator=g) / 3).requires_grad_()
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, stride=2)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    xd = x[:, 0].contiguous().to(DEV)
+    wd = wt.detach().reshape(cout, 9).contiguous().to(DEV)
+    yd = torch.full((n, h // 2, w // 2, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, cout, 3, 2, 0, h // 2, w // 2, 1, None))
+    wsb = L.lib.vs_dwconv2d_wgrad_workspace(cout, 3)
+    ws = torch.empty(wsb // 4, device=DEV)
+    dw = torch.full((cout, 9), float("nan"), device=DEV)
+    dyd = to_nhwc(dy, code)
+    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, cout, 3, 2, 0, h // 2, w // 2, 1, L.ptr(ws), wsb, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    ref = wt.grad.reshape(cout, 9)
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_sample_scale_add_and_rowsum(code):
+    """drop_connect + residual sum in one sweep (mask per sample), and the per-sample sums / dot products for channel counts the fast
+    kernels do not take (144 = 18 vectors)."""
+    L = lib()
+    n, h, w, c = 3, 5, 4, 144
+    g = torch.Generator().manual_seed(81)
+    x, skip = rounded(torch.randn(n, c, h, w, generator=g), code), rounded(torch.randn(n, c, h, w, generator=g), code)
+    mask = torch.tensor([0.0, 1.25, 1.25])
+    xd, sd, md = to_nhwc(x, code), to_nhwc(skip, code), mask.to(DEV)
+    y = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_sample_scale_add(code, L.ptr(xd), L.ptr(md), L.ptr(sd), L.ptr(y), n, h * w * c, None))
+    y2 = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_sample_scale_add(code, L.ptr(xd), L.ptr(md), None, L.ptr(y2), n, h * w * c, None))
+    y3 = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_sample_scale_add(code, L.ptr(xd), None, L.ptr(sd), L.ptr(y3), n, h * w * c, None))
+    mean = torch.full((n, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_spatial_sum(code, L.ptr(xd), L.ptr(mean), n, h * w, c, 1.0 / (h * w), None))
+    dot = torch.full((n, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_channel_dot(code, L.ptr(xd), L.ptr(sd), L.ptr(dot), n, h * w, c, None))
+    sync()
+    m4 = mask[:, None, None, None]
+    assert torch.allclose(from_nhwc(y), x * m4 + skip, **tol(code, 4.0))
+    assert torch.allclose(from_nhwc(y2), x * m4, **tol(code, 4.0))
+    assert torch.allclose(from_nhwc(y3), x + skip, **tol(code, 4.0))
+    assert torch.allclose(mean.float().cpu(), x.mean((2, 3)), **tol(code, 1.0))
+    assert torch.allclose(dot.float().cpu(), (x * skip).sum((2, 3)), **tol(code, 10.0))

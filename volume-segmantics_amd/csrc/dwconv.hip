@@ -298,7 +298,8 @@ extern "C" int vs_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, floa
 // y [n][c] = scale * sum over the hw positions of x [n][hw][c]  (AdaptiveAvgPool2d(1): scale = 1 / hw; the gradient of a broadcast: 1)
 extern "C" int vs_spatial_sum(int dtype, const void* x, void* y, int n, int64_t hw, int c, float scale, void* stream) {
     const int cs = c < 256 ? c : 256;
-    VS_REQUIRE(x && y && c > 0 && c % kVec == 0 && c % cs == 0 && 256 % (cs / kVec) == 0, "spatial_sum: unsupported channel count %d", c);
+    VS_REQUIRE(x && y && c > 0 && c % kVec == 0, "spatial_sum: unsupported channel count %d", c);
+    if (c % cs || 256 % (cs / kVec)) return vs_sample_rowsum(dtype, x, nullptr, y, n, hw, c, scale, stream);   // any other multiple of 8 (csrc/effnet.hip)
     VS_LAUNCH_T(spatial_sum_kernel, dim3(n, c / cs), 0, (hipStream_t)stream, (const T*)x, (T*)y, hw, c, scale);
     return VS_OK;
 }

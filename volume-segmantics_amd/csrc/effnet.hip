@@ -1,0 +1,540 @@
+// Operators of smp's EfficientNet encoders (segmentation-models-pytorch 0.2.1 encoders/efficientnet.py over efficientnet-pytorch
+// 0.6.3: model.py MBConvBlock / EfficientNet, utils.py Conv2dStaticSamePadding / drop_connect) that the ResNet kernels do not cover,
+// NHWC tensors, HBM-bound sweeps (gfx950):
+//   * BatchNorm2d over ANY channel count that is a multiple of 8 (the expanded widths 144 .. 2688), eps / momentum as arguments
+//     (1e-3 / 0.01 there), followed by nothing, ReLU or swish (x * sigmoid(x)); the backward pass recomputes the activation's
+//     derivative from the pre-norm tensor
+//   * depthwise k x k convolution (3 / 5), stride 1 / 2, TF-style "same" static padding (pad_lo rows / columns in front, the rest
+//     behind): forward, data gradient, weight gradient; with a single-channel fp32 input broadcast over the channels the same
+//     kernels ARE the stem nn.Conv2d(1, cout, 3, stride=2)
+//   * drop_connect (one Bernoulli draw per sample, the surviving samples scaled by 1 / keep) fused with the residual sum
+// Everything here is a fixed-order reduction: same input, same bits.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kVec = 8;
+constexpr int kBnBlocks = 512;     // partial rows of the BatchNorm reductions
+constexpr int kDwBlocks = 128;     // partial rows of the depthwise weight gradient
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v / (1.f + __expf(-v));
+    return v;
+}
+__device__ __forceinline__ float act_grad(float v, int act) {   // d act(v) / dv
+    if (act == 1) return v > 0.f ? 1.f : 0.f;
+    if (act == 2) { const float s = 1.f / (1.f + __expf(-v)); return s * (1.f + v * (1.f - s)); }
+    return 1.f;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// A workgroup of 256 lanes covers one slab of up to 256 channel vectors (blockIdx.y) and 256 / cv rows per sweep.
+struct Slab {
+    int cv, rpb, cvi, rl, ch0;   // vectors in this slab, rows per sweep, this lane's vector / row lane, first channel of the lane
+    bool on;
+};
+__device__ __forceinline__ Slab slab_of(int c) {
+    Slab s;
+    const int cv_all = c / kVec, v0 = blockIdx.y * 256;
+    s.cv = min(256, cv_all - v0);
+    s.rpb = 256 / s.cv;
+    s.cvi = threadIdx.x % s.cv;
+    s.rl = threadIdx.x / s.cv;
+    s.ch0 = (v0 + s.cvi) * kVec;
+    s.on = s.rl < s.rpb;
+    return s;
+}
+
+// ---- BatchNorm ----------------------------------------------------------------------------------------------------------
+// partial[blk][2][c]: per workgroup sums of (x - K) and (x - K)^2, K = the tensor's first row (no cancellation when |mean| >> std)
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_stats_partial(const T* __restrict__ x, int64_t rows, int c, float* __restrict__ partial) {
+    __shared__ float red[2][256][kVec + 1];
+    const Slab sl = slab_of(c);
+    float s[kVec], q[kVec], sh[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) s[k] = q[k] = 0.f;
+    ld8(x + sl.ch0, sh);
+    if (sl.on) {
+        for (int64_t r = (int64_t)blockIdx.x * sl.rpb + sl.rl; r < rows; r += (int64_t)gridDim.x * sl.rpb) {
+            float v[kVec];
+            ld8(x + r * c + sl.ch0, v);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) { const float d = v[k] - sh[k]; s[k] += d; q[k] += d * d; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) { red[0][threadIdx.x][k] = s[k]; red[1][threadIdx.x][k] = q[k]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < sl.rpb; ++j) { a += red[0][j * sl.cv + g][k]; b += red[1][j * sl.cv + g][k]; }
+        const int cc = blockIdx.y * 256 * kVec + ch;
+        partial[((size_t)blockIdx.x * 2 + 0) * c + cc] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * c + cc] = b;
+    }
+}
+// one wave per channel: fp64 sums of the partial rows in a fixed order
+template <typename T>
+__global__ __launch_bounds__(64) void bn2_stats_finalize(const float* __restrict__ partial, const T* __restrict__ x, int nblocks, int c, int64_t rows,
+                                                       float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var) {
+    const int ch = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
+        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (threadIdx.x != 0) return;
+    const double dm = s / (double)rows;
+    double var = q / (double)rows - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double mu = dm + (double)Elem<T>::ld(x + ch);
+    mean[ch] = (float)mu;
+    invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
+        running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+    }
+}
+// y = act((x - mean) * invstd * gamma + beta); var_eps >= 0: the second vector holds VARIANCES (evaluation from the running statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int act, float var_eps,
+                                                      T* __restrict__ y, int64_t rows, int c) {
+    const Slab sl = slab_of(c);
+    if (!sl.on) return;
+    float sc[kVec], sf[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = sl.ch0 + k;
+        const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[ch] + var_eps) : invstd[ch];
+        sc[k] = is * gamma[ch];
+        sf[k] = beta[ch] - mean[ch] * sc[k];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * sl.rpb + sl.rl; r < rows; r += (int64_t)gridDim.x * sl.rpb) {
+        float v[kVec];
+        ld8(x + r * c + sl.ch0, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = act_fwd(v[k] * sc[k] + sf[k], act);
+        st8(y + r * c + sl.ch0, v);
+    }
+}
+// backward: g = dy * act'(yhat), partial sums of g and g * xhat
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_bwd_partial(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int act, int64_t rows, int c, float* __restrict__ partial) {
+    __shared__ float red[2][256][kVec + 1];
+    const Slab sl = slab_of(c);
+    float s[kVec], q[kVec], mu[kVec], is[kVec], ga[kVec], be[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = sl.ch0 + k;
+        s[k] = q[k] = 0.f;
+        mu[k] = mean[ch]; is[k] = invstd[ch]; ga[k] = gamma[ch]; be[k] = beta[ch];
+    }
+    if (sl.on) {
+        for (int64_t r = (int64_t)blockIdx.x * sl.rpb + sl.rl; r < rows; r += (int64_t)gridDim.x * sl.rpb) {
+            float g[kVec], v[kVec];
+            ld8(dy + r * c + sl.ch0, g);
+            ld8(x + r * c + sl.ch0, v);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) {
+                const float xh = (v[k] - mu[k]) * is[k];
+                const float gg = g[k] * act_grad(xh * ga[k] + be[k], act);
+                s[k] += gg; q[k] += gg * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) { red[0][threadIdx.x][k] = s[k]; red[1][threadIdx.x][k] = q[k]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < sl.rpb; ++j) { a += red[0][j * sl.cv + g][k]; b += red[1][j * sl.cv + g][k]; }
+        const int cc = blockIdx.y * 256 * kVec + ch;
+        partial[((size_t)blockIdx.x * 2 + 0) * c + cc] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * c + cc] = b;
+    }
+}
+__global__ __launch_bounds__(64) void bn2_bwd_finalize(const float* __restrict__ partial, int nblocks, int c, float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        s += (double)partial[((size_t)b * 2 + 0) * c + ch];
+        q += (double)partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (threadIdx.x == 0) { dbeta[ch] = (float)s; dgamma[ch] = (float)q; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ dgamma, const float* __restrict__ dbeta, int act, T* __restrict__ dx,
+                                                   int64_t rows, int c) {
+    const Slab sl = slab_of(c);
+    if (!sl.on) return;
+    const float inv_m = 1.f / (float)rows;
+    float mu[kVec], is[kVec], ga[kVec], be[kVec], db[kVec], dg[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+        const int ch = sl.ch0 + k;
+        mu[k] = mean[ch]; is[k] = invstd[ch]; ga[k] = gamma[ch]; be[k] = beta[ch];
+        db[k] = dbeta[ch] * inv_m; dg[k] = dgamma[ch] * inv_m;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * sl.rpb + sl.rl; r < rows; r += (int64_t)gridDim.x * sl.rpb) {
+        float g[kVec], v[kVec], o[kVec];
+        ld8(dy + r * c + sl.ch0, g);
+        ld8(x + r * c + sl.ch0, v);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const float xh = (v[k] - mu[k]) * is[k];
+            const float gg = g[k] * act_grad(xh * ga[k] + be[k], act);
+            o[k] = ga[k] * is[k] * (gg - db[k] - xh * dg[k]);
+        }
+        st8(dx + r * c + sl.ch0, o);
+    }
+}
+
+// ---- depthwise k x k convolution, stride s, pad_lo in front ---------------------------------------------------------------------
+// A workgroup covers a slab of up to 64 channel vectors (blockIdx.y; its taps [tap][512] in LDS) and 4 output pixels per sweep.
+// XT / BCAST: the input is a single-channel fp32 map broadcast over the channels (the stem).
+template <typename T, typename XT, bool BCAST>
+__global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
+                                                         int c, int k, int stride, int pad, int ho, int wo) {
+    extern __shared__ float wl[];     // [k * k][64 * 8]
+    const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
+    for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
+    __syncthreads();
+    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    if (cvi >= cv) return;
+    const int ch0 = (v0 + cvi) * kVec;
+    const int64_t pixels = (int64_t)n * ho * wo;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+        const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
+        const int64_t b = p / wo / ho;
+        float acc[kVec];
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) acc[q] = 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int iy = oy * stride + kh - pad;
+            if (iy < 0 || iy >= h) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int ix = ox * stride + kw - pad;
+                if (ix < 0 || ix >= w) continue;
+                const float* wt = wl + (kh * k + kw) * 512 + cvi * kVec;
+                if constexpr (BCAST) {
+                    const float v = (float)x[(b * h + iy) * w + ix];
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) acc[q] += v * wt[q];
+                } else {
+                    float v[kVec];
+                    ld8(x + ((b * h + iy) * w + ix) * c + ch0, v);
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) acc[q] += v[q] * wt[q];
+                }
+            }
+        }
+        st8(y + p * c + ch0, acc);
+    }
+}
+// dx[iy][ix] (+)= sum over the taps (kh, kw) with (iy + pad - kh) and (ix + pad - kw) divisible by the stride of dy[..] * w[kh][kw]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ wgt, T* __restrict__ dx, int n, int h,
+                                                              int w, int c, int k, int stride, int pad, int ho, int wo, int accumulate) {
+    extern __shared__ float wl[];
+    const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
+    for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
+    __syncthreads();
+    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    if (cvi >= cv) return;
+    const int ch0 = (v0 + cvi) * kVec;
+    const int64_t pixels = (int64_t)n * h * w;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+        const int ix = (int)(p % w), iy = (int)(p / w % h);
+        const int64_t b = p / w / h;
+        float acc[kVec];
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) acc[q] = 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int ty = iy + pad - kh;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= ho) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int tx = ix + pad - kw;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= wo) continue;
+                float g[kVec];
+                ld8(dy + ((b * ho + oy) * wo + ox) * c + ch0, g);
+                const float* wt = wl + (kh * k + kw) * 512 + cvi * kVec;
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) acc[q] += g[q] * wt[q];
+            }
+        }
+        if (accumulate) {
+            float old[kVec];
+            ld8(dx + p * c + ch0, old);
+#pragma unroll
+            for (int q = 0; q < kVec; ++q) acc[q] += old[q];
+        }
+        st8(dx + p * c + ch0, acc);
+    }
+}
+// weight gradient, stage 1: blockIdx.z = tap; partial[blk][c][kk] = sum over the workgroup's output pixels of dy * shifted x
+template <typename T, typename XT, bool BCAST>
+__global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restrict__ x, const T* __restrict__ dy, int n, int h, int w, int c, int k,
+                                                            int stride, int pad, int ho, int wo, float* __restrict__ partial) {
+    __shared__ float red[4][64][kVec + 1];
+    const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
+    const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
+    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int ch0 = (v0 + min(cvi, cv - 1)) * kVec;
+    float s[kVec];
+#pragma unroll
+    for (int q = 0; q < kVec; ++q) s[q] = 0.f;
+    const int64_t pixels = (int64_t)n * ho * wo;
+    if (cvi < cv) {
+        for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+            const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
+            const int64_t b = p / wo / ho;
+            const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+            if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+            float g[kVec];
+            ld8(dy + p * c + ch0, g);
+            if constexpr (BCAST) {
+                const float v = (float)x[(b * h + iy) * w + ix];
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) s[q] += g[q] * v;
+            } else {
+                float v[kVec];
+                ld8(x + ((b * h + iy) * w + ix) * c + ch0, v);
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) s[q] += g[q] * v[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kVec; ++q) red[pl][cvi][q] = s[q];
+    __syncthreads();
+    for (int o = threadIdx.x; o < cv * kVec; o += 256) {
+        const int g = o / kVec, q = o % kVec;
+        const float t = (red[0][g][q] + red[1][g][q]) + (red[2][g][q] + red[3][g][q]);
+        partial[((size_t)blockIdx.x * c + v0 * kVec + o) * kk + tap] = t;
+    }
+}
+__global__ void dwconv2d_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int total) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;      // channel * kk + tap
+    if (o >= total) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * total + o];
+    dw[o] = (float)s;
+}
+
+// out = x * mask[n] + skip (mask NULL: 1; skip NULL: 0) - drop_connect + the residual sum, and (on the gradient, without skip) its backward
+template <typename T>
+__global__ void sample_scale_add_kernel(const T* __restrict__ x, const float* __restrict__ mask, const T* __restrict__ skip, T* __restrict__ y, int n,
+                                        int64_t per_sample) {
+    const int64_t pv = per_sample / kVec, total = (int64_t)n * pv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mask ? mask[i / pv] : 1.f;
+        float v[kVec];
+        ld8(x + i * kVec, v);
+        if (skip) {
+            float s[kVec];
+            ld8(skip + i * kVec, s);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = v[k] * m + s[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] *= m;
+        }
+        st8(y + i * kVec, v);
+    }
+}
+
+// out[n][c] = scale * sum over the sample's hw rows of a (* b): the average pool of the squeeze-excitation branch and, with b, the
+// gate's gradient - any channel count that is a multiple of 8 (blockIdx.x = sample, blockIdx.y = slab of 256 channel vectors)
+template <typename T>
+__global__ __launch_bounds__(256) void sample_rowsum_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t hw, int c, float scale) {
+    __shared__ float red[256][kVec + 1];
+    const Slab sl = slab_of(c);
+    const T* as = a + (size_t)blockIdx.x * hw * c + sl.ch0;
+    const T* bs = b ? b + (size_t)blockIdx.x * hw * c + sl.ch0 : nullptr;
+    float s[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) s[k] = 0.f;
+    if (sl.on) {
+        for (int64_t r = sl.rl; r < hw; r += 4 * sl.rpb) {
+            float v[4][kVec], g[4][kVec];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + (int64_t)u * sl.rpb;
+                if (rr < hw) {
+                    ld8(as + rr * c, v[u]);
+                    if (bs) ld8(bs + rr * c, g[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) v[u][k] = 0.f;
+                    if (bs) {
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) g[u][k] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) s[k] += bs ? v[u][k] * g[u][k] : v[u][k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float t = 0.f;
+        for (int j = 0; j < sl.rpb; ++j) t += red[j * sl.cv + g][k];
+        Elem<T>::st(out + (size_t)blockIdx.x * c + blockIdx.y * 256 * kVec + ch, t * scale);
+    }
+}
+
+inline int bn2_blocks(int64_t rows, int c) {
+    const int cv = std::min(c / kVec, 256), rpb = 256 / cv;
+    const int64_t nb = (rows + (int64_t)rpb * 4 - 1) / ((int64_t)rpb * 4);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kBnBlocks, nb));
+}
+
+}  // namespace
+
+#define VS_LAUNCH_T(kernel, grid, lds, s, ...)                                                                          \
+    do {                                                                                                                \
+        if (dtype == VS_BF16) { typedef bf16_t T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); } \
+        else { typedef float T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); }                   \
+        VS_LAUNCH_CHECK();                                                                                              \
+    } while (0)
+
+// nn.BatchNorm2d(c, eps, momentum) on x [rows][c], c any multiple of 8; act 0 none / 1 ReLU / 2 swish.  workspace: vs_bn2_workspace(c).
+extern "C" size_t vs_bn2_workspace(int c) { return (size_t)kBnBlocks * 2 * c * sizeof(float); }
+extern "C" int vs_bn2_stats(int dtype, const void* x, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                            float* running_var, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(x && mean && invstd && rows > 0 && c > 0 && c % kVec == 0, "bn2_stats: channels must be a multiple of 8 (got %d)", c);
+    VS_REQUIRE(workspace && workspace_bytes >= vs_bn2_workspace(c), "bn2_stats: workspace too small");
+    const int nb = bn2_blocks(rows, c), slabs = (c / kVec + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    VS_LAUNCH_T(bn2_stats_partial, dim3(nb, slabs), 0, s, (const T*)x, rows, c, workspace);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(bn2_stats_finalize<bf16_t>, dim3(c), dim3(64), 0, s, workspace, (const bf16_t*)x, nb, c, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    else
+        hipLaunchKernelGGL(bn2_stats_finalize<float>, dim3(c), dim3(64), 0, s, workspace, (const float*)x, nb, c, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+// y = act((x - mean) * invstd * gamma + beta); var_eps >= 0: `invstd` holds VARIANCES and invstd = 1 / sqrt(var + var_eps) (evaluation)
+extern "C" int vs_bn2_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                            float var_eps, void* y, int64_t rows, int c, void* stream) {
+    VS_REQUIRE(x && mean && invstd && gamma && beta && y && rows > 0 && c > 0 && c % kVec == 0 && act >= 0 && act <= 2, "bn2_apply: bad arguments");
+    VS_LAUNCH_T(bn2_apply_kernel, dim3(bn2_blocks(rows, c) * 2, (c / kVec + 255) / 256), 0, (hipStream_t)stream, (const T*)x, mean, invstd, gamma, beta, act,
+                var_eps, (T*)y, rows, c);
+    return VS_OK;
+}
+extern "C" int vs_bn2_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          int act, void* dx, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && dgamma && dbeta && rows > 0 && c > 0 && c % kVec == 0 && act >= 0 && act <= 2,
+               "bn2_bwd: bad arguments");
+    VS_REQUIRE(workspace && workspace_bytes >= vs_bn2_workspace(c), "bn2_bwd: workspace too small");
+    const int nb = bn2_blocks(rows, c), slabs = (c / kVec + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    VS_LAUNCH_T(bn2_bwd_partial, dim3(nb, slabs), 0, s, (const T*)dy, (const T*)x, mean, invstd, gamma, beta, act, rows, c, workspace);
+    hipLaunchKernelGGL(bn2_bwd_finalize, dim3(c), dim3(64), 0, s, workspace, nb, c, dgamma, dbeta);
+    VS_LAUNCH_CHECK();
+    VS_LAUNCH_T(bn2_bwd_apply, dim3(nb * 2, slabs), 0, s, (const T*)dy, (const T*)x, mean, invstd, gamma, beta, dgamma, dbeta, act, (T*)dx, rows, c);
+    return VS_OK;
+}
+
+// nn.Conv2d(c, c, k, stride, groups=c, bias=False) behind efficientnet-pytorch's Conv2dStaticSamePadding: pad_lo zero rows / columns in
+// front (what is needed behind follows from ho / wo); x [n][h][w][c], w fp32 [c][k * k], y [n][ho][wo][c].  x_single_channel = 1: x is an
+// fp32 [n][h][w] map broadcast over the c channels - nn.Conv2d(1, c, k, stride, bias=False), the stem on greyscale slices.
+extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+                           int x_single_channel, void* stream) {
+    VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+               "dwconv2d: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
+    VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
+    const dim3 grid(grid_for((int64_t)n * ho * wo * 64), (c / kVec + 63) / 64);
+    const size_t lds = (size_t)k * k * 512 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_single_channel) {
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+    } else {
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, false>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+    }
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho,
+                                    int wo, int accumulate, void* stream) {
+    VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+               "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
+    const dim3 grid(grid_for((int64_t)n * h * wd * 64), (c / kVec + 63) / 64);
+    VS_LAUNCH_T(dwconv2d_bwd_data_kernel, grid, (size_t)k * k * 512 * sizeof(float), (hipStream_t)stream, (const T*)dy, w, (T*)dx, n, h, wd, c, k, stride, pad_lo,
+                ho, wo, accumulate);
+    return VS_OK;
+}
+extern "C" size_t vs_dwconv2d_wgrad_workspace(int c, int k) { return (size_t)kDwBlocks * c * k * k * sizeof(float); }
+extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+                                 int x_single_channel, float* workspace, size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+               "dwconv2d_wgrad: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
+    VS_REQUIRE(workspace && workspace_bytes >= vs_dwconv2d_wgrad_workspace(c, k), "dwconv2d_wgrad: workspace too small");
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + 3) / 4));
+    const dim3 grid(nblk, (c / kVec + 63) / 64, k * k);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_single_channel) {
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+    } else {
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+    }
+    VS_LAUNCH_CHECK();
+    const int total = c * k * k;
+    hipLaunchKernelGGL(dwconv2d_wgrad_final, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, nblk, total);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// y [n][per_sample] = x * mask[n] + skip (mask may be NULL = 1, skip may be NULL = 0): efficientnet-pytorch's drop_connect (mask from
+// vs_dropout2d_mask with c = 1: 0 or 1 / keep per sample) and the block's `x + inputs` in one sweep
+extern "C" int vs_sample_scale_add(int dtype, const void* x, const float* mask, const void* skip, void* y, int n, int64_t per_sample, void* stream) {
+    VS_REQUIRE(x && y && n > 0 && per_sample > 0 && per_sample % kVec == 0, "sample_scale_add: per-sample size must be a multiple of 8");
+    VS_LAUNCH_T(sample_scale_add_kernel, dim3(grid_for((int64_t)n * per_sample / kVec)), 0, (hipStream_t)stream, (const T*)x, mask, (const T*)skip, (T*)y, n, per_sample);
+    return VS_OK;
+}
+// out [n][c] = scale * sum over hw of a[n][hw][c] (* b[n][hw][c] when b is given), any c that is a multiple of 8
+extern "C" int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream) {
+    VS_REQUIRE(a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "sample_rowsum: channels must be a multiple of 8");
+    VS_LAUNCH_T(sample_rowsum_kernel, dim3(n, (c / kVec + 255) / 256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, hw, c, scale);
+    return VS_OK;
+}

@@ -172,17 +172,17 @@ __global__ void bmm_dp_kernel(const float* __restrict__ dP, const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
                                                     const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ a,
-                                                    float* __restrict__ hid, int C, int R) {
-    __shared__ float ps[2048], hs[128];
+                                                    float* __restrict__ hid, int C, int R, int swish) {
+    __shared__ float ps[4096], hs[128];
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += 256) ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
     __syncthreads();
     if ((int)threadIdx.x < R) {
         float acc = b1[threadIdx.x];
         for (int c = 0; c < C; ++c) acc += w1[(size_t)threadIdx.x * C + c] * ps[c];
-        acc = fmaxf(acc, 0.f);
+        hid[(size_t)b * R + threadIdx.x] = swish ? acc : fmaxf(acc, 0.f);       // kept for the backward pass (swish: the pre-activation)
+        acc = swish ? acc / (1.f + __expf(-acc)) : fmaxf(acc, 0.f);
         hs[threadIdx.x] = acc;
-        hid[(size_t)b * R + threadIdx.x] = acc;       // kept for the backward pass
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -196,8 +196,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const T* __restrict__ da, const T* __restrict__ a, const T* __restrict__ p,
                                                         const float* __restrict__ hid, const float* __restrict__ w1, const float* __restrict__ w2,
                                                         T* __restrict__ dp, float* __restrict__ dw1, float* __restrict__ db1,
-                                                        float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int R) {
-    __shared__ float g2[2048], ps[2048], hs[128], g1[128];
+                                                        float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int R, int swish) {
+    __shared__ float g2[4096], ps[4096], hs[128], g1[128], hd[128];
     const int tid = threadIdx.x;
     // this block owns every output: zero the weight gradients, then accumulate sample by sample
     for (int i = tid; i < R * C; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
@@ -210,12 +210,20 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const T* __restrict__ 
             g2[c] = Elem<T>::ld(da + (size_t)b * C + c) * av * (1.f - av);
             ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
         }
-        if (tid < R) hs[tid] = hid[(size_t)b * R + tid];
+        if (tid < R) {
+            const float hv = hid[(size_t)b * R + tid];
+            if (swish) {      // hid holds the pre-activation: hidden value v * s, derivative s (1 + v (1 - s))
+                const float sg = 1.f / (1.f + __expf(-hv));
+                hs[tid] = hv * sg; hd[tid] = sg * (1.f + hv * (1.f - sg));
+            } else {
+                hs[tid] = hv; hd[tid] = hv > 0.f ? 1.f : 0.f;
+            }
+        }
         __syncthreads();
         if (tid < R) {
             float acc = 0.f;
             for (int c = 0; c < C; ++c) acc += w2[(size_t)c * R + tid] * g2[c];
-            g1[tid] = hs[tid] > 0.f ? acc : 0.f;
+            g1[tid] = acc * hd[tid];
             db1[tid] += g1[tid];
         }
         for (int c = tid; c < C; c += 256) db2[c] += g2[c];
@@ -316,17 +324,18 @@ extern "C" int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, 
 extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C) { return ((size_t)n * hw * C + (size_t)n * hw * hw) * sizeof(float); }
 
 // squeeze-excitation gate on pooled features (MFAB's SE_ll / SE_hl after the average pool): a = sigmoid(W2 relu(W1 p + b1) + b2);
-// hid [n][R] fp32 keeps the hidden activations for the backward pass.  C <= 2048, R <= 128.
+// hid [n][R] fp32 keeps the hidden activations for the backward pass.  C <= 4096, R <= 128.  swish = 1: the hidden activation is
+// x * sigmoid(x) instead of ReLU (efficientnet-pytorch's MBConvBlock: _se_reduce, swish, _se_expand, sigmoid).
 extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
-                              int n, int C, int R, void* stream) {
-    VS_REQUIRE(p && w1 && b1 && w2 && b2 && a && hid && C >= 1 && C <= 2048 && R >= 1 && R <= 128, "se_gate_fwd: C <= 2048, R <= 128");
-    VS_LAUNCH_T(se_gate_kernel, dim3(n), (hipStream_t)stream, (const T*)p, w1, b1, w2, b2, (T*)a, hid, C, R);
+                              int n, int C, int R, int swish, void* stream) {
+    VS_REQUIRE(p && w1 && b1 && w2 && b2 && a && hid && C >= 1 && C <= 4096 && R >= 1 && R <= 128, "se_gate_fwd: C <= 4096, R <= 128");
+    VS_LAUNCH_T(se_gate_kernel, dim3(n), (hipStream_t)stream, (const T*)p, w1, b1, w2, b2, (T*)a, hid, C, R, swish);
     return VS_OK;
 }
 extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream) {
-    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && C <= 2048 && R <= 128, "se_gate_bwd: bad arguments");
-    VS_LAUNCH_T(se_gate_bwd_kernel, dim3(1), (hipStream_t)stream, (const T*)da, (const T*)a, (const T*)p, hid, w1, w2, (T*)dp, dw1, db1, dw2, db2, n, C, R);
+                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream) {
+    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && C <= 4096 && R <= 128, "se_gate_bwd: bad arguments");
+    VS_LAUNCH_T(se_gate_bwd_kernel, dim3(1), (hipStream_t)stream, (const T*)da, (const T*)a, (const T*)p, hid, w1, w2, (T*)dp, dw1, db1, dw2, db2, n, C, R, swish);
     return VS_OK;
 }
 // y = x * g[n][c] broadcast over the hw positions; vs_channel_dot: dg[n][c] = sum over positions of x * dy
@@ -337,7 +346,8 @@ extern "C" int vs_channel_gate(int dtype, const void* x, const void* g, void* y,
 }
 extern "C" int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream) {
     const int cs = c < 256 ? c : 256;
-    VS_REQUIRE(x && dy && dg && c > 0 && c % kVec == 0 && c % cs == 0 && 256 % (cs / kVec) == 0, "channel_dot: unsupported channel count %d", c);
+    VS_REQUIRE(x && dy && dg && c > 0 && c % kVec == 0, "channel_dot: unsupported channel count %d", c);
+    if (c % cs || 256 % (cs / kVec)) return vs_sample_rowsum(dtype, x, dy, dg, n, hw, c, 1.f, stream);   // any other multiple of 8 (csrc/effnet.hip)
     VS_LAUNCH_T(channel_dot_kernel, dim3(n, c / cs), (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dg, hw, c);
     return VS_OK;
 }

@@ -47,9 +47,9 @@ extern "C" int vs_pab_attention_bwd(int dtype, const void* dy, const void* top, 
                                     void* dcenter, void* dbottom, float* scratch, int n, int hw, int K, int C, void* stream);
 extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C);
 extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
-                              int n, int C, int R, void* stream);
+                              int n, int C, int R, int swish, void* stream);
 extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, void* stream);
+                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream);
 extern "C" int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 extern "C" int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 extern "C" int vs_maxpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
@@ -1234,7 +1234,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_SE: {
             if ((rc = vs_se_gate_fwd(dt, c.a(u.src0), c.P(u.w_idx), c.P(u.w_idx + 1), c.P(u.w_idx + 2), c.P(u.w_idx + 3), c.a(u.out),
-                                     (float*)(c.ws + u.off_gn), n, u.cout, u.cin1, stream))) return rc;
+                                     (float*)(c.ws + u.off_gn), n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
             continue;
         }
         case U_CGATE: {
@@ -1698,7 +1698,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             VS_REQUIRE(written[u.out] && !written[u.src0], "backward: SE gate gradients out of order");
             if ((rc = vs_se_gate_bwd(dt, c.da(u.out), c.a(u.out), c.a(u.src0), (const float*)(c.ws + u.off_gn), c.P(u.w_idx), c.P(u.w_idx + 2),
                                      c.da(u.src0), grads + c.t(u.w_idx).offset, grads + c.t(u.w_idx + 1).offset, grads + c.t(u.w_idx + 2).offset,
-                                     grads + c.t(u.w_idx + 3).offset, n, u.cout, u.cin1, stream))) return rc;
+                                     grads + c.t(u.w_idx + 3).offset, n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
             written[u.src0] = 1;
             continue;
         }
