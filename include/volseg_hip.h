@@ -138,6 +138,9 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   103 / 104: smp's efficientnet-b3 / efficientnet-b4 encoders (efficientnet-pytorch 0.6.3: 3x3 / 2 stem, 26 / 32 MBConv blocks -
+ *   expand 1x1, depthwise 3x3 / 5x5 behind static same padding, squeeze-excitation with swish, project 1x1, drop_connect + skip;
+ *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - topology 0 only;
  *   topology 7: smp.PAN (layer4 dilated; FPABlock with its single-channel 7x7 / 5x5 / 3x3 pyramid, three GAUBlocks, 3x3 head at 1/4
  *   resolution + x4 bilinear; slices must be multiples of 128) - depths 18 / 34 / 50;
  *   topology 6: smp.MAnet (PAB position attention at the deepest level, four MFAB blocks with squeeze-excitation gates on skip and
@@ -373,7 +376,8 @@ size_t vs_pab_scratch_bytes(int n, int hw, int C);
 int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid, int n,
                    int C, int R, int swish, void* stream);
 int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                   float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream);
+                   float* dw1, float* db1, float* dw2, float* db2, float* scratch, int n, int C, int R, int swish, void* stream);
+size_t vs_se_gate_scratch_floats(int n, int C, int R);      /* floats of vs_se_gate_bwd's scratch */
 int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 
@@ -437,6 +441,9 @@ int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const float* gra
  * topology has no dropout (tests feed the mask to the oracle). */
 int vs_unet_set_rng(vs_unet_t* net, uint32_t seed, const int64_t* counter);
 int64_t vs_unet_dropout_mask_offset(const vs_unet_t* net);
+/* the drop-connect draws of the last training forward (EfficientNet encoders): per MBConv block with a skip and a non-zero rate its block
+ * index, rate and the byte offset in the training workspace of its [n] fp32 mask (0 or 1 / keep); returns their number */
+int vs_unet_drop_connect_masks(const vs_unet_t* net, int64_t* offsets, int* blocks, float* rates, int cap);
 /* the per-step scalars of a replayed optimiser step (see vs_adamw_args.hyper): one tiny launch on `stream` that also adds 1
  * to the n_bn BatchNorm num_batches_tracked counters (int64, may be NULL with n_bn = 0). */
 int vs_train_hyper_set(float* hyper, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -15,6 +15,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .efficientnet_torch import OUT_CHANNELS as EFFICIENTNET_OUT_CHANNELS, EfficientNetEncoder
 from .unet_resnet34_torch import DECODER_CHANNELS, BasicBlock, DecoderBlock
 
 LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnext50_32x4d": (3, 4, 6, 3)}
@@ -475,10 +476,16 @@ class PANDecoder(nn.Module):
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
-        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # smp's EfficientNetEncoder (oracle/efficientnet_torch.py); U-Net only
+            assert topology == "unet", "the EfficientNet encoders are restated for smp.Unet only"
+            self.encoder = EfficientNetEncoder(encoder_name, in_channels)
+            out_channels = EFFICIENTNET_OUT_CHANNELS[encoder_name]
+        else:
+            self.encoder = ResNetEncoder(encoder_name, in_channels)
+            out_channels = OUT_CHANNELS[encoder_name]
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
                         "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder,
-                        "manet": MAnetDecoder, "pan": PANDecoder}[topology](OUT_CHANNELS[encoder_name])
+                        "manet": MAnetDecoder, "pan": PANDecoder}[topology](out_channels)
         if topology == "pan":               # encoder_dilation=True: make_dilated(stage_list=[5], dilation_list=[2])
             replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "deeplabv3":         # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])

@@ -994,8 +994,9 @@ def test_se_gate_and_channel_gate_fwd_bwd(code, shape, swish):
     dp = torch.full((n, C), float("nan"), device=DEV, dtype=tdtype(code))
     dw1, db1 = torch.full((R, C), float("nan"), device=DEV), torch.full((R,), float("nan"), device=DEV)
     dw2, db2 = torch.full((C, R), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
+    scr = torch.empty(L.lib.vs_se_gate_scratch_floats(n, C, R), device=DEV)
     L.check(L.lib.vs_se_gate_bwd(code, L.ptr(da), L.ptr(ad), L.ptr(pd), L.ptr(hid), L.ptr(w1d), L.ptr(w2d), L.ptr(dp), L.ptr(dw1), L.ptr(db1),
-                                 L.ptr(dw2), L.ptr(db2), n, C, R, swish, None))
+                                 L.ptr(dw2), L.ptr(db2), L.ptr(scr), n, C, R, swish, None))
     sync()
     t = tol(code, 1.0)
     assert torch.allclose(ad.float().cpu(), a.detach(), **t)

@@ -677,3 +677,104 @@ def test_pan_eval_and_train_vs_oracle(encoder):
         sync()
         runs.append((m._flat.clone(), m._bnstate.clone()))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), encoder
+
+
+@pytest.mark.parametrize("encoder", ["efficientnet-b3", "efficientnet-b4"])
+def test_efficientnet_unet_eval_and_train_vs_oracle(encoder):
+    """smp.Unet over smp's efficientnet-b3 / b4 encoders (BASELINE configs[4] names b4) against oracle/efficientnet_torch.py: eval
+    logits, one training step's loss and EVERY gradient with the engine's drop-connect draws replayed in the oracle (one Bernoulli
+    per sample and block, a function of (dropout_seed, num_batches_tracked, block): recomputed here through vs_dropout2d_mask),
+    the running statistics (momentum 0.01), `_conv_head` / `_bn1` without a gradient, fp32 and bf16, and the recorded step against
+    the call-by-call step."""
+    import ctypes
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle_unet(encoder, 3, seed=2)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 64, 96, generator=g)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), (encoder, (got - ref).abs().max().item())
+    lab = (torch.rand(4, 64, 64, generator=g) > 0.6).to(torch.uint8)
+    xt = torch.randn(4, 1, 64, 64, generator=g)
+    _, t = P.prepare_training_batch(xt, lab, 2)
+    refs = {}
+    for precision, ltol, gtol in (("fp32", 2e-5, 3e-2), ("bf16", 3e-2, None)):
+        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder=encoder)
+        model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False).state_dict())
+        model.train()
+        loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
+        loss.backward()
+        sync()
+        plan = model._plans[(64, 64)]
+        cap = 64
+        offs, blocks, rates = (ctypes.c_int64 * cap)(), (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
+        nm = L.lib.vs_unet_drop_connect_masks(plan["handle"], offs, blocks, rates, cap)
+        n_blocks = len(oracle.encoder._blocks)
+        assert 0 < nm <= n_blocks
+        masks = {}
+        counter = torch.tensor([1], dtype=torch.int64, device=DEV)      # the first training forward of a fresh model reads counter 1
+        for i in range(nm):
+            used = plan["ws"][offs[i]:offs[i] + 16].view(torch.float32).clone()
+            assert abs(rates[i] - 0.2 * blocks[i] / n_blocks) < 1e-6
+            want = torch.empty(4, device=DEV)
+            L.check(L.lib.vs_dropout2d_mask(L.ptr(want), 4, 1, rates[i], 0x2545f491, L.ptr(counter), blocks[i] << 32, None))
+            sync()
+            assert torch.equal(used, want), "a drop-connect draw is not f(seed, num_batches_tracked, block)"
+            keep = 1.0 - rates[i]
+            assert all(abs(v) < 1e-7 or abs(v - 1.0 / keep) < 1e-5 for v in used.tolist())
+            masks[blocks[i]] = used.cpu()
+        if precision == "fp32":
+            oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False)
+            oracle.encoder.drop_masks = masks
+            oracle.train()
+            ref_loss = P.dice_loss_none(oracle(xt), t.float())
+            ref_loss.backward()
+            refs = dict(oracle.named_parameters())
+            sd = oracle.state_dict()
+            for k in ("encoder._bn0.running_mean", "encoder._blocks.3._bn1.running_var", f"encoder._blocks.{n_blocks - 1}._bn2.running_mean"):
+                assert torch.allclose(model.state_dict()[k].cpu(), sd[k], rtol=1e-4, atol=1e-5), k
+        assert abs(loss.item() - ref_loss.item()) < ltol, (encoder, precision, loss.item(), ref_loss.item())
+        worst, errs = ("", 0.0), []
+        for name, p in model.named_parameters():
+            if name.startswith(VolSegUnet.UNUSED_PREFIXES):
+                assert p.grad is None and refs[name].grad is None, name
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            r = refs[name].grad
+            if precision == "fp32":
+                err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
+                errs.append((err, name))
+                if err > worst[1]:
+                    worst = (name, err)
+                assert err < gtol or r.norm().item() < 1e-7, (encoder, name, err, r.norm().item())
+            elif name.startswith(("segmentation_head", "decoder.blocks.4")):
+                assert _cos(p.grad.cpu(), r) > 0.9, (encoder, name)
+        print(encoder, precision, "worst relative gradient errors", sorted(errs, reverse=True)[:8], "median", sorted(errs)[len(errs) // 2] if errs else None)
+    # the recorded step equals the call-by-call step (same draws: both read the advanced counter), with and without the frozen encoder
+    for frozen in (False, True):
+        runs = []
+        for graph in (True, False):
+            m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder)
+            if frozen:
+                for name, p in m.named_parameters():
+                    if "encoder" in name and "conv" in name:
+                        p.requires_grad = False
+            o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
+            m.train()
+            tt = t.to(DEV).contiguous()
+            for _ in range(3):
+                if graph:
+                    assert m.can_fuse_step(o, xt.to(DEV), tt)
+                    m.fused_train_step(xt.to(DEV), tt, o)
+                else:
+                    o.zero_grad(); l = HipDiceLoss()(m(xt.to(DEV)), tt); l.backward(); o.step()
+            sync()
+            runs.append(m._flat.clone())
+        assert torch.equal(runs[0], runs[1]), (encoder, frozen)
+        assert torch.isfinite(runs[0]).all()

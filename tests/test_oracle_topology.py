@@ -235,3 +235,31 @@ def test_pan_restatement_and_engine_table_agree():
     assert sd["decoder.gau1.conv2.conv.weight"].shape == (32, 64, 3, 3) and sd["segmentation_head.0.weight"].shape == (2, 32, 3, 3)
     with torch.no_grad():
         assert net.eval()(torch.zeros(1, 3, 128, 128)).shape == (1, 1, 128, 128)
+
+
+def test_efficientnet_restatement_matches_published_parameter_counts_and_engine_table():
+    """smp's efficientnet-b3 / b4 encoders (oracle/efficientnet_torch.py): with the 3-channel stem and the 1000-way `_fc` added back
+    the restated encoders carry exactly efficientnet-pytorch's published parameter counts (12,233,232 / 19,341,616), their feature
+    widths are smp's out_channels, the static same padding is (0, 1) / (1, 2) at stride 2, and the engine's tensor table has the
+    same keys / shapes in state_dict order (incl. the never-run `_conv_head` / `_bn1`); the freeze predicate picks every
+    convolution except the squeeze-excitation ones (their names lack "conv")."""
+    from oracle.efficientnet_torch import COEFFS, OUT_CHANNELS, PUBLISHED_PARAMS, EfficientNetEncoder, SamePadConv2d, block_plan, round_filters
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    for name, code in (("efficientnet-b3", 103), ("efficientnet-b4", 104)):
+        enc = EfficientNetEncoder(name, 3)
+        head = round_filters(1280, COEFFS[name][0])
+        assert sum(p.numel() for p in enc.parameters()) + head * 1000 + 1000 == PUBLISHED_PARAMS[name], name
+        with torch.no_grad():
+            feats = enc.eval()(torch.zeros(1, 3, 64, 96))
+        assert [f.shape[1] for f in feats[1:]] == list(OUT_CHANNELS[name][1:])
+        assert [tuple(f.shape[2:]) for f in feats] == [(64 >> i, 96 >> i) for i in range(6)]
+        sd = OracleUnet(name, 1, 3).state_dict()
+        table = _lib.unet_tensor_table(3, code)
+        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
+        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+        frozen = [k for k, _ in OracleUnet(name, 1, 2).named_parameters() if "encoder" in k and "conv" in k]
+        n_blocks, n_expand = len(block_plan(name)), sum(1 for b in block_plan(name) if b[2] != 1)
+        assert len(frozen) == 2 + 2 * n_blocks + n_expand and not any("_se_" in k for k in frozen)
+    for k, s, want in ((3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)), (3, 1, (1, 1, 1, 1)), (5, 1, (2, 2, 2, 2)), (1, 1, (0, 0, 0, 0))):
+        assert SamePadConv2d(8, 8, k, s, image_size=380).static_pad == want and SamePadConv2d(8, 8, k, s, image_size=300).static_pad == want

@@ -108,7 +108,8 @@ _SIGS = {
     "vs_sample_scale_add": (I, [I, P, P, P, P, I, I64, P]),
     "vs_sample_rowsum": (I, [I, P, P, P, I, I64, I, F, P]),
     "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vs_se_gate_scratch_floats": (SZ, [I, I, I]),
     "vs_channel_gate": (I, [I, P, P, P, I, C.c_int64, I, P]),
     "vs_channel_dot": (I, [I, P, P, P, I, C.c_int64, I, P]),
     "vs_colsum_workspace": (SZ, [I]),
@@ -159,6 +160,7 @@ _SIGS = {
     "vs_comm_allgather": (I, [P, P, P, C.c_int64, P]),
     "vs_comm_broadcast": (I, [P, P, C.c_int64, I, P]),
     "vs_unet_dropout_mask_offset": (C.c_int64, [P]),
+    "vs_unet_drop_connect_masks": (I, [P, P, P, P, I]),
     "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply(const T* __restrict__ dy, c
 }
 
 // ---- depthwise k x k convolution, stride s, pad_lo in front ---------------------------------------------------------------------
-// A workgroup covers a slab of up to 64 channel vectors (blockIdx.y; its taps [tap][512] in LDS) and 4 output pixels per sweep.
+// A workgroup covers a slab of up to 64 channel vectors (blockIdx.y; its taps [tap][512] in LDS) and 256 / (vectors in the slab) output
+// pixels per sweep.
 // XT / BCAST: the input is a single-channel fp32 map broadcast over the channels (the stem).
 template <typename T, typename XT, bool BCAST>
 __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
@@ -225,11 +226,11 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
     __syncthreads();
-    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    if (cvi >= cv) return;
+    const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;     // 256 / cv pixels per sweep (narrow layers: many)
+    if (pl >= ppb) return;
     const int ch0 = (v0 + cvi) * kVec;
     const int64_t pixels = (int64_t)n * ho * wo;
-    for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+    for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < pixels; p += (int64_t)gridDim.x * ppb) {
         const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
         const int64_t b = p / wo / ho;
         float acc[kVec];
@@ -265,11 +266,11 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restr
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
     __syncthreads();
-    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    if (cvi >= cv) return;
+    const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
+    if (pl >= ppb) return;
     const int ch0 = (v0 + cvi) * kVec;
     const int64_t pixels = (int64_t)n * h * w;
-    for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+    for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < pixels; p += (int64_t)gridDim.x * ppb) {
         const int ix = (int)(p % w), iy = (int)(p / w % h);
         const int64_t b = p / w / h;
         float acc[kVec];
@@ -305,17 +306,17 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restr
 template <typename T, typename XT, bool BCAST>
 __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restrict__ x, const T* __restrict__ dy, int n, int h, int w, int c, int k,
                                                             int stride, int pad, int ho, int wo, float* __restrict__ partial) {
-    __shared__ float red[4][64][kVec + 1];
+    __shared__ float red[256][kVec + 1];
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
-    const int cvi = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int ch0 = (v0 + min(cvi, cv - 1)) * kVec;
+    const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int ch0 = (v0 + cvi) * kVec;
     float s[kVec];
 #pragma unroll
     for (int q = 0; q < kVec; ++q) s[q] = 0.f;
     const int64_t pixels = (int64_t)n * ho * wo;
-    if (cvi < cv) {
-        for (int64_t p = (int64_t)blockIdx.x * 4 + pl; p < pixels; p += (int64_t)gridDim.x * 4) {
+    if (pl < ppb) {
+        for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < pixels; p += (int64_t)gridDim.x * ppb) {
             const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
             const int64_t b = p / wo / ho;
             const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
@@ -335,11 +336,12 @@ __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restri
         }
     }
 #pragma unroll
-    for (int q = 0; q < kVec; ++q) red[pl][cvi][q] = s[q];
+    for (int q = 0; q < kVec; ++q) red[threadIdx.x][q] = s[q];
     __syncthreads();
     for (int o = threadIdx.x; o < cv * kVec; o += 256) {
         const int g = o / kVec, q = o % kVec;
-        const float t = (red[0][g][q] + red[1][g][q]) + (red[2][g][q] + red[3][g][q]);
+        float t = 0.f;
+        for (int j = 0; j < ppb; ++j) t += red[j * cv + g][q];
         partial[((size_t)blockIdx.x * c + v0 * kVec + o) * kk + tap] = t;
     }
 }
@@ -480,7 +482,8 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
     VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
                "dwconv2d: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
-    const dim3 grid(grid_for((int64_t)n * ho * wo * 64), (c / kVec + 63) / 64);
+    const int ppb = 256 / std::min(c / kVec, 64);
+    const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * ho * wo + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (x_single_channel) {
@@ -497,7 +500,8 @@ extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, v
                                     int wo, int accumulate, void* stream) {
     VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
-    const dim3 grid(grid_for((int64_t)n * h * wd * 64), (c / kVec + 63) / 64);
+    const int ppb = 256 / std::min(c / kVec, 64);
+    const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * h * wd + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     VS_LAUNCH_T(dwconv2d_bwd_data_kernel, grid, (size_t)k * k * 512 * sizeof(float), (hipStream_t)stream, (const T*)dy, w, (T*)dx, n, h, wd, c, k, stride, pad_lo,
                 ho, wo, accumulate);
     return VS_OK;
@@ -508,7 +512,8 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
     VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
                "dwconv2d_wgrad: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(workspace && workspace_bytes >= vs_dwconv2d_wgrad_workspace(c, k), "dwconv2d_wgrad: workspace too small");
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + 3) / 4));
+    const int ppb = 256 / std::min(c / kVec, 64);
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + ppb - 1) / ppb));
     const dim3 grid(nblk, (c / kVec + 63) / 64, k * k);
     hipStream_t s = (hipStream_t)stream;
     if (x_single_channel) {

@@ -168,74 +168,101 @@ __global__ void bmm_dp_kernel(const float* __restrict__ dP, const T* __restrict_
     }
 }
 
-// ---- squeeze-excitation gate on pooled features p [n][C] (T): a = sigmoid(W2 relu(W1 p + b1) + b2), W1 [R][C], W2 [C][R] fp32 -------
+// ---- squeeze-excitation gate on pooled features p [n][C] (T): a = sigmoid(W2 act(W1 p + b1) + b2), W1 [R][C], W2 [C][R] fp32; act = ReLU
+// (MFAB) or swish (efficientnet-pytorch).  One workgroup per sample; every dot product is a wave's coalesced sweep + butterfly.
+__device__ __forceinline__ float se_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
                                                     const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ a,
                                                     float* __restrict__ hid, int C, int R, int swish) {
     __shared__ float ps[4096], hs[128];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < C; c += 256) ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
     __syncthreads();
-    if ((int)threadIdx.x < R) {
-        float acc = b1[threadIdx.x];
-        for (int c = 0; c < C; ++c) acc += w1[(size_t)threadIdx.x * C + c] * ps[c];
-        hid[(size_t)b * R + threadIdx.x] = swish ? acc : fmaxf(acc, 0.f);       // kept for the backward pass (swish: the pre-activation)
-        acc = swish ? acc / (1.f + __expf(-acc)) : fmaxf(acc, 0.f);
-        hs[threadIdx.x] = acc;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w1[(size_t)r * C + c] * ps[c];
+        acc = se_wave_sum(acc) + b1[r];
+        if (lane == 0) {
+            hid[(size_t)b * R + r] = swish ? acc : fmaxf(acc, 0.f);       // kept for the backward pass (swish: the pre-activation)
+            hs[r] = swish ? acc / (1.f + __expf(-acc)) : fmaxf(acc, 0.f);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = b2[c];
-        for (int r = 0; r < R; ++r) acc += w2[(size_t)c * R + r] * hs[r];
-        Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
+    for (int c = wave; c < C; c += 4) {
+        float acc = 0.f;
+        for (int r = lane; r < R; r += 64) acc += w2[(size_t)c * R + r] * hs[r];
+        acc = se_wave_sum(acc) + b2[c];
+        if (lane == 0) Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
     }
 }
-// backward of the gate for all samples in one block (sequential over n: fixed order): da [n][C] (T) -> dp [n][C] (T), dW1, db1, dW2, db2
+// backward, stage 1 (one workgroup per sample): g2 = da a (1 - a) (gradient at the second layer's pre-activation), g1 = (W2^T g2) act'(hidden)
+// (first layer's), dp = W1^T g1; g2 / g1 go to scratch G2 [n][C] / G1 [n][R] for the parameter gradients
 template <typename T>
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const T* __restrict__ da, const T* __restrict__ a, const T* __restrict__ p,
-                                                        const float* __restrict__ hid, const float* __restrict__ w1, const float* __restrict__ w2,
-                                                        T* __restrict__ dp, float* __restrict__ dw1, float* __restrict__ db1,
-                                                        float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int R, int swish) {
-    __shared__ float g2[4096], ps[4096], hs[128], g1[128], hd[128];
-    const int tid = threadIdx.x;
-    // this block owns every output: zero the weight gradients, then accumulate sample by sample
-    for (int i = tid; i < R * C; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
-    for (int i = tid; i < R; i += 256) db1[i] = 0.f;
-    for (int i = tid; i < C; i += 256) db2[i] = 0.f;
+__global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(const T* __restrict__ da, const T* __restrict__ a, const float* __restrict__ hid,
+                                                               const float* __restrict__ w1, const float* __restrict__ w2, T* __restrict__ dp,
+                                                               float* __restrict__ G2, float* __restrict__ G1, int C, int R, int swish) {
+    __shared__ float g2[4096], g1[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        const float av = Elem<T>::ld(a + (size_t)b * C + c);
+        const float v = Elem<T>::ld(da + (size_t)b * C + c) * av * (1.f - av);
+        g2[c] = v;
+        G2[(size_t)b * C + c] = v;
+    }
     __syncthreads();
-    for (int b = 0; b < n; ++b) {
-        for (int c = tid; c < C; c += 256) {
-            const float av = Elem<T>::ld(a + (size_t)b * C + c);
-            g2[c] = Elem<T>::ld(da + (size_t)b * C + c) * av * (1.f - av);
-            ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
+    if (tid < R) {                       // W2 [C][R]: the R lanes read one row per step (contiguous)
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += w2[(size_t)c * R + tid] * g2[c];
+        const float hv = hid[(size_t)b * R + tid];
+        float d;
+        if (swish) { const float sg = 1.f / (1.f + __expf(-hv)); d = sg * (1.f + hv * (1.f - sg)); }
+        else d = hv > 0.f ? 1.f : 0.f;
+        g1[tid] = acc * d;
+        G1[(size_t)b * R + tid] = acc * d;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += w1[(size_t)r * C + c] * g1[r];
+        Elem<T>::st(dp + (size_t)b * C + c, acc);
+    }
+}
+// stage 2: dW1[r][c] = sum_b G1[b][r] p[b][c], dW2[c][r] = sum_b G2[b][c] act(hid[b][r]), db1 = sum_b G1, db2 = sum_b G2 - one lane per
+// output, samples in order
+template <typename T>
+__global__ void se_gate_bwd_params_kernel(const T* __restrict__ p, const float* __restrict__ hid, const float* __restrict__ G2, const float* __restrict__ G1,
+                                          float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int n, int C,
+                                          int R, int swish) {
+    const int64_t rc = (int64_t)R * C, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rc) {
+        const int r = (int)(i / C), c = (int)(i % C);
+        float acc = 0.f;
+        for (int b = 0; b < n; ++b) acc += G1[(size_t)b * R + r] * Elem<T>::ld(p + (size_t)b * C + c);
+        dw1[i] = acc;
+    } else if (i < 2 * rc) {
+        const int64_t j = i - rc;
+        const int c = (int)(j / R), r = (int)(j % R);
+        float acc = 0.f;
+        for (int b = 0; b < n; ++b) {
+            const float hv = hid[(size_t)b * R + r];
+            acc += G2[(size_t)b * C + c] * (swish ? hv / (1.f + __expf(-hv)) : hv);
         }
-        if (tid < R) {
-            const float hv = hid[(size_t)b * R + tid];
-            if (swish) {      // hid holds the pre-activation: hidden value v * s, derivative s (1 + v (1 - s))
-                const float sg = 1.f / (1.f + __expf(-hv));
-                hs[tid] = hv * sg; hd[tid] = sg * (1.f + hv * (1.f - sg));
-            } else {
-                hs[tid] = hv; hd[tid] = hv > 0.f ? 1.f : 0.f;
-            }
-        }
-        __syncthreads();
-        if (tid < R) {
-            float acc = 0.f;
-            for (int c = 0; c < C; ++c) acc += w2[(size_t)c * R + tid] * g2[c];
-            g1[tid] = acc * hd[tid];
-            db1[tid] += g1[tid];
-        }
-        for (int c = tid; c < C; c += 256) db2[c] += g2[c];
-        for (int i = tid; i < R * C; i += 256) dw2[i] += g2[i / R] * hs[i % R];       // dw2[c][r]
-        __syncthreads();
-        for (int i = tid; i < R * C; i += 256) dw1[i] += g1[i / C] * ps[i % C];       // dw1[r][c]
-        for (int c = tid; c < C; c += 256) {
-            float acc = 0.f;
-            for (int r = 0; r < R; ++r) acc += w1[(size_t)r * C + c] * g1[r];
-            Elem<T>::st(dp + (size_t)b * C + c, acc);
-        }
-        __syncthreads();
+        dw2[j] = acc;
+    } else if (i < 2 * rc + R) {
+        const int r = (int)(i - 2 * rc);
+        float acc = 0.f;
+        for (int b = 0; b < n; ++b) acc += G1[(size_t)b * R + r];
+        db1[r] = acc;
+    } else if (i < 2 * rc + R + C) {
+        const int c = (int)(i - 2 * rc - R);
+        float acc = 0.f;
+        for (int b = 0; b < n; ++b) acc += G2[(size_t)b * C + c];
+        db2[c] = acc;
     }
 }
 
@@ -332,10 +359,17 @@ extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const f
     VS_LAUNCH_T(se_gate_kernel, dim3(n), (hipStream_t)stream, (const T*)p, w1, b1, w2, b2, (T*)a, hid, C, R, swish);
     return VS_OK;
 }
+// scratch: vs_se_gate_scratch_floats(n, C, R) floats (the two layers' pre-activation gradients, per sample)
+extern "C" size_t vs_se_gate_scratch_floats(int n, int C, int R) { return (size_t)n * ((size_t)C + R); }
 extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream) {
-    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && C <= 4096 && R <= 128, "se_gate_bwd: bad arguments");
-    VS_LAUNCH_T(se_gate_bwd_kernel, dim3(1), (hipStream_t)stream, (const T*)da, (const T*)a, (const T*)p, hid, w1, w2, (T*)dp, dw1, db1, dw2, db2, n, C, R, swish);
+                              float* dw1, float* db1, float* dw2, float* db2, float* scratch, int n, int C, int R, int swish, void* stream) {
+    VS_REQUIRE(da && a && p && hid && w1 && w2 && dp && dw1 && db1 && dw2 && db2 && scratch && n > 0 && C >= 1 && C <= 4096 && R >= 1 && R <= 128,
+               "se_gate_bwd: bad arguments (C <= 4096, R <= 128)");
+    float* G2 = scratch;
+    float* G1 = scratch + (size_t)n * C;
+    VS_LAUNCH_T(se_gate_bwd_sample_kernel, dim3(n), (hipStream_t)stream, (const T*)da, (const T*)a, hid, w1, w2, (T*)dp, G2, G1, C, R, swish);
+    const int64_t total = 2 * (int64_t)R * C + R + C;
+    VS_LAUNCH_T(se_gate_bwd_params_kernel, dim3((unsigned)((total + 255) / 256)), (hipStream_t)stream, (const T*)p, hid, G2, G1, dw1, db1, dw2, db2, n, C, R, swish);
     return VS_OK;
 }
 // y = x * g[n][c] broadcast over the hw positions; vs_channel_dot: dg[n][c] = sum over positions of x * dy

@@ -8,6 +8,7 @@
 // backward walks the units in reverse with a statically known first-write / accumulate discipline for
 // the gradients of tensors with two consumers (ResNet identities, U-Net skips).
 #include <cstdlib>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -49,7 +50,8 @@ extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C);
 extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
                               int n, int C, int R, int swish, void* stream);
 extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const void* p, const float* hid, const float* w1, const float* w2, void* dp,
-                              float* dw1, float* db1, float* dw2, float* db2, int n, int C, int R, int swish, void* stream);
+                              float* dw1, float* db1, float* dw2, float* db2, float* scratch, int n, int C, int R, int swish, void* stream);
+extern "C" size_t vs_se_gate_scratch_floats(int n, int C, int R);
 extern "C" int vs_channel_gate(int dtype, const void* x, const void* g, void* y, int n, int64_t hw, int c, void* stream);
 extern "C" int vs_channel_dot(int dtype, const void* x, const void* dy, void* dg, int n, int64_t hw, int c, void* stream);
 extern "C" int vs_maxpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
@@ -95,6 +97,11 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_SE,           // squeeze-excitation gate on a pooled [n][1][1][c] feature: tensors w_idx .. w_idx + 3 = W1, b1, W2, b2; cin1 = hidden width
                 U_CGATE,        // out = a(src0) * gate a(src1) ([n][1][1][c]) over the map
                 U_SIGMOID,      // element-wise sigmoid (smp PAN's GAU gate)
+                U_BN,           // standalone nn.BatchNorm2d(cout, bn_eps, bn_mom) + activation `relu` (0 none / 1 ReLU / 2 swish) on a(src0), any
+                                // channel count (csrc/effnet.hip): the norms of smp's EfficientNet encoders
+                U_DWCONV2,      // depthwise k x k convolution, stride 1 / 2, `pad` zero rows / columns in front (static same padding), no
+                                // norm; bcast: the network input (one fp32 channel) broadcast over cout = the EfficientNet stem
+                U_DROPADD,      // out = drop_connect(a(src0), drop_p) + a(src1) (the MBConv skip); evaluation: the plain sum
                 U_FPA };        // smp PAN's FPABlock pyramid + combination: out = plane(src0) * a(src1) + a(res) broadcast; tens = its 24
                                 // parameter tensors (6 x conv weight, conv bias, BN gamma, BN beta)
 
@@ -115,6 +122,9 @@ struct Unit {
     int relu = 1;
     int gn_idx = -1, gn_groups = 0;   // U_CONV followed by nn.GroupNorm(gn_groups, cout) + ReLU instead of BatchNorm (gamma at gn_idx)
     size_t off_gn = 0;                // its statistics [n][groups][2] fp32
+    float bn_eps = 1e-5f, bn_mom = 0.1f;   // U_BN
+    float drop_p = 0.f; int salt = 0;      // U_DROPADD: drop-connect rate, block index (separates the blocks' draws)
+    int bcast = 0;                         // U_DWCONV2 on the single-channel network input
     int dil = 1;    // dilation of a stride-1 3x3 convolution (2: smp's replace_strides_with_dilation; any for U_DWCONV)
     int factor = 2; // U_BILINEAR: integer scale factor
     int colr = 0;   // U_CONV: a 3x3 convolution with dilation = padding = colr (DeepLabV3's dense ASPP rates 12 / 24 / 36), run as the
@@ -181,6 +191,7 @@ struct vs_unet {
     int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
     size_t off_pab = 0, pab_bytes = 0; // scratch of the PAB attention (vs_pab_scratch_bytes)
+    size_t off_sews = 0;               // scratch of the squeeze-excitation gates' backward pass (vs_se_gate_scratch_floats)
     size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
@@ -212,24 +223,112 @@ int build(vs_unet* net) {
         return (int)A.size() - 1;
     };
     // ---- encoder ----
+    int feat[6]; int featc[6] = {0, 64, 0, 0, 0, 0};          // activations / channels of the encoder features the decoder taps
+    int cur = -1, inpl = 64, ch = H / 4, cw = W / 4;
+    if (net->encoder == 103 || net->encoder == 104) {
+        // smp's EfficientNetEncoder (encoders/efficientnet.py) over efficientnet-pytorch 0.6.3's EfficientNet-b3 / b4: stem 3x3 / 2 + BN +
+        // swish; MBConv blocks = [expand 1x1 + BN + swish] depthwise k x k + BN + swish, squeeze-excitation (hidden = max(1, input
+        // filters / 4), swish), project 1x1 + BN, drop_connect(0.2 * i / blocks) + skip when the shape is kept; BatchNorm2d(momentum 0.01,
+        // eps 1e-3); Conv2dStaticSamePadding at the (even) nominal image size: (0, 1) for k = 3 and (1, 2) for k = 5 at stride 2.
+        // _conv_head / _bn1 stay in the state dict and are never run.  Registration order = execution order.
+        const bool b4 = net->encoder == 104;
+        const double width = b4 ? 1.4 : 1.2, depth = b4 ? 1.8 : 1.4;
+        auto round_filters = [&](int f) { const double x = f * width; int nw = std::max(8, (int)(x + 4) / 8 * 8); if (nw < 0.9 * x) nw += 8; return nw; };
+        auto round_repeats = [&](int r) { return (int)std::ceil(depth * r); };
+        static const int base[7][6] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80}, {3, 5, 1, 6, 80, 112},
+                                       {4, 5, 2, 6, 112, 192}, {1, 3, 1, 6, 192, 320}};
+        static const int ends_b3[4] = {5, 8, 18, 26}, ends_b4[4] = {6, 10, 22, 32};
+        const int* ends = b4 ? ends_b4 : ends_b3;
+        auto bn_unit = [&](const std::string& name, int src, int cch, int hh, int ww, int act) {
+            Unit u; u.kind = U_BN; u.src0 = src; u.cin0 = cch; u.cout = cch; u.hin = u.hout = hh; u.win = u.wout = ww; u.relu = act;
+            u.bn_eps = 1e-3f; u.bn_mom = 0.01f; u.bn_idx = add_bn(L, name, cch); u.out = new_act(cch, hh, ww, false);
+            U.push_back(u);
+            return u.out;
+        };
+        auto pw_conv = [&](const std::string& name, int src, int cin, int cout, int hh, int ww) {    // 1x1, no bias, no norm of its own
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = 1; u.pad = 0; u.stride = 1; u.hin = u.hout = hh; u.win = u.wout = ww;
+            u.relu = 0; u.frozen_candidate = true; u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cout, cin, 1, 1}, 0);
+            u.out = new_act(cout, hh, ww, false);
+            U.push_back(u);
+            return u.out;
+        };
+        auto dw_conv = [&](const std::string& name, int src, int cch, int k, int st, int hh, int ww, int bcast) {
+            Unit u; u.kind = U_DWCONV2; u.src0 = src; u.cin0 = bcast ? 1 : cch; u.cout = cch; u.k = k; u.stride = st;
+            u.pad = st == 2 ? (k == 3 ? 0 : 1) : k / 2;
+            u.hin = hh; u.win = ww; u.hout = hh / st; u.wout = ww / st; u.bcast = bcast; u.relu = 0; u.frozen_candidate = true;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cch, 1, k, k}, 0);
+            u.out = new_act(cch, hh / st, ww / st, false);
+            U.push_back(u);
+            return u.out;
+        };
+        const int stem_c = round_filters(32);
+        cur = dw_conv("encoder._conv_stem.weight", -1, stem_c, 3, 2, H, W, 1);
+        cur = bn_unit("encoder._bn0", cur, stem_c, H / 2, W / 2, 2);
+        feat[1] = cur; featc[1] = stem_c;
+        ch = H / 2; cw = W / 2;
+        int nblocks = 0;
+        for (auto& b : base) nblocks += round_repeats(b[0]);
+        int bi = 0, stage = 0;
+        for (auto& b : base) {
+            const int k = b[1], e = b[3], o = round_filters(b[5]);
+            for (int j = 0; j < round_repeats(b[0]); ++j, ++bi) {
+                const int st = j == 0 ? b[2] : 1, inp = j == 0 ? round_filters(b[4]) : o, oup = inp * e;
+                const std::string pre = "encoder._blocks." + std::to_string(bi);
+                const int x_in = cur;
+                int t = cur;
+                if (e != 1) {
+                    t = pw_conv(pre + "._expand_conv.weight", t, inp, oup, ch, cw);
+                    t = bn_unit(pre + "._bn0", t, oup, ch, cw, 2);
+                }
+                t = dw_conv(pre + "._depthwise_conv.weight", t, oup, k, st, ch, cw, 0);
+                const int oh = ch / st, ow = cw / st;
+                t = bn_unit(pre + "._bn1", t, oup, oh, ow, 2);
+                const int R = std::max(1, inp / 4);
+                Unit gp; gp.kind = U_GAP; gp.src0 = t; gp.cout = oup; gp.hin = oh; gp.win = ow; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+                gp.out = new_act(oup, 1, 1, false);
+                U.push_back(gp);
+                Unit se; se.kind = U_SE; se.src0 = gp.out; se.cout = oup; se.cin0 = oup; se.cin1 = R; se.hout = 1; se.wout = 1; se.relu = 2;
+                se.w_idx = (int)L.tensors.size();
+                add_tensor(L, pre + "._se_reduce.weight", {R, oup, 1, 1}, 0); add_tensor(L, pre + "._se_reduce.bias", {R}, 3);
+                add_tensor(L, pre + "._se_expand.weight", {oup, R, 1, 1}, 0); add_tensor(L, pre + "._se_expand.bias", {oup}, 3);
+                se.out = new_act(oup, 1, 1, false);
+                U.push_back(se);
+                Unit cg; cg.kind = U_CGATE; cg.src0 = t; cg.src1 = se.out; cg.cout = oup; cg.hout = oh; cg.wout = ow; cg.relu = 0;
+                cg.out = new_act(oup, oh, ow, false);
+                U.push_back(cg);
+                t = pw_conv(pre + "._project_conv.weight", cg.out, oup, o, oh, ow);
+                t = bn_unit(pre + "._bn2", t, o, oh, ow, 0);
+                if (st == 1 && inp == o) {
+                    Unit da; da.kind = U_DROPADD; da.src0 = t; da.src1 = x_in; da.cout = o; da.hin = da.hout = oh; da.win = da.wout = ow; da.relu = 0;
+                    da.drop_p = 0.2f * (float)bi / (float)nblocks; da.salt = bi;
+                    da.out = new_act(o, oh, ow, false);
+                    U.push_back(da);
+                    t = da.out;
+                }
+                cur = t; ch = oh; cw = ow; inpl = o;
+                if (stage < 4 && bi + 1 == ends[stage]) { feat[stage + 2] = cur; featc[stage + 2] = o; ++stage; }
+            }
+        }
+        add_tensor(L, "encoder._conv_head.weight", {round_filters(1280), inpl, 1, 1}, 0);     // registered by efficientnet-pytorch, never run
+        add_bn(L, "encoder._bn1", round_filters(1280));
+    } else {
     add_tensor(L, "encoder.conv1.weight", {64, 1, 7, 7}, 0);
     Unit stem; stem.kind = U_STEM; stem.cout = 64; stem.k = 7; stem.stride = 2; stem.pad = 3;
     stem.hin = H; stem.win = W; stem.hout = H / 2; stem.wout = W / 2;
     stem.w_idx = 0; stem.bn_idx = add_bn(L, "encoder.bn1", 64);
     stem.out = new_act(64, H / 2, W / 2, true); stem.frozen_candidate = true;
     U.push_back(stem);
-    int feat[6]; feat[1] = stem.out;
+    feat[1] = stem.out;
     Unit pool; pool.kind = U_POOL; pool.src0 = stem.out; pool.cout = 64; pool.hin = H / 2; pool.win = W / 2;
     pool.hout = H / 4; pool.wout = W / 4; pool.out = new_act(64, H / 4, W / 4, false);
     U.push_back(pool);
-    int cur = pool.out, inpl = 64, ch = H / 4, cw = W / 4;
+    cur = pool.out; inpl = 64; ch = H / 4; cw = W / 4;
     const int planes[4] = {64, 128, 256, 512};
     const int blocks18[4] = {2, 2, 2, 2}, blocks34[4] = {3, 4, 6, 3};   // resnet50 uses the resnet34 block counts
     const int* blocks = net->encoder == 18 ? blocks18 : blocks34;
     const bool bottleneck = net->encoder == 50 || net->encoder == 51;   // 51 = resnext50_32x4d: Bottleneck with groups = 32,
     const int groups = net->encoder == 51 ? 32 : 1;                     // width_per_group = 4 (torchvision): width = planes * 2
     const int expansion = bottleneck ? 4 : 1;
-    int featc[6] = {0, 64, 0, 0, 0, 0};          // channels of the encoder features the decoder taps
     for (int l = 0; l < 4; ++l) {
         for (int b = 0; b < blocks[l]; ++b) {
             const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(b);
@@ -279,6 +378,7 @@ int build(vs_unet* net) {
         }
         feat[l + 2] = cur;
         featc[l + 2] = inpl;
+    }
     }
     // ---- decoder ----
     const int dec[5] = {256, 128, 64, 32, 16};
@@ -780,7 +880,7 @@ size_t plan_workspace(vs_unet* net) {
         u.off_fpa_plane = take(2 * N * u.hin * u.win * sizeof(float));     // the plane and (backward) its gradient
     }
     {
-        size_t pab = 0;
+        size_t pab = 0, sews = 0;
         for (auto& u : net->units) {
             if (u.kind == U_PAB) {
                 const size_t hw = (size_t)u.hout * u.wout;
@@ -788,9 +888,12 @@ size_t plan_workspace(vs_unet* net) {
                 pab = std::max(pab, vs_pab_scratch_bytes((int)N, (int)hw, u.cout));
             }
             if (u.kind == U_SE) u.off_gn = take(N * (size_t)u.cin1 * sizeof(float));   // hidden activations
+            if (u.kind == U_SE) sews = std::max(sews, vs_se_gate_scratch_floats((int)N, u.cout, u.cin1) * sizeof(float));
+            if (u.kind == U_DROPADD) u.off_gn = take(N * sizeof(float));               // the drop-connect draw per sample
         }
         net->pab_bytes = pab;
         net->off_pab = take(pab);
+        net->off_sews = take(sews);
     }
     {
         size_t ys = 0;
@@ -869,8 +972,10 @@ size_t plan_workspace(vs_unet* net) {
         const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
-    for (auto& u : net->units)
+    for (auto& u : net->units) {
         if (u.kind == U_DWCONV) wg = std::max(wg, vs_dwconv3x3_wgrad_workspace(u.cout));
+        if (u.kind == U_DWCONV2) wg = std::max(wg, vs_dwconv2d_wgrad_workspace(u.cout, u.k));
+    }
     net->wgws_bytes = wg;
     net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
     {
@@ -949,7 +1054,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
     VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && encoder_code < 1000),
+               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topology 0, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -1003,7 +1109,9 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
     VS_REQUIRE(topology >= 0 && topology <= 7, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", topology);
     VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51, "unet_create: encoder must be 18, 34, 50 or 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), got %d", encoder);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104,
+               "unet_create: encoder must be 18, 34, 50, 51, 103 or 104 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / efficientnet-b4), got %d", encoder);
+    VS_REQUIRE(encoder < 100 || topology == 0, "unet_create: the EfficientNet encoders are built for smp.Unet (topology 0) only");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
@@ -1119,6 +1227,18 @@ extern "C" int64_t vs_unet_dropout_mask_offset(const vs_unet_t* net) {
         if (u.kind == U_DROPOUT) return (int64_t)net->off_dropmask;
     return -1;
 }
+// the drop-connect draws of the last training forward (EfficientNet encoders): for every MBConv block with a skip and a non-zero rate,
+// its block index, rate and the byte offset in the training workspace of its [n] fp32 mask (0 or 1 / keep); returns their number (tests)
+extern "C" int vs_unet_drop_connect_masks(const vs_unet_t* net, int64_t* offsets, int* blocks, float* rates, int cap) {
+    if (!net) return 0;
+    int k = 0;
+    for (auto& u : net->units) {
+        if (u.kind != U_DROPADD || u.drop_p <= 0.f) continue;
+        if (k < cap) { if (offsets) offsets[k] = (int64_t)u.off_gn; if (blocks) blocks[k] = u.salt; if (rates) rates[k] = u.drop_p; }
+        ++k;
+    }
+    return k;
+}
 extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
     VS_REQUIRE(net, "unet_flip_weight_set: null pointer");
     net->wset ^= 1;
@@ -1206,6 +1326,35 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             if ((rc = vs_dwconv3x3(dt, c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.dil, 0, stream))) return rc;
             continue;
         }
+        case U_DWCONV2: {
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * (u.hin * u.win * u.cin0 + u.hout * u.wout * u.cout) * net->esz, c.s);
+            if ((rc = vs_dwconv2d(dt, u.bcast ? (const void*)x : (const void*)c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.k, u.stride,
+                                  u.pad, u.hout, u.wout, u.bcast, stream))) return rc;
+            continue;
+        }
+        case U_BN: {    // batch statistics (training) or the running ones, normalisation + activation in one sweep
+            ProfScope prof(training ? PK_BN_STATS : PK_BN_APPLY, 0, (training ? 3.0 : 2.0) * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t rows = (int64_t)n * u.hout * u.wout;
+            if (training) {
+                if ((rc = vs_bn2_stats(dt, c.a(u.src0), rows, u.cout, u.bn_eps, u.bn_mom, c.bnc(u, 2), c.bnc(u, 3), rm, rv, (float*)(c.ws + net->off_bnws),
+                                       net->bnws_bytes, stream))) return rc;
+                if ((rc = vs_bn2_apply(dt, c.a(u.src0), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, -1.f, c.a(u.out), rows, u.cout, stream))) return rc;
+            } else {
+                if ((rc = vs_bn2_apply(dt, c.a(u.src0), rm, rv, c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, u.bn_eps, c.a(u.out), rows, u.cout, stream))) return rc;
+            }
+            continue;
+        }
+        case U_DROPADD: {
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const float* mask = nullptr;
+            if (training && u.drop_p > 0.f) {
+                float* m = (float*)(c.ws + u.off_gn);
+                if ((rc = vs_dropout2d_mask(m, n, 1, u.drop_p, net->rng_seed ^ 0x2545f491u, net->rng_counter, (int64_t)u.salt << 32, stream))) return rc;
+                mask = m;
+            }
+            if ((rc = vs_sample_scale_add(dt, c.a(u.src0), mask, c.a(u.src1), c.a(u.out), n, (int64_t)u.hout * u.wout * u.cout, stream))) return rc;
+            continue;
+        }
         case U_SIGMOID: {
             if ((rc = vs_sigmoid(dt, c.a(u.src0), c.a(u.out), (int64_t)n * u.hout * u.wout * u.cout, stream))) return rc;
             continue;
@@ -1290,7 +1439,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
             prof_set_variant(0);
             if (u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution (FPN's lateral 1x1s): no norm, no activation
-                p.out = c.a(u.out); p.shift = c.P(u.bias_idx);
+                p.out = c.a(u.out); p.shift = u.bias_idx >= 0 ? c.P(u.bias_idx) : nullptr;   // (EfficientNet's 1x1 convolutions: no bias either)
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 continue;
             }
@@ -1458,11 +1607,11 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     };
     for (int k = lo; k < hi; ++k) {
         const Unit& v = net->units[k];
-        if (v.w_idx < 0) continue;
+        if (v.w_idx < 0 && v.bn_idx < 0) continue;
         if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
-        if (!(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
+        if (v.w_idx >= 0 && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
         if (v.bias_idx >= 0) push(v.bias_idx);
@@ -1586,6 +1735,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             return opt ? group_update(ui) : VS_OK;
         }
+        if (u.kind == U_DWCONV2) {
+            ProfScope prof(PK_CONV_WGRAD, want_w ? 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k : 0, 0, ws_stream);
+            if (want_w) {
+                if ((rc = vs_dwconv2d_wgrad(dt, u.bcast ? (const void*)x : (const void*)c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.k,
+                                            u.stride, u.pad, u.hout, u.wout, u.bcast, wgws, net->wgws_bytes, (void*)ws_stream))) return rc;
+            } else {
+                VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, (size_t)u.cout * u.k * u.k * sizeof(float), ws_stream));
+            }
+            return opt ? group_update(ui) : VS_OK;
+        }
         if (u.kind == U_DWCONV) {
             ProfScope prof(PK_CONV_WGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, ws_stream);
             if ((rc = vs_dwconv3x3_wgrad(dt, c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.dil, wgws, net->wgws_bytes,
@@ -1650,6 +1809,27 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             continue;
         }
+        if (u.kind == U_DROPADD) {  // the skip takes the gradient as is, the block's branch the surviving samples' (scaled by 1 / keep)
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: gradients of an MBConv skip out of order");
+            ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(u.src1), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, written[u.src1], stream))) return rc;
+            written[u.src1] = 1;
+            if ((rc = vs_sample_scale_add(dt, c.da(u.out), u.drop_p > 0.f ? (const float*)(c.ws + u.off_gn) : nullptr, nullptr, c.da(u.src0), n,
+                                          (int64_t)u.hout * u.wout * u.cout, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_BN) {       // dx, dgamma, dbeta; the activation's derivative is recomputed from the pre-norm tensor
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: gradients of a BatchNorm unit out of order");
+            ProfScope prof(PK_BN_BWD, 0, 5.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_bn2_bwd(dt, c.da(u.out), c.a(u.src0), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.da(u.src0),
+                                 grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, (int64_t)n * u.hout * u.wout, u.cout,
+                                 (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
         if (u.kind == U_SIGMOID) {
             if (!do_main) continue;
             VS_REQUIRE(written[u.out] && !written[u.src0], "backward: sigmoid gradients out of order");
@@ -1698,7 +1878,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             VS_REQUIRE(written[u.out] && !written[u.src0], "backward: SE gate gradients out of order");
             if ((rc = vs_se_gate_bwd(dt, c.da(u.out), c.a(u.out), c.a(u.src0), (const float*)(c.ws + u.off_gn), c.P(u.w_idx), c.P(u.w_idx + 2),
                                      c.da(u.src0), grads + c.t(u.w_idx).offset, grads + c.t(u.w_idx + 1).offset, grads + c.t(u.w_idx + 2).offset,
-                                     grads + c.t(u.w_idx + 3).offset, n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
+                                     grads + c.t(u.w_idx + 3).offset, (float*)(c.ws + net->off_sews), n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
             written[u.src0] = 1;
             continue;
         }
@@ -1792,14 +1972,15 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             dzp = c.dz(u.out); dz_c = u.cout;
             if (u.kind == U_CONVT) { dzp = c.da(u.out); dz_c = 4 * u.cout; }
             if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) dzp = c.da(u.out);
-            if (u.kind == U_DWCONV) dzp = c.da(u.out);
-        } else if (u.kind == U_DWCONV) {      // no norm, no activation: dz IS the output's gradient
+            if (u.kind == U_DWCONV || u.kind == U_DWCONV2) dzp = c.da(u.out);
+        } else if (u.kind == U_DWCONV || u.kind == U_DWCONV2) {      // no norm, no activation: dz IS the output's gradient
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             dzp = c.da(u.out); dz_c = u.cout;
         } else if (u.kind == U_CONV && u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution: dz IS the output's gradient
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hout * u.wout * u.cout * net->esz, c.s);
-            if ((rc = vs_colsum(dt, c.da(u.out), c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            if (u.bias_idx >= 0 &&
+                (rc = vs_colsum(dt, c.da(u.out), c.rows(u), u.cout, grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
             dzp = c.da(u.out); dz_c = u.cout;
         } else if (u.kind == U_CONV && u.gn_idx >= 0) {                  // GroupNorm + ReLU backward
             VS_REQUIRE(written[u.out], "backward: gradient of unit %d output missing", ui);
@@ -1860,6 +2041,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             if ((rc = vs_dilated_im2col(dt, p.out, c.da(u.src0), n, u.hin, u.win, u.cin0, u.colr, 1, written[u.src0] ? 1 : 0, stream))) return rc;
             written[u.src0] = 1;
+        } else if (u.kind == U_DWCONV2 && do_main) {  // data gradient of a strided / padded depthwise convolution (none for the stem: the input)
+            if (!u.bcast) {
+                ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k, 0, c.s);
+                if ((rc = vs_dwconv2d_bwd_data(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.k, u.stride, u.pad, u.hout, u.wout,
+                                               written[u.src0] ? 1 : 0, stream))) return rc;
+                written[u.src0] = 1;
+            }
         } else if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
             ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, c.s);
             if ((rc = vs_dwconv3x3(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.dil, 1 | (written[u.src0] ? 2 : 0), stream))) return rc;
@@ -2015,7 +2203,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
-    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : u.kind == U_BN ? net->layout.tensors[u.bn_idx].name.c_str() : u.kind == U_DROPADD ? "drop_connect+add" : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
                          : (u.kind == U_DROPOUT ? "dropout2d" : (u.kind == U_GAP ? "avgpool" : (u.kind == U_BCAST ? "broadcast" : (u.kind == U_DROPOUT_E ? "dropout"
                          : (u.kind == U_PAB ? "pab attention" : (u.kind == U_CGATE ? "channel gate" : (u.kind == U_SIGMOID ? "sigmoid" : "maxpool")))))))))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;

@@ -71,7 +71,10 @@ class _UnetFn(torch.autograd.Function):
 
 
 class VolSegUnet(nn.Module):
-    ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51}
+    ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51,
+                "efficientnet-b3": 103, "efficientnet-b4": 104}      # the EfficientNets: smp.Unet only (csrc/unet.hip build())
+    # efficientnet-pytorch registers these and smp's encoder never runs them: torch leaves their .grad at None, AdamW skips them
+    UNUSED_PREFIXES = ("encoder._conv_head.", "encoder._bn1.")
     TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2, "fpn": 3,
                   "deeplabv3plus": 4, "deeplabv3": 5, "manet": 6,
                   "pan": 7}     # smp.Unet, UnetPlusPlus, Linknet, FPN, DeepLabV3Plus, DeepLabV3, MAnet, PAN
@@ -147,6 +150,7 @@ class VolSegUnet(nn.Module):
                     _attach(self, name.rsplit(".", 1)[0] + ".num_batches_tracked", self._nbt[bn_i], False)
                     bn_i += 1
         self._param_cache = None
+        self._unused_ids = {id(self._views[t[0]]) for t in self._table if t[2] <= KIND_BIAS and t[0].startswith(self.UNUSED_PREFIXES)}
 
     def reset_parameters(self, seed: int | None = None):
         """smp / torchvision initialisation: encoder convs kaiming_normal(fan_out, relu),
@@ -157,9 +161,20 @@ class VolSegUnet(nn.Module):
             gen = torch.Generator(device="cpu").manual_seed(seed)
         convt_bound = None
         with torch.no_grad():
+            effnet = self.encoder_name.startswith("efficientnet")
+            fan_in = None
             for name, shape, kind, off in self._table:
                 v = self._views[name]
-                if kind == KIND_CONV:
+                if kind == KIND_CONV and effnet and name.startswith("encoder."):
+                    # efficientnet-pytorch initialises nothing itself: nn.Conv2d's default (kaiming_uniform(a = sqrt(5)), uniform bias)
+                    w = torch.empty(shape, dtype=torch.float32)
+                    nn.init.kaiming_uniform_(w, a=math.sqrt(5), generator=gen)
+                    v.copy_(w)
+                    fan_in = shape[1] * shape[2] * shape[3]
+                elif kind == KIND_BIAS and effnet and name.startswith("encoder.") and len(shape) == 1:
+                    bound = 1.0 / math.sqrt(fan_in)
+                    v.copy_(torch.empty(shape, dtype=torch.float32).uniform_(-bound, bound, generator=gen))
+                elif kind == KIND_CONV:
                     w = torch.empty(shape, dtype=torch.float32)
                     if name.startswith("encoder."):
                         nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu", generator=gen)
@@ -350,7 +365,7 @@ class VolSegUnet(nn.Module):
 
     def _attach_grads(self, accumulate: bool = True):
         for p, shape, kind, off, _ in self._param_cache:
-            if not p.requires_grad:
+            if not p.requires_grad or id(p) in self._unused_ids:
                 continue
             g = self._view_of(self._flat_grad, shape, kind, off)
             if p.grad is None:
@@ -583,7 +598,11 @@ class VolSegUnet(nn.Module):
         layer3, then stem + layer1 + layer2.  Backward fills the flat buffer from its end towards its start."""
         names = _lib.unit_names(handle)
         cuts = [len(names)]
-        for prefix in ("decoder.", "encoder.layer4.0.", "encoder.layer3.0."):
+        prefixes = ("decoder.", "encoder.layer4.0.", "encoder.layer3.0.")
+        if self.encoder_name.startswith("efficientnet"):     # the MBConv stages behind the 1/32 and 1/16 features (smp's stage_idxs)
+            s16, s32 = {"efficientnet-b3": (8, 18), "efficientnet-b4": (10, 22)}[self.encoder_name]
+            prefixes = ("decoder.", f"encoder._blocks.{s32}.", f"encoder._blocks.{s16}.")
+        for prefix in prefixes:
             cuts.append(next(i for i, nm in enumerate(names) if nm.startswith(prefix)))
         cuts.append(0)
         plan = []
@@ -711,15 +730,17 @@ class FusedAdamW(torch.optim.Optimizer):
     def _grad_mask_for(self, model, need_enc: bool):
         """uint8 mask over the flat buffer for the data-parallel fused step: None (everything trains) or zeros on the frozen
         encoder convolutions (_can_fuse has already established that these are the only two patterns)."""
-        if need_enc:
+        unused = [t for t in model._table if t[2] <= KIND_BIAS and t[0].startswith(model.UNUSED_PREFIXES)]
+        if need_enc and not unused:
             return None
-        if getattr(self, "_frozen_mask", None) is None:
+        key = "_frozen_mask" if not need_enc else "_unused_mask"
+        if getattr(self, key, None) is None:
             m = torch.ones(model._flat.numel(), dtype=torch.uint8)
             for (name, shape, kind, off) in [t for t in model._table if t[2] <= KIND_BIAS]:
-                if "encoder" in name and "conv" in name:
+                if (not need_enc and "encoder" in name and "conv" in name) or name.startswith(model.UNUSED_PREFIXES):
                     m[off:off + math.prod(shape)] = 0
-            self._frozen_mask = m.to(model.device)
-        return self._frozen_mask
+            setattr(self, key, m.to(model.device))
+        return getattr(self, key)
 
     def _grad_mask(self):
         params = list(self.model.parameters())
