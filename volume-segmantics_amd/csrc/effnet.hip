@@ -17,7 +17,7 @@ namespace {
 
 constexpr int kVec = 8;
 constexpr int kBnBlocks = 512;     // partial rows of the BatchNorm reductions
-constexpr int kDwBlocks = 128;     // partial rows of the depthwise weight gradient
+constexpr int kDwBlocks = 512;     // partial rows of the depthwise weight gradient (its pixel loop is latency-bound: many workgroups)
 
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
@@ -302,47 +302,60 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restr
         st8(dx + p * c + ch0, acc);
     }
 }
-// weight gradient, stage 1: blockIdx.z = tap; partial[blk][c][kk] = sum over the workgroup's output pixels of dy * shifted x
+// weight gradient, stage 1: blockIdx.z = kernel row kh; partial[blk][c][kk] = sum over the workgroup's output pixels of dy * shifted x,
+// the row's k taps accumulated together (dy is read once per kernel row, not once per tap)
 template <typename T, typename XT, bool BCAST>
 __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restrict__ x, const T* __restrict__ dy, int n, int h, int w, int c, int k,
                                                             int stride, int pad, int ho, int wo, float* __restrict__ partial) {
     __shared__ float red[256][kVec + 1];
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
-    const int tap = blockIdx.z, kh = tap / k, kw = tap % k;
+    const int kh = blockIdx.z;
     const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
     const int ch0 = (v0 + cvi) * kVec;
-    float s[kVec];
+    float s[5][kVec];
 #pragma unroll
-    for (int q = 0; q < kVec; ++q) s[q] = 0.f;
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) s[t][q] = 0.f;
     const int64_t pixels = (int64_t)n * ho * wo;
     if (pl < ppb) {
         for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < pixels; p += (int64_t)gridDim.x * ppb) {
             const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
             const int64_t b = p / wo / ho;
-            const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-            if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+            const int iy = oy * stride + kh - pad;
+            if (iy < 0 || iy >= h) continue;
             float g[kVec];
             ld8(dy + p * c + ch0, g);
-            if constexpr (BCAST) {
-                const float v = (float)x[(b * h + iy) * w + ix];
 #pragma unroll
-                for (int q = 0; q < kVec; ++q) s[q] += g[q] * v;
-            } else {
-                float v[kVec];
-                ld8(x + ((b * h + iy) * w + ix) * c + ch0, v);
+            for (int kw = 0; kw < 5; ++kw) {
+                const int ix = ox * stride + kw - pad;
+                if (kw >= k || ix < 0 || ix >= w) continue;
+                if constexpr (BCAST) {
+                    const float v = (float)x[(b * h + iy) * w + ix];
 #pragma unroll
-                for (int q = 0; q < kVec; ++q) s[q] += g[q] * v[q];
+                    for (int q = 0; q < kVec; ++q) s[kw][q] += g[q] * v;
+                } else {
+                    float v[kVec];
+                    ld8(x + ((b * h + iy) * w + ix) * c + ch0, v);
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) s[kw][q] += g[q] * v[q];
+                }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < kVec; ++q) red[threadIdx.x][q] = s[q];
-    __syncthreads();
-    for (int o = threadIdx.x; o < cv * kVec; o += 256) {
-        const int g = o / kVec, q = o % kVec;
-        float t = 0.f;
-        for (int j = 0; j < ppb; ++j) t += red[j * cv + g][q];
-        partial[((size_t)blockIdx.x * c + v0 * kVec + o) * kk + tap] = t;
+    for (int kw = 0; kw < 5; ++kw) {
+        if (kw >= k) break;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) red[threadIdx.x][q] = s[kw][q];
+        __syncthreads();
+        for (int o = threadIdx.x; o < cv * kVec; o += 256) {
+            const int g = o / kVec, q = o % kVec;
+            float t = 0.f;
+            for (int j = 0; j < ppb; ++j) t += red[j * cv + g][q];
+            partial[((size_t)blockIdx.x * c + v0 * kVec + o) * kk + kh * k + kw] = t;
+        }
     }
 }
 __global__ void dwconv2d_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int total) {
@@ -377,10 +390,20 @@ __global__ void sample_scale_add_kernel(const T* __restrict__ x, const float* __
 
 // out[n][c] = scale * sum over the sample's hw rows of a (* b): the average pool of the squeeze-excitation branch and, with b, the
 // gate's gradient - any channel count that is a multiple of 8 (blockIdx.x = sample, blockIdx.y = slab of 256 channel vectors)
+// (1024 lanes: one workgroup per sample and slab is all the parallelism there is, so the rows are spread over as many lanes as fit)
 template <typename T>
-__global__ __launch_bounds__(256) void sample_rowsum_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t hw, int c, float scale) {
-    __shared__ float red[256][kVec + 1];
-    const Slab sl = slab_of(c);
+__global__ __launch_bounds__(1024) void sample_rowsum_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t hw, int c, float scale) {
+    __shared__ float red[1024][kVec + 1];
+    Slab sl;
+    {
+        const int cv_all = c / kVec, v0 = blockIdx.y * 256;
+        sl.cv = min(256, cv_all - v0);
+        sl.rpb = 1024 / sl.cv;
+        sl.cvi = threadIdx.x % sl.cv;
+        sl.rl = threadIdx.x / sl.cv;
+        sl.ch0 = (v0 + sl.cvi) * kVec;
+        sl.on = sl.rl < sl.rpb;
+    }
     const T* as = a + (size_t)blockIdx.x * hw * c + sl.ch0;
     const T* bs = b ? b + (size_t)blockIdx.x * hw * c + sl.ch0 : nullptr;
     float s[kVec];
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(256) void sample_rowsum_kernel(const T* __restrict_
 #pragma unroll
     for (int k = 0; k < kVec; ++k) red[threadIdx.x][k] = s[k];
     __syncthreads();
-    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 256) {
+    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 1024) {
         const int g = ch / kVec, k = ch % kVec;
         float t = 0.f;
         for (int j = 0; j < sl.rpb; ++j) t += red[j * sl.cv + g][k];
@@ -513,8 +536,9 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
                "dwconv2d_wgrad: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(workspace && workspace_bytes >= vs_dwconv2d_wgrad_workspace(c, k), "dwconv2d_wgrad: workspace too small");
     const int ppb = 256 / std::min(c / kVec, 64);
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + ppb - 1) / ppb));
-    const dim3 grid(nblk, (c / kVec + 63) / 64, k * k);
+    // >= 16 pixels per lane where the layer has them: few partial rows for the deep 8 x 8 maps (their reduction reads nblk * c * k * k floats)
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + (int64_t)ppb * 16 - 1) / ((int64_t)ppb * 16)));
+    const dim3 grid(nblk, (c / kVec + 63) / 64, k);
     hipStream_t s = (hipStream_t)stream;
     if (x_single_channel) {
         if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
@@ -540,6 +564,12 @@ extern "C" int vs_sample_scale_add(int dtype, const void* x, const float* mask, 
 // out [n][c] = scale * sum over hw of a[n][hw][c] (* b[n][hw][c] when b is given), any c that is a multiple of 8
 extern "C" int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream) {
     VS_REQUIRE(a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "sample_rowsum: channels must be a multiple of 8");
-    VS_LAUNCH_T(sample_rowsum_kernel, dim3(n, (c / kVec + 255) / 256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, hw, c, scale);
+    if (dtype == VS_BF16)
+        hipLaunchKernelGGL(sample_rowsum_kernel<bf16_t>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)out, hw, c, scale);
+    else
+        hipLaunchKernelGGL(sample_rowsum_kernel<float>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
+                           (float*)out, hw, c, scale);
+    VS_LAUNCH_CHECK();
     return VS_OK;
 }
