@@ -691,6 +691,8 @@ def test_efficientnet_unet_eval_and_train_vs_oracle(encoder):
     from volume_segmantics_amd import _lib as L
     from volume_segmantics_amd.data.losses import HipDiceLoss
     from volume_segmantics_amd.engine import VolSegUnet
+    poison = torch.full((1 << 28,), float("nan"), device=DEV)     # 1 GiB of NaNs handed back to the caching allocator: a workspace
+    del poison                                                      # entry that is read before it is written would surface below
     oracle = seeded_oracle_unet(encoder, 3, seed=2)
     model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder)
     model.load_state_dict(oracle.state_dict())
