@@ -140,7 +140,8 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
  *   103 / 104: smp's efficientnet-b3 / efficientnet-b4 encoders (efficientnet-pytorch 0.6.3: 3x3 / 2 stem, 26 / 32 MBConv blocks -
  *   expand 1x1, depthwise 3x3 / 5x5 behind static same padding, squeeze-excitation with swish, project 1x1, drop_connect + skip;
- *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - topology 0 only;
+ *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - topologies 0 and 4
+ *   (under DeepLabV3+ the last stage runs at stride 1 / dilation 2: smp's replace_strides_with_dilation);
  *   topology 7: smp.PAN (layer4 dilated; FPABlock with its single-channel 7x7 / 5x5 / 3x3 pyramid, three GAUBlocks, 3x3 head at 1/4
  *   resolution + x4 bilinear; slices must be multiples of 128) - depths 18 / 34 / 50;
  *   topology 6: smp.MAnet (PAB position attention at the deepest level, four MFAB blocks with squeeze-excitation gates on skip and
@@ -338,7 +339,8 @@ int vs_dilated_im2col(int dtype, const void* src, void* dst, int n, int h, int w
  *   (act 0), ReLU (1) or swish x * sigmoid(x) (2); bwd recomputes the activation's derivative from x.  vs_bn2_apply with var_eps >= 0
  *   reads VARIANCES in place of invstd (evaluation straight from the running statistics).  workspace: vs_bn2_workspace(c) bytes.
  * vs_dwconv2d*: nn.Conv2d(c, c, k, stride, groups=c, bias=False), k 3 / 5, stride 1 / 2, pad_lo zero rows / columns in front (TF "same"
- *   static padding: (0, 1) for k = 3 and (1, 2) for k = 5 at stride 2); w fp32 [c][k * k].  x_single_channel = 1: x is an fp32 [n][h][w]
+ *   static padding: (0, 1) for k = 3 and (1, 2) for k = 5 at stride 2; dilation > 1 with pad_lo = (k / 2) * dilation: what smp's
+ *   replace_strides_with_dilation leaves of a stage under DeepLabV3+); w fp32 [c][k * k].  x_single_channel = 1: x is an fp32 [n][h][w]
  *   map broadcast over the channels = nn.Conv2d(1, c, k, stride, bias=False), the stem on greyscale slices.
  * vs_sample_scale_add: y = x * mask[n] + skip - drop_connect (mask from vs_dropout2d_mask with c = 1) and the residual sum in one sweep;
  *   on the gradient (skip NULL) its backward.  vs_sample_rowsum: out[n][c] = scale * sum over hw of a (* b) for any c % 8 == 0. */
@@ -349,13 +351,13 @@ int vs_bn2_apply(int dtype, const void* x, const float* mean, const float* invst
                  void* y, int64_t rows, int c, void* stream);
 int vs_bn2_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
                void* dx, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace, size_t workspace_bytes, void* stream);
-int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
-                int x_single_channel, void* stream);
-int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho,
-                         int wo, int accumulate, void* stream);
+int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho,
+                int wo, int x_single_channel, void* stream);
+int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation,
+                         int ho, int wo, int accumulate, void* stream);
 size_t vs_dwconv2d_wgrad_workspace(int c, int k);
-int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
-                      int x_single_channel, float* workspace, size_t workspace_bytes, void* stream);
+int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho,
+                      int wo, int x_single_channel, float* workspace, size_t workspace_bytes, void* stream);
 int vs_sample_scale_add(int dtype, const void* x, const float* mask, const void* skip, void* y, int n, int64_t per_sample, void* stream);
 int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream);
 

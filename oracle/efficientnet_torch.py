@@ -64,10 +64,10 @@ class SamePadConv2d(nn.Conv2d):
         pad = max((out - 1) * s + (k - 1) + 1 - image_size, 0)
         self.static_pad = (pad // 2, pad - pad // 2, pad // 2, pad - pad // 2)
 
-    def forward(self, x):
+    def forward(self, x):      # utils.Conv2dStaticSamePadding.forward: the static padding, then the convolution with its OWN attributes
         if any(self.static_pad):
             x = F.pad(x, self.static_pad)
-        return F.conv2d(x, self.weight, self.bias, self.stride, 0, 1, self.groups)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 def swish(x):

@@ -260,6 +260,8 @@ def replace_strides_with_dilation(module: nn.Module, dilation_rate: int) -> None
             mod.dilation = (dilation_rate, dilation_rate)
             kh, _ = mod.kernel_size
             mod.padding = ((kh // 2) * dilation_rate, (kh // 2) * dilation_rate)
+            if hasattr(mod, "static_pad"):      # smp: "Kostyl for EfficientNet" - mod.static_padding = nn.Identity()
+                mod.static_pad = (0, 0, 0, 0)
 
 
 class SeparableConv2d(nn.Sequential):
@@ -477,7 +479,7 @@ class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # smp's EfficientNetEncoder (oracle/efficientnet_torch.py); U-Net only
-            assert topology == "unet", "the EfficientNet encoders are restated for smp.Unet only"
+            assert topology in ("unet", "deeplabv3plus"), "the EfficientNet encoders are restated for smp.Unet and smp.DeepLabV3Plus"
             self.encoder = EfficientNetEncoder(encoder_name, in_channels)
             out_channels = EFFICIENTNET_OUT_CHANNELS[encoder_name]
         else:
@@ -492,7 +494,11 @@ class OracleUnet(nn.Module):
             replace_strides_with_dilation(self.encoder.layer3, 2)
             replace_strides_with_dilation(self.encoder.layer4, 4)
         if topology == "deeplabv3plus":     # encoder_output_stride = 16: encoder.make_dilated(stage_list=[5], dilation_list=[2])
-            replace_strides_with_dilation(self.encoder.layer4, 2)
+            if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # get_stages()[5] = self._blocks[stage_idxs[2]:]
+                from .efficientnet_torch import STAGE_IDXS
+                replace_strides_with_dilation(self.encoder._blocks[STAGE_IDXS[encoder_name][2]:], 2)
+            else:
+                replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "linknet":     # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=1)
             self.segmentation_head = nn.Sequential(nn.Conv2d(32, classes, 1))
         elif topology == "pan":             # SegmentationHead(in_channels=32, out_channels=classes, kernel_size=3, upsampling=4)

@@ -74,10 +74,10 @@ def test_config2_backward_is_linear_in_the_output_gradient():
     assert torch.equal(grads[0] * 2.0, grads[1])
 
 
-def _predictor(classes: int, batch: int, precision: str = "bf16"):
+def _predictor(classes: int, batch: int, precision: str = "bf16", encoder: str = "resnet34", topology: str = "unet"):
     from volume_segmantics_amd.engine import VolSegUnet
     from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
-    model = VolSegUnet(classes, device=DEV, precision=precision, seed=1)
+    model = VolSegUnet(classes, device=DEV, precision=precision, seed=1, encoder=encoder, topology=topology)
     with torch.no_grad():   # centre the head bias so that a random-init network uses every class
         model.eval()
         mean_logit = model(torch.randn(4, 1, 256, 256, generator=torch.Generator().manual_seed(7)).to(DEV)).mean(dim=(0, 2, 3))
@@ -204,3 +204,25 @@ def test_config5_sized_volume_1024_cube_three_axis_prediction_stays_resident_and
     won = probs[1000:1008] == pz[1000:1008]
     assert won.mean() > 0.05 and np.array_equal(labels[1000:1008][won], lz[1000:1008][won])
     assert (probs[1000:1008] >= pz[1000:1008]).all()
+
+
+def test_config5_network_deeplabv3plus_efficientnet_b4_on_1024_square_slices():
+    """BASELINE configs[4]'s NETWORK (smp.DeepLabV3Plus over efficientnet-b4, 2 classes) on 1024 x 1024 slices of its volume: a 96-slice
+    slab predicted along Z in batches of 8 (the encoder's expansions are 144 channels at 512 x 512: 75 MB per slice and tensor).
+    Properties as above: shape / dtypes, both classes present, a slice of the run equals the same slice predicted on its own."""
+    import time
+    from volume_segmantics_amd.utilities.base_data_utils import Axis
+    pred = _predictor(2, 8, encoder="efficientnet-b4", topology="deeplabv3plus")
+    small = bench.synth_volume(256, seed=99)
+    vol = np.tile(small[:96], (1, 4, 4))
+    assert vol.shape == (96, 1024, 1024)
+    lz, pz = pred._predict_single_axis(vol[:8], axis=Axis.Z)          # plans, weight copies
+    t0 = time.perf_counter()
+    lz, pz = pred._predict_single_axis(vol, axis=Axis.Z)
+    dt = time.perf_counter() - t0
+    print(f"DeepLabV3+ / efficientnet-b4, 96 slices of 1024^2: {dt:.2f} s = {96 / dt:.0f} slices/s")
+    assert lz.shape == vol.shape and lz.dtype == np.uint8 and pz.dtype == np.float16
+    assert 0 < (lz[::4, ::8, ::8] == 1).mean() < 1
+    for k in (0, 50, 95):
+        l1, p1 = pred._predict_single_axis(vol[k:k + 1], axis=Axis.Z)
+        assert np.array_equal(lz[k], l1[0]) and np.array_equal(pz[k].view(np.uint16), p1[0].view(np.uint16)), k

@@ -1151,36 +1151,36 @@ def test_bn2_any_channel_count_swish(code, act, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
-@pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 0), (5, 1, 2), (5, 2, 1)])      # kernel, stride, zero rows / columns in front
+@pytest.mark.parametrize("geom", [(3, 1, 1, 1), (3, 2, 0, 1), (5, 1, 2, 1), (5, 2, 1, 1), (3, 1, 2, 2), (5, 1, 4, 2)])   # kernel, stride, front padding, dilation
 @pytest.mark.parametrize("shape", [(2, 12, 16, 48), (1, 8, 8, 528), (2, 7, 9, 144)])
 def test_dwconv2d_static_same_padding(code, geom, shape):
     """efficientnet-pytorch's depthwise Conv2dStaticSamePadding (kernel 3 / 5, stride 1 / 2; at stride 2 the padding is (0, 1) resp.
     (1, 2): TF's "same" for an even nominal image size) - forward, data gradient (with and without accumulation) and weight gradient
     against F.conv2d on the explicitly padded input + autograd; 528 channels = two slabs (64 + 2 vectors)."""
     L = lib()
-    k, s, lo = geom
+    k, s, lo, dil = geom          # dilation 2 with padding (k // 2) * 2: a stage after smp's replace_strides_with_dilation (DeepLabV3+)
     n, h, w, c = shape
     g = torch.Generator().manual_seed(61)
     ho, wo = -(-h // s), -(-w // s)
-    hi_h, hi_w = max((ho - 1) * s + k - h, 0) - lo, max((wo - 1) * s + k - w, 0) - lo
+    hi_h, hi_w = max((ho - 1) * s + (k - 1) * dil + 1 - h, 0) - lo, max((wo - 1) * s + (k - 1) * dil + 1 - w, 0) - lo
     x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
     wt = (torch.randn(c, 1, k, k, generator=g) / k).requires_grad_()
-    y = F.conv2d(F.pad(x, (lo, hi_w, lo, hi_h)), wt, stride=s, groups=c)
+    y = F.conv2d(F.pad(x, (lo, hi_w, lo, hi_h)), wt, stride=s, groups=c, dilation=dil)
     assert y.shape[2:] == (ho, wo)
     dy = rounded(torch.randn(y.shape, generator=g), code)
     y.backward(dy)
     xd, dyd = to_nhwc(x.detach(), code), to_nhwc(dy, code)
     wd = wt.detach().reshape(c, k * k).contiguous().to(DEV)
     yd = torch.full((n, ho, wo, c), float("nan"), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, c, k, s, lo, ho, wo, 0, None))
+    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, c, k, s, lo, dil, ho, wo, 0, None))
     dx = torch.full_like(xd, float("nan"))
-    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(dx), n, h, w, c, k, s, lo, ho, wo, 0, None))
+    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(dx), n, h, w, c, k, s, lo, dil, ho, wo, 0, None))
     twice = dx.clone()
-    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(twice), n, h, w, c, k, s, lo, ho, wo, 1, None))
+    L.check(L.lib.vs_dwconv2d_bwd_data(code, L.ptr(dyd), L.ptr(wd), L.ptr(twice), n, h, w, c, k, s, lo, dil, ho, wo, 1, None))
     wsb = L.lib.vs_dwconv2d_wgrad_workspace(c, k)
     ws = torch.empty(wsb // 4, device=DEV)
     dw = torch.full((c, k * k), float("nan"), device=DEV)
-    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, c, k, s, lo, ho, wo, 0, L.ptr(ws), wsb, None))
+    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, c, k, s, lo, dil, ho, wo, 0, L.ptr(ws), wsb, None))
     sync()
     assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
     assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
@@ -1205,12 +1205,12 @@ def test_efficientnet_stem_on_a_single_channel(code, cout):
     xd = x[:, 0].contiguous().to(DEV)
     wd = wt.detach().reshape(cout, 9).contiguous().to(DEV)
     yd = torch.full((n, h // 2, w // 2, cout), float("nan"), device=DEV, dtype=tdtype(code))
-    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, cout, 3, 2, 0, h // 2, w // 2, 1, None))
+    L.check(L.lib.vs_dwconv2d(code, L.ptr(xd), L.ptr(wd), L.ptr(yd), n, h, w, cout, 3, 2, 0, 1, h // 2, w // 2, 1, None))
     wsb = L.lib.vs_dwconv2d_wgrad_workspace(cout, 3)
     ws = torch.empty(wsb // 4, device=DEV)
     dw = torch.full((cout, 9), float("nan"), device=DEV)
     dyd = to_nhwc(dy, code)
-    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, cout, 3, 2, 0, h // 2, w // 2, 1, L.ptr(ws), wsb, None))
+    L.check(L.lib.vs_dwconv2d_wgrad(code, L.ptr(xd), L.ptr(dyd), L.ptr(dw), n, h, w, cout, 3, 2, 0, 1, h // 2, w // 2, 1, L.ptr(ws), wsb, None))
     sync()
     assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
     ref = wt.grad.reshape(cout, 9)

@@ -254,10 +254,14 @@ def test_efficientnet_restatement_matches_published_parameter_counts_and_engine_
             feats = enc.eval()(torch.zeros(1, 3, 64, 96))
         assert [f.shape[1] for f in feats[1:]] == list(OUT_CHANNELS[name][1:])
         assert [tuple(f.shape[2:]) for f in feats] == [(64 >> i, 96 >> i) for i in range(6)]
-        sd = OracleUnet(name, 1, 3).state_dict()
-        table = _lib.unet_tensor_table(3, code)
-        assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
-        assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), name
+        for topology, tcode in (("unet", 0), ("deeplabv3plus", 4000)):      # smp.Unet and smp.DeepLabV3Plus (BASELINE configs[4]) over it
+            sd = OracleUnet(name, 1, 3, topology).state_dict()
+            table = _lib.unet_tensor_table(3, tcode + code)
+            assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], (name, topology)
+            assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), (name, topology)
+        with torch.no_grad():      # output stride 16: the last stage keeps the 1/16 resolution (stride -> dilation 2)
+            f = OracleUnet(name, 1, 2, "deeplabv3plus").eval().encoder(torch.zeros(1, 1, 64, 64))
+        assert tuple(f[5].shape[2:]) == (4, 4) and tuple(f[4].shape[2:]) == (4, 4)
         frozen = [k for k, _ in OracleUnet(name, 1, 2).named_parameters() if "encoder" in k and "conv" in k]
         n_blocks, n_expand = len(block_plan(name)), sum(1 for b in block_plan(name) if b[2] != 1)
         assert len(frozen) == 2 + 2 * n_blocks + n_expand and not any("_se_" in k for k in frozen)

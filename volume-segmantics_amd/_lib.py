@@ -101,10 +101,10 @@ _SIGS = {
     "vs_bn2_stats": (I, [I, P, I64, I, F, F, P, P, P, P, P, SZ, P]),
     "vs_bn2_apply": (I, [I, P, P, P, P, P, I, F, P, I64, I, P]),
     "vs_bn2_bwd": (I, [I, P, P, P, P, P, P, I, P, P, P, I64, I, P, SZ, P]),
-    "vs_dwconv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "vs_dwconv2d_bwd_data": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "vs_dwconv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "vs_dwconv2d_bwd_data": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "vs_dwconv2d_wgrad_workspace": (SZ, [I, I]),
-    "vs_dwconv2d_wgrad": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
+    "vs_dwconv2d_wgrad": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "vs_sample_scale_add": (I, [I, P, P, P, P, I, I64, P]),
     "vs_sample_rowsum": (I, [I, P, P, P, I, I64, I, F, P]),
     "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply(const T* __restrict__ dy, c
 // XT / BCAST: the input is a single-channel fp32 map broadcast over the channels (the stem).
 template <typename T, typename XT, bool BCAST>
 __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
-                                                         int c, int k, int stride, int pad, int ho, int wo) {
+                                                         int c, int k, int stride, int pad, int dil, int ho, int wo) {
     extern __shared__ float wl[];     // [k * k][64 * 8]
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
 #pragma unroll
         for (int q = 0; q < kVec; ++q) acc[q] = 0.f;
         for (int kh = 0; kh < k; ++kh) {
-            const int iy = oy * stride + kh - pad;
+            const int iy = oy * stride + kh * dil - pad;
             if (iy < 0 || iy >= h) continue;
             for (int kw = 0; kw < k; ++kw) {
-                const int ix = ox * stride + kw - pad;
+                const int ix = ox * stride + kw * dil - pad;
                 if (ix < 0 || ix >= w) continue;
                 const float* wt = wl + (kh * k + kw) * 512 + cvi * kVec;
                 if constexpr (BCAST) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
 // dx[iy][ix] (+)= sum over the taps (kh, kw) with (iy + pad - kh) and (ix + pad - kw) divisible by the stride of dy[..] * w[kh][kw]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ wgt, T* __restrict__ dx, int n, int h,
-                                                              int w, int c, int k, int stride, int pad, int ho, int wo, int accumulate) {
+                                                              int w, int c, int k, int stride, int pad, int dil, int ho, int wo, int accumulate) {
     extern __shared__ float wl[];
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     for (int o = threadIdx.x; o < cv * kVec * kk; o += 256) wl[(o % kk) * 512 + o / kk] = wgt[(size_t)v0 * kVec * kk + o];
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restr
 #pragma unroll
         for (int q = 0; q < kVec; ++q) acc[q] = 0.f;
         for (int kh = 0; kh < k; ++kh) {
-            const int ty = iy + pad - kh;
+            const int ty = iy + pad - kh * dil;
             if (ty < 0 || ty % stride) continue;
             const int oy = ty / stride;
             if (oy >= ho) continue;
             for (int kw = 0; kw < k; ++kw) {
-                const int tx = ix + pad - kw;
+                const int tx = ix + pad - kw * dil;
                 if (tx < 0 || tx % stride) continue;
                 const int ox = tx / stride;
                 if (ox >= wo) continue;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restr
 // the row's k taps accumulated together (dy is read once per kernel row, not once per tap)
 template <typename T, typename XT, bool BCAST>
 __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restrict__ x, const T* __restrict__ dy, int n, int h, int w, int c, int k,
-                                                            int stride, int pad, int ho, int wo, float* __restrict__ partial) {
+                                                            int stride, int pad, int dil, int ho, int wo, float* __restrict__ partial) {
     __shared__ float red[256][kVec + 1];
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0), kk = k * k;
     const int kh = blockIdx.z;
@@ -322,13 +322,13 @@ __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restri
         for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < pixels; p += (int64_t)gridDim.x * ppb) {
             const int ox = (int)(p % wo), oy = (int)(p / wo % ho);
             const int64_t b = p / wo / ho;
-            const int iy = oy * stride + kh - pad;
+            const int iy = oy * stride + kh * dil - pad;
             if (iy < 0 || iy >= h) continue;
             float g[kVec];
             ld8(dy + p * c + ch0, g);
 #pragma unroll
             for (int kw = 0; kw < 5; ++kw) {
-                const int ix = ox * stride + kw - pad;
+                const int ix = ox * stride + kw * dil - pad;
                 if (kw >= k || ix < 0 || ix >= w) continue;
                 if constexpr (BCAST) {
                     const float v = (float)x[(b * h + iy) * w + ix];
@@ -500,9 +500,9 @@ extern "C" int vs_bn2_bwd(int dtype, const void* dy, const void* x, const float*
 // nn.Conv2d(c, c, k, stride, groups=c, bias=False) behind efficientnet-pytorch's Conv2dStaticSamePadding: pad_lo zero rows / columns in
 // front (what is needed behind follows from ho / wo); x [n][h][w][c], w fp32 [c][k * k], y [n][ho][wo][c].  x_single_channel = 1: x is an
 // fp32 [n][h][w] map broadcast over the c channels - nn.Conv2d(1, c, k, stride, bias=False), the stem on greyscale slices.
-extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho, int wo,
                            int x_single_channel, void* stream) {
-    VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+    VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
     const int ppb = 256 / std::min(c / kVec, 64);
@@ -510,29 +510,29 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (x_single_channel) {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
-        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
+        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
     } else {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
-        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, false>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, ho, wo);
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
+        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, false>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
-extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho,
-                                    int wo, int accumulate, void* stream) {
-    VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation,
+                                    int ho, int wo, int accumulate, void* stream) {
+    VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     const int ppb = 256 / std::min(c / kVec, 64);
     const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * h * wd + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     VS_LAUNCH_T(dwconv2d_bwd_data_kernel, grid, (size_t)k * k * 512 * sizeof(float), (hipStream_t)stream, (const T*)dy, w, (T*)dx, n, h, wd, c, k, stride, pad_lo,
-                ho, wo, accumulate);
+                dilation, ho, wo, accumulate);
     return VS_OK;
 }
 extern "C" size_t vs_dwconv2d_wgrad_workspace(int c, int k) { return (size_t)kDwBlocks * c * k * k * sizeof(float); }
-extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int ho, int wo,
+extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho, int wo,
                                  int x_single_channel, float* workspace, size_t workspace_bytes, void* stream) {
-    VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && pad_lo < k,
+    VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_wgrad: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(workspace && workspace_bytes >= vs_dwconv2d_wgrad_workspace(c, k), "dwconv2d_wgrad: workspace too small");
     const int ppb = 256 / std::min(c / kVec, 64);
@@ -541,11 +541,11 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
     const dim3 grid(nblk, (c / kVec + 63) / 64, k);
     hipStream_t s = (hipStream_t)stream;
     if (x_single_channel) {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
-        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
+        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
     } else {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
-        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, ho, wo, workspace);
+        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
+        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
     }
     VS_LAUNCH_CHECK();
     const int total = c * k * k;

@@ -252,9 +252,9 @@ int build(vs_unet* net) {
             U.push_back(u);
             return u.out;
         };
-        auto dw_conv = [&](const std::string& name, int src, int cch, int k, int st, int hh, int ww, int bcast) {
-            Unit u; u.kind = U_DWCONV2; u.src0 = src; u.cin0 = bcast ? 1 : cch; u.cout = cch; u.k = k; u.stride = st;
-            u.pad = st == 2 ? (k == 3 ? 0 : 1) : k / 2;
+        auto dw_conv = [&](const std::string& name, int src, int cch, int k, int st, int hh, int ww, int bcast, int dil = 1) {
+            Unit u; u.kind = U_DWCONV2; u.src0 = src; u.cin0 = bcast ? 1 : cch; u.cout = cch; u.k = k; u.stride = st; u.dil = dil;
+            u.pad = dil > 1 ? (k / 2) * dil : (st == 2 ? (k == 3 ? 0 : 1) : k / 2);
             u.hin = hh; u.win = ww; u.hout = hh / st; u.wout = ww / st; u.bcast = bcast; u.relu = 0; u.frozen_candidate = true;
             u.w_idx = (int)L.tensors.size(); add_tensor(L, name, {cch, 1, k, k}, 0);
             u.out = new_act(cch, hh / st, ww / st, false);
@@ -272,7 +272,10 @@ int build(vs_unet* net) {
         for (auto& b : base) {
             const int k = b[1], e = b[3], o = round_filters(b[5]);
             for (int j = 0; j < round_repeats(b[0]); ++j, ++bi) {
-                const int st = j == 0 ? b[2] : 1, inp = j == 0 ? round_filters(b[4]) : o, oup = inp * e;
+                // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation on the last stage (blocks[ends[2]:]) - every
+                // convolution stride 1, dilation 2, padding (k / 2) * 2, the static padding dropped ("Kostyl for EfficientNet")
+                const bool dilated = net->topology == 4 && bi >= ends[2];
+                const int st = (j == 0 && !dilated) ? b[2] : 1, inp = j == 0 ? round_filters(b[4]) : o, oup = inp * e;
                 const std::string pre = "encoder._blocks." + std::to_string(bi);
                 const int x_in = cur;
                 int t = cur;
@@ -280,7 +283,7 @@ int build(vs_unet* net) {
                     t = pw_conv(pre + "._expand_conv.weight", t, inp, oup, ch, cw);
                     t = bn_unit(pre + "._bn0", t, oup, ch, cw, 2);
                 }
-                t = dw_conv(pre + "._depthwise_conv.weight", t, oup, k, st, ch, cw, 0);
+                t = dw_conv(pre + "._depthwise_conv.weight", t, oup, k, st, ch, cw, 0, dilated ? 2 : 1);
                 const int oh = ch / st, ow = cw / st;
                 t = bn_unit(pre + "._bn1", t, oup, oh, ow, 2);
                 const int R = std::max(1, inp / 4);
@@ -1054,8 +1057,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
     VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && encoder_code < 1000),
-               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topology 0, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && (tmp.topology == 0 || tmp.topology == 4)),
+               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topologies 0 and 4, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -1111,7 +1114,7 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104,
                "unet_create: encoder must be 18, 34, 50, 51, 103 or 104 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / efficientnet-b4), got %d", encoder);
-    VS_REQUIRE(encoder < 100 || topology == 0, "unet_create: the EfficientNet encoders are built for smp.Unet (topology 0) only");
+    VS_REQUIRE(encoder < 100 || topology == 0 || topology == 4, "unet_create: the EfficientNet encoders are built for smp.Unet and smp.DeepLabV3Plus (topologies 0 and 4) only");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
@@ -1329,7 +1332,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         case U_DWCONV2: {
             ProfScope prof(PK_POOL_MISC, 0, (double)n * (u.hin * u.win * u.cin0 + u.hout * u.wout * u.cout) * net->esz, c.s);
             if ((rc = vs_dwconv2d(dt, u.bcast ? (const void*)x : (const void*)c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.k, u.stride,
-                                  u.pad, u.hout, u.wout, u.bcast, stream))) return rc;
+                                  u.pad, u.dil, u.hout, u.wout, u.bcast, stream))) return rc;
             continue;
         }
         case U_BN: {    // batch statistics (training) or the running ones, normalisation + activation in one sweep
@@ -1739,7 +1742,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             ProfScope prof(PK_CONV_WGRAD, want_w ? 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k : 0, 0, ws_stream);
             if (want_w) {
                 if ((rc = vs_dwconv2d_wgrad(dt, u.bcast ? (const void*)x : (const void*)c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.k,
-                                            u.stride, u.pad, u.hout, u.wout, u.bcast, wgws, net->wgws_bytes, (void*)ws_stream))) return rc;
+                                            u.stride, u.pad, u.dil, u.hout, u.wout, u.bcast, wgws, net->wgws_bytes, (void*)ws_stream))) return rc;
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, (size_t)u.cout * u.k * u.k * sizeof(float), ws_stream));
             }
@@ -2044,7 +2047,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         } else if (u.kind == U_DWCONV2 && do_main) {  // data gradient of a strided / padded depthwise convolution (none for the stem: the input)
             if (!u.bcast) {
                 ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k, 0, c.s);
-                if ((rc = vs_dwconv2d_bwd_data(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.k, u.stride, u.pad, u.hout, u.wout,
+                if ((rc = vs_dwconv2d_bwd_data(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.k, u.stride, u.pad, u.dil, u.hout, u.wout,
                                                written[u.src0] ? 1 : 0, stream))) return rc;
                 written[u.src0] = 1;
             }
