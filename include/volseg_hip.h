@@ -360,6 +360,10 @@ int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n
                       int wo, int x_single_channel, float* workspace, size_t workspace_bytes, void* stream);
 int vs_sample_scale_add(int dtype, const void* x, const float* mask, const void* skip, void* y, int n, int64_t per_sample, void* stream);
 int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream);
+/* the same with a sample's rows spread over up to 64 workgroups and a fixed-order finish (few samples, large maps: prediction batches) */
+size_t vs_sample_rowsum_workspace(int n, int c);
+int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, float* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
  * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom

@@ -1244,3 +1244,29 @@ def test_sample_scale_add_and_rowsum(code):
     assert torch.allclose(from_nhwc(y3), x + skip, **tol(code, 4.0))
     assert torch.allclose(mean.float().cpu(), x.mean((2, 3)), **tol(code, 1.0))
     assert torch.allclose(dot.float().cpu(), (x * skip).sum((2, 3)), **tol(code, 10.0))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 96, 80, 144), (1, 64, 64, 2688), (3, 40, 40, 48)])
+def test_sample_rowsum_split_over_workgroups(code, shape):
+    """vs_sample_rowsum_ws: the per-sample means / dot products of prediction-sized maps with a sample's rows spread over up to 64
+    workgroups and a fixed-order finish - against torch, and bit-identical between two calls."""
+    L = lib()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(91)
+    x, y = rounded(torch.randn(n, c, h, w, generator=g), code), rounded(torch.randn(n, c, h, w, generator=g), code)
+    xd, yd = to_nhwc(x, code), to_nhwc(y, code)
+    wsb = L.lib.vs_sample_rowsum_workspace(n, c)
+    ws = torch.empty(wsb // 4, device=DEV)
+    outs = []
+    for _ in range(2):
+        mean = torch.full((n, c), float("nan"), device=DEV, dtype=tdtype(code))
+        dot = torch.full((n, c), float("nan"), device=DEV, dtype=tdtype(code))
+        L.check(L.lib.vs_sample_rowsum_ws(code, L.ptr(xd), None, L.ptr(mean), n, h * w, c, 1.0 / (h * w), L.ptr(ws), wsb, None))
+        L.check(L.lib.vs_sample_rowsum_ws(code, L.ptr(xd), L.ptr(yd), L.ptr(dot), n, h * w, c, 1.0, L.ptr(ws), wsb, None))
+        sync()
+        outs.append((mean.clone(), dot.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(outs[0][0].float().cpu(), x.mean((2, 3)), **tol(code, 1.0))
+    ref = (x * y).sum((2, 3))
+    assert torch.allclose(outs[0][1].float().cpu(), ref, **tol(code, ref.abs().max().item()))

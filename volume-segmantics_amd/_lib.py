@@ -107,6 +107,8 @@ _SIGS = {
     "vs_dwconv2d_wgrad": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "vs_sample_scale_add": (I, [I, P, P, P, P, I, I64, P]),
     "vs_sample_rowsum": (I, [I, P, P, P, I, I64, I, F, P]),
+    "vs_sample_rowsum_workspace": (SZ, [I, I]),
+    "vs_sample_rowsum_ws": (I, [I, P, P, P, I, I64, I, F, P, SZ, P]),
     "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_scratch_floats": (SZ, [I, I, I]),

@@ -444,6 +444,59 @@ __global__ __launch_bounds__(1024) void sample_rowsum_kernel(const T* __restrict
     }
 }
 
+// the same sums with the sample's rows split over blockIdx.z (few samples, large maps: prediction batches): fp32 partials
+// ws[(sample * splits + z)][c], then one lane per (sample, channel) adds the splits in order
+template <typename T>
+__global__ __launch_bounds__(256) void sample_rowsum_split_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ ws, int64_t hw, int c) {
+    __shared__ float red[256][kVec + 1];
+    const Slab sl = slab_of(c);
+    const int splits = gridDim.z;
+    const int64_t r0 = hw * blockIdx.z / splits, r1 = hw * (blockIdx.z + 1) / splits;
+    const T* as = a + (size_t)blockIdx.x * hw * c + sl.ch0;
+    const T* bs = b ? b + (size_t)blockIdx.x * hw * c + sl.ch0 : nullptr;
+    float s[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) s[k] = 0.f;
+    if (sl.on) {
+        for (int64_t r = r0 + sl.rl; r < r1; r += 4 * sl.rpb) {
+            float v[4][kVec], g[4][kVec];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + (int64_t)u * sl.rpb;
+                const bool ok = rr < r1;
+                ld8(as + (ok ? rr : r) * c, v[u]);
+                if (bs) ld8(bs + (ok ? rr : r) * c, g[u]);
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) v[u][k] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) s[k] += bs ? v[u][k] * g[u][k] : v[u][k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < sl.cv * kVec; ch += 256) {
+        const int g = ch / kVec, k = ch % kVec;
+        float t = 0.f;
+        for (int j = 0; j < sl.rpb; ++j) t += red[j * sl.cv + g][k];
+        ws[((size_t)blockIdx.x * splits + blockIdx.z) * c + blockIdx.y * 256 * kVec + ch] = t;
+    }
+}
+template <typename T>
+__global__ void sample_rowsum_finish_kernel(const float* __restrict__ ws, T* __restrict__ out, int n, int c, int splits, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int b = i / c, ch = i % c;
+    float t = 0.f;
+    for (int z = 0; z < splits; ++z) t += ws[((size_t)b * splits + z) * c + ch];
+    Elem<T>::st(out + i, t * scale);
+}
+
 inline int bn2_blocks(int64_t rows, int c) {
     const int cv = std::min(c / kVec, 256), rpb = 256 / cv;
     const int64_t nb = (rows + (int64_t)rpb * 4 - 1) / ((int64_t)rpb * 4);
@@ -571,5 +624,18 @@ extern "C" int vs_sample_rowsum(int dtype, const void* a, const void* b, void* o
         hipLaunchKernelGGL(sample_rowsum_kernel<float>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
                            (float*)out, hw, c, scale);
     VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+// the same with the rows of a sample spread over up to 64 workgroups (workspace: vs_sample_rowsum_workspace(n, c) bytes; NULL or too
+// small: the one-workgroup-per-sample form above)
+extern "C" size_t vs_sample_rowsum_workspace(int n, int c) { return (size_t)n * 64 * c * sizeof(float); }
+extern "C" int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, float* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "sample_rowsum: channels must be a multiple of 8");
+    const int rpb = 256 / std::min(c / kVec, 256);
+    int splits = (int)std::min<int64_t>(64, hw / ((int64_t)rpb * 16));       // >= 16 rows per lane and split
+    if (splits < 2 || !workspace || workspace_bytes < vs_sample_rowsum_workspace(n, c)) return vs_sample_rowsum(dtype, a, b, out, n, hw, c, scale, stream);
+    VS_LAUNCH_T(sample_rowsum_split_kernel, dim3(n, (c / kVec + 255) / 256, splits), 0, (hipStream_t)stream, (const T*)a, (const T*)b, workspace, hw, c);
+    VS_LAUNCH_T(sample_rowsum_finish_kernel, dim3((n * c + 255) / 256), 0, (hipStream_t)stream, workspace, (T*)out, n, c, splits, scale);
     return VS_OK;
 }

@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, c
         }
     }
     __syncthreads();
-    for (int c = wave; c < C; c += 4) {
-        float acc = 0.f;
-        for (int r = lane; r < R; r += 64) acc += w2[(size_t)c * R + r] * hs[r];
-        acc = se_wave_sum(acc) + b2[c];
-        if (lane == 0) Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
+    for (int c = threadIdx.x; c < C; c += 256) {      // one lane per output: its R weights are contiguous, the hidden layer sits in LDS
+        float acc = b2[c];
+        const float* wr = w2 + (size_t)c * R;
+        for (int r = 0; r < R; ++r) acc += wr[r] * hs[r];
+        Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
     }
 }
 // backward, stage 1 (one workgroup per sample): g2 = da a (1 - a) (gradient at the second layer's pre-activation), g1 = (W2^T g2) act'(hidden)

@@ -192,6 +192,7 @@ struct vs_unet {
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
     size_t off_pab = 0, pab_bytes = 0; // scratch of the PAB attention (vs_pab_scratch_bytes)
     size_t off_sews = 0;               // scratch of the squeeze-excitation gates' backward pass (vs_se_gate_scratch_floats)
+    size_t off_gapws = 0, gapws_bytes = 0;   // split partial sums of the average pools / gate gradients (vs_sample_rowsum_ws)
     size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
@@ -883,7 +884,7 @@ size_t plan_workspace(vs_unet* net) {
         u.off_fpa_plane = take(2 * N * u.hin * u.win * sizeof(float));     // the plane and (backward) its gradient
     }
     {
-        size_t pab = 0, sews = 0;
+        size_t pab = 0, sews = 0, gapws = 0;
         for (auto& u : net->units) {
             if (u.kind == U_PAB) {
                 const size_t hw = (size_t)u.hout * u.wout;
@@ -892,11 +893,14 @@ size_t plan_workspace(vs_unet* net) {
             }
             if (u.kind == U_SE) u.off_gn = take(N * (size_t)u.cin1 * sizeof(float));   // hidden activations
             if (u.kind == U_SE) sews = std::max(sews, vs_se_gate_scratch_floats((int)N, u.cout, u.cin1) * sizeof(float));
+            if (u.kind == U_GAP || u.kind == U_CGATE) gapws = std::max(gapws, vs_sample_rowsum_workspace((int)N, u.cout));
             if (u.kind == U_DROPADD) u.off_gn = take(N * sizeof(float));               // the drop-connect draw per sample
         }
         net->pab_bytes = pab;
         net->off_pab = take(pab);
         net->off_sews = take(sews);
+        net->gapws_bytes = gapws;
+        net->off_gapws = take(gapws);
     }
     {
         size_t ys = 0;
@@ -1385,6 +1389,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             continue;
         }
         case U_SE: {
+            ProfScope prof(PK_POOL_MISC, 4.0 * n * u.cout * u.cin1, 0, c.s);
             if ((rc = vs_se_gate_fwd(dt, c.a(u.src0), c.P(u.w_idx), c.P(u.w_idx + 1), c.P(u.w_idx + 2), c.P(u.w_idx + 3), c.a(u.out),
                                      (float*)(c.ws + u.off_gn), n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
             continue;
@@ -1396,7 +1401,8 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_GAP: {
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * u.cout * net->esz, c.s);
-            if ((rc = vs_spatial_sum(dt, c.a(u.src0), c.a(u.out), n, (int64_t)u.hin * u.win, u.cout, 1.f / (float)(u.hin * u.win), stream))) return rc;
+            if ((rc = vs_sample_rowsum_ws(dt, c.a(u.src0), nullptr, c.a(u.out), n, (int64_t)u.hin * u.win, u.cout, 1.f / (float)(u.hin * u.win),
+                                          (float*)(c.ws + net->off_gapws), net->gapws_bytes, stream))) return rc;
             continue;
         }
         case U_BCAST: {
@@ -1879,6 +1885,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (u.kind == U_SE) {       // the gate's parameter gradients are produced here, on the caller's stream (a few hundred values)
             if (!do_main) continue;
             VS_REQUIRE(written[u.out] && !written[u.src0], "backward: SE gate gradients out of order");
+            ProfScope prof(PK_POOL_MISC, 12.0 * n * u.cout * u.cin1, 0, c.s);
             if ((rc = vs_se_gate_bwd(dt, c.da(u.out), c.a(u.out), c.a(u.src0), (const float*)(c.ws + u.off_gn), c.P(u.w_idx), c.P(u.w_idx + 2),
                                      c.da(u.src0), grads + c.t(u.w_idx).offset, grads + c.t(u.w_idx + 1).offset, grads + c.t(u.w_idx + 2).offset,
                                      grads + c.t(u.w_idx + 3).offset, (float*)(c.ws + net->off_sews), n, u.cout, u.cin1, u.relu == 2, stream))) return rc;
@@ -1889,7 +1896,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if (!do_main) continue;
             VS_REQUIRE(written[u.out] && !written[u.src0] && !written[u.src1], "backward: channel gate gradients out of order");
             ProfScope prof(PK_POOL_MISC, 0, 4.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
-            if ((rc = vs_channel_dot(dt, c.a(u.src0), c.da(u.out), c.da(u.src1), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            if ((rc = vs_sample_rowsum_ws(dt, c.a(u.src0), c.da(u.out), c.da(u.src1), n, (int64_t)u.hout * u.wout, u.cout, 1.f,
+                                          (float*)(c.ws + net->off_gapws), net->gapws_bytes, stream))) return rc;
             if ((rc = vs_channel_gate(dt, c.da(u.out), c.a(u.src1), c.da(u.src0), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
             written[u.src0] = 1; written[u.src1] = 1;
             continue;
