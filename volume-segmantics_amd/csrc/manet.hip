@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, c
     __syncthreads();
     for (int r = wave; r < R; r += 4) {
         float acc = 0.f;
+#pragma unroll 8
         for (int c = lane; c < C; c += 64) acc += w1[(size_t)r * C + c] * ps[c];
         acc = se_wave_sum(acc) + b1[r];
         if (lane == 0) {
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, c
     for (int c = threadIdx.x; c < C; c += 256) {      // one lane per output: its R weights are contiguous, the hidden layer sits in LDS
         float acc = b2[c];
         const float* wr = w2 + (size_t)c * R;
+#pragma unroll 8
         for (int r = 0; r < R; ++r) acc += wr[r] * hs[r];
         Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
     }
@@ -206,7 +208,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(const T* __restrict__ da, const T* __restrict__ a, const float* __restrict__ hid,
                                                                const float* __restrict__ w1, const float* __restrict__ w2, T* __restrict__ dp,
                                                                float* __restrict__ G2, float* __restrict__ G1, int C, int R, int swish) {
-    __shared__ float g2[4096], g1[128];
+    __shared__ float g2[4096], g1[128], part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) {
         const float av = Elem<T>::ld(a + (size_t)b * C + c);
@@ -215,9 +217,20 @@ __global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(const T* __rest
         G2[(size_t)b * C + c] = v;
     }
     __syncthreads();
-    if (tid < R) {                       // W2 [C][R]: the R lanes read one row per step (contiguous)
+    {                                    // W2 [C][R]: R lanes read one row per step (contiguous), 256 / R row groups share the C rows
+        const int groups = 256 / R, r = tid % R, gi = tid / R;
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += w2[(size_t)c * R + tid] * g2[c];
+        if (gi < groups) {
+#pragma unroll 8
+            for (int c = gi; c < C; c += groups) acc += w2[(size_t)c * R + r] * g2[c];
+        }
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < R) {
+        const int groups = 256 / R;
+        float acc = 0.f;
+        for (int gi = 0; gi < groups; ++gi) acc += part[gi * R + tid];
         const float hv = hid[(size_t)b * R + tid];
         float d;
         if (swish) { const float sg = 1.f / (1.f + __expf(-hv)); d = sg * (1.f + hv * (1.f - sg)); }
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(const T* __rest
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float acc = 0.f;
+#pragma unroll 8
         for (int r = 0; r < R; ++r) acc += w1[(size_t)r * C + c] * g1[r];
         Elem<T>::st(dp + (size_t)b * C + c, acc);
     }
@@ -242,6 +256,7 @@ __global__ void se_gate_bwd_params_kernel(const T* __restrict__ p, const float* 
     if (i < rc) {
         const int r = (int)(i / C), c = (int)(i % C);
         float acc = 0.f;
+#pragma unroll 8
         for (int b = 0; b < n; ++b) acc += G1[(size_t)b * R + r] * Elem<T>::ld(p + (size_t)b * C + c);
         dw1[i] = acc;
     } else if (i < 2 * rc) {
