@@ -479,7 +479,7 @@ class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # smp's EfficientNetEncoder (oracle/efficientnet_torch.py); U-Net only
-            assert topology in ("unet", "deeplabv3plus"), "the EfficientNet encoders are restated for smp.Unet and smp.DeepLabV3Plus"
+            assert topology not in ("linknet", "pan"), "the EfficientNet encoders are not restated under smp.Linknet / smp.PAN"
             self.encoder = EfficientNetEncoder(encoder_name, in_channels)
             out_channels = EFFICIENTNET_OUT_CHANNELS[encoder_name]
         else:
@@ -490,7 +490,12 @@ class OracleUnet(nn.Module):
                         "manet": MAnetDecoder, "pan": PANDecoder}[topology](out_channels)
         if topology == "pan":               # encoder_dilation=True: make_dilated(stage_list=[5], dilation_list=[2])
             replace_strides_with_dilation(self.encoder.layer4, 2)
-        if topology == "deeplabv3":         # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])
+        if topology == "deeplabv3" and encoder_name in EFFICIENTNET_OUT_CHANNELS:     # get_stages()[4] / [5] = _blocks[s1:s2] / _blocks[s2:]
+            from .efficientnet_torch import STAGE_IDXS
+            _, s1, s2, _ = STAGE_IDXS[encoder_name]
+            replace_strides_with_dilation(self.encoder._blocks[s1:s2], 2)
+            replace_strides_with_dilation(self.encoder._blocks[s2:], 4)
+        elif topology == "deeplabv3":       # encoder_output_stride = 8: make_dilated(stage_list=[4, 5], dilation_list=[2, 4])
             replace_strides_with_dilation(self.encoder.layer3, 2)
             replace_strides_with_dilation(self.encoder.layer4, 4)
         if topology == "deeplabv3plus":     # encoder_output_stride = 16: encoder.make_dilated(stage_list=[5], dilation_list=[2])

@@ -18,7 +18,7 @@
     } while (0)
 
 int main() {
-    const int encoders[] = {18, 34, 50, 51, 1018, 1034, 1050, 1051, 2018, 2034, 2050, 2051, 3018, 3034, 3050, 3051, 4018, 4034, 4050, 5018, 5034, 5050, 6018, 6034, 6050, 6051, 7018, 7034, 7050, 103, 104, 4103, 4104};     // topology * 1000 + depth
+    const int encoders[] = {18, 34, 50, 51, 1018, 1034, 1050, 1051, 2018, 2034, 2050, 2051, 3018, 3034, 3050, 3051, 4018, 4034, 4050, 5018, 5034, 5050, 6018, 6034, 6050, 6051, 7018, 7034, 7050, 103, 104, 3103, 3104, 4103, 4104, 5103, 5104};     // topology * 1000 + depth
     long plans = 0;
     for (int enc : encoders) {
         for (int classes : {1, 2, 4, 16}) {

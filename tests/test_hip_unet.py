@@ -801,3 +801,102 @@ def test_efficientnet_unet_eval_and_train_vs_oracle(encoder):
             runs.append(m._flat.clone())
         assert torch.equal(runs[0], runs[1]), (encoder, frozen)
         assert torch.isfinite(runs[0]).all()
+
+
+def _drop_connect_masks(L, encoder, n, counter_value=1, seed=0):
+    """The engine's drop-connect draws of a training forward (block -> [n] mask of 0 or 1 / keep), recomputed through the C ABI: a pure
+    function of (dropout_seed, num_batches_tracked, block index)."""
+    from oracle.efficientnet_torch import block_plan
+    counter = torch.tensor([counter_value], dtype=torch.int64, device=DEV)
+    plan_, masks = block_plan(encoder), {}
+    for i, (_, s_, _, inp, out) in enumerate(plan_):
+        rate = 0.2 * i / len(plan_)
+        if s_ == 1 and inp == out and rate > 0:
+            m_ = torch.empty(n, device=DEV)
+            L.check(L.lib.vs_dropout2d_mask(L.ptr(m_), n, 1, rate, seed ^ 0x2545f491, L.ptr(counter), i << 32, None))
+            sync()
+            masks[i] = m_.cpu()
+    return masks
+
+
+@pytest.mark.parametrize("encoder,topology", [("efficientnet-b4", "fpn"), ("efficientnet-b3", "fpn"), ("efficientnet-b3", "deeplabv3"),
+                                              ("efficientnet-b4", "deeplabv3")])
+def test_efficientnet_under_other_decoders(encoder, topology):
+    """smp's EfficientNet encoders under FPN and DeepLabV3 (stages 4 / 5 at stride 1 with dilation 2 / 4) - these decoders are generic
+    in the feature widths (40 / 48, 32, 48 / 56, 136 / 160, 384 / 448): eval logits, one fp32 training step's loss and every
+    gradient with all random draws replayed in the oracle (drop-connect per block; FPN's Dropout2d; DeepLabV3's Dropout), and the
+    recorded bf16 step against the call-by-call step."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    size = 128 if topology == "deeplabv3" else 64
+    oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topology)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, size, size + 32, generator=g)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), (encoder, topology, (got - ref).abs().max().item())
+    n = 4
+    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology)
+    oracle.encoder.drop_masks = _drop_connect_masks(L, encoder, n)
+    counter = torch.tensor([1], dtype=torch.int64, device=DEV)
+    if topology == "fpn":
+        mask = torch.empty(n, 128, device=DEV)
+        L.check(L.lib.vs_dropout2d_mask(L.ptr(mask), n, 128, 0.2, 0, L.ptr(counter), 0, None))
+        sync()
+        oracle.decoder.mask = mask.cpu()
+    if topology == "deeplabv3":
+        hh = size // 8
+        ones = torch.ones(n, hh, hh, 256, device=DEV)
+        em = torch.empty_like(ones)
+        L.check(L.lib.vs_dropout(0, L.ptr(ones), L.ptr(em), ones.numel(), 0.5, 0 ^ 0x5bd1e995, L.ptr(counter), 0, None))
+        sync()
+        em_nchw = em.permute(0, 3, 1, 2).contiguous().cpu()
+        oracle.decoder[0].drop = lambda t_: t_ * em_nchw
+    lab = (torch.rand(n, size, size, generator=g) > 0.6).to(torch.uint8)
+    xt = torch.randn(n, 1, size, size, generator=g)
+    _, t = P.prepare_training_batch(xt, lab, 2)
+    oracle.train()
+    ref_loss = P.dice_loss_none(oracle(xt), t.float())
+    ref_loss.backward()
+    refg = dict(oracle.named_parameters())
+    model = VolSegUnet(2, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
+    model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology).state_dict())
+    model.train()
+    loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
+    loss.backward()
+    sync()
+    assert abs(loss.item() - ref_loss.item()) < 2e-5, (encoder, topology, loss.item(), ref_loss.item())
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        if name.startswith(VolSegUnet.UNUSED_PREFIXES):
+            assert p.grad is None and refg[name].grad is None, name
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        r = refg[name].grad
+        if r.norm().item() < 1e-6:          # (a constant the next BatchNorm removes: zero in exact arithmetic)
+            assert p.grad.norm().item() < 1e-5, (name, p.grad.norm().item())
+            continue
+        err = ((p.grad.cpu() - r).norm() / r.norm()).item()
+        worst = max(worst, (err, name))
+        assert err < 5e-2 and _cos(p.grad.cpu(), r) > 0.98, (encoder, topology, name, err)
+    print(encoder, topology, "worst relative gradient error", worst)
+    runs = []
+    xs, ts = xt[:, :, :64, :64].contiguous().to(DEV), t[:, :, :64, :64].contiguous().to(DEV)
+    for graph in (True, False):
+        m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
+        o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
+        m.train()
+        for _ in range(3):
+            if graph:
+                assert m.can_fuse_step(o, xs, ts)
+                m.fused_train_step(xs, ts, o)
+            else:
+                o.zero_grad(); l = HipDiceLoss()(m(xs), ts); l.backward(); o.step()
+        sync()
+        runs.append(m._flat.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.isfinite(runs[0]).all(), (encoder, topology)

@@ -275,7 +275,9 @@ int build(vs_unet* net) {
             for (int j = 0; j < round_repeats(b[0]); ++j, ++bi) {
                 // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation on the last stage (blocks[ends[2]:]) - every
                 // convolution stride 1, dilation 2, padding (k / 2) * 2, the static padding dropped ("Kostyl for EfficientNet")
-                const bool dilated = net->topology == 4 && bi >= ends[2];
+                // DeepLabV3 (output stride 8): stages 4 and 5 (blocks[ends[1]:ends[2]], blocks[ends[2]:]) with dilation 2 and 4
+                const int stage_dil = net->topology == 4 ? (bi >= ends[2] ? 2 : 1) : net->topology == 5 ? (bi >= ends[2] ? 4 : (bi >= ends[1] ? 2 : 1)) : 1;
+                const bool dilated = stage_dil > 1;
                 const int st = (j == 0 && !dilated) ? b[2] : 1, inp = j == 0 ? round_filters(b[4]) : o, oup = inp * e;
                 const std::string pre = "encoder._blocks." + std::to_string(bi);
                 const int x_in = cur;
@@ -284,7 +286,7 @@ int build(vs_unet* net) {
                     t = pw_conv(pre + "._expand_conv.weight", t, inp, oup, ch, cw);
                     t = bn_unit(pre + "._bn0", t, oup, ch, cw, 2);
                 }
-                t = dw_conv(pre + "._depthwise_conv.weight", t, oup, k, st, ch, cw, 0, dilated ? 2 : 1);
+                t = dw_conv(pre + "._depthwise_conv.weight", t, oup, k, st, ch, cw, 0, stage_dil);
                 const int oh = ch / st, ow = cw / st;
                 t = bn_unit(pre + "._bn1", t, oup, oh, ow, 2);
                 const int R = std::max(1, inp / 4);
@@ -1061,8 +1063,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
     VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && (tmp.topology == 0 || tmp.topology == 4)),
-               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topologies 0 and 4, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && (tmp.topology == 0 || tmp.topology == 3 || tmp.topology == 4 || tmp.topology == 5)),
+               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topologies 0 / 3 / 4 / 5, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -1118,7 +1120,9 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104,
                "unet_create: encoder must be 18, 34, 50, 51, 103 or 104 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / efficientnet-b4), got %d", encoder);
-    VS_REQUIRE(encoder < 100 || topology == 0 || topology == 4, "unet_create: the EfficientNet encoders are built for smp.Unet and smp.DeepLabV3Plus (topologies 0 and 4) only");
+    VS_REQUIRE(encoder < 100 || topology == 0 || topology == 3 || topology == 4 || topology == 5,
+               "unet_create: the EfficientNet encoders are built under smp.Unet, FPN, DeepLabV3Plus and DeepLabV3 (topologies 0, 3, 4, 5): U-Net++ / MA-Net "
+               "concatenate at 136 / 56 channels (the fused loader wants multiples of 16), Linknet narrows 56 / 48 channels to 14 / 12, PAN is not restated");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
