@@ -258,6 +258,91 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
         st8(y + p * c + ch0, acc);
     }
 }
+// The same convolution, four consecutive outputs of a row per lane: each input row of the window is loaded once ((WT - 1) S + K vectors)
+// and reused across the K taps and the WT outputs - 10 instead of 25 vector loads per output at K = 5 (the plain kernel is bound by
+// these L2 re-reads).  flip = 1: taps reversed = the data gradient of a stride-1 layer with symmetric padding; accumulate adds to y.
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
+                                                           int c, int pad, int ho, int wo, int flip, int accumulate) {
+    constexpr int WT = 4, NW = (WT - 1) * S + K, KK = K * K;
+    extern __shared__ float wl[];     // [K * K][64 * 8]
+    const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0);
+    for (int o = threadIdx.x; o < cv * kVec * KK; o += 256) {
+        const int t = o % KK;
+        wl[(flip ? KK - 1 - t : t) * 512 + o / KK] = wgt[(size_t)v0 * kVec * KK + o];
+    }
+    __syncthreads();
+    const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
+    if (pl >= ppb) return;
+    const int ch0 = (v0 + cvi) * kVec;
+    const int spr = (wo + WT - 1) / WT;                 // strips per output row
+    const int64_t strips = (int64_t)n * ho * spr;
+    for (int64_t sidx = (int64_t)blockIdx.x * ppb + pl; sidx < strips; sidx += (int64_t)gridDim.x * ppb) {
+        const int sx = (int)(sidx % spr), oy = (int)(sidx / spr % ho);
+        const int64_t b = sidx / spr / ho;
+        const int ox0 = sx * WT, ix0 = ox0 * S - pad;
+        float acc[WT][kVec];
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+#pragma unroll
+            for (int q = 0; q < kVec; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int iy = oy * S + kh - pad;
+            if (iy < 0 || iy >= h) continue;
+            const T* row = x + ((b * h + iy) * w) * c + ch0;
+            float v[NW][kVec];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int ix = ix0 + i;
+                if (ix >= 0 && ix < w) ld8(row + (size_t)ix * c, v[i]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) v[i][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const float* wt = wl + (kh * K + kw) * 512 + cvi * kVec;
+                float wq[kVec];
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) wq[q] = wt[q];
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) acc[j][q] += v[j * S + kw][q] * wq[q];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= wo) break;
+            T* yo = y + (((b * ho + oy) * wo) + ox) * c + ch0;
+            if (accumulate) {
+                float old[kVec];
+                ld8(yo, old);
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) acc[j][q] += old[q];
+            }
+            st8(yo, acc[j]);
+        }
+    }
+}
+template <typename T>
+static void launch_dw_strip(const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad, int ho, int wo, int flip,
+                            int accumulate, hipStream_t s) {
+    const int ppb = 256 / std::min(c / kVec, 64);
+    const int64_t strips = (int64_t)n * ho * ((wo + 3) / 4);
+    const dim3 grid((unsigned)std::min<int64_t>((strips + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
+    const size_t lds = (size_t)k * k * 512 * sizeof(float);
+#define VS_STRIP(K_, S_) hipLaunchKernelGGL((dwconv2d_strip_kernel<T, K_, S_>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, pad, ho, wo, flip, accumulate)
+    if (k == 3 && stride == 1) VS_STRIP(3, 1);
+    else if (k == 3) VS_STRIP(3, 2);
+    else if (stride == 1) VS_STRIP(5, 1);
+    else VS_STRIP(5, 2);
+#undef VS_STRIP
+}
+
 // dx[iy][ix] (+)= sum over the taps (kh, kw) with (iy + pad - kh) and (ix + pad - kw) divisible by the stride of dy[..] * w[kh][kw]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv2d_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ wgt, T* __restrict__ dx, int n, int h,
@@ -358,12 +443,80 @@ __global__ __launch_bounds__(256) void dwconv2d_wgrad_partial(const XT* __restri
         }
     }
 }
-__global__ void dwconv2d_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int total) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;      // channel * kk + tap
-    if (o >= total) return;
+// the same partial sums with four consecutive outputs of a row per lane and trip (the input row window and the four gradients are
+// loaded once and shared by the row's K taps)
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv2d_wgrad_strip(const T* __restrict__ x, const T* __restrict__ dy, int n, int h, int w, int c, int pad, int ho,
+                                                          int wo, float* __restrict__ partial) {
+    constexpr int WT = 4, NW = (WT - 1) * S + K, KK = K * K;
+    __shared__ float red[256][kVec + 1];
+    const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0);
+    const int kh = blockIdx.z;
+    const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int ch0 = (v0 + cvi) * kVec;
+    float s[K][kVec];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) s[t][q] = 0.f;
+    const int spr = (wo + WT - 1) / WT;
+    const int64_t strips = (int64_t)n * ho * spr;
+    if (pl < ppb) {
+        for (int64_t sidx = (int64_t)blockIdx.x * ppb + pl; sidx < strips; sidx += (int64_t)gridDim.x * ppb) {
+            const int sx = (int)(sidx % spr), oy = (int)(sidx / spr % ho);
+            const int64_t b = sidx / spr / ho;
+            const int iy = oy * S + kh - pad;
+            if (iy < 0 || iy >= h) continue;
+            const int ox0 = sx * WT, ix0 = ox0 * S - pad;
+            const T* row = x + ((b * h + iy) * w) * c + ch0;
+            const T* grow = dy + (((b * ho + oy) * wo) + ox0) * c + ch0;
+            float v[NW][kVec], g[WT][kVec];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int ix = ix0 + i;
+                if (ix >= 0 && ix < w) ld8(row + (size_t)ix * c, v[i]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) v[i][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                if (ox0 + j < wo) ld8(grow + (size_t)j * c, g[j]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) g[j][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+#pragma unroll
+                    for (int q = 0; q < kVec; ++q) s[kw][q] += g[j][q] * v[j * S + kw][q];
+        }
+    }
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) red[threadIdx.x][q] = s[kw][q];
+        __syncthreads();
+        for (int o = threadIdx.x; o < cv * kVec; o += 256) {
+            const int gq = o / kVec, q = o % kVec;
+            float t = 0.f;
+            for (int j = 0; j < ppb; ++j) t += red[j * cv + gq][q];
+            partial[((size_t)blockIdx.x * c + v0 * kVec + o) * KK + kh * K + kw] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void dwconv2d_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int total) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per output (channel * kk + tap): the partial
+    if (o >= total) return;                                                          // rows spread over its lanes, fp64 butterfly
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * total + o];
-    dw[o] = (float)s;
+    for (int b = lane; b < nblk; b += 64) s += (double)partial[(size_t)b * total + o];
+    s = wave_sum_f64(s);
+    if (lane == 0) dw[o] = (float)s;
 }
 
 // out = x * mask[n] + skip (mask NULL: 1; skip NULL: 0) - drop_connect + the residual sum, and (on the gradient, without skip) its backward
@@ -562,6 +715,12 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
     const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * ho * wo + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    if (!x_single_channel && dilation == 1) {      // four outputs per lane, every input row of the window loaded once
+        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, ho, wo, 0, 0, s);
+        else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, ho, wo, 0, 0, s);
+        VS_LAUNCH_CHECK();
+        return VS_OK;
+    }
     if (x_single_channel) {
         if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
         else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
@@ -576,6 +735,12 @@ extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, v
                                     int ho, int wo, int accumulate, void* stream) {
     VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
+    if (stride == 1 && dilation == 1 && 2 * pad_lo == k - 1 && ho == h && wo == wd) {   // a stride-1 "same" layer: the forward sweep with the taps reversed
+        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, h, wd, 1, accumulate, (hipStream_t)stream);
+        else launch_dw_strip<float>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, h, wd, 1, accumulate, (hipStream_t)stream);
+        VS_LAUNCH_CHECK();
+        return VS_OK;
+    }
     const int ppb = 256 / std::min(c / kVec, 64);
     const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * h * wd + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     VS_LAUNCH_T(dwconv2d_bwd_data_kernel, grid, (size_t)k * k * 512 * sizeof(float), (hipStream_t)stream, (const T*)dy, w, (T*)dx, n, h, wd, c, k, stride, pad_lo,
@@ -593,7 +758,15 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kDwBlocks, ((int64_t)n * ho * wo + (int64_t)ppb * 16 - 1) / ((int64_t)ppb * 16)));
     const dim3 grid(nblk, (c / kVec + 63) / 64, k);
     hipStream_t s = (hipStream_t)stream;
-    if (x_single_channel) {
+    if (!x_single_channel && dilation == 1) {
+#define VS_WSTRIP(T_, K_, S_) hipLaunchKernelGGL((dwconv2d_wgrad_strip<T_, K_, S_>), grid, dim3(256), 0, s, (const T_*)x, (const T_*)dy, n, h, wd, c, pad_lo, ho, wo, workspace)
+        if (dtype == VS_BF16) {
+            if (k == 3 && stride == 1) VS_WSTRIP(bf16_t, 3, 1); else if (k == 3) VS_WSTRIP(bf16_t, 3, 2); else if (stride == 1) VS_WSTRIP(bf16_t, 5, 1); else VS_WSTRIP(bf16_t, 5, 2);
+        } else {
+            if (k == 3 && stride == 1) VS_WSTRIP(float, 3, 1); else if (k == 3) VS_WSTRIP(float, 3, 2); else if (stride == 1) VS_WSTRIP(float, 5, 1); else VS_WSTRIP(float, 5, 2);
+        }
+#undef VS_WSTRIP
+    } else if (x_single_channel) {
         if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
         else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
     } else {
@@ -602,7 +775,7 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
     }
     VS_LAUNCH_CHECK();
     const int total = c * k * k;
-    hipLaunchKernelGGL(dwconv2d_wgrad_final, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, nblk, total);
+    hipLaunchKernelGGL(dwconv2d_wgrad_final, dim3((total + 3) / 4), dim3(256), 0, s, workspace, dw, nblk, total);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
