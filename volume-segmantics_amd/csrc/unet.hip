@@ -1301,6 +1301,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     net->last_n = n;
     bool head_scattered = false;
     int unit_index = -1;
+    int carried_stat_rows = 0;     // partial statistic rows a plain convolution's epilogue left in bnws for the U_BN unit right behind it
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
         int fused_stat_rows = 0;
@@ -1347,7 +1348,11 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             ProfScope prof(training ? PK_BN_STATS : PK_BN_APPLY, 0, (training ? 3.0 : 2.0) * n * u.hout * u.wout * u.cout * net->esz, c.s);
             const int64_t rows = (int64_t)n * u.hout * u.wout;
             if (training) {
-                if ((rc = vs_bn2_stats(dt, c.a(u.src0), rows, u.cout, u.bn_eps, u.bn_mom, c.bnc(u, 2), c.bnc(u, 3), rm, rv, (float*)(c.ws + net->off_bnws),
+                if (carried_stat_rows) {
+                    if ((rc = launch_bn_finalize_partials((const float*)(c.ws + net->off_bnws), carried_stat_rows, u.cout, rows, u.bn_eps, u.bn_mom,
+                                                          c.bnc(u, 2), c.bnc(u, 3), rm, rv, c.s))) return rc;
+                    carried_stat_rows = 0;
+                } else if ((rc = vs_bn2_stats(dt, c.a(u.src0), rows, u.cout, u.bn_eps, u.bn_mom, c.bnc(u, 2), c.bnc(u, 3), rm, rv, (float*)(c.ws + net->off_bnws),
                                        net->bnws_bytes, stream))) return rc;
                 if ((rc = vs_bn2_apply(dt, c.a(u.src0), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, -1.f, c.a(u.out), rows, u.cout, stream))) return rc;
             } else {
@@ -1453,6 +1458,15 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             prof_set_variant(0);
             if (u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution (FPN's lateral 1x1s): no norm, no activation
                 p.out = c.a(u.out); p.shift = u.bias_idx >= 0 ? c.P(u.bias_idx) : nullptr;   // (EfficientNet's 1x1 convolutions: no bias either)
+                // its BatchNorm is the next unit (U_BN): the batch statistics come straight from the fp32 accumulators, as for the fused units
+                if (training && dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0 && unit_index + 1 < (int)net->units.size() &&
+                    net->units[unit_index + 1].kind == U_BN && net->units[unit_index + 1].src0 == u.out) {
+                    const int rows_needed = conv_igemm_stat_rows(dt, p);
+                    if (rows_needed > 0 && (size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
+                        p.stats_partial = (float*)(c.ws + net->off_bnws);
+                        carried_stat_rows = rows_needed;
+                    }
+                }
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 continue;
             }
