@@ -140,8 +140,9 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
  *   103 / 104: smp's efficientnet-b3 / efficientnet-b4 encoders (efficientnet-pytorch 0.6.3: 3x3 / 2 stem, 26 / 32 MBConv blocks -
  *   expand 1x1, depthwise 3x3 / 5x5 behind static same padding, squeeze-excitation with swish, project 1x1, drop_connect + skip;
- *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - topologies 0, 3, 4 and 5
- *   (under DeepLabV3+ / DeepLabV3 the last stage(s) run at stride 1 with dilation 2 / 2 and 4: smp's replace_strides_with_dilation);
+ *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - every topology but 2
+ *   (under DeepLabV3+ / PAN / DeepLabV3 the last stage(s) run at stride 1 with dilation 2 / 2 / 2 and 4: smp's
+ *   replace_strides_with_dilation);
  *   topology 7: smp.PAN (layer4 dilated; FPABlock with its single-channel 7x7 / 5x5 / 3x3 pyramid, three GAUBlocks, 3x3 head at 1/4
  *   resolution + x4 bilinear; slices must be multiples of 128) - depths 18 / 34 / 50;
  *   topology 6: smp.MAnet (PAB position attention at the deepest level, four MFAB blocks with squeeze-excitation gates on skip and

@@ -479,7 +479,7 @@ class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
         if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # smp's EfficientNetEncoder (oracle/efficientnet_torch.py); U-Net only
-            assert topology not in ("linknet", "pan"), "the EfficientNet encoders are not restated under smp.Linknet / smp.PAN"
+            assert topology != "linknet", "the EfficientNet encoders are not restated under smp.Linknet"
             self.encoder = EfficientNetEncoder(encoder_name, in_channels)
             out_channels = EFFICIENTNET_OUT_CHANNELS[encoder_name]
         else:
@@ -488,7 +488,10 @@ class OracleUnet(nn.Module):
         self.decoder = {"unet": UnetDecoder, "unetplusplus": UnetPlusPlusDecoder, "linknet": LinknetDecoder,
                         "fpn": FPNDecoder, "deeplabv3plus": DeepLabV3PlusDecoder, "deeplabv3": DeepLabV3Decoder,
                         "manet": MAnetDecoder, "pan": PANDecoder}[topology](out_channels)
-        if topology == "pan":               # encoder_dilation=True: make_dilated(stage_list=[5], dilation_list=[2])
+        if topology == "pan" and encoder_name in EFFICIENTNET_OUT_CHANNELS:
+            from .efficientnet_torch import STAGE_IDXS
+            replace_strides_with_dilation(self.encoder._blocks[STAGE_IDXS[encoder_name][2]:], 2)
+        elif topology == "pan":             # encoder_dilation=True: make_dilated(stage_list=[5], dilation_list=[2])
             replace_strides_with_dilation(self.encoder.layer4, 2)
         if topology == "deeplabv3" and encoder_name in EFFICIENTNET_OUT_CHANNELS:     # get_stages()[4] / [5] = _blocks[s1:s2] / _blocks[s2:]
             from .efficientnet_torch import STAGE_IDXS

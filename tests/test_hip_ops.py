@@ -1270,3 +1270,22 @@ def test_sample_rowsum_split_over_workgroups(code, shape):
     assert torch.allclose(outs[0][0].float().cpu(), x.mean((2, 3)), **tol(code, 1.0))
     ref = (x * y).sum((2, 3))
     assert torch.allclose(outs[0][1].float().cpu(), ref, **tol(code, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(700, 448), (96, 136), (2048, 304), (33, 8), (5000, 2688)])
+def test_colsum_any_channel_count(code, shape):
+    """vs_colsum (bias gradients: the column sums of a gradient map) for channel counts beyond 8 .. 128 / multiples of 256 - the
+    EfficientNet feature widths 448 / 136 that smp.MAnet's biased PAB convolutions see, and slabs with a narrower tail."""
+    L = lib()
+    rows, c = shape
+    g = torch.Generator().manual_seed(17)
+    x = rounded(torch.randn(rows, c, generator=g), code)
+    xd = x.to(DEV, tdtype(code)).contiguous()
+    wsb = L.lib.vs_colsum_workspace(c)
+    ws = torch.empty(wsb // 4, device=DEV)
+    out = torch.full((c,), float("nan"), device=DEV)
+    L.check(L.lib.vs_colsum(code, L.ptr(xd), rows, c, L.ptr(out), L.ptr(ws), wsb, None))
+    sync()
+    ref = x.double().sum(0).float()
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-3 * rows ** 0.5)

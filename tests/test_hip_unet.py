@@ -820,22 +820,26 @@ def _drop_connect_masks(L, encoder, n, counter_value=1, seed=0):
 
 
 @pytest.mark.parametrize("encoder,topology", [("efficientnet-b4", "fpn"), ("efficientnet-b3", "fpn"), ("efficientnet-b3", "deeplabv3"),
-                                              ("efficientnet-b4", "deeplabv3")])
+                                              ("efficientnet-b4", "deeplabv3"), ("efficientnet-b3", "unetplusplus"), ("efficientnet-b4", "unetplusplus"),
+                                              ("efficientnet-b3", "manet"), ("efficientnet-b4", "manet"), ("efficientnet-b3", "pan"),
+                                              ("efficientnet-b4", "pan")])
 def test_efficientnet_under_other_decoders(encoder, topology):
-    """smp's EfficientNet encoders under FPN and DeepLabV3 (stages 4 / 5 at stride 1 with dilation 2 / 4) - these decoders are generic
-    in the feature widths (40 / 48, 32, 48 / 56, 136 / 160, 384 / 448): eval logits, one fp32 training step's loss and every
+    """smp's EfficientNet encoders under FPN, DeepLabV3 (stages 4 / 5 at stride 1 with dilation 2 / 4), U-Net++ and MA-Net - the decoders
+    are generic in the feature widths (40 / 48, 32, 48 / 56, 136 / 160, 384 / 448); where U-Net++ / MA-Net concatenate behind an
+    upsampled tensor of 136 / 56 / 48 channels the concatenation is materialised (U_UP2 + U_CONCAT) instead of riding the convolution's
+    loader: eval logits, one fp32 training step's loss and every
     gradient with all random draws replayed in the oracle (drop-connect per block; FPN's Dropout2d; DeepLabV3's Dropout), and the
     recorded bf16 step against the call-by-call step."""
     from oracle.unet_resnet_torch import seeded_oracle_unet
     from volume_segmantics_amd import _lib as L
     from volume_segmantics_amd.data.losses import HipDiceLoss
     from volume_segmantics_amd.engine import VolSegUnet
-    size = 128 if topology == "deeplabv3" else 64
+    size = 128 if topology in ("deeplabv3", "pan") else 64       # (PAN: the stride-16 bottleneck must be a multiple of 8)
     oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topology)
     model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
     model.load_state_dict(oracle.state_dict())
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 1, size, size + 32, generator=g)
+    x = torch.randn(2, 1, size, size + (128 if topology == "pan" else 32), generator=g)
     oracle.eval(); model.eval()
     with torch.no_grad():
         ref, got = oracle(x), model(x.to(DEV)).cpu()
@@ -878,15 +882,22 @@ def test_efficientnet_under_other_decoders(encoder, topology):
             continue
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
         r = refg[name].grad
-        if r.norm().item() < 1e-6:          # (a constant the next BatchNorm removes: zero in exact arithmetic)
-            assert p.grad.norm().item() < 1e-5, (name, p.grad.norm().item())
+        # a per-channel constant the next BatchNorm removes (an MBConv's _bn2.bias inside a stage): zero in exact arithmetic, rounding noise
+        # on both sides - recognised by its size next to the same layer's weight gradient (PAN's logits of ~2 000 scale everything up)
+        sibling = refg[name[:-4] + "weight"].grad.norm().item() if name.endswith("_bn2.bias") else None
+        if r.norm().item() < 1e-6 or (sibling is not None and r.norm().item() < 1e-3 * sibling):
+            assert p.grad.norm().item() < max(1e-5, 1e-2 * (sibling or 0.0)), (name, p.grad.norm().item())
             continue
         err = ((p.grad.cpu() - r).norm() / r.norm()).item()
+        if ".SE_" in name:      # MA-Net's squeeze-excitation gates have 2 - 10 hidden ReLU units here: one unit at the kink moves a whole row
+            assert err < 0.25 and _cos(p.grad.cpu(), r) > 0.95, (encoder, topology, name, err)
+            continue
         worst = max(worst, (err, name))
         assert err < 5e-2 and _cos(p.grad.cpu(), r) > 0.98, (encoder, topology, name, err)
     print(encoder, topology, "worst relative gradient error", worst)
     runs = []
-    xs, ts = xt[:, :, :64, :64].contiguous().to(DEV), t[:, :, :64, :64].contiguous().to(DEV)
+    rs = 128 if topology == "pan" else 64
+    xs, ts = xt[:, :, :rs, :rs].contiguous().to(DEV), t[:, :, :rs, :rs].contiguous().to(DEV)
     for graph in (True, False):
         m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
         o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)

@@ -254,7 +254,8 @@ def test_efficientnet_restatement_matches_published_parameter_counts_and_engine_
             feats = enc.eval()(torch.zeros(1, 3, 64, 96))
         assert [f.shape[1] for f in feats[1:]] == list(OUT_CHANNELS[name][1:])
         assert [tuple(f.shape[2:]) for f in feats] == [(64 >> i, 96 >> i) for i in range(6)]
-        for topology, tcode in (("unet", 0), ("fpn", 3000), ("deeplabv3plus", 4000), ("deeplabv3", 5000)):   # (DeepLabV3+ / b4: BASELINE configs[4])
+        for topology, tcode in (("unet", 0), ("unetplusplus", 1000), ("fpn", 3000), ("deeplabv3plus", 4000), ("deeplabv3", 5000), ("manet", 6000),
+                                ("pan", 7000)):      # every decoder but Linknet (DeepLabV3+ / b4: BASELINE configs[4])
             sd = OracleUnet(name, 1, 3, topology).state_dict()
             table = _lib.unet_tensor_table(3, tcode + code)
             assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], (name, topology)

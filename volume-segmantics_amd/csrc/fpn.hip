@@ -33,10 +33,14 @@ __global__ void upsample2x_add_kernel(const T* __restrict__ x, const T* __restri
         const int b = t / (2 * h);
         float a[kVec], v[kVec];
         ld8(x + (((size_t)b * h + (ho >> 1)) * w + (wo >> 1)) * c + cg * kVec, a);
-        ld8(s + i * kVec, v);
+        if (s) {
+            ld8(s + i * kVec, v);
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) v[k] += a[k];
-        st8(y + i * kVec, v);
+            for (int k = 0; k < kVec; ++k) v[k] += a[k];
+            st8(y + i * kVec, v);
+        } else {            // plain nearest-x2 upsampling (no addend)
+            st8(y + i * kVec, a);
+        }
     }
 }
 
@@ -367,7 +371,7 @@ bool gn_shape_ok(int c, int G) {
     } while (0)
 
 extern "C" int vs_upsample2x_add(int dtype, const void* x, const void* skip, void* y, int n, int h, int w, int c, void* stream) {
-    VS_REQUIRE(x && skip && y && c > 0 && c % kVec == 0, "upsample2x_add: channels must be a multiple of 8");
+    VS_REQUIRE(x && y && c > 0 && c % kVec == 0, "upsample2x_add: channels must be a multiple of 8");      // skip may be NULL: plain nearest x2
     const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
     VS_LAUNCH_T(upsample2x_add_kernel, dim3(grid_for(total)), (hipStream_t)stream, (const T*)x, (const T*)skip, (T*)y, n, h, w, c);
     return VS_OK;

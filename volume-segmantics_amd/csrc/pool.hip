@@ -235,14 +235,17 @@ __global__ void space_to_depth2_kernel(const T* __restrict__ x, T* __restrict__ 
 // up to 256 channels (cs of them, starting at 256 * blockIdx.y)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t rows, int c, int cs, float* __restrict__ partial) {
-    // thread -> (row lane, 8-channel group): 256 / (cs / 8) rows per sweep
-    const int cv = cs / kVec, rl = 256 / cv, c0 = blockIdx.y * 256;
+    // thread -> (row lane, 8-channel group): 256 / (slab width / 8) rows per sweep; blockIdx.y = slab of up to 256 channels (the last
+    // one may be narrower: any channel count that is a multiple of 8)
+    const int c0 = blockIdx.y * 256;
+    cs = min(256, c - c0);
+    const int cv = cs / kVec, rl = 256 / cv;
     const int cg = threadIdx.x % cv, r0 = threadIdx.x / cv;
     __shared__ float red[256 * kVec];
     float s[kVec];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) s[k] = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * rl + r0; r < rows; r += (int64_t)gridDim.x * rl) {
+    for (int64_t r = (int64_t)blockIdx.x * rl + r0; r0 < rl && r < rows; r += (int64_t)gridDim.x * rl) {
         float v[kVec];
         ld8(x + (size_t)r * c + c0 + cg * kVec, v);
 #pragma unroll
@@ -387,12 +390,11 @@ constexpr int kColsumBlocks = 512;
 extern "C" size_t vs_colsum_workspace(int c) { return (size_t)kColsumBlocks * c * sizeof(float); }
 extern "C" int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* out, float* workspace, size_t workspace_bytes, void* stream) {
     const int cs = c < 256 ? c : 256;
-    VS_REQUIRE(x && out && workspace && c >= kVec && c % kVec == 0 && 256 % (cs / kVec) == 0 && c % cs == 0,
-               "colsum: channels must be 8, 16, 32, 64, 128 or a multiple of 256 (got %d)", c);
+    VS_REQUIRE(x && out && workspace && c >= kVec && c % kVec == 0, "colsum: channels must be a multiple of 8 (got %d)", c);
     VS_REQUIRE(workspace_bytes >= vs_colsum_workspace(c), "colsum: workspace too small");
     const int rl = 256 / (cs / kVec);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kColsumBlocks, (rows + rl - 1) / rl));
-    const dim3 grid(blocks, c / cs);
+    const dim3 grid(blocks, (c + 255) / 256);
     if (dtype == VS_BF16)
         hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, cs, workspace);
     else

@@ -102,6 +102,8 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_DWCONV2,      // depthwise k x k convolution, stride 1 / 2, `pad` zero rows / columns in front (static same padding), no
                                 // norm; bcast: the network input (one fp32 channel) broadcast over cout = the EfficientNet stem
                 U_DROPADD,      // out = drop_connect(a(src0), drop_p) + a(src1) (the MBConv skip); evaluation: the plain sum
+                U_UP2,          // out = nearest-x2 upsampling of a(src0), materialised - where a decoder's upsample + concat cannot ride the
+                                // convolution's loader (the boundary is not a multiple of 32 channels: EfficientNet features of 136 / 56 / 48)
                 U_FPA };        // smp PAN's FPABlock pyramid + combination: out = plane(src0) * a(src1) + a(res) broadcast; tens = its 24
                                 // parameter tensors (6 x conv weight, conv bias, BN gamma, BN beta)
 
@@ -223,6 +225,19 @@ int build(vs_unet* net) {
         A.push_back(a);
         return (int)A.size() - 1;
     };
+    // cat([nearest-x2(x), skip members...]) as ONE activation (U_UP2 + U_CONCAT): the route for boundaries the fused loader does not take
+    auto materialised_cat = [&](int x_act, int x_c, const std::vector<int>& skip_members, int skip_c) {
+        const Act xa = A[x_act];
+        Unit up; up.kind = U_UP2; up.src0 = x_act; up.cout = x_c; up.hin = xa.h; up.win = xa.w; up.hout = 2 * xa.h; up.wout = 2 * xa.w; up.relu = 0;
+        up.out = new_act(x_c, 2 * xa.h, 2 * xa.w, false);
+        U.push_back(up);
+        Unit cu; cu.kind = U_CONCAT; cu.members = {up.out};
+        for (int m : skip_members) cu.members.push_back(m);
+        cu.cout = x_c + skip_c; cu.hout = 2 * xa.h; cu.wout = 2 * xa.w; cu.relu = 0;
+        cu.out = new_act(x_c + skip_c, 2 * xa.h, 2 * xa.w, false);
+        U.push_back(cu);
+        return cu.out;
+    };
     // ---- encoder ----
     int feat[6]; int featc[6] = {0, 64, 0, 0, 0, 0};          // activations / channels of the encoder features the decoder taps
     int cur = -1, inpl = 64, ch = H / 4, cw = W / 4;
@@ -276,7 +291,9 @@ int build(vs_unet* net) {
                 // DeepLabV3+ (output stride 16): smp's replace_strides_with_dilation on the last stage (blocks[ends[2]:]) - every
                 // convolution stride 1, dilation 2, padding (k / 2) * 2, the static padding dropped ("Kostyl for EfficientNet")
                 // DeepLabV3 (output stride 8): stages 4 and 5 (blocks[ends[1]:ends[2]], blocks[ends[2]:]) with dilation 2 and 4
-                const int stage_dil = net->topology == 4 ? (bi >= ends[2] ? 2 : 1) : net->topology == 5 ? (bi >= ends[2] ? 4 : (bi >= ends[1] ? 2 : 1)) : 1;
+                // PAN (encoder_dilation): the last stage with dilation 2, as DeepLabV3+
+                const int stage_dil = (net->topology == 4 || net->topology == 7) ? (bi >= ends[2] ? 2 : 1)
+                                      : net->topology == 5 ? (bi >= ends[2] ? 4 : (bi >= ends[1] ? 2 : 1)) : 1;
                 const bool dilated = stage_dil > 1;
                 const int st = (j == 0 && !dilated) ? b[2] : 1, inp = j == 0 ? round_filters(b[4]) : o, oup = inp * e;
                 const std::string pre = "encoder._blocks." + std::to_string(bi);
@@ -441,6 +458,17 @@ int build(vs_unet* net) {
             Node& nd = node[d][l];
             const Act xa = A[x_act];
             const int oh = xa.h * 2, ow = xa.w * 2;
+            if (!skip_members.empty() && x_c % 32 != 0) {   // (EfficientNet features of 136 / 56 / 48 channels as the upsampled input)
+                const int cat = materialised_cat(x_act, x_c, skip_members, nd.skip_ch);
+                Unit u1; u1.kind = U_CONV; u1.src0 = cat; u1.cin0 = x_c + nd.skip_ch; u1.cout = nd.out_ch; u1.hin = oh; u1.win = ow; u1.hout = oh; u1.wout = ow;
+                u1.w_idx = nd.w1; u1.bn_idx = nd.bn1; u1.out = new_act(nd.out_ch, oh, ow, true);
+                Unit u2; u2.kind = U_CONV; u2.src0 = u1.out; u2.cin0 = nd.out_ch; u2.cout = nd.out_ch;
+                u2.hin = oh; u2.win = ow; u2.hout = oh; u2.wout = ow; u2.w_idx = nd.w2; u2.bn_idx = nd.bn2;
+                u2.out = new_act(nd.out_ch, oh, ow, true);
+                U.push_back(u1); U.push_back(u2);
+                nd.out_act = u2.out;
+                return;
+            }
             int skip_act = -1;
             if (!skip_members.empty()) {   // the concatenation is materialised (channel-slice copies): its gradient is split back
                 Unit cu; cu.kind = U_CONCAT; cu.members = skip_members; cu.cout = nd.skip_ch; cu.hout = oh; cu.wout = ow; cu.relu = 0;
@@ -621,7 +649,11 @@ int build(vs_unet* net) {
             }
             xh *= 2; xw *= 2;
             Unit c1 = cbr(pre + "conv1.0.weight", pre + "conv1.1", up_src, up_c + S, oc, 3, xh, xw);
-            c1.up0 = 1; c1.cin0 = up_c; c1.cin1 = S; c1.src1 = S > 0 ? skipa[i] : -1;
+            if (S > 0 && up_c % 32 != 0) {     // (EfficientNet skips of 56 / 48 channels: the concatenation is materialised)
+                c1.src0 = materialised_cat(up_src, up_c, {skipa[i]}, S);
+            } else {
+                c1.up0 = 1; c1.cin0 = up_c; c1.cin1 = S; c1.src1 = S > 0 ? skipa[i] : -1;
+            }
             U.push_back(c1);
             Unit c2 = cbr(pre + "conv2.0.weight", pre + "conv2.1", c1.out, oc, oc, 3, xh, xw);
             U.push_back(c2);
@@ -1063,8 +1095,8 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
     VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && (tmp.topology == 0 || tmp.topology == 3 || tmp.topology == 4 || tmp.topology == 5)),
-               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, for topologies 0 / 3 / 4 / 5, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && tmp.topology != 2),
+               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, except under Linknet, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -1120,9 +1152,8 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104,
                "unet_create: encoder must be 18, 34, 50, 51, 103 or 104 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / efficientnet-b4), got %d", encoder);
-    VS_REQUIRE(encoder < 100 || topology == 0 || topology == 3 || topology == 4 || topology == 5,
-               "unet_create: the EfficientNet encoders are built under smp.Unet, FPN, DeepLabV3Plus and DeepLabV3 (topologies 0, 3, 4, 5): U-Net++ / MA-Net "
-               "concatenate at 136 / 56 channels (the fused loader wants multiples of 16), Linknet narrows 56 / 48 channels to 14 / 12, PAN is not restated");
+    VS_REQUIRE(encoder < 100 || topology != 2,
+               "unet_create: the EfficientNet encoders are not built under smp.Linknet (its decoder narrows 56 / 48 channels to 14 / 12: not multiples of 8)");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
@@ -1427,6 +1458,11 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             } else {
                 if ((rc = vs_channel_slice(dt, c.a(u.src0), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, 0, stream))) return rc;
             }
+            continue;
+        }
+        case U_UP2: {
+            ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_upsample2x_add(dt, c.a(u.src0), nullptr, c.a(u.out), n, u.hin, u.win, u.cout, stream))) return rc;
             continue;
         }
         case U_UPADD: {
@@ -1943,6 +1979,14 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
             if ((rc = vs_dropout(dt, c.da(u.out), c.da(u.src0), (int64_t)n * u.hout * u.wout * u.cout, 0.5f, net->rng_seed ^ 0x5bd1e995u,
                                  net->rng_counter, 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_UP2) {      // the 2x2 sums of the upsampled tensor's gradient
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of an upsampled tensor missing");
+            ProfScope prof(PK_POOL_MISC, 0, 1.25 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = launch_upsample2x_bwd(dt, c.da(u.out), c.da(u.src0), n, u.hin, u.win, u.cout, written[u.src0] ? 1 : 0, c.s))) return rc;
             written[u.src0] = 1;
             continue;
         }
