@@ -227,7 +227,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
                     const float4 rv = ld4((const T*)p.residual + o);
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                 }
-                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                else if (p.relu == 2) {      // swish (evaluation-mode EfficientNet: BatchNorm folded into scale / shift, then x * sigmoid(x))
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+                }
                 if (p.out_f32) st4((float*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
                 else st4((T*)dst + o, make_float4(v[0], v[1], v[2], v[3]));
             } else {
@@ -237,7 +241,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
                     if (p.scale) x = x * p.scale[c + r] + p.shift[c + r];
                     else if (p.shift) x += p.shift[c + r];
                     if (p.residual) x += Elem<T>::ld((const T*)p.residual + pix * p.Cout + c + r);
-                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.relu == 1) x = fmaxf(x, 0.f);
+                    else if (p.relu == 2) x = x / (1.f + __expf(-x));
                     if (g.out_nchw) ((float*)p.out)[(((size_t)n * p.Cout + c + r) * p.Hout + ho) * p.Wout + wo] = x;
                     else if (p.out_f32) ((float*)p.out)[pix * p.Cout + c + r] = x;
                     else Elem<T>::st((T*)p.out + pix * p.Cout + c + r, x);

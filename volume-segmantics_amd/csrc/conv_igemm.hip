@@ -422,7 +422,11 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                         v[0] = v[0] * sc[j].x + sh[j].x; v[1] = v[1] * sc[j].y + sh[j].y;
                         v[2] = v[2] * sc[j].z + sh[j].z; v[3] = v[3] * sc[j].w + sh[j].w;
                     }
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    else if (p.relu == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+                    }
                     if constexpr (MODE == 0) {
                         const int off = live ? ooff[j] : kOob;
                         if constexpr (sizeof(T) == 2) {

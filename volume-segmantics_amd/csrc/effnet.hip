@@ -261,10 +261,10 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
 // The same convolution, four consecutive outputs of a row per lane: each input row of the window is loaded once ((WT - 1) S + K vectors)
 // and reused across the K taps and the WT outputs - 10 instead of 25 vector loads per output at K = 5 (the plain kernel is bound by
 // these L2 re-reads).  flip = 1: taps reversed = the data gradient of a stride-1 layer with symmetric padding; accumulate adds to y.
-template <typename T, int K, int S>
+template <typename T, int K, int S, int D>
 __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
                                                            int c, int pad, int ho, int wo, int flip, int accumulate) {
-    constexpr int WT = 4, NW = (WT - 1) * S + K, KK = K * K;
+    constexpr int WT = 4, NW = (WT - 1) * S + (K - 1) * D + 1, KK = K * K;      // D: dilation (stride-1 stages under DeepLabV3+ / PAN / DeepLabV3)
     extern __shared__ float wl[];     // [K * K][64 * 8]
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0);
     for (int o = threadIdx.x; o < cv * kVec * KK; o += 256) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
             for (int q = 0; q < kVec; ++q) acc[j][q] = 0.f;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
-            const int iy = oy * S + kh - pad;
+            const int iy = oy * S + kh * D - pad;
             if (iy < 0 || iy >= h) continue;
             const T* row = x + ((b * h + iy) * w) * c + ch0;
             float v[NW][kVec];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
 #pragma unroll
                 for (int j = 0; j < WT; ++j)
 #pragma unroll
-                    for (int q = 0; q < kVec; ++q) acc[j][q] += v[j * S + kw][q] * wq[q];
+                    for (int q = 0; q < kVec; ++q) acc[j][q] += v[j * S + kw * D][q] * wq[q];
             }
         }
 #pragma unroll
@@ -329,17 +329,19 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
     }
 }
 template <typename T>
-static void launch_dw_strip(const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad, int ho, int wo, int flip,
-                            int accumulate, hipStream_t s) {
+static void launch_dw_strip(const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad, int dil, int ho, int wo,
+                            int flip, int accumulate, hipStream_t s) {
     const int ppb = 256 / std::min(c / kVec, 64);
     const int64_t strips = (int64_t)n * ho * ((wo + 3) / 4);
     const dim3 grid((unsigned)std::min<int64_t>((strips + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
-#define VS_STRIP(K_, S_) hipLaunchKernelGGL((dwconv2d_strip_kernel<T, K_, S_>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, pad, ho, wo, flip, accumulate)
-    if (k == 3 && stride == 1) VS_STRIP(3, 1);
-    else if (k == 3) VS_STRIP(3, 2);
-    else if (stride == 1) VS_STRIP(5, 1);
-    else VS_STRIP(5, 2);
+#define VS_STRIP(K_, S_, D_) hipLaunchKernelGGL((dwconv2d_strip_kernel<T, K_, S_, D_>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, pad, ho, wo, flip, accumulate)
+    if (dil == 2) { if (k == 3) VS_STRIP(3, 1, 2); else VS_STRIP(5, 1, 2); }
+    else if (dil == 4) VS_STRIP(3, 1, 4);
+    else if (k == 3 && stride == 1) VS_STRIP(3, 1, 1);
+    else if (k == 3) VS_STRIP(3, 2, 1);
+    else if (stride == 1) VS_STRIP(5, 1, 1);
+    else VS_STRIP(5, 2, 1);
 #undef VS_STRIP
 }
 
@@ -715,9 +717,10 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
     const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * ho * wo + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (!x_single_channel && dilation == 1) {      // four outputs per lane, every input row of the window loaded once
-        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, ho, wo, 0, 0, s);
-        else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, ho, wo, 0, 0, s);
+    const bool strip_ok = dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3)));
+    if (!x_single_channel && strip_ok) {      // four outputs per lane, every input row of the window loaded once
+        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
+        else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
         VS_LAUNCH_CHECK();
         return VS_OK;
     }
@@ -735,9 +738,10 @@ extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, v
                                     int ho, int wo, int accumulate, void* stream) {
     VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
-    if (stride == 1 && dilation == 1 && 2 * pad_lo == k - 1 && ho == h && wo == wd) {   // a stride-1 "same" layer: the forward sweep with the taps reversed
-        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, h, wd, 1, accumulate, (hipStream_t)stream);
-        else launch_dw_strip<float>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, h, wd, 1, accumulate, (hipStream_t)stream);
+    const bool strip_ok = dilation == 1 || dilation == 2 || (dilation == 4 && k == 3);
+    if (stride == 1 && strip_ok && 2 * pad_lo == (k - 1) * dilation && ho == h && wo == wd) {   // a stride-1 "same" layer: the forward sweep with the taps reversed
+        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
+        else launch_dw_strip<float>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
         VS_LAUNCH_CHECK();
         return VS_OK;
     }

@@ -1218,7 +1218,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
         if (u.bn_idx >= 0 && !training) {  // eval-mode folding from the running statistics
             const float* rm = bnstate + c.t(u.bn_idx + 2).offset;
             const float* rv = bnstate + c.t(u.bn_idx + 3).offset;
-            int rc = vs_bn_fold(c.P(u.bn_idx), c.P(u.bn_idx + 1), rm, rv, 1e-5f, c.bnc(u, 0), c.bnc(u, 1), u.cout, stream);
+            int rc = vs_bn_fold(c.P(u.bn_idx), c.P(u.bn_idx + 1), rm, rv, u.kind == U_BN ? u.bn_eps : 1e-5f, c.bnc(u, 0), c.bnc(u, 1), u.cout, stream);
             if (rc) return rc;
             if (u.kind == U_CONV && u.bias_idx >= 0 && (rc = vs_bn_fold_bias(c.bnc(u, 0), c.P(u.bias_idx), c.bnc(u, 1), u.cout, stream))) return rc;
         }
@@ -1333,6 +1333,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     bool head_scattered = false;
     int unit_index = -1;
     int carried_stat_rows = 0;     // partial statistic rows a plain convolution's epilogue left in bnws for the U_BN unit right behind it
+    bool bn_folded_into_conv = false;   // evaluation: that U_BN's scale / shift / activation already ran in the convolution's epilogue
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
         int fused_stat_rows = 0;
@@ -1376,6 +1377,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             continue;
         }
         case U_BN: {    // batch statistics (training) or the running ones, normalisation + activation in one sweep
+            if (bn_folded_into_conv) { bn_folded_into_conv = false; continue; }
             ProfScope prof(training ? PK_BN_STATS : PK_BN_APPLY, 0, (training ? 3.0 : 2.0) * n * u.hout * u.wout * u.cout * net->esz, c.s);
             const int64_t rows = (int64_t)n * u.hout * u.wout;
             if (training) {
@@ -1502,6 +1504,13 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
                         carried_stat_rows = rows_needed;
                     }
+                }
+                // evaluation: the BatchNorm unit behind it (folded running statistics) and its activation ride in this epilogue
+                if (!training && u.bias_idx < 0 && unit_index + 1 < (int)net->units.size() && net->units[unit_index + 1].kind == U_BN &&
+                    net->units[unit_index + 1].src0 == u.out) {
+                    const Unit& bn = net->units[unit_index + 1];
+                    p.scale = c.bnc(bn, 0); p.shift = c.bnc(bn, 1); p.relu = bn.relu; p.out = c.a(bn.out);
+                    bn_folded_into_conv = true;
                 }
                 if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
                 continue;
