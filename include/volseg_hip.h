@@ -356,6 +356,9 @@ int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h,
                 int wo, int x_single_channel, void* stream);
 int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation,
                          int ho, int wo, int accumulate, void* stream);
+/* evaluation: depthwise convolution + folded BatchNorm (scale / shift from vs_bn_fold) + activation (0 / 1 ReLU / 2 swish) in one sweep */
+int vs_dwconv2d_affine(int dtype, const void* x, const float* w, const float* scale, const float* shift, int act, void* y, int n, int h, int wd, int c,
+                       int k, int stride, int pad_lo, int dilation, int ho, int wo, void* stream);
 size_t vs_dwconv2d_wgrad_workspace(int c, int k);
 int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho,
                       int wo, int x_single_channel, float* workspace, size_t workspace_bytes, void* stream);

@@ -1289,3 +1289,32 @@ def test_colsum_any_channel_count(code, shape):
     sync()
     ref = x.double().sum(0).float()
     assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-3 * rows ** 0.5)
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("geom", [(3, 1, 1, 1), (5, 2, 1, 1), (5, 1, 4, 2)])
+def test_dwconv2d_affine_eval_form(code, geom):
+    """Evaluation-mode MBConv middle: depthwise convolution + BatchNorm (running statistics folded by vs_bn_fold) + swish in one sweep
+    (vs_dwconv2d_affine) against F.conv2d + F.batch_norm(training=False) + swish."""
+    L = lib()
+    k, s, lo, dil = geom
+    n, h, w, c = 2, 12, 16, 144
+    g = torch.Generator().manual_seed(63)
+    ho, wo = -(-h // s), -(-w // s)
+    hi_h, hi_w = max((ho - 1) * s + (k - 1) * dil + 1 - h, 0) - lo, max((wo - 1) * s + (k - 1) * dil + 1 - w, 0) - lo
+    x = rounded(torch.randn(n, c, h, w, generator=g), code)
+    wt = torch.randn(c, 1, k, k, generator=g) / k
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    rm, rv = 0.1 * torch.randn(c, generator=g), 0.75 + 0.5 * torch.rand(c, generator=g)
+    z = F.conv2d(F.pad(x, (lo, hi_w, lo, hi_h)), wt, stride=s, groups=c, dilation=dil)
+    v = F.batch_norm(z, rm, rv, gamma, beta, False, 0.01, 1e-3)
+    ref = v * torch.sigmoid(v)
+    dev = lambda t_: t_.contiguous().to(DEV)
+    scale, shift = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    gd, bd, rmd, rvd = dev(gamma), dev(beta), dev(rm), dev(rv)
+    L.check(L.lib.vs_bn_fold(L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 1e-3, L.ptr(scale), L.ptr(shift), c, None))
+    xd, wd = to_nhwc(x, code), dev(wt.reshape(c, k * k))
+    yd = torch.full((n, ho, wo, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_dwconv2d_affine(code, L.ptr(xd), L.ptr(wd), L.ptr(scale), L.ptr(shift), 2, L.ptr(yd), n, h, w, c, k, s, lo, dil, ho, wo, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), ref, **tol(code, ref.abs().max().item()))

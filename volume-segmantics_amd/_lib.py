@@ -103,6 +103,7 @@ _SIGS = {
     "vs_bn2_bwd": (I, [I, P, P, P, P, P, P, I, P, P, P, I64, I, P, SZ, P]),
     "vs_dwconv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "vs_dwconv2d_bwd_data": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "vs_dwconv2d_affine": (I, [I, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "vs_dwconv2d_wgrad_workspace": (SZ, [I, I]),
     "vs_dwconv2d_wgrad": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "vs_sample_scale_add": (I, [I, P, P, P, P, I, I64, P]),

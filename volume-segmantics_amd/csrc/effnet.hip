@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const XT* __restrict_
 // these L2 re-reads).  flip = 1: taps reversed = the data gradient of a stride-1 layer with symmetric padding; accumulate adds to y.
 template <typename T, int K, int S, int D>
 __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict__ x, const float* __restrict__ wgt, T* __restrict__ y, int n, int h, int w,
-                                                           int c, int pad, int ho, int wo, int flip, int accumulate) {
+                                                           int c, int pad, int ho, int wo, int flip, int accumulate, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act) {
     constexpr int WT = 4, NW = (WT - 1) * S + (K - 1) * D + 1, KK = K * K;      // D: dilation (stride-1 stages under DeepLabV3+ / PAN / DeepLabV3)
     extern __shared__ float wl[];     // [K * K][64 * 8]
     const int cv_all = c / kVec, v0 = blockIdx.y * 64, cv = min(64, cv_all - v0);
@@ -275,6 +276,9 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
     const int ppb = 256 / cv, cvi = threadIdx.x % cv, pl = threadIdx.x / cv;
     if (pl >= ppb) return;
     const int ch0 = (v0 + cvi) * kVec;
+    float sc[kVec], sf[kVec];           // evaluation: the BatchNorm behind the convolution (folded) and its activation in the same sweep
+#pragma unroll
+    for (int q = 0; q < kVec; ++q) { sc[q] = scale ? scale[ch0 + q] : 1.f; sf[q] = scale ? shift[ch0 + q] : 0.f; }
     const int spr = (wo + WT - 1) / WT;                 // strips per output row
     const int64_t strips = (int64_t)n * ho * spr;
     for (int64_t sidx = (int64_t)blockIdx.x * ppb + pl; sidx < strips; sidx += (int64_t)gridDim.x * ppb) {
@@ -318,6 +322,10 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
             const int ox = ox0 + j;
             if (ox >= wo) break;
             T* yo = y + (((b * ho + oy) * wo) + ox) * c + ch0;
+            if (scale) {
+#pragma unroll
+                for (int q = 0; q < kVec; ++q) acc[j][q] = act_fwd(acc[j][q] * sc[q] + sf[q], act);
+            }
             if (accumulate) {
                 float old[kVec];
                 ld8(yo, old);
@@ -330,12 +338,12 @@ __global__ __launch_bounds__(256) void dwconv2d_strip_kernel(const T* __restrict
 }
 template <typename T>
 static void launch_dw_strip(const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad, int dil, int ho, int wo,
-                            int flip, int accumulate, hipStream_t s) {
+                            int flip, int accumulate, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, int act = 0) {
     const int ppb = 256 / std::min(c / kVec, 64);
     const int64_t strips = (int64_t)n * ho * ((wo + 3) / 4);
     const dim3 grid((unsigned)std::min<int64_t>((strips + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
-#define VS_STRIP(K_, S_, D_) hipLaunchKernelGGL((dwconv2d_strip_kernel<T, K_, S_, D_>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, pad, ho, wo, flip, accumulate)
+#define VS_STRIP(K_, S_, D_) hipLaunchKernelGGL((dwconv2d_strip_kernel<T, K_, S_, D_>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, pad, ho, wo, flip, accumulate, scale, shift, act)
     if (dil == 2) { if (k == 3) VS_STRIP(3, 1, 2); else VS_STRIP(5, 1, 2); }
     else if (dil == 4) VS_STRIP(3, 1, 4);
     else if (k == 3 && stride == 1) VS_STRIP(3, 1, 1);
@@ -814,5 +822,18 @@ extern "C" int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void
     if (splits < 2 || !workspace || workspace_bytes < vs_sample_rowsum_workspace(n, c)) return vs_sample_rowsum(dtype, a, b, out, n, hw, c, scale, stream);
     VS_LAUNCH_T(sample_rowsum_split_kernel, dim3(n, (c / kVec + 255) / 256, splits), 0, (hipStream_t)stream, (const T*)a, (const T*)b, workspace, hw, c);
     VS_LAUNCH_T(sample_rowsum_finish_kernel, dim3((n * c + 255) / 256), 0, (hipStream_t)stream, workspace, (T*)out, n, c, splits, scale);
+    return VS_OK;
+}
+// evaluation form of depthwise convolution + BatchNorm + activation in ONE sweep: y = act(conv(x) * scale[c] + shift[c]) (scale / shift
+// = the folded running statistics, vs_bn_fold).  Takes what the strip kernels take: dilation 1, or stride 1 with dilation 2 (4 for k = 3).
+extern "C" int vs_dwconv2d_affine(int dtype, const void* x, const float* w, const float* scale, const float* shift, int act, void* y, int n, int h, int wd,
+                                  int c, int k, int stride, int pad_lo, int dilation, int ho, int wo, void* stream) {
+    VS_REQUIRE(x && w && scale && shift && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && act >= 0 && act <= 2,
+               "dwconv2d_affine: bad arguments");
+    VS_REQUIRE(dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3))), "dwconv2d_affine: dilation %d at stride %d, kernel %d is not taken", dilation, stride, k);
+    VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d_affine: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
+    if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, (hipStream_t)stream, scale, shift, act);
+    else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, (hipStream_t)stream, scale, shift, act);
+    VS_LAUNCH_CHECK();
     return VS_OK;
 }

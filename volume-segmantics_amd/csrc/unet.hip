@@ -1372,6 +1372,14 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_DWCONV2: {
             ProfScope prof(PK_POOL_MISC, 0, (double)n * (u.hin * u.win * u.cin0 + u.hout * u.wout * u.cout) * net->esz, c.s);
+            if (!training && !u.bcast && unit_index + 1 < (int)net->units.size() && net->units[unit_index + 1].kind == U_BN &&
+                net->units[unit_index + 1].src0 == u.out && (u.dil == 1 || (u.stride == 1 && (u.dil == 2 || (u.dil == 4 && u.k == 3))))) {
+                const Unit& bn = net->units[unit_index + 1];      // evaluation: its BatchNorm (folded) + swish in the same sweep
+                if ((rc = vs_dwconv2d_affine(dt, c.a(u.src0), c.P(u.w_idx), c.bnc(bn, 0), c.bnc(bn, 1), bn.relu, c.a(bn.out), n, u.hin, u.win, u.cout, u.k,
+                                             u.stride, u.pad, u.dil, u.hout, u.wout, stream))) return rc;
+                bn_folded_into_conv = true;
+                continue;
+            }
             if ((rc = vs_dwconv2d(dt, u.bcast ? (const void*)x : (const void*)c.a(u.src0), c.P(u.w_idx), c.a(u.out), n, u.hin, u.win, u.cout, u.k, u.stride,
                                   u.pad, u.dil, u.hout, u.wout, u.bcast, stream))) return rc;
             continue;
