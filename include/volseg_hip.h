@@ -369,6 +369,12 @@ size_t vs_sample_rowsum_workspace(int n, int c);
 int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, float* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- timm's ResNeSt blocks (timm-resnest50d / timm-resnest101e behind smp; csrc/resnest.hip): RadixSoftmax(radix 2, cardinality 1) on
+ * attention logits z [n][2 c] (the two splits' values c apart): a = softmax over each pair; bwd: dz from da and a.  The rest of a block is
+ * composed from the operators above (the two-group 3x3 convolution as a dense one with block-expanded weight copies). */
+int vs_radix2_softmax(int dtype, const void* z, void* a, int n, int c, void* stream);
+int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, void* dz, int n, int c, void* stream);
+
 /* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
  * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom
  *   ([n][hw][C]), y = x + the product's memory reinterpreted as (n, C, h, w) exactly as smp's reshape does; sp fp32 [n][hw][hw] is

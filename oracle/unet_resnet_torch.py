@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .efficientnet_torch import OUT_CHANNELS as EFFICIENTNET_OUT_CHANNELS, EfficientNetEncoder
+from .resnest_torch import OUT_CHANNELS as RESNEST_OUT_CHANNELS, ResNestEncoder
 from .unet_resnet34_torch import DECODER_CHANNELS, BasicBlock, DecoderBlock
 
 LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnext50_32x4d": (3, 4, 6, 3)}
@@ -478,7 +479,11 @@ class PANDecoder(nn.Module):
 class OracleUnet(nn.Module):
     def __init__(self, encoder_name: str, in_channels: int = 1, classes: int = 2, topology: str = "unet"):
         super().__init__()
-        if encoder_name in EFFICIENTNET_OUT_CHANNELS:     # smp's EfficientNetEncoder (oracle/efficientnet_torch.py); U-Net only
+        if encoder_name in RESNEST_OUT_CHANNELS:          # smp's ResNestEncoder over timm 0.4.12 (oracle/resnest_torch.py)
+            assert topology not in ("deeplabv3", "deeplabv3plus", "pan"), "ResNeSt under the dilating decoders is not restated"
+            self.encoder = ResNestEncoder(encoder_name, in_channels)
+            out_channels = RESNEST_OUT_CHANNELS[encoder_name]
+        elif encoder_name in EFFICIENTNET_OUT_CHANNELS:   # smp's EfficientNetEncoder (oracle/efficientnet_torch.py)
             assert topology != "linknet", "the EfficientNet encoders are not restated under smp.Linknet"
             self.encoder = EfficientNetEncoder(encoder_name, in_channels)
             out_channels = EFFICIENTNET_OUT_CHANNELS[encoder_name]

@@ -911,3 +911,100 @@ def test_efficientnet_under_other_decoders(encoder, topology):
         sync()
         runs.append(m._flat.clone())
     assert torch.equal(runs[0], runs[1]) and torch.isfinite(runs[0]).all(), (encoder, topology)
+
+
+@pytest.mark.parametrize("encoder,topology", [("timm-resnest50d", "unet"), ("timm-resnest101e", "unet"), ("timm-resnest50d", "fpn"),
+                                              ("timm-resnest50d", "unetplusplus"), ("timm-resnest50d", "linknet"), ("timm-resnest50d", "manet")])
+def test_resnest_eval_and_train_vs_oracle(encoder, topology):
+    """smp's timm-resnest50d / timm-resnest101e encoders (timm 0.4.12: deep stem, ResNestBottleneck with the radix-2 split-attention 3x3
+    convolution - run as a dense convolution with block-expanded weight copies -, RadixSoftmax, the avd / avg_down average pools as
+    constant-tap depthwise convolutions) against oracle/resnest_torch.py: eval logits, one fp32 training step's loss and gradients, the
+    recorded bf16 step against the call-by-call step, and the frozen phase - the reference's predicate ("encoder" and "conv" in the name)
+    also takes the BatchNorms / biases inside conv2 and the stem: the step fused into backward equals the plain masked step bit for bit."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    poison = torch.full((1 << 28,), float("nan"), device=DEV)
+    del poison
+    oracle = seeded_oracle_unet(encoder, 3, seed=2, topology=topology)
+    model = VolSegUnet(3, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 64, 96, generator=g)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), (encoder, topology, (got - ref).abs().max().item())
+    n = 4
+    oracle = seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology)
+    counter = torch.tensor([1], dtype=torch.int64, device=DEV)
+    if topology == "fpn":
+        mask = torch.empty(n, 128, device=DEV)
+        L.check(L.lib.vs_dropout2d_mask(L.ptr(mask), n, 128, 0.2, 0, L.ptr(counter), 0, None))
+        sync()
+        oracle.decoder.mask = mask.cpu()
+    lab = (torch.rand(n, 64, 64, generator=g) > 0.6).to(torch.uint8)
+    xt = torch.randn(n, 1, 64, 64, generator=g)
+    _, t = P.prepare_training_batch(xt, lab, 2)
+    oracle.train()
+    ref_loss = P.dice_loss_none(oracle(xt), t.float())
+    ref_loss.backward()
+    refg = dict(oracle.named_parameters())
+    model = VolSegUnet(2, device=DEV, precision="fp32", init="none", encoder=encoder, topology=topology)
+    model.load_state_dict(seeded_oracle_unet(encoder, 2, seed=3, perturb_bn=False, topology=topology).state_dict())
+    model.train()
+    loss = P.dice_loss_none(model(xt.to(DEV)), t.to(DEV).float())
+    loss.backward()
+    sync()
+    assert abs(loss.item() - ref_loss.item()) < 2e-5, (encoder, topology, loss.item(), ref_loss.item())
+    sd = oracle.state_dict()
+    for k in ("encoder.conv1.1.running_mean", "encoder.layer1.0.conv2.bn0.running_var", "encoder.layer2.0.conv2.bn1.running_mean", "encoder.layer4.0.downsample.2.running_var"):
+        assert torch.allclose(model.state_dict()[k].cpu(), sd[k], rtol=1e-3, atol=1e-5), k
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        r = refg[name].grad
+        if r.norm().item() < 1e-7 or name.endswith("conv2.fc1.bias"):      # (fc1's bias sits in front of a train-mode BatchNorm: zero in exact arithmetic)
+            assert p.grad.norm().item() < 1e-5, (name, p.grad.norm().item())
+            continue
+        err = ((p.grad.cpu() - r).norm() / r.norm()).item()
+        worst = max(worst, (err, name))
+        if ".SE_" in name or name.endswith("block.1.0.bias"):
+            continue
+        # (ReLU networks: BatchNorm-ReLU mask flips on pre-activations ~1e-6 from zero, as for the ResNets - direction and size, not bits)
+        if "conv2.fc1" in name or "conv2.bn1" in name:
+            # the attention branch's BatchNorm sees FOUR values per channel here (batch 4, 1 x 1 maps): rstd amplifies fp32 rounding
+            assert _cos(p.grad.cpu(), r) > 0.85, (encoder, topology, name, err, _cos(p.grad.cpu(), r))
+            continue
+        assert _cos(p.grad.cpu(), r) > 0.98 and err < 0.2, (encoder, topology, name, err, _cos(p.grad.cpu(), r))
+    print(encoder, topology, "worst relative gradient error", worst)
+    if encoder == "timm-resnest101e":
+        return
+    for frozen in (False, True):
+        runs = []
+        for mode in ("graph", "fused", "plain"):
+            m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
+            if frozen:
+                for name, p in m.named_parameters():
+                    if "encoder" in name and "conv" in name:
+                        p.requires_grad = False
+            o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=mode != "plain")
+            m.train()
+            tt = t.to(DEV).contiguous()
+            for _ in range(3):
+                if mode == "graph":
+                    assert m.can_fuse_step(o, xt.to(DEV), tt)
+                    m.fused_train_step(xt.to(DEV), tt, o)
+                else:
+                    o.zero_grad(); l = HipDiceLoss()(m(xt.to(DEV)), tt); l.backward(); o.step()
+            sync()
+            runs.append(m._flat.clone())
+        assert torch.equal(runs[0], runs[1]), (encoder, topology, frozen, "recorded step vs call-by-call")
+        assert torch.equal(runs[1], runs[2]), (encoder, topology, frozen, "step fused into backward vs plain masked step")
+        if frozen:      # the BatchNorm inside the split-attention convolution did not move, the block's own bn1 did
+            m0 = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
+            a, b = dict(m0.named_parameters()), dict(m.named_parameters())
+            assert torch.equal(a["encoder.layer2.0.conv2.bn0.weight"], b["encoder.layer2.0.conv2.bn0.weight"])
+            assert torch.equal(a["encoder.conv1.1.bias"], b["encoder.conv1.1.bias"]) and torch.equal(a["encoder.layer3.1.conv2.fc2.bias"], b["encoder.layer3.1.conv2.fc2.bias"])
+            assert not torch.equal(a["encoder.layer2.0.bn1.weight"], b["encoder.layer2.0.bn1.weight"])

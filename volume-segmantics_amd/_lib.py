@@ -110,6 +110,8 @@ _SIGS = {
     "vs_sample_rowsum": (I, [I, P, P, P, I, I64, I, F, P]),
     "vs_sample_rowsum_workspace": (SZ, [I, I]),
     "vs_sample_rowsum_ws": (I, [I, P, P, P, I, I64, I, F, P, SZ, P]),
+    "vs_radix2_softmax": (I, [I, P, P, I, I, P]),
+    "vs_radix2_softmax_bwd": (I, [I, P, P, P, I, I, P]),
     "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_scratch_floats": (SZ, [I, I, I]),

@@ -207,3 +207,4 @@ int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt,
 // w fp32 [cin][cout][4][4] -> wc [4 * cout][9][cin] and wt [cin][9 reversed][4 * cout]; and the way back for the gradient
 int launch_convt_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, hipStream_t s);
 int launch_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, hipStream_t s);
+int launch_two_group_wgrad_extract(const float* dense, float* dw, int cout, int taps, int cin, hipStream_t s);

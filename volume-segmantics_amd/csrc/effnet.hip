@@ -718,14 +718,14 @@ extern "C" int vs_bn2_bwd(int dtype, const void* dy, const void* x, const float*
 // fp32 [n][h][w] map broadcast over the c channels - nn.Conv2d(1, c, k, stride, bias=False), the stem on greyscale slices.
 extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho, int wo,
                            int x_single_channel, void* stream) {
-    VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
+    VS_REQUIRE(x && w && y && n > 0 && c > 0 && c % kVec == 0 && (k == 2 || k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
     const int ppb = 256 / std::min(c / kVec, 64);
     const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n * ho * wo + ppb - 1) / ppb, 4096), (c / kVec + 63) / 64);
     const size_t lds = (size_t)k * k * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    const bool strip_ok = dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3)));
+    const bool strip_ok = k != 2 && (dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3))));
     if (!x_single_channel && strip_ok) {      // four outputs per lane, every input row of the window loaded once
         if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
         else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
@@ -744,9 +744,9 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
 }
 extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, void* dx, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation,
                                     int ho, int wo, int accumulate, void* stream) {
-    VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
+    VS_REQUIRE(dy && w && dx && n > 0 && c > 0 && c % kVec == 0 && (k == 2 || k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
-    const bool strip_ok = dilation == 1 || dilation == 2 || (dilation == 4 && k == 3);
+    const bool strip_ok = k != 2 && (dilation == 1 || dilation == 2 || (dilation == 4 && k == 3));
     if (stride == 1 && strip_ok && 2 * pad_lo == (k - 1) * dilation && ho == h && wo == wd) {   // a stride-1 "same" layer: the forward sweep with the taps reversed
         if (dtype == VS_BF16) launch_dw_strip<bf16_t>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
         else launch_dw_strip<float>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
@@ -762,7 +762,7 @@ extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, v
 extern "C" size_t vs_dwconv2d_wgrad_workspace(int c, int k) { return (size_t)kDwBlocks * c * k * k * sizeof(float); }
 extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h, int wd, int c, int k, int stride, int pad_lo, int dilation, int ho, int wo,
                                  int x_single_channel, float* workspace, size_t workspace_bytes, void* stream) {
-    VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
+    VS_REQUIRE(x && dy && dw && n > 0 && c > 0 && c % kVec == 0 && (k == 2 || k == 3 || k == 5) && (stride == 1 || stride == 2) && pad_lo >= 0 && dilation >= 1 && pad_lo <= (k - 1) * dilation,
                "dwconv2d_wgrad: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     VS_REQUIRE(workspace && workspace_bytes >= vs_dwconv2d_wgrad_workspace(c, k), "dwconv2d_wgrad: workspace too small");
     const int ppb = 256 / std::min(c / kVec, 64);

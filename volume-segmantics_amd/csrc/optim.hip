@@ -56,11 +56,19 @@ template <typename T>
 __device__ __forceinline__ void weight_prepare_tile(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout, int taps,
                                                     int cin, int cout_pad, int cg, int bx, int by, int tap, int tx, int ty,
                                                     float (&tile)[32][33]) {
+    const bool two_groups = cg == 255;      // radix-2 split-attention convolution (ResNeSt): cin -> cout = 2 cin in TWO groups; w is
+    if (two_groups) cg = 0;                 // [cout][taps][cin / 2], the copies are dense [cout][taps][cin] with the other group's half zero
     const int ci0 = bx * 32, co0 = (cg ? bx : by) * 32;
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         float v = 0.f;
-        if (cg) {
+        if (two_groups) {
+            if (co < cout && ci < cin) {
+                const int half = cin / 2, cl = ci - (co / (cout / 2)) * half;
+                if (cl >= 0 && cl < half) v = w[((size_t)co * taps + tap) * half + cl];
+                if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
+            }
+        } else if (cg) {
             if (co / cg == ci / cg) v = w[((size_t)co * taps + tap) * cg + ci % cg];
             if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * 32 + tx, v);
         } else if (co < cout && ci < cin) {
@@ -115,6 +123,15 @@ __global__ void convt_wgrad_gather_kernel(const float* __restrict__ dense, float
     }
 }
 
+// weight gradient of a two-group convolution: dense[cout][taps][cin] -> dw[cout][taps][cin / 2], every output channel's own group half
+__global__ void two_group_wgrad_extract_kernel(const float* __restrict__ dense, float* __restrict__ dw, int cout, int taps, int cin) {
+    const int half = cin / 2, total = cout * taps * half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int cl = i % half, row = i / half, co = row / taps;
+        dw[i] = dense[(size_t)row * cin + (co / (cout / 2)) * half + cl];
+    }
+}
+
 // all layers in ONE launch: the descriptor table travels in the kernel arguments; a block finds its layer by a linear
 // scan over the (<= 64) cumulative block counts
 struct PrepTable {
@@ -131,7 +148,7 @@ __global__ void weight_prepare_all_kernel(const float* __restrict__ params, char
     int l = 0;
     while (l + 1 < t.n && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
     const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l], cg = t.cg[l];
-    const int cib = (cin + 31) / 32, cob = cg ? 1 : ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
+    const int cib = (cin + 31) / 32, cob = (cg && cg != 255) ? 1 : ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
     int b = blockIdx.x - t.first_block[l];
     const int bx = b % cib; b /= cib;
     const int by = b % cob;
@@ -272,6 +289,11 @@ int launch_convt_weight_prepare(int dtype, const float* w, void* wc, void* wt, i
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
+int launch_two_group_wgrad_extract(const float* dense, float* dw, int cout, int taps, int cin, hipStream_t s) {
+    hipLaunchKernelGGL(two_group_wgrad_extract_kernel, dim3(grid_for((int64_t)cout * taps * (cin / 2))), dim3(256), 0, s, dense, dw, cout, taps, cin);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
 int launch_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, hipStream_t s) {
     hipLaunchKernelGGL(convt_wgrad_gather_kernel, dim3(grid_for((int64_t)cin * cout * 16)), dim3(256), 0, s, dense, dw, cin, cout);
     VS_LAUNCH_CHECK();
@@ -301,7 +323,7 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
         t.w_off[i] = w_off[i]; t.wc_off[i] = wc_off[i]; t.wt_off[i] = wt_off[i];
         t.cout[i] = (short)cout[i]; t.cin[i] = (short)cin[i]; t.cout_pad[i] = (short)cout_pad[i]; t.taps[i] = (unsigned char)taps[i];
         t.cg[i] = (unsigned char)(cg ? cg[i] : 0);
-        blocks += cdiv(cin[i], 32) * (t.cg[i] ? 1 : cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32)) * taps[i];
+        blocks += cdiv(cin[i], 32) * ((t.cg[i] && t.cg[i] != 255) ? 1 : cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32)) * taps[i];
     }
     t.first_block[n] = blocks;
     if (dtype == VS_BF16)

@@ -1,0 +1,54 @@
+// What timm's ResNeSt blocks (models/resnest.py ResNestBottleneck, models/layers/split_attn.py SplitAttnConv2d; timm 0.4.12 behind smp's
+// timm-resnest50d / timm-resnest101e encoders) add to the existing operators (gfx950):
+//   * RadixSoftmax for radix 2, cardinality 1: the attention logits [n][2 C] hold the two splits' values C apart; a = softmax over the pair
+//   * everything else of the block is composed from existing kernels: the radix-2 grouped 3x3 convolution as a dense convolution with
+//     block-expanded weight copies (optim.hip: two_groups), the sum of the splits and its adjoint as channel-slice copies, the gated sum
+//     as vs_channel_gate + that fold, avd / avg_down pools as depthwise convolutions with constant taps (effnet.hip)
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void radix2_softmax_kernel(const T* __restrict__ z, T* __restrict__ a, int n, int c) {
+    const int total = n * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / c, ch = i % c;
+        const float z0 = Elem<T>::ld(z + (size_t)b * 2 * c + ch), z1 = Elem<T>::ld(z + (size_t)b * 2 * c + c + ch);
+        const float a0 = 1.f / (1.f + __expf(z1 - z0));        // softmax over two values
+        Elem<T>::st(a + (size_t)b * 2 * c + ch, a0);
+        Elem<T>::st(a + (size_t)b * 2 * c + c + ch, 1.f - a0);
+    }
+}
+// dz_r = a_r (da_r - sum_r' a_r' da_r')
+template <typename T>
+__global__ void radix2_softmax_bwd_kernel(const T* __restrict__ da, const T* __restrict__ a, T* __restrict__ dz, int n, int c) {
+    const int total = n * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / c, ch = i % c;
+        const size_t o0 = (size_t)b * 2 * c + ch, o1 = o0 + c;
+        const float a0 = Elem<T>::ld(a + o0), a1 = Elem<T>::ld(a + o1), g0 = Elem<T>::ld(da + o0), g1 = Elem<T>::ld(da + o1);
+        const float dot = a0 * g0 + a1 * g1;
+        Elem<T>::st(dz + o0, a0 * (g0 - dot));
+        Elem<T>::st(dz + o1, a1 * (g1 - dot));
+    }
+}
+
+}  // namespace
+
+// z, a [n][2 c]: a[b][r c + ch] = softmax over r of z[b][r c + ch] (timm's RadixSoftmax(radix 2, cardinality 1)); bwd: dz from da and a
+extern "C" int vs_radix2_softmax(int dtype, const void* z, void* a, int n, int c, void* stream) {
+    VS_REQUIRE(z && a && n > 0 && c > 0, "radix2_softmax: bad arguments");
+    const int blocks = (n * c + 255) / 256;
+    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_softmax_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)a, n, c);
+    else hipLaunchKernelGGL(radix2_softmax_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)a, n, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+extern "C" int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, void* dz, int n, int c, void* stream) {
+    VS_REQUIRE(da && a && dz && n > 0 && c > 0, "radix2_softmax_bwd: bad arguments");
+    const int blocks = (n * c + 255) / 256;
+    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_softmax_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, (const bf16_t*)a, (bf16_t*)dz, n, c);
+    else hipLaunchKernelGGL(radix2_softmax_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)da, (const float*)a, (float*)dz, n, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}

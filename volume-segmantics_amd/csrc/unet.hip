@@ -102,6 +102,10 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_DWCONV2,      // depthwise k x k convolution, stride 1 / 2, `pad` zero rows / columns in front (static same padding), no
                                 // norm; bcast: the network input (one fp32 channel) broadcast over cout = the EfficientNet stem
                 U_DROPADD,      // out = drop_connect(a(src0), drop_p) + a(src1) (the MBConv skip); evaluation: the plain sum
+                U_FOLD2,        // out [.., c] = in [.., :c] + in [.., c:] (the sum over ResNeSt's two radix splits; maps and pooled vectors)
+                U_RSOFTMAX,     // timm's RadixSoftmax(2, 1) on attention logits [n][2 c]
+                U_AVGPOOL,      // nn.AvgPool2d(k, stride) of ResNeSt's avd (3, padding 1, zeros counted) / avg_down (2): a depthwise convolution
+                                // with constant taps pool_w
                 U_UP2,          // out = nearest-x2 upsampling of a(src0), materialised - where a decoder's upsample + concat cannot ride the
                                 // convolution's loader (the boundary is not a multiple of 32 channels: EfficientNet features of 136 / 56 / 48)
                 U_FPA };        // smp PAN's FPABlock pyramid + combination: out = plane(src0) * a(src1) + a(res) broadcast; tens = its 24
@@ -127,6 +131,10 @@ struct Unit {
     float bn_eps = 1e-5f, bn_mom = 0.1f;   // U_BN
     float drop_p = 0.f; int salt = 0;      // U_DROPADD: drop-connect rate, block index (separates the blocks' draws)
     int bcast = 0;                         // U_DWCONV2 on the single-channel network input
+    int g2 = 0;                            // U_CONV: cin -> cout = 2 cin in TWO groups (ResNeSt's radix-2 split-attention 3x3); weights [cout][taps][cin / 2],
+                                           // the compute copies dense with the other group's half zero (optim.hip: two_groups)
+    bool aux_frozen = false;               // the unit's BatchNorm / bias tensors also match the freeze predicate ("encoder" and "conv" in the name)
+    float pool_w = 0.f;                    // U_AVGPOOL: the constant tap (1 / 9 or 1 / 4)
     int dil = 1;    // dilation of a stride-1 3x3 convolution (2: smp's replace_strides_with_dilation; any for U_DWCONV)
     int factor = 2; // U_BILINEAR: integer scale factor
     int colr = 0;   // U_CONV: a 3x3 convolution with dilation = padding = colr (DeepLabV3's dense ASPP rates 12 / 24 / 36), run as the
@@ -195,6 +203,7 @@ struct vs_unet {
     size_t off_pab = 0, pab_bytes = 0; // scratch of the PAB attention (vs_pab_scratch_bytes)
     size_t off_sews = 0;               // scratch of the squeeze-excitation gates' backward pass (vs_se_gate_scratch_floats)
     size_t off_gapws = 0, gapws_bytes = 0;   // split partial sums of the average pools / gate gradients (vs_sample_rowsum_ws)
+    size_t off_avgw9 = 0, off_avgw4 = 0; int avgw_c = 0;   // constant taps of U_AVGPOOL: [c][9] of 1 / 9 and [c][4] of 1 / 4
     size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
@@ -334,6 +343,111 @@ int build(vs_unet* net) {
         }
         add_tensor(L, "encoder._conv_head.weight", {round_filters(1280), inpl, 1, 1}, 0);     // registered by efficientnet-pytorch, never run
         add_bn(L, "encoder._bn1", round_filters(1280));
+    } else if (net->encoder == 150 || net->encoder == 201) {
+        // smp's timm-resnest50d / timm-resnest101e (timm 0.4.12 ResNet(ResNestBottleneck, stem_type 'deep', avg_down, radix 2, avd)):
+        // deep stem conv1 = [3x3 / 2 (1 -> sw) BN ReLU, 3x3 (sw -> sw) BN ReLU, 3x3 (sw -> 2 sw)], bn1, ReLU, MaxPool(3, 2, 1); blocks = conv1 1x1 +
+        // bn1 + ReLU, conv2 = SplitAttnConv2d (3x3 onto 2 C channels in two groups + bn0 + ReLU; the splits summed and average-pooled;
+        // fc1 (bias) + bn1 + ReLU; fc2 (bias); RadixSoftmax; the attention-weighted sum of the splits), avd_last = AvgPool2d(3, 2, 1) in
+        // the stride-2 blocks, conv3 1x1 + bn3 (+ shortcut, ReLU); shortcut = [AvgPool2d(2, 2)] + 1x1 + BN.  The reference's freeze
+        // predicate ("encoder" and "conv" in the name) also takes conv2.bn0 / conv2.fc1 / conv2.bn1 / conv2.fc2 and the stem's BatchNorms.
+        const bool e101 = net->encoder == 201;
+        const int sw = e101 ? 64 : 32;
+        const int blocks_n[4] = {3, 4, e101 ? 23 : 6, 3};
+        auto conv_bn = [&](const std::string& wname, const std::string& bnname, int src, int cin, int cout, int k, int hh, int ww, int relu,
+                           bool frozen, bool bn_frozen, int two_groups = 0) {
+            Unit u; u.kind = U_CONV; u.src0 = src; u.cin0 = cin; u.cout = cout; u.k = k; u.pad = k / 2; u.stride = 1; u.g2 = two_groups;
+            u.hin = hh; u.win = ww; u.hout = hh; u.wout = ww; u.relu = relu; u.frozen_candidate = frozen; u.aux_frozen = bn_frozen;
+            u.w_idx = (int)L.tensors.size(); add_tensor(L, wname, {cout, two_groups ? cin / 2 : cin, k, k}, 0);
+            u.bn_idx = add_bn(L, bnname, cout);
+            u.out = new_act(cout, hh, ww, true);
+            return u;
+        };
+        {   // deep stem
+            Unit d; d.kind = U_DWCONV2; d.src0 = -1; d.cin0 = 1; d.cout = sw; d.k = 3; d.stride = 2; d.pad = 1; d.bcast = 1; d.relu = 0; d.frozen_candidate = true;
+            d.hin = H; d.win = W; d.hout = H / 2; d.wout = W / 2;
+            d.w_idx = (int)L.tensors.size(); add_tensor(L, "encoder.conv1.0.weight", {sw, 1, 3, 3}, 0);
+            d.out = new_act(sw, H / 2, W / 2, false);
+            U.push_back(d);
+            Unit b; b.kind = U_BN; b.src0 = d.out; b.cin0 = sw; b.cout = sw; b.hin = b.hout = H / 2; b.win = b.wout = W / 2; b.relu = 1; b.aux_frozen = true;
+            b.bn_idx = add_bn(L, "encoder.conv1.1", sw); b.out = new_act(sw, H / 2, W / 2, false);
+            U.push_back(b);
+            Unit c3 = conv_bn("encoder.conv1.3.weight", "encoder.conv1.4", b.out, sw, sw, 3, H / 2, W / 2, 1, true, true);
+            U.push_back(c3);
+            Unit c6 = conv_bn("encoder.conv1.6.weight", "encoder.bn1", c3.out, sw, 2 * sw, 3, H / 2, W / 2, 1, true, false);
+            U.push_back(c6);
+            feat[1] = c6.out; featc[1] = 2 * sw;
+            Unit pool; pool.kind = U_POOL; pool.src0 = c6.out; pool.cout = 2 * sw; pool.hin = H / 2; pool.win = W / 2;
+            pool.hout = H / 4; pool.wout = W / 4; pool.out = new_act(2 * sw, H / 4, W / 4, false);
+            U.push_back(pool);
+            cur = pool.out; inpl = 2 * sw; ch = H / 4; cw = W / 4;
+        }
+        const int planes_r[4] = {64, 128, 256, 512};
+        for (int l = 0; l < 4; ++l) {
+            for (int bidx = 0; bidx < blocks_n[l]; ++bidx) {
+                const std::string pre = "encoder.layer" + std::to_string(l + 1) + "." + std::to_string(bidx);
+                const int stride = (bidx == 0 && l > 0) ? 2 : 1, C = planes_r[l], outc = 4 * C, A = std::max(C * 2 / 4, 32);
+                const int oh = ch / stride, ow = cw / stride;
+                const int x_in = cur;
+                Unit u1 = conv_bn(pre + ".conv1.weight", pre + ".bn1", cur, inpl, C, 1, ch, cw, 1, true, false);
+                U.push_back(u1);
+                Unit u2 = conv_bn(pre + ".conv2.conv.weight", pre + ".conv2.bn0", u1.out, C, 2 * C, 3, ch, cw, 1, true, true, 1);   // [2 C][C / 2][3][3]
+                U.push_back(u2);
+                Unit gp; gp.kind = U_GAP; gp.src0 = u2.out; gp.cout = 2 * C; gp.hin = ch; gp.win = cw; gp.hout = 1; gp.wout = 1; gp.relu = 0;
+                gp.out = new_act(2 * C, 1, 1, false);
+                U.push_back(gp);
+                Unit fd; fd.kind = U_FOLD2; fd.src0 = gp.out; fd.cout = C; fd.hin = fd.hout = 1; fd.win = fd.wout = 1; fd.relu = 0;
+                fd.out = new_act(C, 1, 1, false);
+                U.push_back(fd);
+                Unit f1; f1.kind = U_CONV; f1.src0 = fd.out; f1.cin0 = C; f1.cout = A; f1.k = 1; f1.pad = 0; f1.hin = f1.hout = 1; f1.win = f1.wout = 1; f1.relu = 1;
+                f1.frozen_candidate = true; f1.aux_frozen = true;
+                f1.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.fc1.weight", {A, C, 1, 1}, 0);
+                f1.bias_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.fc1.bias", {A}, 3);
+                f1.bn_idx = add_bn(L, pre + ".conv2.bn1", A);
+                f1.out = new_act(A, 1, 1, true);
+                U.push_back(f1);
+                Unit f2; f2.kind = U_CONV; f2.src0 = f1.out; f2.cin0 = A; f2.cout = 2 * C; f2.k = 1; f2.pad = 0; f2.hin = f2.hout = 1; f2.win = f2.wout = 1; f2.relu = 0;
+                f2.frozen_candidate = true; f2.aux_frozen = true;
+                f2.w_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.fc2.weight", {2 * C, A, 1, 1}, 0);
+                f2.bias_idx = (int)L.tensors.size(); add_tensor(L, pre + ".conv2.fc2.bias", {2 * C}, 3);
+                f2.out = new_act(2 * C, 1, 1, false);
+                U.push_back(f2);
+                Unit rs; rs.kind = U_RSOFTMAX; rs.src0 = f2.out; rs.cout = 2 * C; rs.hin = rs.hout = 1; rs.win = rs.wout = 1; rs.relu = 0;
+                rs.out = new_act(2 * C, 1, 1, false);
+                U.push_back(rs);
+                Unit cg; cg.kind = U_CGATE; cg.src0 = u2.out; cg.src1 = rs.out; cg.cout = 2 * C; cg.hout = ch; cg.wout = cw; cg.relu = 0;
+                cg.out = new_act(2 * C, ch, cw, false);
+                U.push_back(cg);
+                Unit fo; fo.kind = U_FOLD2; fo.src0 = cg.out; fo.cout = C; fo.hin = fo.hout = ch; fo.win = fo.wout = cw; fo.relu = 0;
+                fo.out = new_act(C, ch, cw, false);
+                U.push_back(fo);
+                int t = fo.out;
+                if (stride == 2) {      // avd_last = nn.AvgPool2d(3, 2, padding=1): the padding zeros count (count_include_pad)
+                    Unit ap; ap.kind = U_AVGPOOL; ap.src0 = t; ap.cout = C; ap.k = 3; ap.stride = 2; ap.pad = 1; ap.pool_w = 1.f / 9.f; ap.relu = 0;
+                    ap.hin = ch; ap.win = cw; ap.hout = oh; ap.wout = ow; ap.out = new_act(C, oh, ow, false);
+                    U.push_back(ap);
+                    t = ap.out;
+                }
+                Unit u3 = conv_bn(pre + ".conv3.weight", pre + ".bn3", t, C, outc, 1, oh, ow, 1, true, false);
+                if (bidx == 0) {        // downsample_avg: [AvgPool2d(2, 2, ceil_mode, count_include_pad=False)] + 1x1 convolution + BatchNorm
+                    int ds = x_in;
+                    if (stride == 2) {
+                        Unit ap; ap.kind = U_AVGPOOL; ap.src0 = x_in; ap.cout = inpl; ap.k = 2; ap.stride = 2; ap.pad = 0; ap.pool_w = 0.25f; ap.relu = 0;
+                        ap.hin = ch; ap.win = cw; ap.hout = oh; ap.wout = ow; ap.out = new_act(inpl, oh, ow, false);
+                        U.push_back(ap);
+                        ds = ap.out;
+                    }
+                    Unit ud = conv_bn(pre + ".downsample.1.weight", pre + ".downsample.2", ds, inpl, outc, 1, oh, ow, 0, false, false);
+                    // state-dict order: conv3, bn3, then downsample.* - the tensors of u3 were registered first (conv_bn above)
+                    U.push_back(ud);
+                    u3.res = ud.out;
+                } else {
+                    u3.res = x_in;
+                }
+                U.push_back(u3);
+                cur = u3.out; inpl = outc; ch = oh; cw = ow;
+            }
+            feat[l + 2] = cur; featc[l + 2] = inpl;
+        }
     } else {
     add_tensor(L, "encoder.conv1.weight", {64, 1, 7, 7}, 0);
     Unit stem; stem.kind = U_STEM; stem.cout = 64; stem.k = 7; stem.stride = 2; stem.pad = 3;
@@ -933,6 +1047,10 @@ size_t plan_workspace(vs_unet* net) {
         net->pab_bytes = pab;
         net->off_pab = take(pab);
         net->off_sews = take(sews);
+        for (auto& u : net->units)
+            if (u.kind == U_AVGPOOL) net->avgw_c = std::max(net->avgw_c, u.cout);
+        net->off_avgw9 = take((size_t)net->avgw_c * 9 * sizeof(float));
+        net->off_avgw4 = take((size_t)net->avgw_c * 4 * sizeof(float));
         net->gapws_bytes = gapws;
         net->off_gapws = take(gapws);
     }
@@ -979,6 +1097,7 @@ size_t plan_workspace(vs_unet* net) {
             u.off_wt2 = take((size_t)u.cin0 * 9 * 4 * u.cout * esz);
             ctdw = std::max(ctdw, (size_t)4 * u.cout * 9 * u.cin0 * sizeof(float));
         }
+        if (u.kind == U_CONV && u.g2) ctdw = std::max(ctdw, (size_t)u.cout * u.k * u.k * u.cin0 * sizeof(float));
         if (u.kind != U_CONV && u.kind != U_HEAD) continue;
         const size_t taps = (size_t)u.k * u.k, cin = (size_t)u.cin0 + u.cin1;
         u.off_wc2 = take((size_t)u.cout * taps * (u.cg ? 32 : cin) * esz);
@@ -1051,7 +1170,7 @@ struct Ctx {
     const TensorInfo& t(int idx) const { return net->layout.tensors[idx]; }
     const float* P(int idx) const { return params + t(idx).offset; }
     const void* wfwd(const Unit& u) const {  // weights in the compute dtype
-        return (net->dtype == VS_F32 && !u.cg) ? (const void*)P(u.w_idx) : (const void*)(ws + wc_off(u, net->wset));
+        return (net->dtype == VS_F32 && !u.cg && !u.g2) ? (const void*)P(u.w_idx) : (const void*)(ws + wc_off(u, net->wset));
     }
     static size_t wc_off(const Unit& u, int set) { return set ? u.off_wc2 : u.off_wc; }
     static size_t wt_off(const Unit& u, int set) { return set ? u.off_wt2 : u.off_wt; }
@@ -1095,8 +1214,10 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
     VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && tmp.topology != 2),
-               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d) or, except under Linknet, 103 / 104 (efficientnet-b3 / b4), got %d", encoder_code);
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && tmp.topology != 2) ||
+               ((encoder == 150 || encoder == 201) && tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7),
+               "encoder must be 18, 34, 50, 51 (resnet18 / resnet34 / resnet50 / resnext50_32x4d), 103 / 104 (efficientnet-b3 / b4; not under Linknet) or "
+               "150 / 201 (timm-resnest50d / 101e; not under DeepLabV3(+) / PAN), got %d", encoder_code);
     build(&tmp);
     out = tmp.layout;
     return VS_OK;
@@ -1150,10 +1271,14 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
     VS_REQUIRE(topology >= 0 && topology <= 7, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", topology);
     VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
-    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104,
-               "unet_create: encoder must be 18, 34, 50, 51, 103 or 104 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / efficientnet-b4), got %d", encoder);
-    VS_REQUIRE(encoder < 100 || topology != 2,
+    VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104 || encoder == 150 || encoder == 201,
+               "unet_create: encoder must be 18, 34, 50, 51, 103, 104, 150 or 201 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / "
+               "efficientnet-b4 / timm-resnest50d / timm-resnest101e), got %d", encoder);
+    VS_REQUIRE((encoder != 103 && encoder != 104) || topology != 2,
                "unet_create: the EfficientNet encoders are not built under smp.Linknet (its decoder narrows 56 / 48 channels to 14 / 12: not multiples of 8)");
+    VS_REQUIRE((encoder != 150 && encoder != 201) || (topology != 4 && topology != 5 && topology != 7),
+               "unet_create: the ResNeSt encoders are not built under the dilating decoders (DeepLabV3 / DeepLabV3+ / PAN: smp's "
+               "replace_strides_with_dilation leaves their parameter-free average pools at stride 2)");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
@@ -1191,9 +1316,9 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
         };
         for (auto& u : net->units) {
             if (u.kind != U_CONV && u.kind != U_HEAD) continue;
-            const bool wc = net->dtype == VS_BF16 || u.cg, wt = training != 0;
+            const bool wc = net->dtype == VS_BF16 || u.cg || u.g2, wt = training != 0;
             if (!wc && !wt) continue;
-            cgs[nl] = u.cg;
+            cgs[nl] = u.g2 ? 255 : u.cg;
             w_off[nl] = c.t(u.w_idx).offset;
             wc_off[nl] = wc ? (long)Ctx::wc_off(u, net->wset) : -1;
             wt_off[nl] = wt ? (long)Ctx::wt_off(u, net->wset) : -1;
@@ -1213,6 +1338,11 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
                                                        training ? c.ws + Ctx::wt_off(u, net->wset) : nullptr, u.cin0, u.cout, c.s);
             if (rc) return rc;
         }
+    }
+    if (net->avgw_c) {     // the average pools' constant taps (the workspace may be a fresh allocation)
+        const float w9 = 1.f / 9.f, w4 = 0.25f;
+        VS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(c.ws + net->off_avgw9), *reinterpret_cast<const int*>(&w9), (size_t)net->avgw_c * 9, c.s));
+        VS_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(c.ws + net->off_avgw4), *reinterpret_cast<const int*>(&w4), (size_t)net->avgw_c * 4, c.s));
     }
     for (auto& u : net->units) {
         if (u.bn_idx >= 0 && !training) {  // eval-mode folding from the running statistics
@@ -1245,10 +1375,10 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
         if (v.kind != U_CONV && v.kind != U_HEAD) continue;
         VS_REQUIRE(nl < 64, "unet_prepare_range: too many layers in one range");
         w_off[nl] = net->layout.tensors[v.w_idx].offset;
-        wc_off[nl] = (net->dtype == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
+        wc_off[nl] = (net->dtype == VS_BF16 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
         wt_off[nl] = (long)Ctx::wt_off(v, other);
         cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
-        cgs[nl] = v.cg;
+        cgs[nl] = v.g2 ? 255 : v.cg;
         ++nl;
     }
     if (!nl) return VS_OK;
@@ -1468,6 +1598,23 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             } else {
                 if ((rc = vs_channel_slice(dt, c.a(u.src0), u.cout, 0, c.a(u.out), u.cout, 0, u.cout, (int64_t)n * u.hout * u.wout, 0, stream))) return rc;
             }
+            continue;
+        }
+        case U_FOLD2: {     // the two radix splits summed
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t rows = (int64_t)n * u.hout * u.wout;
+            if ((rc = vs_channel_slice(dt, c.a(u.src0), 2 * u.cout, 0, c.a(u.out), u.cout, 0, u.cout, rows, 0, stream))) return rc;
+            if ((rc = vs_channel_slice(dt, c.a(u.src0), 2 * u.cout, u.cout, c.a(u.out), u.cout, 0, u.cout, rows, 1, stream))) return rc;
+            continue;
+        }
+        case U_RSOFTMAX: {
+            if ((rc = vs_radix2_softmax(dt, c.a(u.src0), c.a(u.out), n, u.cout / 2, stream))) return rc;
+            continue;
+        }
+        case U_AVGPOOL: {
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * (u.hin * u.win + u.hout * u.wout) * u.cout * net->esz, c.s);
+            const float* taps = (const float*)(c.ws + (u.k == 3 ? net->off_avgw9 : net->off_avgw4));
+            if ((rc = vs_dwconv2d(dt, c.a(u.src0), taps, c.a(u.out), n, u.hin, u.win, u.cout, u.k, u.stride, u.pad, 1, u.hout, u.wout, 0, stream))) return rc;
             continue;
         }
         case U_UP2: {
@@ -1692,15 +1839,16 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
         if (v.w_idx >= 0 && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
-        if (v.bn_idx >= 0) { push(v.bn_idx); push(v.bn_idx + 1); }
+        const bool aux_on = !(v.aux_frozen && !need_encoder_wgrad);      // (ResNeSt: BatchNorms / biases named conv2.bn0, conv2.fc1, conv1.1 ..)
+        if (v.bn_idx >= 0 && aux_on) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
-        if (v.bias_idx >= 0) push(v.bias_idx);
+        if (v.bias_idx >= 0 && aux_on) push(v.bias_idx);
         if (v.kind == U_CONV || v.kind == U_HEAD) {
             w_off[nl] = c.t(v.w_idx).offset;
-            wc_off[nl] = (dt == VS_BF16 || v.cg) ? (long)Ctx::wc_off(v, other) : -1;
+            wc_off[nl] = (dt == VS_BF16 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
             wt_off[nl] = (long)Ctx::wt_off(v, other);
             cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
-            cgs[nl] = v.cg;
+            cgs[nl] = v.g2 ? 255 : v.cg;
             ++nl;
         }
     }
@@ -1847,6 +1995,11 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 p.dw = (float*)(c.ws + net->off_ctdw + k * net->ctdw_bytes);
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
                 if ((rc = launch_convt_wgrad_gather(p.dw, grads + c.t(u.w_idx).offset, u.cin0, u.cout, ws_stream))) return rc;
+            } else if (u.g2) {        // dense gradient, then every output channel's own group half into the [cout][taps][cin / 2] tensor
+                const size_t k = ((const char*)wgws - (c.ws + net->off_wgws)) / net->wgws_bytes;
+                p.dw = (float*)(c.ws + net->off_ctdw + k * net->ctdw_bytes);
+                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                if ((rc = launch_two_group_wgrad_extract(p.dw, grads + c.t(u.w_idx).offset, u.cout, u.k * u.k, u.cin0, ws_stream))) return rc;
             } else if (u.kind == U_HEAD) {
                 p.dw = (float*)(c.ws + net->off_headdw);
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
@@ -1858,7 +2011,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
         } else {
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
-                                        (size_t)u.cout * u.k * u.k * (u.cg ? u.cg : u.cin0 + u.cin1) * sizeof(float), ws_stream));
+                                        (size_t)u.cout * u.k * u.k * (u.cg ? u.cg : (u.cin0 + u.cin1) / (u.g2 ? 2 : 1)) * sizeof(float), ws_stream));
         }
         return opt ? group_update(ui) : VS_OK;
     };
@@ -1996,6 +2149,34 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             ProfScope prof(PK_POOL_MISC, 0, 2.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
             if ((rc = vs_dropout(dt, c.da(u.out), c.da(u.src0), (int64_t)n * u.hout * u.wout * u.cout, 0.5f, net->rng_seed ^ 0x5bd1e995u,
                                  net->rng_counter, 0, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_FOLD2) {    // both splits receive the sum's gradient
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of a radix sum missing");
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            const int64_t rows = (int64_t)n * u.hout * u.wout;
+            const int acc = written[u.src0] ? 1 : 0;
+            if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(u.src0), 2 * u.cout, 0, u.cout, rows, acc, stream))) return rc;
+            if ((rc = vs_channel_slice(dt, c.da(u.out), u.cout, 0, c.da(u.src0), 2 * u.cout, u.cout, u.cout, rows, acc, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_RSOFTMAX) {
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0], "backward: radix softmax gradients out of order");
+            if ((rc = vs_radix2_softmax_bwd(dt, c.da(u.out), c.a(u.out), c.da(u.src0), n, u.cout / 2, stream))) return rc;
+            written[u.src0] = 1;
+            continue;
+        }
+        if (u.kind == U_AVGPOOL) {  // the adjoint of the constant-tap depthwise convolution
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out], "backward: gradient of an average pool missing");
+            ProfScope prof(PK_POOL_MISC, 0, (double)n * (u.hin * u.win + u.hout * u.wout) * u.cout * net->esz, c.s);
+            const float* taps = (const float*)(c.ws + (u.k == 3 ? net->off_avgw9 : net->off_avgw4));
+            if ((rc = vs_dwconv2d_bwd_data(dt, c.da(u.out), taps, c.da(u.src0), n, u.hin, u.win, u.cout, u.k, u.stride, u.pad, 1, u.hout, u.wout,
+                                           written[u.src0] ? 1 : 0, stream))) return rc;
             written[u.src0] = 1;
             continue;
         }

@@ -72,7 +72,8 @@ class _UnetFn(torch.autograd.Function):
 
 class VolSegUnet(nn.Module):
     ENCODERS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnext50_32x4d": 51,
-                "efficientnet-b3": 103, "efficientnet-b4": 104}      # the EfficientNets: smp.Unet only (csrc/unet.hip build())
+                "efficientnet-b3": 103, "efficientnet-b4": 104,      # every topology but Linknet (csrc/unet.hip build())
+                "timm-resnest50d": 150, "timm-resnest101e": 201}     # not under the dilating decoders (DeepLabV3(+), PAN)
     # efficientnet-pytorch registers these and smp's encoder never runs them: torch leaves their .grad at None, AdamW skips them
     UNUSED_PREFIXES = ("encoder._conv_head.", "encoder._bn1.")
     TOPOLOGIES = {"unet": 0, "unetplusplus": 1, "linknet": 2, "fpn": 3,
