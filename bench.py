@@ -317,7 +317,7 @@ def main():
                          "during the untimed set-up and keep the faster one on this box")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
-    ap.add_argument("--encoder", default="resnet34", choices=["resnet18", "resnet34", "resnet50", "resnext50_32x4d", "efficientnet-b3", "efficientnet-b4"])
+    ap.add_argument("--encoder", default="resnet34", choices=["resnet18", "resnet34", "resnet50", "resnext50_32x4d", "efficientnet-b3", "efficientnet-b4", "timm-resnest50d", "timm-resnest101e"])
     ap.add_argument("--topology", default="unet", choices=["unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "deeplabv3", "manet", "pan"],
                     help="with --encoder / --size / --classes: other rows of the model matrix, e.g. BASELINE configs[3] = "
                          "--topology unetplusplus --encoder resnet50 --size 512 --classes 4 (not the headline metric: no FLOP model)")

@@ -18,7 +18,7 @@
     } while (0)
 
 int main() {
-    const int encoders[] = {18, 34, 50, 51, 1018, 1034, 1050, 1051, 2018, 2034, 2050, 2051, 3018, 3034, 3050, 3051, 4018, 4034, 4050, 5018, 5034, 5050, 6018, 6034, 6050, 6051, 7018, 7034, 7050, 103, 104, 1103, 1104, 3103, 3104, 4103, 4104, 5103, 5104, 6103, 6104, 7103, 7104};     // topology * 1000 + depth
+    const int encoders[] = {18, 34, 50, 51, 1018, 1034, 1050, 1051, 2018, 2034, 2050, 2051, 3018, 3034, 3050, 3051, 4018, 4034, 4050, 5018, 5034, 5050, 6018, 6034, 6050, 6051, 7018, 7034, 7050, 103, 104, 1103, 1104, 3103, 3104, 4103, 4104, 5103, 5104, 6103, 6104, 7103, 7104, 150, 201, 1150, 2150, 3150, 6150, 6201};     // topology * 1000 + depth
     long plans = 0;
     for (int enc : encoders) {
         for (int classes : {1, 2, 4, 16}) {
@@ -74,6 +74,7 @@ int main() {
     CHECK(vs_unet_create_ex(&net, VS_BF16, 2, 4, 64, 64, 33) == VS_ERR_INVALID && vs_unet_create_ex(&net, 7, 2, 4, 64, 64, 34) == VS_ERR_INVALID);
     CHECK(vs_unet_create_ex(&net, VS_BF16, 0, 4, 64, 64, 34) == VS_ERR_INVALID && vs_unet_create_ex(&net, VS_BF16, 2, 4, 64, 64, 8034) == VS_ERR_INVALID);
     CHECK(vs_unet_create_ex(&net, VS_BF16, 2, 4, 64, 64, 2104) == VS_ERR_INVALID && strstr(vs_last_error(), "EfficientNet"));     // not under Linknet
+    CHECK(vs_unet_create_ex(&net, VS_BF16, 2, 4, 64, 64, 4150) == VS_ERR_INVALID && strstr(vs_last_error(), "ResNeSt"));          // not under DeepLabV3+
     CHECK(vs_unet_num_tensors_ex(99, 34) < 0 && vs_unet_param_elems_ex(2, 35) < 0);
     CHECK(vs_set_option("no_such_option", 1) == VS_ERR_INVALID && vs_set_option("fork_every", 2) == VS_OK && vs_get_option("fork_every") == 2);
     vs_conv_desc d{};

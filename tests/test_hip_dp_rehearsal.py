@@ -23,7 +23,7 @@ def _torchrun(worker, *args):
     return subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("topology,encoder", [("unet", "resnet34"), ("unetplusplus", "resnet50"), ("fpn", "resnet34"), ("unet", "efficientnet-b3")])
+@pytest.mark.parametrize("topology,encoder", [("unet", "resnet34"), ("unetplusplus", "resnet50"), ("fpn", "resnet34"), ("unet", "efficientnet-b3"), ("unet", "timm-resnest50d")])
 def test_two_rank_data_parallel_fused_step_matches_plain_step(topology, encoder):
     """U-Net / ResNet-34 (the headline), U-Net++ / ResNet-50 (BASELINE configs[3]'s data-parallel training) and FPN (GroupNorm,
     biased laterals and a Dropout2d whose mask differs per rank)."""

@@ -185,7 +185,7 @@ def test_prediction_manager_qualities_and_outputs(tmp_path):
 
 @pytest.mark.parametrize("mtype,encoder", [("U_Net", "resnet34"), ("U_Net_Plus_Plus", "resnet34"), ("Linknet", "resnet34"), ("FPN", "resnet34"),
                                            ("DeepLabV3", "resnet34"), ("DeepLabV3_Plus", "resnet34"), ("MA_Net", "resnet34"),
-                                           ("U_Net", "resnext50_32x4d"), ("U_Net", "efficientnet-b4"), ("DeepLabV3_Plus", "efficientnet-b3")])
+                                           ("U_Net", "resnext50_32x4d"), ("U_Net", "efficientnet-b4"), ("DeepLabV3_Plus", "efficientnet-b3"), ("U_Net", "timm-resnest50d")])
 def test_trainer_end_to_end_on_synthetic_slices(tmp_path, mtype, encoder):
     """1 frozen + 1 unfrozen epoch through LR finder, one-cycle schedule, early-stopping checkpoint and reload
     (reference flow: scripts/train_2d_model.py:56-71, tests/test_vol_seg_2d_trainer.py:95-116), for every topology the engine

@@ -268,3 +268,31 @@ def test_efficientnet_restatement_matches_published_parameter_counts_and_engine_
         assert len(frozen) == 2 + 2 * n_blocks + n_expand and not any("_se_" in k for k in frozen)
     for k, s, want in ((3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)), (3, 1, (1, 1, 1, 1)), (5, 1, (2, 2, 2, 2)), (1, 1, (0, 0, 0, 0))):
         assert SamePadConv2d(8, 8, k, s, image_size=380).static_pad == want and SamePadConv2d(8, 8, k, s, image_size=300).static_pad == want
+
+
+def test_resnest_restatement_matches_published_parameter_counts_and_engine_table():
+    """smp's timm-resnest50d / timm-resnest101e encoders (oracle/resnest_torch.py, restated from timm 0.4.12): with the 3-channel stem and
+    the 1000-way fc added back exactly timm's published parameter counts (27,483,240 / 48,275,016); feature widths = smp's out_channels;
+    the engine's tensor table has the same keys / shapes in state_dict order under every decoder it builds them for (conv3 / bn3 in front
+    of downsample.*, the two-group weight [2 C][C / 2][3][3]); the freeze predicate takes conv2's BatchNorms and biases too."""
+    from oracle.resnest_torch import OUT_CHANNELS, PUBLISHED_PARAMS, ResNestEncoder
+    from oracle.unet_resnet_torch import OracleUnet
+    from volume_segmantics_amd import _lib
+    for name, code in (("timm-resnest50d", 150), ("timm-resnest101e", 201)):
+        enc = ResNestEncoder(name, 3)
+        assert sum(p.numel() for p in enc.parameters()) + 2048 * 1000 + 1000 == PUBLISHED_PARAMS[name], name
+        with torch.no_grad():
+            feats = enc.eval()(torch.zeros(1, 3, 64, 96))
+        assert [f.shape[1] for f in feats[1:]] == list(OUT_CHANNELS[name][1:])
+        assert [tuple(f.shape[2:]) for f in feats] == [(64 >> i, 96 >> i) for i in range(6)]
+        for topology, tcode in (("unet", 0), ("unetplusplus", 1000), ("linknet", 2000), ("fpn", 3000), ("manet", 6000)):
+            sd = OracleUnet(name, 1, 3, topology).state_dict()
+            table = _lib.unet_tensor_table(3, tcode + code)
+            assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], (name, topology)
+            assert all(tuple(sd[t[0]].shape) == tuple(t[1]) for t in table), (name, topology)
+        sd = OracleUnet(name, 1, 2).state_dict()
+        assert sd["encoder.layer2.0.conv2.conv.weight"].shape == (256, 64, 3, 3) and sd["encoder.layer2.0.conv2.fc1.weight"].shape == (64, 128, 1, 1)
+        assert sd["encoder.layer1.0.conv2.fc1.weight"].shape == (32, 64, 1, 1) and sd["encoder.layer1.0.downsample.1.weight"].shape[0] == 256
+        frozen = [k for k, _ in OracleUnet(name, 1, 2).named_parameters() if "encoder" in k and "conv" in k]
+        assert "encoder.layer1.0.conv2.bn0.weight" in frozen and "encoder.conv1.1.bias" in frozen and "encoder.layer1.0.conv2.fc2.bias" in frozen
+        assert "encoder.layer1.0.bn1.weight" not in frozen and "encoder.layer1.0.downsample.1.weight" not in frozen and "encoder.bn1.weight" not in frozen

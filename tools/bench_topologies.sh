@@ -7,7 +7,7 @@ out=gpurun_out/${tag}_topologies.jsonl
 for t in unet unetplusplus linknet fpn deeplabv3plus deeplabv3 manet pan; do
   python bench.py --topology $t --steps 10 --warmup 3 --no-cpu-baseline --no-predict >> $out 2>> gpurun_out/${tag}_topologies.err
 done
-for e in resnet18 resnet50 resnext50_32x4d efficientnet-b3 efficientnet-b4; do
+for e in resnet18 resnet50 resnext50_32x4d efficientnet-b3 efficientnet-b4 timm-resnest50d timm-resnest101e; do
   python bench.py --encoder $e --steps 10 --warmup 3 --no-cpu-baseline --no-predict >> $out 2>> gpurun_out/${tag}_topologies.err
 done
 python - "$out" <<'P'

@@ -1151,7 +1151,12 @@ size_t plan_workspace(vs_unet* net) {
     }
     net->off_dup = take(dup);
     net->off_zs = take(zs);
-    net->off_idx = take(N * (net->h / 4) * (net->w / 4) * 64);
+    {
+        size_t idx = 0;      // the max-pool's argmax bytes (one per output element; 64 channels for the ResNets, 128 for timm-resnest101e's stem)
+        for (auto& u : net->units)
+            if (u.kind == U_POOL) idx = std::max(idx, N * (size_t)u.hout * u.wout * u.cout);
+        net->off_idx = take(idx);
+    }
     net->ws_train = off;
     return off;
 }
