@@ -138,6 +138,8 @@ int vs_unet_create(vs_unet_t** net, int dtype, int classes, int max_batch, int h
  *   depth 18, 34 or 50: resnet18 / resnet34 (BasicBlock) / resnet50 (Bottleneck v1.5, expansion 4: 1x1 - 3x3(stride) - 1x1 plus a
  *   1x1 projection shortcut); 51: resnext50_32x4d (the same Bottleneck with groups = 32, width_per_group = 4: the 3x3
  *   convolution is grouped, 4 / 8 / 16 / 32 channels per group - see vs_weights_prepare_grouped);
+ *   150 / 201: smp's timm-resnest50d / timm-resnest101e encoders (timm 0.4.12: deep stem, ResNestBottleneck with the radix-2 split-attention
+ *   3x3 convolution, RadixSoftmax, avd / avg_down average pools) - topologies 0, 1, 2, 3, 6;
  *   103 / 104: smp's efficientnet-b3 / efficientnet-b4 encoders (efficientnet-pytorch 0.6.3: 3x3 / 2 stem, 26 / 32 MBConv blocks -
  *   expand 1x1, depthwise 3x3 / 5x5 behind static same padding, squeeze-excitation with swish, project 1x1, drop_connect + skip;
  *   BatchNorm2d(eps 1e-3, momentum 0.01) + swish; features (40, 32, 48, 136, 384) / (48, 32, 56, 160, 448)) - every topology but 2
