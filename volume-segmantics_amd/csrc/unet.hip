@@ -1282,8 +1282,8 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE((encoder != 103 && encoder != 104) || topology != 2,
                "unet_create: the EfficientNet encoders are not built under smp.Linknet (its decoder narrows 56 / 48 channels to 14 / 12: not multiples of 8)");
     VS_REQUIRE((encoder != 150 && encoder != 201) || (topology != 4 && topology != 5 && topology != 7),
-               "unet_create: the ResNeSt encoders are not built under the dilating decoders (DeepLabV3 / DeepLabV3+ / PAN: smp's "
-               "replace_strides_with_dilation leaves their parameter-free average pools at stride 2)");
+               "unet_create: the ResNeSt encoders do not support the dilating decoders (DeepLabV3 / DeepLabV3+ / PAN) - smp's ResNestEncoder.make_dilated "
+               "raises for them as well (their parameter-free average pools would stay at stride 2)");
     VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
