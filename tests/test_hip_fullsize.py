@@ -247,3 +247,29 @@ def test_config5_full_volume_with_its_own_network_three_axis_1024_cube():
     lz, pz = pred._predict_single_axis(vol[512:520], axis=Axis.Z)
     won = probs[512:520] == pz
     assert (probs[512:520] >= pz).all() and won.mean() > 0.05 and np.array_equal(labels[512:520][won], lz[won])
+
+
+@pytest.mark.parametrize("topology,encoder", [("unetplusplus", "efficientnet-b3"), ("unet", "timm-resnest101e"), ("manet", "efficientnet-b4")])
+def test_bench_sized_training_step_for_pairs_the_parity_tests_see_small(topology, encoder):
+    """One bf16 training step at the bench shape (256^2, batch 32) for encoder / decoder pairs whose parity tests run at 64^2, batch 4: the
+    tile picks and buffer sizes that depend on the problem size (timm-resnest101e's 128-channel max-pool once overran a 64-channel argmax
+    buffer; U-Net++ / efficientnet-b3 splits a data gradient at 32 + 40 channels, which a 64-wide cout tile cannot) - finite loss, finite
+    non-zero gradients, and a second step that moves the loss."""
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 1, 256, 256, generator=g).to(DEV)
+    t = torch.nn.functional.one_hot((torch.rand(32, 256, 256, generator=g) > 0.5).long(), 2).permute(0, 3, 1, 2).contiguous().to(torch.uint8).to(DEV)
+    m = VolSegUnet(2, device=DEV, precision="bf16", seed=0, encoder=encoder, topology=topology)
+    o = m.fused_adamw(lr=1e-3, fuse_step_into_backward=True)
+    m.train()
+    losses = []
+    for _ in range(2):
+        o.zero_grad()
+        loss = HipDiceLoss()(m(x), t)
+        loss.backward()
+        o.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[0] != losses[1], losses
+    assert torch.isfinite(m._flat_grad).all() and m._flat_grad.abs().sum().item() > 0 and torch.isfinite(m._flat).all()

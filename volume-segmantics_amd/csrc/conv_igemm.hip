@@ -709,6 +709,9 @@ Pick pick_cfg(const ConvParams& p) {
     };
     int bn = p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16);
     if (p.gc) bn = 32;     // grouped: one 32-channel super-group per cout tile
+    if (p.out1 && p.split_c % 64 != 0 && bn == 64) bn = 32;   // a split data gradient (decoder concat): no cout tile may straddle the boundary (32 + 40
+                                                               // channels under U-Net++ / efficientnet-b3)
+    if (p.out1 && p.split_c % 32 != 0 && bn == 32) bn = 16;
     if (can8 && wgs(bn, 256) >= vs_option("conv_nw8_min_wgs")) { c.NW = 8; c.PT = 2; }
     if (bn == 64 && wgs(64, c.NW * c.PT * 16) < vs_option("conv_min_wgs")) bn = 32;
     c.BN = bn;
