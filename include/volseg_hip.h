@@ -376,6 +376,12 @@ int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void* out, int 
  * composed from the operators above (the two-group 3x3 convolution as a dense one with block-expanded weight copies). */
 int vs_radix2_softmax(int dtype, const void* z, void* a, int n, int c, void* stream);
 int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, void* dz, int n, int c, void* stream);
+/* SplitAttnConv2d's last step in one sweep: out [n][hw][c] = x[.., ch] a[n][ch] + x[.., c + ch] a[n][c + ch] (x [n][hw][2 c], a [n][2 c]); bwd: dx from
+ * dout.  vs_sample_rowsum_b: out [n][c] = sum over hw of a [n][hw][c] * b [n][hw][cb], b repeated across the c / cb blocks (the attention's gradient). */
+int vs_radix2_gated_sum(int dtype, const void* x, const void* a, void* out, int n, int64_t hw, int c, void* stream);
+int vs_radix2_gated_sum_bwd(int dtype, const void* dout, const void* a, void* dx, int n, int64_t hw, int c, void* stream);
+int vs_sample_rowsum_b(int dtype, const void* a, const void* b, int cb, void* out, int n, int64_t hw, int c, float* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* ---- the attention operators of smp.MAnet's decoder (decoders/manet/decoder.py), NHWC ---------------------------------------------------
  * vs_pab_attention_fwd/bwd: PAB - sp = softmax over ALL hw x hw entries of center top^T (top, center [n][hw][K]), out = sp bottom

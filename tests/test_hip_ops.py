@@ -1318,3 +1318,40 @@ def test_dwconv2d_affine_eval_form(code, geom):
     L.check(L.lib.vs_dwconv2d_affine(code, L.ptr(xd), L.ptr(wd), L.ptr(scale), L.ptr(shift), 2, L.ptr(yd), n, h, w, c, k, s, lo, dil, ho, wo, None))
     sync()
     assert torch.allclose(from_nhwc(yd), ref, **tol(code, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(3, 6, 5, 64), (2, 40, 48, 128), (4, 1, 1, 512)])
+def test_radix2_softmax_and_gated_sum_fwd_bwd(code, shape):
+    """timm's SplitAttnConv2d tail (radix 2, cardinality 1): RadixSoftmax on the attention logits [n][2 c] and the attention-weighted sum
+    of the two splits - restated in torch exactly as split_attn.py writes it, forward and (autograd) backward: the data gradient, the
+    attention's gradient (vs_sample_rowsum_b: sums of x * dout with dout repeated per split) and the softmax's."""
+    L = lib()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(101)
+    x = rounded(torch.randn(n, 2 * c, h, w, generator=g), code).requires_grad_()
+    z = rounded(torch.randn(n, 2 * c, generator=g), code).requires_grad_()
+    att = torch.softmax(z.view(n, 1, 2, -1).transpose(1, 2), dim=1).reshape(n, -1)
+    out = (x.reshape(n, 2, c, h, w) * att.reshape(n, 2, c, 1, 1)).sum(1)
+    dout = rounded(torch.randn(out.shape, generator=g), code)
+    out.backward(dout)
+    dev = lambda t_: t_.detach().contiguous().to(DEV, tdtype(code))
+    xd, zd, dd = to_nhwc(x.detach(), code), dev(z), to_nhwc(dout, code)
+    ad = torch.full((n, 2 * c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_radix2_softmax(code, L.ptr(zd), L.ptr(ad), n, c, None))
+    od = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_radix2_gated_sum(code, L.ptr(xd), L.ptr(ad), L.ptr(od), n, h * w, c, None))
+    dx = torch.full_like(xd, float("nan"))
+    L.check(L.lib.vs_radix2_gated_sum_bwd(code, L.ptr(dd), L.ptr(ad), L.ptr(dx), n, h * w, c, None))
+    wsb = L.lib.vs_sample_rowsum_workspace(n, 2 * c)
+    ws = torch.empty(wsb // 4, device=DEV)
+    da = torch.full((n, 2 * c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_sample_rowsum_b(code, L.ptr(xd), L.ptr(dd), c, L.ptr(da), n, h * w, 2 * c, L.ptr(ws), wsb, None))
+    dz = torch.full((n, 2 * c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_radix2_softmax_bwd(code, L.ptr(da), L.ptr(ad), L.ptr(dz), n, c, None))
+    sync()
+    assert torch.allclose(ad.float().cpu(), att.detach(), **tol(code, 1.0))
+    assert torch.allclose(from_nhwc(od), out.detach(), **tol(code, out.abs().max().item()))
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+    lim = 5e-2 if code else 1e-4
+    assert torch.allclose(dz.float().cpu(), z.grad, rtol=lim, atol=lim * z.grad.abs().max().item())

@@ -112,6 +112,9 @@ _SIGS = {
     "vs_sample_rowsum_ws": (I, [I, P, P, P, I, I64, I, F, P, SZ, P]),
     "vs_radix2_softmax": (I, [I, P, P, I, I, P]),
     "vs_radix2_softmax_bwd": (I, [I, P, P, P, I, I, P]),
+    "vs_radix2_gated_sum": (I, [I, P, P, P, I, I64, I, P]),
+    "vs_radix2_gated_sum_bwd": (I, [I, P, P, P, I, I64, I, P]),
+    "vs_sample_rowsum_b": (I, [I, P, P, I, P, I, I64, I, P, SZ, P]),
     "vs_se_gate_fwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vs_se_gate_scratch_floats": (SZ, [I, I, I]),

@@ -610,13 +610,14 @@ __global__ __launch_bounds__(1024) void sample_rowsum_kernel(const T* __restrict
 // the same sums with the sample's rows split over blockIdx.z (few samples, large maps: prediction batches): fp32 partials
 // ws[(sample * splits + z)][c], then one lane per (sample, channel) adds the splits in order
 template <typename T>
-__global__ __launch_bounds__(256) void sample_rowsum_split_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ ws, int64_t hw, int c) {
+__global__ __launch_bounds__(256) void sample_rowsum_split_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ ws, int64_t hw, int c,
+                                                                int cb) {      // cb: channels of b (<= c, dividing it: b repeats across the blocks of c)
     __shared__ float red[256][kVec + 1];
     const Slab sl = slab_of(c);
     const int splits = gridDim.z;
     const int64_t r0 = hw * blockIdx.z / splits, r1 = hw * (blockIdx.z + 1) / splits;
     const T* as = a + (size_t)blockIdx.x * hw * c + sl.ch0;
-    const T* bs = b ? b + (size_t)blockIdx.x * hw * c + sl.ch0 : nullptr;
+    const T* bs = b ? b + (size_t)blockIdx.x * hw * cb + sl.ch0 % cb : nullptr;
     float s[kVec];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) s[k] = 0.f;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void sample_rowsum_split_kernel(const T* __res
                 const int64_t rr = r + (int64_t)u * sl.rpb;
                 const bool ok = rr < r1;
                 ld8(as + (ok ? rr : r) * c, v[u]);
-                if (bs) ld8(bs + (ok ? rr : r) * c, g[u]);
+                if (bs) ld8(bs + (ok ? rr : r) * cb, g[u]);
                 if (!ok) {
 #pragma unroll
                     for (int k = 0; k < kVec; ++k) v[u][k] = 0.f;
@@ -820,8 +821,20 @@ extern "C" int vs_sample_rowsum_ws(int dtype, const void* a, const void* b, void
     const int rpb = 256 / std::min(c / kVec, 256);
     int splits = (int)std::min<int64_t>(64, hw / ((int64_t)rpb * 16));       // >= 16 rows per lane and split
     if (splits < 2 || !workspace || workspace_bytes < vs_sample_rowsum_workspace(n, c)) return vs_sample_rowsum(dtype, a, b, out, n, hw, c, scale, stream);
-    VS_LAUNCH_T(sample_rowsum_split_kernel, dim3(n, (c / kVec + 255) / 256, splits), 0, (hipStream_t)stream, (const T*)a, (const T*)b, workspace, hw, c);
+    VS_LAUNCH_T(sample_rowsum_split_kernel, dim3(n, (c / kVec + 255) / 256, splits), 0, (hipStream_t)stream, (const T*)a, (const T*)b, workspace, hw, c, c);
     VS_LAUNCH_T(sample_rowsum_finish_kernel, dim3((n * c + 255) / 256), 0, (hipStream_t)stream, workspace, (T*)out, n, c, splits, scale);
+    return VS_OK;
+}
+// out [n][c] = sum over hw of a[n][hw][c] * b[n][hw][cb], b repeated across the c / cb channel blocks of a (ResNeSt: the attention's gradient
+// = sums of the split tensor times the gated sum's gradient).  Always the split form (workspace as for vs_sample_rowsum_ws).
+extern "C" int vs_sample_rowsum_b(int dtype, const void* a, const void* b, int cb, void* out, int n, int64_t hw, int c, float* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    VS_REQUIRE(a && b && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0 && cb > 0 && cb % kVec == 0 && c % cb == 0, "sample_rowsum_b: bad channel counts %d / %d", c, cb);
+    VS_REQUIRE(workspace && workspace_bytes >= vs_sample_rowsum_workspace(n, c), "sample_rowsum_b: workspace too small");
+    const int rpb = 256 / std::min(c / kVec, 256);
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(64, hw / ((int64_t)rpb * 16)));
+    VS_LAUNCH_T(sample_rowsum_split_kernel, dim3(n, (c / kVec + 255) / 256, splits), 0, (hipStream_t)stream, (const T*)a, (const T*)b, workspace, hw, c, cb);
+    VS_LAUNCH_T(sample_rowsum_finish_kernel, dim3((n * c + 255) / 256), 0, (hipStream_t)stream, workspace, (T*)out, n, c, splits, 1.f);
     return VS_OK;
 }
 // evaluation form of depthwise convolution + BatchNorm + activation in ONE sweep: y = act(conv(x) * scale[c] + shift[c]) (scale / shift

@@ -33,6 +33,50 @@ __global__ void radix2_softmax_bwd_kernel(const T* __restrict__ da, const T* __r
     }
 }
 
+constexpr int kVec = 8;
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+// the attention-weighted sum of the two radix splits: out[n][p][ch] = x[n][p][ch] a[n][ch] + x[n][p][c + ch] a[n][c + ch]  (x: 2 c channels)
+template <typename T>
+__global__ void radix2_gated_sum_kernel(const T* __restrict__ x, const T* __restrict__ a, T* __restrict__ out, int n, int64_t hw, int c) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * hw * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cv);
+        const int64_t row = i / cv;
+        const int b = (int)(row / hw);
+        float x0[kVec], x1[kVec], a0[kVec], a1[kVec], o[kVec];
+        ld8(x + row * 2 * c + cg * kVec, x0);
+        ld8(x + row * 2 * c + c + cg * kVec, x1);
+        ld8(a + (size_t)b * 2 * c + cg * kVec, a0);
+        ld8(a + (size_t)b * 2 * c + c + cg * kVec, a1);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) o[k] = x0[k] * a0[k] + x1[k] * a1[k];
+        st8(out + i * kVec, o);
+    }
+}
+// its data gradient: dx[n][p][r c + ch] = dout[n][p][ch] a[n][r c + ch]
+template <typename T>
+__global__ void radix2_gated_sum_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ a, T* __restrict__ dx, int n, int64_t hw, int c) {
+    const int cv = c / kVec;
+    const int64_t total = (int64_t)n * hw * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cv);
+        const int64_t row = i / cv;
+        const int b = (int)(row / hw);
+        float g[kVec], a0[kVec], a1[kVec], d0[kVec], d1[kVec];
+        ld8(dout + i * kVec, g);
+        ld8(a + (size_t)b * 2 * c + cg * kVec, a0);
+        ld8(a + (size_t)b * 2 * c + c + cg * kVec, a1);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) { d0[k] = g[k] * a0[k]; d1[k] = g[k] * a1[k]; }
+        st8(dx + row * 2 * c + cg * kVec, d0);
+        st8(dx + row * 2 * c + c + cg * kVec, d1);
+    }
+}
+
 }  // namespace
 
 // z, a [n][2 c]: a[b][r c + ch] = softmax over r of z[b][r c + ch] (timm's RadixSoftmax(radix 2, cardinality 1)); bwd: dz from da and a
@@ -49,6 +93,25 @@ extern "C" int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, v
     const int blocks = (n * c + 255) / 256;
     if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_softmax_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, (const bf16_t*)a, (bf16_t*)dz, n, c);
     else hipLaunchKernelGGL(radix2_softmax_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)da, (const float*)a, (float*)dz, n, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// SplitAttnConv2d's last step: out [n][hw][c] = sum over the two radix splits of x [n][hw][2 c] weighted by the attention a [n][2 c]; bwd: the
+// data gradient dx [n][hw][2 c] from dout (the attention's gradient is vs_sample_rowsum_b: sums of x * dout with dout repeated per split)
+extern "C" int vs_radix2_gated_sum(int dtype, const void* x, const void* a, void* out, int n, int64_t hw, int c, void* stream) {
+    VS_REQUIRE(x && a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "radix2_gated_sum: channels must be a multiple of 8");
+    const dim3 grid(grid_for((int64_t)n * hw * (c / kVec)));
+    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_gated_sum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)a, (bf16_t*)out, n, hw, c);
+    else hipLaunchKernelGGL(radix2_gated_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)a, (float*)out, n, hw, c);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+extern "C" int vs_radix2_gated_sum_bwd(int dtype, const void* dout, const void* a, void* dx, int n, int64_t hw, int c, void* stream) {
+    VS_REQUIRE(dout && a && dx && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "radix2_gated_sum_bwd: channels must be a multiple of 8");
+    const dim3 grid(grid_for((int64_t)n * hw * (c / kVec)));
+    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_gated_sum_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)a, (bf16_t*)dx, n, hw, c);
+    else hipLaunchKernelGGL(radix2_gated_sum_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, (const float*)a, (float*)dx, n, hw, c);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -104,6 +104,8 @@ enum UnitKind { U_STEM, U_POOL, U_CONV, U_HEAD, U_CONCAT,
                 U_DROPADD,      // out = drop_connect(a(src0), drop_p) + a(src1) (the MBConv skip); evaluation: the plain sum
                 U_FOLD2,        // out [.., c] = in [.., :c] + in [.., c:] (the sum over ResNeSt's two radix splits; maps and pooled vectors)
                 U_RSOFTMAX,     // timm's RadixSoftmax(2, 1) on attention logits [n][2 c]
+                U_RADIXSUM,     // out [.., c] = a(src0)[.., :c] * gate[:c] + a(src0)[.., c:] * gate[c:], gate = a(src1) [n][2 c] (the attention-weighted
+                                // sum of ResNeSt's two splits in one sweep)
                 U_AVGPOOL,      // nn.AvgPool2d(k, stride) of ResNeSt's avd (3, padding 1, zeros counted) / avg_down (2): a depthwise convolution
                                 // with constant taps pool_w
                 U_UP2,          // out = nearest-x2 upsampling of a(src0), materialised - where a decoder's upsample + concat cannot ride the
@@ -414,10 +416,7 @@ int build(vs_unet* net) {
                 Unit rs; rs.kind = U_RSOFTMAX; rs.src0 = f2.out; rs.cout = 2 * C; rs.hin = rs.hout = 1; rs.win = rs.wout = 1; rs.relu = 0;
                 rs.out = new_act(2 * C, 1, 1, false);
                 U.push_back(rs);
-                Unit cg; cg.kind = U_CGATE; cg.src0 = u2.out; cg.src1 = rs.out; cg.cout = 2 * C; cg.hout = ch; cg.wout = cw; cg.relu = 0;
-                cg.out = new_act(2 * C, ch, cw, false);
-                U.push_back(cg);
-                Unit fo; fo.kind = U_FOLD2; fo.src0 = cg.out; fo.cout = C; fo.hin = fo.hout = ch; fo.win = fo.wout = cw; fo.relu = 0;
+                Unit fo; fo.kind = U_RADIXSUM; fo.src0 = u2.out; fo.src1 = rs.out; fo.cout = C; fo.hin = fo.hout = ch; fo.win = fo.wout = cw; fo.relu = 0;
                 fo.out = new_act(C, ch, cw, false);
                 U.push_back(fo);
                 int t = fo.out;
@@ -1042,6 +1041,7 @@ size_t plan_workspace(vs_unet* net) {
             if (u.kind == U_SE) u.off_gn = take(N * (size_t)u.cin1 * sizeof(float));   // hidden activations
             if (u.kind == U_SE) sews = std::max(sews, vs_se_gate_scratch_floats((int)N, u.cout, u.cin1) * sizeof(float));
             if (u.kind == U_GAP || u.kind == U_CGATE) gapws = std::max(gapws, vs_sample_rowsum_workspace((int)N, u.cout));
+            if (u.kind == U_RADIXSUM) gapws = std::max(gapws, vs_sample_rowsum_workspace((int)N, 2 * u.cout));
             if (u.kind == U_DROPADD) u.off_gn = take(N * sizeof(float));               // the drop-connect draw per sample
         }
         net->pab_bytes = pab;
@@ -1612,6 +1612,11 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             if ((rc = vs_channel_slice(dt, c.a(u.src0), 2 * u.cout, u.cout, c.a(u.out), u.cout, 0, u.cout, rows, 1, stream))) return rc;
             continue;
         }
+        case U_RADIXSUM: {
+            ProfScope prof(PK_POOL_MISC, 0, 3.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_radix2_gated_sum(dt, c.a(u.src0), c.a(u.src1), c.a(u.out), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            continue;
+        }
         case U_RSOFTMAX: {
             if ((rc = vs_radix2_softmax(dt, c.a(u.src0), c.a(u.out), n, u.cout / 2, stream))) return rc;
             continue;
@@ -2168,6 +2173,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             written[u.src0] = 1;
             continue;
         }
+        if (u.kind == U_RADIXSUM) { // d(splits) = dout * gate per split; d(gate)[n][r c + ch] = sum over the map of dout * split r
+            if (!do_main) continue;
+            VS_REQUIRE(written[u.out] && !written[u.src0] && !written[u.src1], "backward: gradients of a radix sum out of order");
+            ProfScope prof(PK_POOL_MISC, 0, 6.0 * n * u.hout * u.wout * u.cout * net->esz, c.s);
+            if ((rc = vs_sample_rowsum_b(dt, c.a(u.src0), c.da(u.out), u.cout, c.da(u.src1), n, (int64_t)u.hout * u.wout, 2 * u.cout,
+                                         (float*)(c.ws + net->off_gapws), net->gapws_bytes, stream))) return rc;
+            if ((rc = vs_radix2_gated_sum_bwd(dt, c.da(u.out), c.a(u.src1), c.da(u.src0), n, (int64_t)u.hout * u.wout, u.cout, stream))) return rc;
+            written[u.src0] = 1; written[u.src1] = 1;
+            continue;
+        }
         if (u.kind == U_RSOFTMAX) {
             if (!do_main) continue;
             VS_REQUIRE(written[u.out] && !written[u.src0], "backward: radix softmax gradients out of order");
@@ -2479,7 +2494,7 @@ extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, i
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
     VS_REQUIRE(net && unit >= 0 && unit < (int)net->units.size(), "debug_unit: bad index");
     const Unit& u = net->units[unit];
-    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : u.kind == U_BN ? net->layout.tensors[u.bn_idx].name.c_str() : u.kind == U_DROPADD ? "drop_connect+add" : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
+    const char* nm = u.w_idx >= 0 ? net->layout.tensors[u.w_idx].name.c_str() : u.kind == U_BN ? net->layout.tensors[u.bn_idx].name.c_str() : u.kind == U_DROPADD ? "drop_connect+add" : u.kind == U_RADIXSUM ? "radix-weighted sum" : u.kind == U_FOLD2 ? "radix fold" : u.kind == U_RSOFTMAX ? "radix softmax" : u.kind == U_AVGPOOL ? "avgpool k" : (u.kind == U_CONCAT ? "concat" : (u.kind == U_ADD ? "add" : (u.kind == U_UPADD ? "upsample+add" : (u.kind == U_BILINEAR ? "bilinear"
                          : (u.kind == U_DROPOUT ? "dropout2d" : (u.kind == U_GAP ? "avgpool" : (u.kind == U_BCAST ? "broadcast" : (u.kind == U_DROPOUT_E ? "dropout"
                          : (u.kind == U_PAB ? "pab attention" : (u.kind == U_CGATE ? "channel gate" : (u.kind == U_SIGMOID ? "sigmoid" : "maxpool")))))))))));
     strncpy(wname, nm, name_len - 1); wname[name_len - 1] = 0;
