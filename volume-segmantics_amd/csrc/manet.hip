@@ -169,82 +169,86 @@ __global__ void bmm_dp_kernel(const float* __restrict__ dP, const T* __restrict_
 }
 
 // ---- squeeze-excitation gate on pooled features p [n][C] (T): a = sigmoid(W2 act(W1 p + b1) + b2), W1 [R][C], W2 [C][R] fp32; act = ReLU
-// (MFAB) or swish (efficientnet-pytorch).  One workgroup per sample; every dot product is a wave's coalesced sweep + butterfly.
+// (MFAB) or swish (efficientnet-pytorch).  Workgroups per (sample, 4 hidden units) / (sample, 256 outputs): every first-layer dot product is a wave's coalesced sweep + butterfly.
 __device__ __forceinline__ float se_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// forward, layer 1: hid[b][r] = act-input of the hidden unit (swish: the pre-activation; ReLU: the activation) - one wave per (sample, r), the
+// C products spread over its lanes (coalesced rows of W1); blockIdx = (sample, group of 4 hidden units)
 template <typename T>
-__global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                    const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ a,
-                                                    float* __restrict__ hid, int C, int R, int swish) {
-    __shared__ float ps[4096], hs[128];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < C; c += 256) ps[c] = Elem<T>::ld(p + (size_t)b * C + c);
-    __syncthreads();
-    for (int r = wave; r < R; r += 4) {
-        float acc = 0.f;
+__global__ __launch_bounds__(256) void se_hidden_kernel(const T* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      float* __restrict__ hid, int C, int R, int swish) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const T* ps = p + (size_t)b * C;
+    float acc = 0.f;
 #pragma unroll 8
-        for (int c = lane; c < C; c += 64) acc += w1[(size_t)r * C + c] * ps[c];
-        acc = se_wave_sum(acc) + b1[r];
-        if (lane == 0) {
-            hid[(size_t)b * R + r] = swish ? acc : fmaxf(acc, 0.f);       // kept for the backward pass (swish: the pre-activation)
-            hs[r] = swish ? acc / (1.f + __expf(-acc)) : fmaxf(acc, 0.f);
-        }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {      // one lane per output: its R weights are contiguous, the hidden layer sits in LDS
-        float acc = b2[c];
-        const float* wr = w2 + (size_t)c * R;
-#pragma unroll 8
-        for (int r = 0; r < R; ++r) acc += wr[r] * hs[r];
-        Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
-    }
+    for (int c = lane; c < C; c += 64) acc += w1[(size_t)r * C + c] * Elem<T>::ld(ps + c);
+    acc = se_wave_sum(acc) + b1[r];
+    if (lane == 0) hid[(size_t)b * R + r] = swish ? acc : fmaxf(acc, 0.f);
 }
-// backward, stage 1 (one workgroup per sample): g2 = da a (1 - a) (gradient at the second layer's pre-activation), g1 = (W2^T g2) act'(hidden)
-// (first layer's), dp = W1^T g1; g2 / g1 go to scratch G2 [n][C] / G1 [n][R] for the parameter gradients
+// forward, layer 2: a[b][c] = sigmoid(W2[c] . act(hid[b]) + b2[c]) - one lane per output, blockIdx = (sample, 256 outputs)
 template <typename T>
-__global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(const T* __restrict__ da, const T* __restrict__ a, const float* __restrict__ hid,
-                                                               const float* __restrict__ w1, const float* __restrict__ w2, T* __restrict__ dp,
-                                                               float* __restrict__ G2, float* __restrict__ G1, int C, int R, int swish) {
-    __shared__ float g2[4096], g1[128], part[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        const float av = Elem<T>::ld(a + (size_t)b * C + c);
-        const float v = Elem<T>::ld(da + (size_t)b * C + c) * av * (1.f - av);
-        g2[c] = v;
-        G2[(size_t)b * C + c] = v;
+__global__ __launch_bounds__(256) void se_output_kernel(const float* __restrict__ hid, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      T* __restrict__ a, int C, int R, int swish) {
+    __shared__ float hs[128];
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if ((int)threadIdx.x < R) {
+        const float hv = hid[(size_t)b * R + threadIdx.x];
+        hs[threadIdx.x] = swish ? hv / (1.f + __expf(-hv)) : hv;
     }
     __syncthreads();
-    {                                    // W2 [C][R]: R lanes read one row per step (contiguous), 256 / R row groups share the C rows
-        const int groups = 256 / R, r = tid % R, gi = tid / R;
-        float acc = 0.f;
-        if (gi < groups) {
+    if (c >= C) return;
+    float acc = b2[c];
+    const float* wr = w2 + (size_t)c * R;
 #pragma unroll 8
-            for (int c = gi; c < C; c += groups) acc += w2[(size_t)c * R + r] * g2[c];
+    for (int r = 0; r < R; ++r) acc += wr[r] * hs[r];
+    Elem<T>::st(a + (size_t)b * C + c, 1.f / (1.f + __expf(-acc)));
+}
+// backward, stage 1a: g2 = da a (1 - a) (the second layer's pre-activation gradient, kept in G2) and g1[r] = (sum_c W2[c][r] g2[c]) act'(hidden)
+// (kept in G1): one wave per (sample, r); the blocks of hidden-unit group 0 also write G2
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const T* __restrict__ da, const T* __restrict__ a, const float* __restrict__ hid,
+                                                          const float* __restrict__ w2, float* __restrict__ G2, float* __restrict__ G1, int C, int R, int swish) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const T* das = da + (size_t)b * C;
+    const T* as = a + (size_t)b * C;
+    if (blockIdx.y == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float av = Elem<T>::ld(as + c);
+            G2[(size_t)b * C + c] = Elem<T>::ld(das + c) * av * (1.f - av);
         }
-        part[tid] = acc;
     }
-    __syncthreads();
-    if (tid < R) {
-        const int groups = 256 / R;
-        float acc = 0.f;
-        for (int gi = 0; gi < groups; ++gi) acc += part[gi * R + tid];
-        const float hv = hid[(size_t)b * R + tid];
+    if (r >= R) return;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = lane; c < C; c += 64) {
+        const float av = Elem<T>::ld(as + c);
+        acc += w2[(size_t)c * R + r] * (Elem<T>::ld(das + c) * av * (1.f - av));
+    }
+    acc = se_wave_sum(acc);
+    if (lane == 0) {
+        const float hv = hid[(size_t)b * R + r];
         float d;
         if (swish) { const float sg = 1.f / (1.f + __expf(-hv)); d = sg * (1.f + hv * (1.f - sg)); }
         else d = hv > 0.f ? 1.f : 0.f;
-        g1[tid] = acc * d;
-        G1[(size_t)b * R + tid] = acc * d;
+        G1[(size_t)b * R + r] = acc * d;
     }
+}
+// stage 1b: dp[b][c] = sum_r W1[r][c] g1[b][r] - one lane per output
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_input_kernel(const float* __restrict__ G1, const float* __restrict__ w1, T* __restrict__ dp, int C, int R) {
+    __shared__ float g1[128];
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if ((int)threadIdx.x < R) g1[threadIdx.x] = G1[(size_t)b * R + threadIdx.x];
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float acc = 0.f;
+    if (c >= C) return;
+    float acc = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < R; ++r) acc += w1[(size_t)r * C + c] * g1[r];
-        Elem<T>::st(dp + (size_t)b * C + c, acc);
-    }
+    for (int r = 0; r < R; ++r) acc += w1[(size_t)r * C + c] * g1[r];
+    Elem<T>::st(dp + (size_t)b * C + c, acc);
 }
 // stage 2: dW1[r][c] = sum_b G1[b][r] p[b][c], dW2[c][r] = sum_b G2[b][c] act(hid[b][r]), db1 = sum_b G1, db2 = sum_b G2 - one lane per
 // output, samples in order
@@ -371,7 +375,8 @@ extern "C" size_t vs_pab_scratch_bytes(int n, int hw, int C) { return ((size_t)n
 extern "C" int vs_se_gate_fwd(int dtype, const void* p, const float* w1, const float* b1, const float* w2, const float* b2, void* a, float* hid,
                               int n, int C, int R, int swish, void* stream) {
     VS_REQUIRE(p && w1 && b1 && w2 && b2 && a && hid && C >= 1 && C <= 4096 && R >= 1 && R <= 128, "se_gate_fwd: C <= 4096, R <= 128");
-    VS_LAUNCH_T(se_gate_kernel, dim3(n), (hipStream_t)stream, (const T*)p, w1, b1, w2, b2, (T*)a, hid, C, R, swish);
+    VS_LAUNCH_T(se_hidden_kernel, dim3(n, (R + 3) / 4), (hipStream_t)stream, (const T*)p, w1, b1, hid, C, R, swish);
+    VS_LAUNCH_T(se_output_kernel, dim3(n, (C + 255) / 256), (hipStream_t)stream, hid, w2, b2, (T*)a, C, R, swish);
     return VS_OK;
 }
 // scratch: vs_se_gate_scratch_floats(n, C, R) floats (the two layers' pre-activation gradients, per sample)
@@ -382,7 +387,8 @@ extern "C" int vs_se_gate_bwd(int dtype, const void* da, const void* a, const vo
                "se_gate_bwd: bad arguments (C <= 4096, R <= 128)");
     float* G2 = scratch;
     float* G1 = scratch + (size_t)n * C;
-    VS_LAUNCH_T(se_gate_bwd_sample_kernel, dim3(n), (hipStream_t)stream, (const T*)da, (const T*)a, hid, w1, w2, (T*)dp, G2, G1, C, R, swish);
+    VS_LAUNCH_T(se_bwd_hidden_kernel, dim3(n, (R + 3) / 4), (hipStream_t)stream, (const T*)da, (const T*)a, hid, w2, G2, G1, C, R, swish);
+    VS_LAUNCH_T(se_bwd_input_kernel, dim3(n, (C + 255) / 256), (hipStream_t)stream, G1, w1, (T*)dp, C, R);
     const int64_t total = 2 * (int64_t)R * C + R + C;
     VS_LAUNCH_T(se_gate_bwd_params_kernel, dim3((unsigned)((total + 255) / 256)), (hipStream_t)stream, (const T*)p, hid, G2, G1, dw1, db1, dw2, db2, n, C, R, swish);
     return VS_OK;
