@@ -1,0 +1,160 @@
+"""-m gpu: the whole network against the CPU oracle AT THE SLICE SIZES BASELINE.json NAMES, with the library's default
+options - so the kernels compared are the ones bench.py runs (8-wave / ring tiles, direct kernels, split-K sizing of the
+weight gradient, inline BatchNorm finalisation), not the small-tile variants the 32^2 - 128^2 tests pick.
+
+  * configs[1]  U-Net / ResNet-34, 256 x 256, 2 classes: batch 4, evaluation logits (fp32 < 1e-3) and one training step
+    (loss, head / last-block gradients, the rest with the ReLU-flip tolerant rule of tests/test_hip_unet.py), fp32 and bf16;
+  * configs[2]  512 x 512, 4 classes: batch 2, evaluation logits and arg-max labels on decidable pixels;
+  * configs[3]  U-Net++ / ResNet-50 at 512 x 512, one slice (evaluation);
+  * configs[4]  DeepLabV3+ / EfficientNet-b4 at ONE 1024 x 1024 slice (evaluation), fp32 and the low-precision mode.
+Reference call sites: vol_seg_2d_trainer.py:424-429, vol_seg_2d_predictor.py:44.  The oracle is oracle/unet_resnet34_torch.py /
+oracle/unet_resnet_torch.py on the host cores (a few seconds per case)."""
+import pytest
+import torch
+
+from hip_helpers import DEV, sync
+from oracle import predictor_numpy as P
+from oracle.unet_resnet34_torch import seeded_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    if not a.any() and not b.any():
+        return 1.0
+    return (torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-300)).item()
+
+
+def _decidable(ref, margin=1e-3):
+    top2 = ref.topk(2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]) > margin
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_unet_resnet34_256_batch4_eval_logits_and_labels(precision):
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle(2, 0, True)
+    model = VolSegUnet(2, device=DEV, precision=precision, init="none")
+    model.load_state_dict(oracle.state_dict())
+    x = torch.randn(4, 1, 256, 256, generator=torch.Generator().manual_seed(11))
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    if precision == "fp32":
+        assert (got - ref).abs().max().item() < 1e-3, (got - ref).abs().max().item()      # north_star: logits within 1e-3 fp32
+        m = _decidable(ref)
+        assert m.float().mean().item() > 0.98
+        assert torch.equal(got.argmax(1)[m], ref.argmax(1)[m])                              # labels bit-exact where decidable
+    else:
+        assert ((got - ref).norm() / ref.norm()).item() < 0.05
+        assert (got.argmax(1) == ref.argmax(1)).float().mean().item() > 0.9
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_unet_resnet34_256_batch4_training_step(precision):
+    """forward (train-mode BN) + DiceLoss + backward at 256 x 256: the step bench.py times, at batch 4."""
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle(2, 3, False)
+    model = VolSegUnet(2, device=DEV, precision=precision, init="none")
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 1, 256, 256, generator=g)
+    mask = (torch.rand(4, 256, 256, generator=g) > 0.65).to(torch.uint8)
+    _, t = P.prepare_training_batch(x, mask, 2)
+    oracle.train(); model.train()
+    ref_out = oracle(x)
+    ref_loss = P.dice_loss_none(ref_out, t.float())
+    ref_loss.backward()
+    out = model(x.to(DEV))
+    loss = P.dice_loss_none(out, t.to(DEV).float())
+    loss.backward()
+    sync()
+    refg = {k: v.grad for k, v in oracle.named_parameters()}
+    if precision == "fp32":
+        assert abs(loss.item() - ref_loss.item()) < 1e-5, (loss.item(), ref_loss.item())
+        assert ((out.detach().cpu() - ref_out.detach()).norm() / ref_out.detach().norm()).item() < 1e-4
+    else:
+        assert abs(loss.item() - ref_loss.item()) < 2e-2, (loss.item(), ref_loss.item())
+        assert ((out.detach().cpu() - ref_out.detach()).norm() / ref_out.detach().norm()).item() < 0.15
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        r = refg[name]
+        err = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
+        if precision == "fp32":
+            if name.startswith(("segmentation_head", "decoder.blocks.4.conv2")):
+                assert err < 1e-3, (name, err)          # upstream of every ReLU but one
+            else:
+                assert _cos(p.grad.cpu(), r) > 0.99 and err < 0.15, (name, err)
+        elif name.startswith(("segmentation_head", "decoder.blocks.4")):
+            assert _cos(p.grad.cpu(), r) > 0.9, (name, err)
+    if precision == "fp32":
+        osd, msd = oracle.state_dict(), model.state_dict()
+        for k in osd:
+            if "running" in k:
+                assert torch.allclose(msd[k].cpu(), osd[k], rtol=1e-3, atol=1e-5), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_unet_resnet34_512_batch2_four_classes_eval(precision):
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle(4, 1, True)
+    model = VolSegUnet(4, device=DEV, precision=precision, init="none")
+    model.load_state_dict(oracle.state_dict())
+    x = torch.randn(2, 1, 512, 512, generator=torch.Generator().manual_seed(12))
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref, got = oracle(x), model(x.to(DEV)).cpu()
+    assert torch.isfinite(got).all()
+    if precision == "fp32":
+        assert (got - ref).abs().max().item() < 1e-3, (got - ref).abs().max().item()
+        m = _decidable(ref)
+        assert m.float().mean().item() > 0.97
+        assert torch.equal(got.argmax(1)[m], ref.argmax(1)[m])
+    else:
+        assert ((got - ref).norm() / ref.norm()).item() < 0.05
+        assert (got.argmax(1) == ref.argmax(1)).float().mean().item() > 0.85
+
+
+def test_unetplusplus_resnet50_512_one_slice_eval():
+    """BASELINE configs[3]'s network at its slice size."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle_unet("resnet50", 4, seed=2, topology="unetplusplus")
+    x = torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(13))
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(x)
+    for precision in ("fp32", "bf16"):
+        model = VolSegUnet(4, device=DEV, precision=precision, init="none", encoder="resnet50", topology="unetplusplus")
+        model.load_state_dict(oracle.state_dict())
+        model.eval()
+        with torch.no_grad():
+            got = model(x.to(DEV)).cpu()
+        if precision == "fp32":
+            assert (got - ref).abs().max().item() < 1e-3, (got - ref).abs().max().item()
+        else:
+            assert ((got - ref).norm() / ref.norm()).item() < 0.08
+        del model
+
+
+def test_deeplabv3plus_efficientnet_b4_1024_one_slice_eval():
+    """BASELINE configs[4]'s network at its slice size (one 1024 x 1024 slice)."""
+    from oracle.unet_resnet_torch import seeded_oracle_unet
+    from volume_segmantics_amd.engine import VolSegUnet
+    oracle = seeded_oracle_unet("efficientnet-b4", 2, seed=2, topology="deeplabv3plus")
+    x = torch.randn(1, 1, 1024, 1024, generator=torch.Generator().manual_seed(14))
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(x)
+    for precision in ("fp32", "bf16"):
+        model = VolSegUnet(2, device=DEV, precision=precision, init="none", encoder="efficientnet-b4", topology="deeplabv3plus")
+        model.load_state_dict(oracle.state_dict())
+        model.eval()
+        with torch.no_grad():
+            got = model(x.to(DEV)).cpu()
+        if precision == "fp32":
+            assert (got - ref).abs().max().item() < 1e-3, (got - ref).abs().max().item()
+        else:
+            assert ((got - ref).norm() / ref.norm()).item() < 0.1
+        del model

@@ -285,3 +285,56 @@ def test_fit_to_square_downscales_without_antialiasing():
     assert set(np.unique(m).tolist()) <= {0, 3} and m[1].tolist() == [0, 0, 3, 3]
     same, _ = fit_to_square(np.arange(16, dtype=np.uint8).reshape(4, 4), None, 4)
     assert np.array_equal(same, np.arange(16, dtype=np.uint8).reshape(4, 4))
+
+
+@pytest.mark.parametrize("encoder", ["resnet34", "resnet50", "efficientnet-b3", "timm-resnest50d"])
+def test_pretrained_encoder_loader_patches_the_first_convolution(encoder):
+    """smp's patch_first_conv (in_channels=1: the pretrained 3-channel kernel summed over its input channels) applies to
+    whichever tensor is the encoder's first convolution: conv1.weight (torchvision ResNets), _conv_stem.weight
+    (efficientnet-pytorch), conv1.0.weight (timm ResNeSt's deep stem) - model_2d.py:15-16 of the reference via
+    smp.Unet(encoder_weights="imagenet", in_channels=1)."""
+    from volume_segmantics_amd.engine import VolSegUnet
+    from volume_segmantics_amd.model.model_2d import load_pretrained_encoder
+    donor = VolSegUnet(2, seed=11, encoder=encoder)
+    own = donor.state_dict()
+    firsts = [k for k, v in own.items() if k.startswith("encoder.") and v.ndim == 4 and v.shape[1] == 1 and v.shape[2] > 1]
+    first = {"resnet34": "encoder.conv1.weight", "resnet50": "encoder.conv1.weight", "efficientnet-b3": "encoder._conv_stem.weight",
+             "timm-resnest50d": "encoder.conv1.0.weight"}[encoder]
+    assert first in firsts
+    g = torch.Generator().manual_seed(3)
+    upstream = {k[len("encoder."):]: v.clone() for k, v in own.items() if k.startswith("encoder.")}
+    w3 = torch.randn(own[first].shape[0], 3, *own[first].shape[2:], generator=g)
+    upstream[first[len("encoder."):]] = w3
+    upstream["fc.weight"] = torch.zeros(10, 7)                 # a classifier head: ignored
+    model = VolSegUnet(2, seed=5, encoder=encoder)
+    load_pretrained_encoder(model, upstream)
+    got = model.state_dict()
+    assert torch.allclose(got[first], w3.sum(1, keepdim=True))
+    for k, v in own.items():
+        if k.startswith("encoder.") and k != first:
+            assert torch.equal(got[k], v), k
+    with pytest.raises(ValueError):
+        load_pretrained_encoder(model, {"conv_that_is_not_there.weight": torch.zeros(1)})
+
+
+def test_fused_adamw_state_dict_has_no_entries_for_frozen_parameters():
+    """torch.optim.AdamW (the reference's optimiser) keeps no state for a parameter that never received a gradient: the
+    frozen encoder convolutions of the first phase (vol_seg_2d_trainer.py:102-108) must not appear with `step` = N and
+    empty moments, or a reference-side resume would bias-correct them as if they had been updated N times."""
+    from volume_segmantics_amd.engine import FusedAdamW, VolSegUnet
+    from oracle.unet_resnet34_torch import OracleUnetResnet34
+    m = VolSegUnet(2, seed=4)
+    names = [n for n, _ in m.named_parameters()]
+    for n, p in m.named_parameters():
+        if "encoder" in n and "conv" in n:
+            p.requires_grad = False
+    fo = FusedAdamW(m, lr=1e-3)
+    assert fo.state_dict()["state"] == {}                     # nothing stepped yet: empty, like a fresh torch optimiser
+    fo.exp_avg.uniform_(-1, 1); fo.exp_avg_sq.uniform_(0, 1); fo.step_count = 5
+    sd = fo.state_dict()
+    frozen = {i for i, n in enumerate(names) if "encoder" in n and "conv" in n}
+    assert frozen and not (frozen & set(sd["state"])) and set(sd["state"]) == set(range(len(names))) - frozen
+    assert sd["param_groups"][0]["params"] == list(range(len(names)))
+    ref = torch.optim.AdamW(OracleUnetResnet34(1, 2).parameters(), lr=1e-3)
+    ref.load_state_dict(sd)                                    # the reference's _load_in_weights(optimizer=True) path
+    assert len(ref.state) == len(names) - len(frozen)

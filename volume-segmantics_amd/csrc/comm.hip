@@ -6,6 +6,8 @@
 // VOLSEG_COMM=rccl).  librccl is opened lazily (dlopen): the library loads, and everything else works, where RCCL is absent.
 #include <dlfcn.h>
 
+#include <string>
+
 #include "common.h"
 
 namespace {
@@ -29,6 +31,9 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 
+// why librccl could not be used: captured ONCE, right where the dlopen / dlsym failed (dlerror() clears itself when read)
+std::string& rccl_load_error() { static std::string e; return e; }
+
 Rccl* rccl() {
     static Rccl r;
     static bool tried = false;
@@ -37,6 +42,8 @@ Rccl* rccl() {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
+        const char* e = dlerror();
+        rccl_load_error() += std::string(rccl_load_error().empty() ? "" : "; ") + (e ? e : "dlopen failed");
     }
     if (!r.handle) return nullptr;
 #define VS_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym))
@@ -45,6 +52,7 @@ Rccl* rccl() {
     VS_SYM(Broadcast, "ncclBroadcast"); VS_SYM(GetErrorString, "ncclGetErrorString");
 #undef VS_SYM
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.ReduceScatter || !r.AllGather || !r.Broadcast) {
+        rccl_load_error() = "librccl was opened but a required nccl* symbol is missing";
         dlclose(r.handle);
         r.handle = nullptr;
         return nullptr;
@@ -67,7 +75,7 @@ struct vs_comm {
 
 #define VS_NEED_RCCL(r)                                                                   \
     Rccl* r = rccl();                                                                     \
-    if (!r) { vs_set_error("vs_comm: librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing"); return VS_ERR_UNSUPPORTED; }
+    if (!r) { vs_set_error("vs_comm: librccl could not be used (%s)", rccl_load_error().c_str()); return VS_ERR_UNSUPPORTED; }
 
 extern "C" int vs_comm_unique_id(char id[128]) {
     VS_REQUIRE(id, "comm_unique_id: null pointer");

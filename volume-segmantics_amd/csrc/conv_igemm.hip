@@ -30,6 +30,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "conv_ring.h"
 #include "prof.h"
 
 namespace {
@@ -718,6 +719,30 @@ Pick pick_cfg(const ConvParams& p) {
     return c;
 }
 
+// conv_ring_kernel (conv_ring.h) takes the deep stride-1 3x3 layers of small launches: >= 4 chunks of input channels
+// (the ring needs a main loop to pay for its longer prologue) and grids of at most a few workgroups per CU, where one
+// workgroup per CU with its staging off the registers beats two that stage through them (tools/convlab: layer2 / layer3 /
+// layer4 / dec0 / dec1 shapes of the batch-32 step 12 - 22 % faster, the short-K 64- and 32-channel layers slower).
+// 0 = no; 1 = 256-pixel tiles x 64 couts; 2 = 256-pixel tiles x 32 couts; 3 = pairs of 8 x 8 images x 32 couts
+static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
+    if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
+        out_nchw || (p.Cout & 3) || p.out_f32) return 0;
+    const int Cin = p.C0 + p.C1;
+    if (Cin < 128 || (Cin & 7) || (p.C1 && (p.C0 & 31))) return 0;
+    if (p.out1 && (p.split_c & 31)) return 0;
+    if ((double)p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 * 2 >= 4.0e9) return 0;
+    if (p.Hout == 8 && p.Wout == 8 && p.up0 == 0) {
+        if (p.N % 2 == 0 && !p.pool0 && p.Cout >= 32 && (long)(p.N / 2) * cdiv(p.Cout, 32) <= 1024) return 3;
+        return 0;
+    }
+    if (p.Hout < 16 || p.Wout < 16) return 0;
+    const long tiles = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
+    const long w64 = tiles * cdiv(p.Cout, 64), w32 = tiles * cdiv(p.Cout, 32);
+    if (p.Cout >= 64 && w64 >= 224 && w64 <= 1024 && (!p.out1 || p.split_c % 64 == 0)) return 1;
+    if (p.Cout >= 32 && w32 >= 128 && w32 <= 1024) return 2;
+    return 0;
+}
+
 template <typename T>
 int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
@@ -754,6 +779,16 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
+    if constexpr (sizeof(T) == 2) {
+        const int rm = ring_mode(VS_BF16, p, out_nchw);
+        if (rm) {
+            const long groups = rm == 3 ? p.N / 2 : (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
+            unsigned long long* probe = vs_probe_buffer((size_t)(cdiv((int)groups, 8) * 8) * cdiv(p.Cout, rm == 1 ? 64 : 32));
+            if (rm == 1) return ring::launch_ring<64, 2, 8, 4, 1, 2, 2>(p, out_nchw, probe, s);
+            if (rm == 2) return ring::launch_ring<32, 2, 8, 4, 1, 4, 2>(p, out_nchw, probe, s);
+            return ring::launch_ring<32, 2, 4, 3, 2, 1, 2>(p, out_nchw, probe, s);
+        }
+    }
     VS_REQUIRE(!p.scatter, "conv_igemm: the volume-scatter epilogue needs the direct kernel (check conv_head_scatter_ok first)");
     TileGeom g;
     g.tw_shift = tile_tw(p, PT) == 16 ? 4 : 3;
@@ -785,13 +820,14 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
 }  // namespace
 
 bool conv_igemm_can_pool(const ConvParams& p) {
-    return pick_cfg(p).PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);
+    return pick_cfg(p).PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);   // (the ring kernel's 16 x 16 tiles: the same condition)
 }
 
 // instantiation code of the kernel launch_conv_igemm picks: BN*1000 + PT*100 + NTAPS*10 + code
 // (code 1 = stride 1, 2 = stride 2, 4 = direct (LDS-free) shallow-layer kernel, 8 = 8-wave 256-pixel tiles)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return 16 * 1000 + 2 * 100 + 9 * 10 + 4;
+    if (const int rm = ring_mode(dtype, p, p.out_f32 >> 1)) return (rm == 1 ? 64 : 32) * 1000 + 2 * 100 + 9 * 10 + 6;   // 6 = LDS-DMA ring
     const Pick c = pick_cfg(p);
     return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : (p.stride == 2 ? 2 : 1));
 }
@@ -800,6 +836,7 @@ bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && 
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave
+    if (const int rm = ring_mode(dtype, p, p.out_f32 >> 1)) return rm == 3 ? p.N / 2 : p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
     const Pick c = pick_cfg(p);
     const int TW = tile_tw(p, c.PT), TH = c.NW * 16 * c.PT / TW;
     return p.N * cdiv(p.Hout, TH) * cdiv(p.Wout, TW);

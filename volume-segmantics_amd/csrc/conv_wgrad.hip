@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "prof.h"
+#include "conv_wgrad_ring.h"
 
 namespace {
 
@@ -30,6 +31,8 @@ struct WGeom {
     int ctiles, cchunks, nsplit, total_tiles, dys;  // dys: LDS bytes per dy pixel row
     unsigned pw_magic, tw_magic, th_magic;          // x / PW, x / tiles_w, x / tiles_h by umulhi (bf16 fast path)
     int fast;                                        // bf16 fast path (conv_wgrad_bf16_kernel) applies
+    int ring;                                        // 1 / 2: conv_wgrad_ring_kernel on 16 x 8 tiles / on pairs of 8 x 8 images
+    unsigned long long* probe;                       // phase timestamps (tools/convlab); null in normal operation
 };
 
 __device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
@@ -251,6 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
                  "s"(g.tiles_w), "s"(g.tiles_h), "s"(g.tw_magic), "s"(g.th_magic), "s"(g.pw_magic), "s"(g.tw_shift), "s"(p.cg));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
+    unsigned long long tprobe[5];
+    if (g.probe) tprobe[0] = wall_clock64();
     const int wc = wave & 1, wg2 = wave >> 1;
     const int wt = TG == 2 ? wg2 : 0, wk = KG == 2 ? wg2 : 0;
     const int tw_shift = kStatic ? kTWS : g.tw_shift;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
         for (int m = 0; m < MO; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (t0 < t1) load_tile(t0);
+    if (g.probe) tprobe[1] = wall_clock64();
     for (int tile = t0; tile < t1; ++tile) {
         __syncthreads();
 #pragma unroll
@@ -349,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
         for (int i = 0; i < DITEMS; ++i)
             *reinterpret_cast<uint4*>(smem + ((DITEMS * RPP <= BM || r0 + i * RPP < BM) ? ddst0 + i * RPP * DYP : dummy)) = dreg[i];
         __syncthreads();
+        if (g.probe && tile == t0) tprobe[2] = wall_clock64();
         if (tile + 1 < t1) load_tile(tile + 1);  // in flight while the MFMAs below run
 #pragma unroll
         for (int ks = wk; ks < KS; ks += KG) {
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
         }
     }
 
+    if (g.probe) tprobe[3] = wall_clock64();
     if constexpr (KG == 2) {   // 1x1 kernels: the two K-groups of a cin slice meet in LDS
         f32x4* red = reinterpret_cast<f32x4*>(smem);
         __syncthreads();
@@ -408,6 +416,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
                     const int co = co0 + m * 16 + lq * 4 + r;
                     if (co < p.Cout) out[((size_t)co * NTAPS + t) * Cw + ci - cwb] = acc[tt][m][r];
                 }
+        }
+    }
+    if (g.probe) {
+        __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged
+        tprobe[4] = wall_clock64();
+        if (tid == 0) {
+            unsigned long long* o = g.probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            for (int i = 0; i < 5; ++i) o[i] = tprobe[i];
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[5] = hw; o[6] = xcc; o[7] = 0;
         }
     }
 }
@@ -473,8 +493,17 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     const int target = vs_option("wgrad_target");
     const double dw_bytes = (double)p.Cout * p.KH * p.KW * (p.cg ? 32 : Cin) * 4.0;
     // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
+    g.probe = nullptr;
     g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
+    g.ring = 0;
+    if (g.fast && vs_option("wgrad_ring") && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && (p.C0 % 32) == 0 && (p.C1 % 32) == 0) {
+        if (PT == 2) g.ring = 1;
+        else if (p.Hout == 8 && p.Wout == 8 && p.N % 2 == 0 && p.Cout >= 64) {   // 8 x 8 maps: two images per 128-pixel tile
+            g.ring = 2;
+            g.total_tiles = p.N / 2;
+        }
+    }
     if (g.fast) {
         WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);   // = MO
         if (p.cg) WO = 2;
@@ -528,10 +557,34 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     }
     WgradParams q = p;
     if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
-    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
+    WGeom gg = g;
+    gg.probe = vs_probe_buffer((size_t)g.ctiles * g.cchunks * g.nsplit);
+    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, gg);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
+}
+
+// the ring-staged, pipelined kernel (conv_wgrad_ring.h): stride-1 3x3 layers on 128-pixel tiles
+template <int MO, int TWS, int IMGS>
+int launch_ring_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = ring::conv_wgrad_ring_kernel<MO, TWS, IMGS, 2>;
+    constexpr size_t lds = ring::wgrad_ring_lds<MO, TWS, IMGS>();
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    WgradParams q = p;
+    if (g.nsplit == 1) q.partials = p.dw;
+    ring::WGeomR gr{};
+    gr.tiles_h = g.tiles_h; gr.tiles_w = g.tiles_w; gr.total_tiles = g.total_tiles; gr.cchunks = g.cchunks; gr.nsplit = g.nsplit;
+    gr.tw_magic = g.tw_magic; gr.th_magic = g.th_magic;
+    gr.probe = vs_probe_buffer((size_t)g.ctiles * g.cchunks * g.nsplit);
+    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, gr);
+    VS_LAUNCH_CHECK();
+    if (g.nsplit == 1) return VS_OK;
+    return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * 9 * (p.C0 + p.C1), g.nsplit, s);
 }
 
 template <typename T, int WO, int NTAPS, int STRIDE, int PT, int DIL = 1>
@@ -551,11 +604,7 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
-    const size_t n = (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1);
-    const int nparts = g.nsplit;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, p.partials, p.dw, n, nparts);
-    VS_LAUNCH_CHECK();
-    return VS_OK;
+    return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
 template <typename T>
@@ -591,6 +640,12 @@ int dispatch(const WgradParams& p, hipStream_t s) {
                 if (WO == 2) return launch_fast<2, 9, 1, 1, 4>(p, g, s);
                 return VS_ERR_UNSUPPORTED;
             }
+            if (g.ring == 1) {        // 16 x 8 tiles
+                if (WO == 4) return launch_ring_wgrad<4, 4, 1>(p, g, s);
+                if (WO == 2) return launch_ring_wgrad<2, 4, 1>(p, g, s);
+                if (WO == 1) return launch_ring_wgrad<1, 4, 1>(p, g, s);
+            }
+            if (g.ring == 2 && WO == 4) return launch_ring_wgrad<4, 3, 2>(p, g, s);   // two 8 x 8 images per tile
 #define VS_WGF_CASE(mo, t)                                                                \
     if (WO == mo && nt == t) {                                                            \
         if (p.stride == 2) return launch_fast<mo, t, 2, 1>(p, g, s);                      \
@@ -623,8 +678,54 @@ int dispatch(const WgradParams& p, hipStream_t s) {
 
 }  // namespace
 
+// dw = sum over the split-K slabs, 16 bytes per lane: thread (j, g) of a block sums slabs g, g + G, g + 2 G, .. of four
+// consecutive outputs (two accumulators, four loads in flight), the G groups of an output meet in LDS in a fixed order -
+// bitwise reproducible.  G widens the grid for the small tensors (64 x 9 x 64 outputs summed over 128 slabs).
+template <int G>
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restrict__ partials, float4* __restrict__ dw, size_t n4, int nparts) {
+    constexpr int J = 256 / G;
+    __shared__ float4 red[G][J];
+    const int j = threadIdx.x % J, g = threadIdx.x / J;
+    const size_t i = (size_t)blockIdx.x * J + j;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i < n4) {
+        for (int k = g; k < nparts; k += 4 * G) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k + u * G < nparts) ? partials[(size_t)(k + u * G) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s0.x += v[0].x; s0.y += v[0].y; s0.z += v[0].z; s0.w += v[0].w;
+            s1.x += v[1].x; s1.y += v[1].y; s1.z += v[1].z; s1.w += v[1].w;
+            s0.x += v[2].x; s0.y += v[2].y; s0.z += v[2].z; s0.w += v[2].w;
+            s1.x += v[3].x; s1.y += v[3].y; s1.z += v[3].z; s1.w += v[3].w;
+        }
+    }
+    const float4 t = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    if constexpr (G == 1) {
+        if (i < n4) dw[i] = t;
+    } else {
+        red[g][j] = t;
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            float4 a = red[0][j];
+#pragma unroll
+            for (int q = 1; q < G; ++q) { a.x += red[q][j].x; a.y += red[q][j].y; a.z += red[q][j].z; a.w += red[q][j].w; }
+            dw[i] = a;
+        }
+    }
+}
+
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, partials, dw, n, nparts);
+    if ((n & 3) || ((uintptr_t)partials & 15) || ((uintptr_t)dw & 15)) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, partials, dw, n, nparts);
+    } else {
+        const size_t n4 = n / 4;
+        if (n4 >= 131072 || nparts < 8)
+            hipLaunchKernelGGL(slab_reduce4_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);
+        else if (n4 >= 32768 || nparts < 32)
+            hipLaunchKernelGGL(slab_reduce4_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);
+        else
+            hipLaunchKernelGGL(slab_reduce4_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);
+    }
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -421,7 +421,7 @@ class VolSegUnet(nn.Module):
         plan = self._plan(n, h, w, True)
         self._prepare(plan, True)
         is_f32 = targets.dtype == torch.float32
-        key = (n, h, w, need_enc, is_f32)
+        key = (n, h, w, need_enc, is_f32, id(opt), opt.exp_avg.data_ptr())
         st = self._steps.get(key)
         if st is not None and st["plan"] is not plan:      # the plan was rebuilt (larger batch): recorded pointers are stale
             self._drop_steps()
@@ -713,6 +713,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model = model
         self._stepped_in_backward = False
         model._fused_optimizer = self if fuse_step_into_backward else None
+        # recorded steps (fused_train_step) bake in the moment buffers and hyper-parameter block of the optimiser they were
+        # recorded with: a new optimiser on the same model must never replay them
+        model._drop_steps()
         self.exp_avg = torch.zeros_like(model._flat)
         self.exp_avg_sq = torch.zeros_like(model._flat)
         self.step_count = 0
@@ -791,7 +794,13 @@ class FusedAdamW(torch.optim.Optimizer):
         ``_load_in_weights(optimizer=True)`` (vol_seg_2d_trainer.py:276-296)."""
         m = self.model
         state = {}
+        params = list(m.parameters())
         for i, (name, shape, kind, off) in enumerate(self._param_table()):
+            # torch.optim.AdamW holds no state for a parameter that never received a gradient (the frozen encoder
+            # convolutions of the reference's first phase, tensors the forward never reads): no entry, so that a later
+            # unfreeze starts its bias correction from step 1 of THAT parameter on the reference side
+            if self.step_count == 0 or (i < len(params) and not params[i].requires_grad) or name.startswith(m.UNUSED_PREFIXES):
+                continue
             state[i] = {"step": torch.tensor(float(self.step_count)),
                         "exp_avg": m._view_of(self.exp_avg, shape, kind, off).clone(memory_format=torch.contiguous_format),
                         "exp_avg_sq": m._view_of(self.exp_avg_sq, shape, kind, off).clone(memory_format=torch.contiguous_format)}
@@ -800,7 +809,7 @@ class FusedAdamW(torch.optim.Optimizer):
             d = {k: v for k, v in g.items() if k != "params"}
             d.setdefault("amsgrad", False); d.setdefault("maximize", False); d.setdefault("foreach", None)
             d.setdefault("capturable", False); d.setdefault("differentiable", False); d.setdefault("fused", None)
-            d["params"] = list(range(len(state)))
+            d["params"] = list(range(len(self._param_table())))
             groups.append(d)
         return {"state": state, "param_groups": groups}
 

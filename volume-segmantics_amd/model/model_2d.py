@@ -45,7 +45,7 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
         # same encoder can be supplied instead (env VOLSEG_ENCODER_WEIGHTS; VOLSEG_RESNET34_WEIGHTS for resnet34)
         path = os.environ.get("VOLSEG_ENCODER_WEIGHTS") or (os.environ.get("VOLSEG_RESNET34_WEIGHTS") if encoder == "resnet34" else None)
         if path and Path(path).exists():
-            load_torchvision_resnet34(model, torch.load(path, map_location="cpu"))
+            load_pretrained_encoder(model, torch.load(path, map_location="cpu"))
             logging.info(f"Loaded {weights} encoder weights from {path}")
         elif struct.get("allow_random_encoder"):
             logging.warning(f"encoder_weights={weights!r} requested but no local weights available "
@@ -61,18 +61,33 @@ def create_model_on_device(device_num: int, model_struc_dict: dict) -> torch.nn.
     return model
 
 
-def load_torchvision_resnet34(model: VolSegUnet, sd: dict) -> None:
-    """Copy a torchvision resnet34 state dict into the encoder; the 3-channel stem is summed over its input
-    channels exactly as smp's patch_first_conv does for in_channels=1."""
+def load_pretrained_encoder(model: VolSegUnet, sd: dict) -> None:
+    """Copy an encoder state dict (torchvision ResNet / ResNeXt, efficientnet-pytorch, timm ResNeSt - the packages smp
+    takes its ImageNet weights from) into ``model.encoder``.  smp's ``patch_first_conv`` rule for ``in_channels=1``
+    (segmentation_models_pytorch/encoders/_utils.py, called from model_2d.py:15-16 of the reference through
+    ``smp.Unet(in_channels=1, encoder_weights="imagenet")``) is applied to whichever tensor IS the encoder's first
+    convolution - ``conv1.weight`` (ResNets), ``_conv_stem.weight`` (EfficientNet), ``conv1.0.weight`` (ResNeSt's deep stem):
+    a 3-channel kernel where this model holds a 1-channel one is summed over its input channels.  Keys may carry an
+    ``encoder.`` prefix (an smp checkpoint) or not (the upstream package's own file); classifier heads are skipped."""
     own = model.state_dict()
+    loaded = 0
     for k, v in sd.items():
-        name = "encoder." + k
+        name = k if k.startswith("encoder.") else "encoder." + k
         if name not in own:
-            continue  # fc.*
-        if k == "conv1.weight" and v.shape[1] == 3:
-            v = v.sum(1, keepdim=True)
+            continue  # fc.* / _fc.* / classifier heads
+        tgt = own[name]
+        if v.ndim == 4 and tgt.ndim == 4 and v.shape[1] == 3 and tgt.shape[1] == 1 and v.shape[0] == tgt.shape[0] and v.shape[2:] == tgt.shape[2:]:
+            v = v.sum(1, keepdim=True)          # patch_first_conv: new_in_channels == 1
+        if tuple(v.shape) != tuple(tgt.shape):
+            raise ValueError(f"pretrained encoder tensor {k}: shape {tuple(v.shape)} does not fit {name} {tuple(tgt.shape)}")
         own[name] = v
+        loaded += 1
+    if not loaded:
+        raise ValueError("the state dict holds no tensor of this encoder (wrong encoder_name for the weights file?)")
     model.load_state_dict(own)
+
+
+load_torchvision_resnet34 = load_pretrained_encoder   # earlier name
 
 
 def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int = 0) -> Tuple[torch.nn.Module, int, dict]:

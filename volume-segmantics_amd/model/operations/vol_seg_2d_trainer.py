@@ -56,8 +56,18 @@ class VolSeg2dTrainer:
         self.lr_find_epochs = settings.lr_find_epochs
         self.lr_reduce_factor = settings.lr_reduce_factor
         # one GPU per rank (LOCAL_RANK); VOLSEG_DP_SINGLE_DEVICE=1 keeps every rank on settings.cuda_device (rehearsals on one GPU)
-        self.model_device_num = (local_rank if self.world > 1 and not os.environ.get("VOLSEG_DP_SINGLE_DEVICE")
-                                 else int(settings.cuda_device))
+        if self.world > 1 and not os.environ.get("VOLSEG_DP_SINGLE_DEVICE"):
+            if "LOCAL_RANK" in os.environ:
+                self.model_device_num = local_rank
+            elif torch.cuda.is_available():
+                # the caller initialised the process group itself (no torchrun environment): its rank's current device,
+                # never "every rank on cuda:0"
+                self.model_device_num = torch.cuda.current_device()
+            else:
+                raise RuntimeError("data-parallel training without LOCAL_RANK: select the rank's device (torch.cuda.set_device) "
+                                   "before constructing VolSeg2dTrainer, or launch with torchrun")
+        else:
+            self.model_device_num = int(settings.cuda_device)
         self.patience = settings.patience
         self.loss_criterion = self._get_loss_criterion()
         self.eval_metric = self._get_eval_metric()
@@ -335,7 +345,10 @@ class VolSeg2dTrainer:
         """Data / ground truth / prediction panels for the first validation batch (:485-535)."""
         model_path = Path(model_path)
         self.model.eval()
-        batch = next(iter(self.validation_loader))
+        # (a rank whose share of a partial validation batch is empty gets None from the loader: the first real batch)
+        batch = next((b for b in self.validation_loader if b is not None), None)
+        if batch is None:
+            return
         with torch.no_grad():
             inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no)
             labels = torch.argmax(torch.softmax(self.model(inputs), dim=1), dim=1)
