@@ -62,8 +62,24 @@ def _worker(rank, world, port, out_dir):
     m.dp_group = dist.group.WORLD
     m._flat_grad = torch.full_like(m._flat, float(rank + 1))
     m._allreduce_grads()
+    gmean = m._flat_grad[:5].numpy().copy()
+    # the same averaging with the gradients travelling as bf16 (dp_grad_dtype): bounded by bf16's rounding of the inputs
+    # and of the sum, i.e. (world + 1) half-ulps of 2^-8 relative to the largest contribution
+    gen = torch.Generator().manual_seed(1000 + rank)
+    grads = torch.randn(4096, generator=gen) * torch.logspace(-6, 0, 4096)
+    m._flat_grad = m._flat.clone(); m._flat_grad[:4096] = grads
+    m._allreduce_grads()
+    exact = m._flat_grad[:4096].clone()
+    m._flat_grad[:4096] = grads
+    m.dp_grad_dtype = torch.bfloat16
+    m._allreduce_grads()
+    low = m._flat_grad[:4096].clone()
+    m.dp_grad_dtype = torch.float32
+    absmax = grads.abs().clone()
+    dist.all_reduce(absmax, op=dist.ReduceOp.MAX)
     np.savez(Path(out_dir) / f"r{rank}.npz", l12=l12, p12=p12, oh3=oh3, l1=l1, p1=p1,
-             shares=np.array([shares[d] for d in sorted(shares)]), gmean=m._flat_grad[:5].numpy())
+             shares=np.array([shares[d] for d in sorted(shares)]), gmean=gmean, g_exact=exact.numpy(), g_low=low.numpy(),
+             g_absmax=absmax.numpy())
     dist.destroy_process_group()
 
 
@@ -96,6 +112,12 @@ def test_sharded_prediction_and_grad_allreduce(tmp_path, world):
         assert np.array_equal(r["oh3"], ref_oh)
         assert np.array_equal(r["l1"], ref_l1) and np.array_equal(r["p1"].view(np.uint16), ref_p1.view(np.uint16))
         assert np.allclose(r["gmean"], (world + 1) / 2)
+        # bf16 transport of the gradient all-reduce: each contribution is rounded to bf16 (relative 2^-8) and so is every partial
+        # sum of the ring; the mean stays within world x 2^-8 of the largest contribution (the test allows twice that) -
+        # against fp32's 2^-24 - and is identical on every rank
+        assert np.all(np.abs(r["g_low"] - r["g_exact"]) <= 2 * world * 2.0 ** -8 * r["g_absmax"] + 1e-30)
+        assert np.abs(r["g_low"] - r["g_exact"]).max() <= 2.0 ** -6 * np.abs(r["g_exact"]).max()
+        assert np.abs(r["g_low"] - r["g_exact"]).max() > 0 and np.array_equal(r["g_low"], rs[0]["g_low"])
     # shares are disjoint and cover every direction's stack
     depths = [29, 32, 40] * 4
     depths[3:6] = [32, 29, 40]; depths[9:12] = [32, 29, 40]   # rot90 / rot270 volumes have shape (Y, Z, X)

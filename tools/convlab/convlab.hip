@@ -48,6 +48,12 @@ __global__ void ref_conv(const uint16_t* s0, const uint16_t* s1, const uint16_t*
     y[idx] = a;
 }
 
+// helpers of the chain experiments: a streaming rewrite of a tensor (y = x, 16 B per lane) and a one-block no-op
+__global__ void copy16_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+__global__ void tiny_kernel(int* p) { if (threadIdx.x == 999) *p = 1; }
+
 struct Shape { const char* name; int N, H, C0, C1, up0, Cout; };
 
 // mean duration (us) of the four phases between the five 100 MHz stamps every workgroup left in a probe buffer
@@ -86,7 +92,7 @@ static bool ok_any(const ConvParams&) { return true; }
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 30;
     const int rounds = argc > 2 ? atoi(argv[2]) : 3;
-    const bool do_probe = argc > 3 && atoi(argv[3]) != 0, do_wgrad = argc > 4 && atoi(argv[4]) != 0, do_conv = !(argc > 5 && atoi(argv[5]) == 0);
+    const bool do_probe = argc > 3 && atoi(argv[3]) != 0, do_wgrad = argc > 4 && atoi(argv[4]) != 0, do_conv = !(argc > 5 && atoi(argv[5]) == 0), do_chain = argc > 6 && atoi(argv[6]) != 0, do_bn = argc > 7 && atoi(argv[7]) != 0;
     std::vector<Shape> shapes = {
         {"layer1 64->64 @64", 32, 64, 64, 0, 0, 64},
         {"layer2 128->128 @32", 32, 32, 128, 0, 0, 128},
@@ -194,6 +200,81 @@ int main(int argc, char** argv) {
                 print_probe(vars[v].name.c_str(), pb, cap);
             }
             CK(hipFree(pb));
+        }
+        if (do_chain && sh.C1 == 0 && sh.up0 == 0 && sh.C0 == sh.Cout) {
+            // how much of an in-step convolution's time is "cold start"?  (a) the same launch back to back; (b) ping-pong
+            // x -> y -> x (every input freshly written by the previous launch, same code); (c) a one-block kernel between
+            // launches (another code object in between, data untouched); (d) a streaming rewrite of the input between
+            // launches (other code AND a freshly written input - what the training step does)
+            uint16_t* dx2; CK(hipMalloc(&dx2, n0 * 2));
+            int* dflag; CK(hipMalloc(&dflag, 4));
+            for (size_t v = 0; v < vars.size(); ++v) {
+                if (errs[v] < 0) continue;
+                ConvParams pa = p, pb = p;
+                pb.src0 = dy; pb.out = d0;
+                auto timeit = [&](auto&& body) {
+                    for (int i = 0; i < 3; ++i) body();
+                    CK(hipEventRecord(e0, st));
+                    for (int i = 0; i < reps; ++i) body();
+                    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms * 1e3f / reps;
+                };
+                const float ta = timeit([&] { vars[v].fn(pa, st); });
+                const float tb = timeit([&] { vars[v].fn(pa, st); vars[v].fn(pb, st); }) / 2;
+                const float tt = timeit([&] { hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, st, dflag); });
+                const float tc = timeit([&] { vars[v].fn(pa, st); hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, st, dflag); }) - tt;
+                const float tcp = timeit([&] { hipLaunchKernelGGL(copy16_kernel, dim3(2048), dim3(256), 0, st, (const uint4*)dx2, (uint4*)d0, n0 / 8); });
+                const float td = timeit([&] { vars[v].fn(pa, st); hipLaunchKernelGGL(copy16_kernel, dim3(2048), dim3(256), 0, st, (const uint4*)dx2, (uint4*)d0, n0 / 8); }) - tcp;
+                // (e) everything cold: a 1 GB streaming rewrite of an unrelated buffer between launches (L2 and the Infinity
+                // Cache hold neither the input nor the weights); timed with events around the convolution alone
+                float te = 0.f;
+                {
+                    static uint4* big = nullptr; const size_t bign = (size_t)1 << 26;   // 64 M x 16 B = 1 GiB
+                    if (!big) CK(hipMalloc(&big, bign * 16));
+                    const int nrep = 8;
+                    for (int i = 0; i < nrep + 1; ++i) {
+                        hipLaunchKernelGGL(copy16_kernel, dim3(4096), dim3(256), 0, st, (const uint4*)big + bign / 2, big, bign / 2);
+                        CK(hipEventRecord(e0, st));
+                        vars[v].fn(pa, st);
+                        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i) te += ms * 1e3f / nrep;
+                    }
+                }
+                printf("   [chain] %-34s cold (1 GB streamed between) %6.2f |", vars[v].name.c_str(), te);
+                printf("   [chain] %-34s back-to-back %6.2f | ping-pong %6.2f | + tiny kernel between %6.2f (tiny alone %.2f) | + input rewritten between %6.2f (copy alone %.2f) us\n",
+                       vars[v].name.c_str(), ta, tb, tc, tt, td, tcp);
+            }
+            CK(hipMemcpy(d0, h0.data(), n0 * 2, hipMemcpyHostToDevice));
+            CK(hipFree(dx2)); CK(hipFree(dflag));
+        }
+        if (do_bn && sh.C1 == 0 && sh.up0 == 0) {   // BatchNorm backward on this layer's output tensor: three launches vs one
+            const int c = sh.Cout; const long rows = (long)sh.N * sh.H * sh.H;
+            uint16_t *bdy, *bz, *bdx; float *bst, *bws;
+            CK(hipMalloc(&bdy, ny * 2)); CK(hipMalloc(&bz, ny * 2)); CK(hipMalloc(&bdx, ny * 2));
+            CK(hipMalloc(&bst, 6 * c * 4)); const size_t wsb = vs_bn_workspace(rows, c); CK(hipMalloc(&bws, wsb));
+            CK(hipMemcpy(bz, dy, ny * 2, hipMemcpyDeviceToDevice)); CK(hipMemcpy(bdy, dy, ny * 2, hipMemcpyDeviceToDevice));
+            std::vector<float> stv(6 * c, 0.f); for (int i = 0; i < c; ++i) { stv[c + i] = 1.f; stv[2 * c + i] = 1.f; stv[3 * c + i] = 0.1f; }
+            CK(hipMemcpy(bst, stv.data(), 6 * c * 4, hipMemcpyHostToDevice));
+            auto run = [&] { return vs_bn_bwd_recompute(VS_BF16, bdy, nullptr, bz, bst, bst + c, bst + 2 * c, bst + 3 * c, 1, bdx, nullptr, bst + 4 * c, bst + 5 * c, rows, c, bws, wsb, st); };
+            auto timeit = [&] { for (int i = 0; i < 3; ++i) run(); CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) run(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms * 1e3f / reps; };
+            vs_set_option("bn_bwd_fused", 0);
+            const float t3 = timeit();
+            std::vector<uint16_t> r0(ny), r1(ny); CK(hipMemcpy(r0.data(), bdx, ny * 2, hipMemcpyDeviceToHost));
+            vs_set_option("bn_bwd_fused", 1);
+            printf("   [bn_bwd] %.1f MB tensors, c = %d: three launches %6.2f us |", ny * 2 / 1e6, c, t3);
+            for (int blocks : {0, 32, 64, 128, 256}) {
+                if (blocks > 128 && (2 * c / 4) * 1 > 256) continue;
+                vs_set_option("bn_fused_blocks", blocks);
+                vs_set_option("bn_fused_dbg", 0); const float tf = timeit();
+                if (blocks == 0) { CK(hipMemcpy(r1.data(), bdx, ny * 2, hipMemcpyDeviceToHost)); size_t bad = 0; for (size_t i = 0; i < ny; ++i) bad += r0[i] != r1[i]; printf(" (fused vs plain: %zu of %zu bf16 values differ)", bad, ny); }
+                vs_set_option("bn_fused_dbg", 1); const float tnb = timeit();
+                vs_set_option("bn_fused_dbg", 3); const float ts1 = timeit();
+                printf(" blocks %3d: %6.2f (no wait %6.2f, sweep 1 + sums only %6.2f) |", blocks, tf, tnb, ts1);
+            }
+            printf("\n");
+            vs_set_option("bn_fused_blocks", 0); vs_set_option("bn_fused_dbg", 0);
+            CK(hipFree(bdy)); CK(hipFree(bz)); CK(hipFree(bdx)); CK(hipFree(bst)); CK(hipFree(bws));
         }
         if (do_wgrad && sh.up0 != 2) {   // the library's weight gradient on the same layer (dy = the reference output, rounded)
             vs_conv_desc d{};

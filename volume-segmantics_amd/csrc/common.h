@@ -178,6 +178,12 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
 
+// BatchNorm backward (dx, dres, dgamma, dbeta): three launches, or ONE with a grid barrier for tensors of a few MB (norm.hip).
+// ctl: 16 zeroed bytes of barrier counters that re-arm themselves (null: the end of `workspace`, zeroed by a memset first)
+int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
+                    size_t workspace_bytes, unsigned* ctl, hipStream_t s);
+
 int launch_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, hipStream_t stream);
 
 struct WgradParams {

@@ -738,8 +738,9 @@ static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (p.Hout < 16 || p.Wout < 16) return 0;
     const long tiles = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
     const long w64 = tiles * cdiv(p.Cout, 64), w32 = tiles * cdiv(p.Cout, 32);
-    if (p.Cout >= 64 && w64 >= 224 && w64 <= 1024 && (!p.out1 || p.split_c % 64 == 0)) return 1;
-    if (p.Cout >= 32 && w32 >= 128 && w32 <= 1024) return 2;
+    const long maxw = vs_option("conv_ring_max_wgs");
+    if (vs_option("conv_ring") == 1 && p.Cout >= 64 && w64 >= 224 && w64 <= maxw && (!p.out1 || p.split_c % 64 == 0)) return 1;
+    if (p.Cout >= 32 && w32 >= 128 && w32 <= maxw) return 2;
     return 0;
 }
 

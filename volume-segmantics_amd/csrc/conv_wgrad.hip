@@ -490,7 +490,6 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;   // unused when the divisor is 1
     g.th_magic = 0xffffffffu / (unsigned)g.tiles_h + 1u;
-    const int target = vs_option("wgrad_target");
     const double dw_bytes = (double)p.Cout * p.KH * p.KW * (p.cg ? 32 : Cin) * 4.0;
     // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
     g.probe = nullptr;
@@ -504,6 +503,10 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
             g.total_tiles = p.N / 2;
         }
     }
+    // K-split target (workgroups per launch).  The ring kernel is sized to half-fill the chip or less: the weight gradients
+    // run on the side stream beside the caller's latency-bound chain, and fewer, longer-running workgroups leave CUs to it
+    // (measured on the batch-32 step: 96 -> 4.68 ms, 256 -> 4.72, 512 -> 5.1; the plain kernel needs its 256: 4.91 at 128)
+    const int target = vs_option(g.ring ? "wgrad_target" : "wgrad_target_plain");
     if (g.fast) {
         WO = p.Cout >= 64 ? 4 : (p.Cout >= 32 ? 2 : 1);   // = MO
         if (p.cg) WO = 2;

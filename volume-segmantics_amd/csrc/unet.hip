@@ -194,7 +194,7 @@ struct vs_unet {
     // workspace regions (bytes)
     size_t off_bnws = 0, bnws_bytes = 0, off_wgws = 0, wgws_bytes = 0, off_headdw = 0, off_dyh = 0, off_dup = 0,
            off_zs = 0, off_idx = 0;
-    size_t ws_eval = 0, ws_train = 0, off_logits = 0;
+    size_t ws_eval = 0, ws_train = 0, off_logits = 0, off_bncnt = 0;
     int last_n = 0;
     std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
@@ -213,10 +213,11 @@ struct vs_unet {
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
     static constexpr int kSide = 2;
     hipStream_t side[kSide] = {nullptr, nullptr};
-    std::vector<hipEvent_t> fork_events;
+    std::vector<hipEvent_t> fork_events, pair_events;
     hipEvent_t join_event[kSide] = {nullptr, nullptr};
     ~vs_unet() {
         for (auto e : fork_events) (void)hipEventDestroy(e);
+        for (auto e : pair_events) (void)hipEventDestroy(e);
         for (int i = 0; i < kSide; ++i) {
             if (join_event[i]) (void)hipEventDestroy(join_event[i]);
             if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -1083,6 +1084,7 @@ size_t plan_workspace(vs_unet* net) {
     for (auto& u : net->units) cmax = std::max(cmax, u.cout);
     net->bnws_bytes = 4 * vs_bn_workspace(0, cmax);  // also receives the conv epilogue's per-tile statistics
     net->off_bnws = take(net->bnws_bytes);
+    net->off_bncnt = take(256);                      // grid-barrier counters of the one-launch BatchNorm backward (zeroed by vs_unet_prepare)
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
         const size_t bytes = N * a.c * a.h * a.w * esz;
@@ -1310,6 +1312,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
     VS_REQUIRE(net && params && bnstate && workspace, "unet_prepare: null pointer");
     Ctx c{net, (char*)workspace, params, const_cast<float*>(bnstate), (hipStream_t)stream, 0};
     ProfScope prof(PK_PREPARE, 0, (double)net->layout.n_params * (4 + net->esz * (training ? 2 : 1)), c.s);
+    VS_CHECK_HIP(hipMemsetAsync(c.ws + net->off_bncnt, 0, 256, c.s));   // (the counters re-arm themselves; this covers a fresh workspace)
     {   // every conv layer's low-precision copy and flipped/transposed dgrad copy in one launch
         long w_off[64], wc_off[64], wt_off[64];
         int cout[64], taps[64], cin[64], cpad[64], cgs[64], nl = 0;
@@ -1896,7 +1899,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     }
     if (do_main && unit_hi == (int)net->units.size()) net->bwd_stat_rows.assign(net->acts.size(), 0);
     VS_REQUIRE(net->written.size() == net->acts.size(), "unet_backward_range: ranges must start at the last unit");
-    VS_REQUIRE(role == ROLE_BOTH || !vs_option("fuse_bn_bwd"), "unet_backward: split roles do not support fuse_bn_bwd");
     std::vector<char>& written = net->written;
     float* wgws = (float*)(c.ws + net->off_wgws);
     const int n_side = role == ROLE_BOTH ? vs_option("side_stream") : 0;  // 0 = everything in order on the given stream
@@ -1956,6 +1958,20 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     // Weight-gradient work of one unit, queued on the side stream (after a fork event that covers its dz).
     struct SideItem { int ui; const void* dzp; int dz_c; };
     std::vector<SideItem> pending;
+    // pair_join: the caller's stream waits for every unit's weight gradient before it goes on (the data gradient and the
+    // weight gradient of a unit - both MFMA-bound, both reading dz - run side by side; the latency-bound BatchNorm sweeps
+    // between them run alone).  The optimiser work stays behind the join.
+    const bool pair_join = use_side && vs_option("wgrad_pair_join") == 1;
+    const bool pair_sched = use_side && vs_option("wgrad_pair_join") == 2;
+    int last_pair = -1;
+    bool defer_group_update = pair_join || pair_sched;
+    if (pair_join || pair_sched) {
+        while (net->pair_events.size() < net->units.size()) {
+            hipEvent_t e;
+            VS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            net->pair_events.push_back(e);
+        }
+    }
     auto side_wgrad = [&](const SideItem& it) -> int {
         const int ui = it.ui;
         const Unit& u = net->units[ui];
@@ -1971,7 +1987,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
             }
-            return opt ? group_update(ui) : VS_OK;
+            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
         }
         if (u.kind == U_DWCONV2) {
             ProfScope prof(PK_CONV_WGRAD, want_w ? 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k : 0, 0, ws_stream);
@@ -1981,13 +1997,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, (size_t)u.cout * u.k * u.k * sizeof(float), ws_stream));
             }
-            return opt ? group_update(ui) : VS_OK;
+            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
         }
         if (u.kind == U_DWCONV) {
             ProfScope prof(PK_CONV_WGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, ws_stream);
             if ((rc = vs_dwconv3x3_wgrad(dt, c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.dil, wgws, net->wgws_bytes,
                                          (void*)ws_stream))) return rc;
-            return opt ? group_update(ui) : VS_OK;
+            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
         }
         if (want_w) {
             ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
@@ -2023,7 +2039,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
                                         (size_t)u.cout * u.k * u.k * (u.cg ? u.cg : (u.cin0 + u.cin1) / (u.g2 ? 2 : 1)) * sizeof(float), ws_stream));
         }
-        return opt ? group_update(ui) : VS_OK;
+        return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
     };
     const int fork_every = std::max(1, vs_option("fork_every"));
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
@@ -2299,10 +2315,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
             const bool recompute_mask = vs_option("recompute_mask") && u.relu && u.res < 0;  // mask from x: two tensor reads fewer
             ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, ((u.relu && !recompute_mask) ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
-            if ((rc = vs_bn_bwd_recompute(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
-                                          c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
-                                          grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
-                                          (float*)(c.ws + net->off_bnws), net->bnws_bytes, stream))) return rc;
+            if ((rc = bn_bwd_dispatch(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
+                                      c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
+                                      grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
+                                      (float*)(c.ws + net->off_bnws), net->bnws_bytes, (unsigned*)(c.ws + net->off_bncnt), c.s))) return rc;
             }
             dzp = c.dz(u.out); dz_c = u.cout;
             if (u.kind == U_CONV && u.bias_idx >= 0) {   // a biased convolution in front of BatchNorm (smp's ConvBnRelu): column sums of dz
@@ -2321,7 +2337,12 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // weight-gradient work of up to `fork_every` consecutive units ----
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
-        if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
+        // wgrad_sched: the weight gradient of a unit never runs beside a data gradient (both MFMA-bound) - it is released
+        // BEHIND this unit's data gradient and the caller's stream waits for it in front of the NEXT data gradient, so it
+        // shares the chip with the (memory-bound) BatchNorm sweeps of the next unit only
+        const bool sched = pair_sched && role == ROLE_BOTH;
+        if (sched && do_main && last_pair >= 0) { VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->pair_events[last_pair], 0)); last_pair = -1; }
+        if (!sched && flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
         if (u.colr && do_main) {   // data gradient of the 1x1 form = the input gradient's column form; its adjoint scatter onto the map
             ConvParams p{};
             p.src0 = dzp; p.C0 = u.cout; p.N = n; p.Hin = p.Hout = u.hin; p.Win = p.Wout = u.win; p.stride = 1; p.pad = 0; p.KH = p.KW = 1;
@@ -2416,11 +2437,26 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             written[u.src0] = 1;
         }
         }
+        if (sched && flush && do_main && (rc = fork_mark(ui))) return rc;   // behind the data gradient
         if (flush) {
             if (do_side) {
                 if ((rc = fork_wait(ui))) return rc;
                 for (const SideItem& it : pending)
                     if ((rc = side_wgrad(it))) return rc;
+                if (sched) {
+                    VS_CHECK_HIP(hipEventRecord(net->pair_events[ui], ws_stream));
+                    last_pair = ui;
+                    if (opt)
+                        for (const SideItem& it : pending)
+                            if ((rc = group_update(it.ui))) return rc;
+                }
+                if (pair_join) {
+                    VS_CHECK_HIP(hipEventRecord(net->pair_events[ui], ws_stream));
+                    VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->pair_events[ui], 0));
+                    if (opt)
+                        for (const SideItem& it : pending)
+                            if ((rc = group_update(it.ui))) return rc;
+                }
             }
             pending.clear();
             prof_set_tag(ui);

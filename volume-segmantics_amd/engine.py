@@ -628,6 +628,12 @@ class VolSegUnet(nn.Module):
             self._dp_side = torch.cuda.Stream(device=self.device)
         side = self._dp_side
         comm = vdist.vs_comm(self.device)     # VOLSEG_COMM=rccl: the C ABI's communicator, stream-ordered on the side stream
+        low = None
+        if self.dp_grad_dtype != torch.float32:
+            comm = None                        # (the C ABI's all-reduce is fp32)
+            if plan.get("grad_low") is None or plan["grad_low"].dtype != self.dp_grad_dtype:
+                plan["grad_low"] = torch.empty(self._flat_grad.numel(), dtype=self.dp_grad_dtype, device=self._flat_grad.device)
+            low = plan["grad_low"]
         for lo, hi, a, b in plan["buckets"]:
             check(lib.vs_unet_backward_range(plan["handle"], ptr(self._flat), ptr(x), ptr(dlogits), n, 1 if need_enc else 0,
                                              ptr(self._flat_grad), ptr(plan["ws"]), _lib.stream_ptr(), lo, hi))
@@ -637,12 +643,20 @@ class VolSegUnet(nn.Module):
                     with torch.cuda.stream(side):
                         comm.allreduce_sum_(self._flat_grad[a:b])
                     handles.append((None, lo, hi, a, b))
+                elif low is not None:
+                    # reduced-precision transport (dp_grad_dtype = bfloat16): the bucket travels as bf16 - half the bytes
+                    # through the per-link-bound xGMI ring - and comes back into the fp32 buffer; master gradients,
+                    # AdamW and the weights stay fp32
+                    low[a:b].copy_(self._flat_grad[a:b])
+                    handles.append((dist.all_reduce(low[a:b], group=self.dp_group, async_op=True), lo, hi, a, b))
                 else:
                     handles.append((dist.all_reduce(self._flat_grad[a:b], group=self.dp_group, async_op=True), lo, hi, a, b))
         if fused is None:
             for h, lo, hi, a, b in handles:
                 if h is not None:
                     h.wait()
+                if low is not None:
+                    self._flat_grad[a:b].copy_(low[a:b])
             main.wait_stream(side)
             self._flat_grad.div_(world)
             return
@@ -652,6 +666,8 @@ class VolSegUnet(nn.Module):
             for h, lo, hi, a, b in handles:
                 if h is not None:
                     h.wait()                               # this (side) stream waits for the bucket's all-reduce
+                if low is not None:
+                    self._flat_grad[a:b].copy_(low[a:b])
                 self._flat_grad[a:b].div_(world)
                 check(lib.vs_adamw_step(ptr(self._flat) + 4 * a, ptr(self._flat_grad) + 4 * a, ptr(fused.exp_avg) + 4 * a,
                                         ptr(fused.exp_avg_sq) + 4 * a, (ptr(mask) + a) if mask is not None else None, b - a,
