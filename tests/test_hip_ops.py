@@ -330,6 +330,46 @@ def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 512, 16, 2), (2, 8, 8, 1024, 32, 2), (1, 16, 24, 1024, 32, 4), (2, 32, 32, 512, 16, 2),
+                                   (3, 20, 12, 64, 8, 2), (8, 32, 32, 1024, 32, 2)])
+def test_grouped_dilated_conv_fwd_dgrad_wgrad(code, shape):
+    """nn.Conv2d(c, c, 3, 1, padding=d, dilation=d, groups=32): what smp's replace_strides_with_dilation makes of the 3x3
+    convolutions of resnext50_32x4d's layer3 / layer4 under DeepLabV3 (rates 2 and 4), DeepLabV3+ and PAN (layer4, rate 2) -
+    forward, data gradient and weight gradient against torch CPU (the super-group kernels with the dilated patch)."""
+    L = lib()
+    n, h, w, c, cg, dil = shape
+    groups = c // cg
+    g = torch.Generator().manual_seed(13)
+    x = rounded(torch.randn(n, c, h, w, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(c, cg, 3, 3, generator=g) / (cg * 9) ** 0.5, code).requires_grad_()
+    y = F.conv2d(x, wt, stride=1, padding=dil, dilation=dil, groups=groups)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    w32 = wt.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    wc = torch.full((c, 9, 32), float("nan"), device=DEV, dtype=tdtype(code))
+    wtr = torch.full((c, 9, 32), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_weights_prepare_grouped(code, L.ptr(w32), L.ptr(wc), L.ptr(wtr), c, 9, cg, None))
+    d = conv_desc(L, code, n, h, w, c, c, 3, 1, dil, groups=groups, dilation=dil)
+    xd = to_nhwc(x.detach(), code)
+    yd = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(xd), None, L.ptr(wc), None, None, None, L.ptr(yd), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), y.detach(), **tol(code, y.abs().max().item()))
+    ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((c, 3, 3, cg), float("nan"), device=DEV)
+    dyd = to_nhwc(dy, code)
+    L.check(L.lib.vs_conv2d_wgrad(d, L.ptr(xd), None, L.ptr(dyd), L.ptr(dw), L.ptr(ws), ws_bytes, None))
+    sync()
+    ref_dw = wt.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    dx = torch.full((n, h, w, c), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(dyd), None, L.ptr(wtr), None, None, None, L.ptr(dx), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
 @pytest.mark.parametrize("shape", [(2, 8, 8, 128, 128), (1, 16, 24, 16, 16), (2, 4, 4, 64, 32), (1, 32, 32, 32, 32)])
 def test_conv_transpose_4x4_stride2_as_conv3x3_plus_pixel_shuffle(code, shape):
     """nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1) - smp Linknet's TransposeX2 - through the C ABI: weight

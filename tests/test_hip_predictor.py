@@ -130,6 +130,22 @@ def test_bit_exact_labels_where_the_oracle_margin_is_clear(predictor_and_golden)
     assert clear.mean() > 0.99 and np.array_equal(l[clear], ref_l[clear])
 
 
+def test_prediction_does_not_depend_on_the_batch_size(predictor_and_golden, tmp_path):
+    """utilities/base_data_utils.py get_batch_size: the reference predicts 4 (or 2) slices per forward, this engine
+    HIP_PRED_BATCH = 32 by default.  Eval-mode results are per slice (running BN statistics, no cross-sample op), so the
+    labels and fp16 probabilities are the same bits for every batch size - including the reference's 4 and 2."""
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    pred, g, _ = predictor_and_golden
+    out = {}
+    for bs in (2, 4, 7, 32):
+        pred.settings.prediction_batch_size = bs
+        out[bs] = pred._predict_3_ways_max_probs(g["vol"])
+    pred.settings.prediction_batch_size = 7
+    for bs in (2, 4, 32):
+        assert np.array_equal(out[bs][0], out[7][0]), bs
+        assert np.array_equal(out[bs][1].view(np.uint16), out[7][1].view(np.uint16)), bs
+
+
 def test_unclipped_uint16_and_float_volumes_predict_like_the_oracle(predictor_and_golden):
     """clip_data: False hands the predictor the volume in its own dtype; the reference then feeds float32(v) / 255 (integers,
     any range) or v itself (floats) to the network (data/datasets.py:128-134).  Labels must equal the oracle's wherever its

@@ -536,7 +536,8 @@ def test_fpn_eval_and_train_vs_oracle(encoder):
 
 
 @pytest.mark.parametrize("encoder,topo", [("resnet34", "deeplabv3plus"), ("resnet50", "deeplabv3plus"), ("resnet34", "deeplabv3"),
-                                          ("resnet50", "deeplabv3"), ("efficientnet-b4", "deeplabv3plus"), ("efficientnet-b3", "deeplabv3plus")])
+                                          ("resnet50", "deeplabv3"), ("efficientnet-b4", "deeplabv3plus"), ("efficientnet-b3", "deeplabv3plus"),
+                                          ("resnext50_32x4d", "deeplabv3plus"), ("resnext50_32x4d", "deeplabv3")])
 def test_deeplabv3plus_eval_and_train_vs_oracle(encoder, topo):
     """smp.DeepLabV3Plus (layer4 with dilation 2 instead of stride; ASPP = 1x1 + three separable 3x3 at rates 12 / 24 / 36 + image
     pooling, concat, 1x1 project + Dropout(0.5); separable 3x3; x4 bilinear; 48-channel 1x1 on the stride-4 feature; concat;
@@ -634,7 +635,7 @@ def test_deeplabv3plus_eval_and_train_vs_oracle(encoder, topo):
     assert torch.equal(runs[0], runs[1]), encoder
 
 
-@pytest.mark.parametrize("encoder", ["resnet34", "resnet50"])
+@pytest.mark.parametrize("encoder", ["resnet34", "resnet50", "resnext50_32x4d"])
 def test_pan_eval_and_train_vs_oracle(encoder):
     """smp.PAN (layer4 dilated; FPABlock = pooled branch + mid branch + the single-channel 7x7 / 5x5 / 3x3 pyramid; three GAUBlocks;
     3x3 head + x4 bilinear; every ConvBnRelu with its convolution bias) against oracle/unet_resnet_torch.py:PANDecoder.  Slices of

@@ -338,3 +338,24 @@ def test_fused_adamw_state_dict_has_no_entries_for_frozen_parameters():
     ref = torch.optim.AdamW(OracleUnetResnet34(1, 2).parameters(), lr=1e-3)
     ref.load_state_dict(sd)                                    # the reference's _load_in_weights(optimizer=True) path
     assert len(ref.state) == len(names) - len(frozen)
+
+
+def test_get_batch_size_follows_the_reference_memory_rule_with_two_documented_changes(monkeypatch):
+    """reference utilities/base_data_utils.py:104-122: < 8 GB free -> 2, else 12 (training) / 4 (prediction).  This engine
+    keeps the training rule (train-mode BN statistics depend on the batch), lets an explicit settings key win, and
+    predicts with HIP_PRED_BATCH slices per forward (eval-mode results are batch independent - see
+    tests/test_hip_predictor.py::test_prediction_is_independent_of_the_batch_size); `prediction_batch_size: 4`
+    reproduces the reference's number."""
+    from volume_segmantics_amd.utilities import config as cfg
+    props = SimpleNamespace(total_memory=288 * 1024 ** 3)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: props)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev: 0)
+    s = SimpleNamespace(cuda_device=0)
+    assert utils.get_batch_size(s) == cfg.BIG_CUDA_TRAIN_BATCH == 12
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev: 283 * 1024 ** 3)       # 5 GB free
+    assert utils.get_batch_size(s) == cfg.SMALL_CUDA_BATCH == 2
+    assert utils.get_batch_size(s, prediction=True) == cfg.HIP_PRED_BATCH == 32
+    assert utils.get_batch_size(SimpleNamespace(cuda_device=0, prediction_batch_size=cfg.BIG_CUDA_PRED_BATCH),
+                                prediction=True) == 4
+    assert utils.get_batch_size(SimpleNamespace(cuda_device=0, batch_size=32)) == 32

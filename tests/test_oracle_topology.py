@@ -158,7 +158,7 @@ def test_deeplabv3plus_restatement_and_engine_table_agree():
     convs = [m for m in net.encoder.layer4.modules() if isinstance(m, torch.nn.Conv2d)]
     assert all(m.stride == (1, 1) and m.dilation == (2, 2) for m in convs)
     assert all(m.padding == ((2, 2) if m.kernel_size == (3, 3) else (0, 0)) for m in convs)
-    for name, code in (("resnet18", 4018), ("resnet34", 4034), ("resnet50", 4050)):
+    for name, code in (("resnet18", 4018), ("resnet34", 4034), ("resnet50", 4050), ("resnext50_32x4d", 4051)):
         sd = OracleUnet(name, 1, 3, "deeplabv3plus").state_dict()
         table = _lib.unet_tensor_table(3, code)
         assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
@@ -183,7 +183,7 @@ def test_deeplabv3_restatement_and_engine_table_agree():
     for stage, rate in ((net.encoder.layer3, 2), (net.encoder.layer4, 4)):
         convs = [m for m in stage.modules() if isinstance(m, torch.nn.Conv2d)]
         assert all(m.stride == (1, 1) and m.dilation == (rate, rate) for m in convs)
-    for name, code in (("resnet18", 5018), ("resnet34", 5034), ("resnet50", 5050)):
+    for name, code in (("resnet18", 5018), ("resnet34", 5034), ("resnet50", 5050), ("resnext50_32x4d", 5051)):
         sd = OracleUnet(name, 1, 3, "deeplabv3").state_dict()
         table = _lib.unet_tensor_table(3, code)
         assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name
@@ -224,7 +224,7 @@ def test_pan_restatement_and_engine_table_agree():
     from volume_segmantics_amd import _lib
     net = OracleUnet("resnet34", 3, 1, "pan")
     assert sum(p.numel() for p in net.parameters()) == 21_475_816
-    for name, code in (("resnet18", 7018), ("resnet34", 7034), ("resnet50", 7050)):
+    for name, code in (("resnet18", 7018), ("resnet34", 7034), ("resnet50", 7050), ("resnext50_32x4d", 7051)):
         sd = OracleUnet(name, 1, 3, "pan").state_dict()
         table = _lib.unet_tensor_table(3, code)
         assert [t[0] for t in table] == [k for k in sd if not k.endswith("num_batches_tracked")], name

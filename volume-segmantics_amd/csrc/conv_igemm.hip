@@ -755,7 +755,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     VS_REQUIRE(((p.KH == 3 && p.KW == 3) || (p.KH == 1 && p.KW == 1)) && (p.stride == 1 || p.stride == 2),
                "conv_igemm: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.stride);
     const int dil = p.dil > 1 ? p.dil : 1;
-    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && p.Cout >= 32 && !p.gc && !p.pool0),
+    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && p.Cout >= 32 && !p.pool0),
                "conv_igemm: dilation 2 / 4 is built for stride-1 3x3 layers of >= 32 channels");
     VS_REQUIRE(p.Hout == (p.Hin + 2 * p.pad - (p.KH - 1) * dil - 1) / p.stride + 1 && p.Wout == (p.Win + 2 * p.pad - (p.KW - 1) * dil - 1) / p.stride + 1,
                "conv_igemm: inconsistent output dims");

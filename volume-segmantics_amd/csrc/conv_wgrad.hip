@@ -480,7 +480,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.tiles_h = cdiv(p.Hout, g.TH);
     g.tiles_w = cdiv(p.Wout, TW);
     const int dil = p.dil > 1 ? p.dil : 1;
-    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && !p.cg && !p.up0 && p.C1 == 0), "conv_wgrad: dilation 2 / 4 is built for plain stride-1 3x3 layers");
+    VS_REQUIRE(dil == 1 || ((dil == 2 || dil == 4) && p.KH == 3 && p.stride == 1 && !p.up0 && p.C1 == 0), "conv_wgrad: dilation 2 / 4 is built for plain stride-1 3x3 layers");
     g.PH = (g.TH - 1) * p.stride + (p.KH - 1) * dil + 1;
     g.PW = (TW - 1) * p.stride + (p.KW - 1) * dil + 1;
     g.cchunks = p.cg ? 32 / CK : cdiv(Cin, CK);      // grouped: cin chunks per 32-channel cout tile

@@ -1219,7 +1219,6 @@ static int with_layout(int classes, int encoder_code, Layout& out) {   // encode
     tmp.classes = classes; tmp.h = 64; tmp.w = 64; tmp.max_batch = 1; tmp.dtype = VS_F32; tmp.esz = 4; tmp.encoder = encoder;
     tmp.topology = encoder_code / 1000;
     VS_REQUIRE(tmp.topology >= 0 && tmp.topology <= 7, "topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", tmp.topology);
-    VS_REQUIRE((tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7) || encoder != 51, "DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(classes >= 1 && classes <= 16, "classes must be in [1,16], got %d", classes);
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || ((encoder == 103 || encoder == 104) && tmp.topology != 2) ||
                ((encoder == 150 || encoder == 201) && tmp.topology != 4 && tmp.topology != 5 && tmp.topology != 7),
@@ -1277,7 +1276,6 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE(out, "unet_create: null out pointer");
     const int encoder = encoder_code % 1000, topology = encoder_code / 1000;
     VS_REQUIRE(topology >= 0 && topology <= 7, "unet_create: topology must be 0 (U-Net), 1 (U-Net++), 2 (Linknet), 3 (FPN), 4 (DeepLabV3+), 5 (DeepLabV3), 6 (MA-Net) or 7 (PAN), got %d", topology);
-    VS_REQUIRE((topology != 4 && topology != 5 && topology != 7) || encoder != 51, "unet_create: DeepLabV3+ over resnext50_32x4d is not built (a grouped AND dilated 3x3 convolution)");
     VS_REQUIRE(encoder == 18 || encoder == 34 || encoder == 50 || encoder == 51 || encoder == 103 || encoder == 104 || encoder == 150 || encoder == 201,
                "unet_create: encoder must be 18, 34, 50, 51, 103, 104, 150 or 201 (resnet18 / resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / "
                "efficientnet-b4 / timm-resnest50d / timm-resnest101e), got %d", encoder);
