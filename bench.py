@@ -51,11 +51,31 @@ def load_traffic(kernel_name: str, workload: str = "train"):
     the entry carries its source file so that it cannot pass for a live one."""
     for f in sorted((REPO / "profiles").glob(f"r*_pmc_traffic{'' if workload == 'train' else '_' + workload}.json"), reverse=True):
         try:
-            t = json.loads(f.read_text()).get(kernel_name)
+            d = json.loads(f.read_text())
+            t = d.get(kernel_name) or next((v for k, v in sorted(d.items()) if k.startswith(kernel_name)), None)   # (a name prefix: ring kernels)
         except Exception:
             t = None
         if t:
             return dict(t, source=f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run)")
+    return None
+
+
+def load_traffic_class(prefixes):
+    """Launch-weighted HBM bytes per launch over every kernel of the newest committed PMC passes whose name starts with one of
+    `prefixes` (a kernel class served by several instantiations), or None."""
+    for f in sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        rows = [v for k, v in d.items() if k.startswith(tuple(prefixes)) and v.get("launches")]
+        if rows:
+            n = sum(v["launches"] for v in rows)
+            return {"bytes_per_launch": int(sum(v["bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "read_bytes_per_launch": int(sum(v["read_bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "write_bytes_per_launch": int(sum(v["write_bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "kernels": len(rows), "launches": n, "correction": rows[0].get("correction"),
+                    "source": f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run)"}
     return None
 
 
@@ -237,6 +257,10 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
     if labels is None:
         labels = np.zeros(1, np.uint8)
     phases = dict(pred.last_timings)     # of the timed call (the instrumented pass below overwrites them)
+    phases_all = [phases]
+    if world > 1:       # every rank's phases: with one direction set per rank the slowest one bounds the job
+        phases_all = [None] * world
+        dist.all_gather_object(phases_all, phases)
     roof = None
     if cube >= 512:     # (every rank runs the instrumented pass - it contains the exchange; rank 0 reports it)
         # roofline of the prediction's dominant kernel: HIP events around every launch of ONE direction (cube slices) on the
@@ -275,6 +299,7 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
             "mfma_frac": round(flop / dt / 1e12 / MFMA_PEAK_BF16_TFLOPS / world, 4), "batch": batch,
             "label_hist": np.bincount(labels.ravel(), minlength=classes).tolist(),
             "phases_rank0": {k: round(v, 4) for k, v in phases.items()},
+            "phases_per_rank": [{k: round(v, 4) for k, v in ph.items()} for ph in phases_all],
             "includes": "H2D volume upload, all directions, key merge, all-reduce(max), unpack, D2H labels+probs",
             **({"roofline": roof} if roof else {})}
 
@@ -525,6 +550,7 @@ def main():
         tname = "unsigned short" if args.precision == "bf16" else "float"
         code = dvar % 10
         dom_name = (f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, 1, 8, 1>" if code == 8 else
+                    f"ring::conv_ring_kernel<{dvar // 1000}, " if code == 6 else
                     f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {code}, 4, 1>")
         dom_ms, dom_fl, dom_calls = byvar[dvar]
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -574,7 +600,28 @@ def main():
             "kernel_classes": breakdown,
             **predict,
         }
+        # the class with the largest time share next to the dominant forward / dgrad kernel (for the headline step: the weight
+        # gradients), same definition: algorithmic FLOPs of its launches / sum of their HIP-event durations
+        big = max(mfma_kinds, key=lambda k: prof[k]["ms"])
+        bms, bfl, bcalls = prof[big]["ms"], prof[big]["flops"], prof[big]["calls"]
+        big_name = {"conv_wgrad": "conv_wgrad_ring_kernel / conv_wgrad_bf16_kernel (+ slab_reduce4_kernel)",
+                    "conv_fwd": "conv_igemm_kernel (forward launches)", "conv_dgrad": "conv_igemm_kernel (data-gradient launches)"}[big]
+        big_prefix = {"conv_wgrad": ("ring::conv_wgrad_ring_kernel", "conv_wgrad_bf16_kernel", "conv_wgrad_kernel"),
+                      "conv_fwd": ("conv_igemm_kernel", "ring::conv_ring_kernel", "conv_direct_kernel"),
+                      "conv_dgrad": ("conv_igemm_kernel", "ring::conv_ring_kernel", "conv_direct_kernel")}[big]
+        out["roofline_largest_class"] = {
+            "bound": "mfma", "class": big, "kernel": big_name, "achieved": round(bfl / (bms * 1e-3) / 1e12, 2) if bms else 0.0,
+            "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bfl / (bms * 1e-3) / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4) if bms else 0.0,
+            "ms_per_step": round(bms / prof_steps, 4), "launches_per_step": bcalls // prof_steps,
+            "share_of_kernel_time": round(bms / sum(v["ms"] for v in prof.values()), 3),
+            "traffic": (load_traffic_class(big_prefix) or {}).get("bytes_per_launch"), "traffic_detail": load_traffic_class(big_prefix)}
         out["peak_crosscheck"] = gemm_crosscheck(dev)
+        if headline:
+            step_tflops = slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12
+            loop = out["peak_crosscheck"].get("mfma_only_loop", {}).get("tflops")
+            out["whole_step"] = {"achieved_tflops": round(step_tflops, 1), "frac_of_vendor_peak": round(step_tflops / MFMA_PEAK_BF16_TFLOPS, 4),
+                                 "frac_of_measured_mfma_loop": round(step_tflops / loop, 4) if loop else None,
+                                 "measured_mfma_loop_tflops": loop, "gflop_per_slice_fwd_bwd": round(FLOP_PER_SLICE_FWD_BWD_256 / 1e9, 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(12, args.cpu_steps)
             if not args.no_predict:

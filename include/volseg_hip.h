@@ -22,7 +22,8 @@ extern "C" {
 #endif
 
 enum { VS_OK = 0, VS_ERR_INVALID = -1, VS_ERR_HIP = -2, VS_ERR_UNSUPPORTED = -3 };
-enum { VS_F32 = 0, VS_BF16 = 1 }; /* compute/storage dtype of activations and conv weights */
+enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 }; /* compute/storage dtype of activations and conv weights (VS_F16: inference only -
+                                                  * the forward pass of a network in evaluation mode) */
 
 const char* vs_last_error(void);
 int vs_version(void);
@@ -35,7 +36,7 @@ int vs_version(void);
  * src1) along channels - smp's DecoderBlock (F.interpolate(scale_factor=2, "nearest") +
  * torch.cat) is never materialised. */
 typedef struct vs_conv_desc {
-    int32_t dtype;             /* VS_F32 | VS_BF16 */
+    int32_t dtype;             /* VS_F32 | VS_BF16 | VS_F16 */
     int32_t n, hin, win;       /* virtual input dims (after upsampling src0) */
     int32_t c0, c1, up0;       /* channels of src0 / src1 (0 = absent); src0: 0 = as is, 1 = nearest x2 upsampling,
                                   2 = zero stuffing x2 (values at the even rows / columns; c1 must be 0) */

@@ -13,7 +13,7 @@ def lib():
 
 
 def tdtype(code):
-    return torch.float32 if code == 0 else torch.bfloat16
+    return {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[code]     # VS_F32 / VS_BF16 / VS_F16 (inference only)
 
 
 def to_nhwc(x_nchw, code):
@@ -31,10 +31,12 @@ def w_krsc(w_oihw, code):
 
 def rounded(x, code):
     """Value the device sees for a CPU fp32 tensor (bf16 rounding for the bf16 path)."""
-    return x if code == 0 else x.to(torch.bfloat16).float()
+    return x if code == 0 else x.to(tdtype(code)).float()
 
 
 def tol(code, scale=1.0):
+    if code == 2:       # fp16: 11 significant bits (8x bf16's): inputs rounded beforehand, fp32 accumulation, one rounding at the store
+        return dict(rtol=2e-3, atol=2e-3 * scale)
     return dict(rtol=2e-4, atol=2e-4 * scale) if code == 0 else dict(rtol=2e-2, atol=2e-2 * scale)
 
 

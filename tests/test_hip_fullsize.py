@@ -228,20 +228,22 @@ def test_config5_network_deeplabv3plus_efficientnet_b4_on_1024_square_slices():
         assert np.array_equal(lz[k], l1[0]) and np.array_equal(pz[k].view(np.uint16), p1[0].view(np.uint16)), k
 
 
-def test_config5_full_volume_with_its_own_network_three_axis_1024_cube():
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_config5_full_volume_with_its_own_network_three_axis_1024_cube(precision):
     """BASELINE configs[4] as it stands: a 1024^3 volume, 2 classes, 3-axis max-probability prediction with smp.DeepLabV3Plus over
-    efficientnet-b4 (bf16, batches of 8 slices of 1024 x 1024; volume, packed keys and outputs resident in HBM).  Properties: shapes /
+    efficientnet-b4 in fp16 - the precision BASELINE names - and in bf16 (batches of 8 slices of 1024 x 1024; volume, packed keys
+    and outputs resident in HBM).  Properties: shapes /
     dtypes, both classes present, the merged probability is nowhere below the Z pass's and where it equals it the Z label survived."""
     import time
     from volume_segmantics_amd.utilities.base_data_utils import Axis
-    pred = _predictor(2, 8, encoder="efficientnet-b4", topology="deeplabv3plus")
+    pred = _predictor(2, 8, precision=precision, encoder="efficientnet-b4", topology="deeplabv3plus")
     vol = np.tile(bench.synth_volume(256, seed=4321), (4, 4, 4))
     assert vol.shape == (1024, 1024, 1024)
     pred._predict_single_axis(vol[:8], axis=Axis.Z)                 # plans, weight copies
     t0 = time.perf_counter()
     labels, probs = pred._predict_3_ways_max_probs(vol)
     dt = time.perf_counter() - t0
-    print(f"configs[4]: 1024^3, 3 axes, DeepLabV3+ / efficientnet-b4: {dt:.2f} s = {3072 / dt:.0f} slices/s")
+    print(f"configs[4]: 1024^3, 3 axes, DeepLabV3+ / efficientnet-b4 {precision}: {dt:.2f} s = {3072 / dt:.0f} slices/s")
     assert labels.shape == vol.shape and labels.dtype == np.uint8 and probs.shape == vol.shape and probs.dtype == np.float16
     assert 0 < (labels[::8, ::8, ::8] == 1).mean() < 1
     lz, pz = pred._predict_single_axis(vol[512:520], axis=Axis.Z)

@@ -329,6 +329,39 @@ def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
     assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1, 1, 0, 1), (3, 20, 28, 40, 48, 3, 1, 1, 0, 1), (2, 32, 32, 64, 128, 3, 2, 1, 0, 1),
+                                  (2, 16, 16, 96, 32, 1, 1, 0, 0, 1), (1, 64, 64, 16, 16, 3, 1, 1, 0, 1), (2, 16, 16, 128, 64, 3, 1, 2, 0, 2),
+                                  (2, 8, 8, 256, 128, 3, 1, 1, 64, 1), (8, 64, 64, 64, 64, 3, 1, 1, 0, 1), (2, 128, 128, 32, 16, 3, 1, 1, 0, 1)])
+def test_fp16_conv_forward_with_eval_epilogue(case):
+    """VS_F16 (BASELINE configs[4] names fp16; inference only): the implicit-GEMM kernels on v_mfma_f32_16x16x32_f16 with the
+    evaluation-mode epilogue (folded BatchNorm scale / shift + ReLU), fp16 storage, fp32 accumulation - every tile family
+    (64 / 128 / 256-pixel tiles, stride 2, 1x1, dilated, decoder form with x2 upsampling + concatenation, direct shallow-layer
+    kernel, ragged channel counts) against torch CPU on the fp16-rounded operands.  Training epilogues are refused."""
+    L = lib()
+    code = 2
+    n, h, w, cin, cout, k, stride, pad, c1, dil = case
+    g = torch.Generator().manual_seed(17)
+    up = 1 if c1 else 0
+    x0 = rounded(torch.randn(n, cin, h >> up, w >> up, generator=g), code)
+    x1 = rounded(torch.randn(n, c1, h, w, generator=g), code) if c1 else None
+    xin = x0 if not c1 else torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1)
+    wt = rounded(torch.randn(cout, cin + c1, k, k, generator=g) / ((cin + c1) * k * k) ** 0.5, code)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(xin, wt, stride=stride, padding=pad, dilation=dil) * scale[None, :, None, None] + shift[None, :, None, None])
+    ho, wo = ref.shape[2:]
+    d = conv_desc(L, code, n, h, w, cin, cout, k, stride, pad, c1=c1, up0=up, relu=1, dilation=dil if dil > 1 else 0)
+    yd = torch.full((n, ho, wo, cout), float("nan"), device=DEV, dtype=torch.float16)
+    x0d, x1d, wd, scd, shd = to_nhwc(x0, code), (to_nhwc(x1, code) if c1 else None), w_krsc(wt, code), scale.to(DEV), shift.to(DEV)
+    L.check(L.lib.vs_conv2d_fwd(d, L.ptr(x0d), L.ptr(x1d) if c1 else None, L.ptr(wd), L.ptr(scd), L.ptr(shd), None, L.ptr(yd), None, None))
+    sync()
+    assert torch.allclose(from_nhwc(yd), ref, **tol(code, ref.abs().max().item()))
+    # no training forms in fp16: the weight gradient is refused with an error, not computed in another precision
+    ws = torch.empty(max(L.lib.vs_conv2d_wgrad_workspace(d), 16), dtype=torch.uint8, device=DEV)
+    dw = torch.zeros(cout, k, k, cin + c1, device=DEV)
+    rc = L.lib.vs_conv2d_wgrad(d, L.ptr(x0d), L.ptr(x1d) if c1 else None, L.ptr(yd), L.ptr(dw), L.ptr(ws), ws.numel(), None)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("code", CODES)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 512, 16, 2), (2, 8, 8, 1024, 32, 2), (1, 16, 24, 1024, 32, 4), (2, 32, 32, 512, 16, 2),
                                    (3, 20, 12, 64, 8, 2), (8, 32, 32, 1024, 32, 2)])

@@ -11,7 +11,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VOLSEG_HIP_LIB", _HERE / "lib" / "libvolseg_hip.so"))
 
-VS_F32, VS_BF16 = 0, 1
+VS_F32, VS_BF16, VS_F16 = 0, 1, 2
 VS_VOL = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7,
           "int64": 8, "uint64": 9}   # volume dtypes
 
@@ -247,6 +247,8 @@ def dtype_code(torch_dtype) -> int:
         return VS_F32
     if torch_dtype == torch.bfloat16:
         return VS_BF16
+    if torch_dtype == torch.float16:
+        return VS_F16
     raise ValueError(f"unsupported compute dtype {torch_dtype}")
 
 

@@ -13,6 +13,9 @@ typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(8))) short short8v;
 
 typedef uint16_t bf16_t;  // storage type for bf16 tensors
+typedef _Float16 f16_t;   // storage type for fp16 tensors (VS_F16: the inference-only precision)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 // ---- error plumbing ------------------------------------------------------------------------------
 void vs_set_error(const char* fmt, ...);
@@ -53,6 +56,24 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+template <> struct Elem<f16_t> {
+    static constexpr int kDtype = VS_F16;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+};
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {       // v_cvt_pkrtz would truncate: two RNE conversions
+    f16x2 h = {(f16_t)a, (f16_t)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float2 unpack_f16(uint32_t u) {
+    const f16x2 h = __builtin_bit_cast(f16x2, u);
+    return make_float2((float)h.x, (float)h.y);
+}
+// two values -> one 32-bit word of T's storage format (16-bit types only)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) { return pack_f16(a, b); }
+
 // 4 consecutive elements <-> float4
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
@@ -60,6 +81,12 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
+__device__ __forceinline__ float4 ld4(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    const float2 a = unpack_f16(u.x), b = unpack_f16(u.y);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st4(f16_t* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w)); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
@@ -71,6 +98,13 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 template <typename T> struct Raw4;
 template <> struct Raw4<float> { typedef float4 type; };
 template <> struct Raw4<bf16_t> { typedef uint2 type; };
+struct f16raw4 { uint2 u; };
+template <> struct Raw4<f16_t> { typedef f16raw4 type; };
+__device__ __forceinline__ f16raw4 ld4raw(const f16_t* p) { return f16raw4{*reinterpret_cast<const uint2*>(p)}; }
+__device__ __forceinline__ float4 unpack4(f16raw4 r) {
+    const float2 a = unpack_f16(r.u.x), b = unpack_f16(r.u.y);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 __device__ __forceinline__ float4 ld4raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ uint2 ld4raw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
 __device__ __forceinline__ float4 unpack4(float4 v) { return v; }
@@ -84,6 +118,14 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
     o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
     o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
     o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8(const f16_t* p, float* o) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const float2 a = unpack_f16(u.x), b = unpack_f16(u.y), c = unpack_f16(u.z), d = unpack_f16(u.w);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
+}
+__device__ __forceinline__ void st8(f16_t* p, const float* v) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
 }
 __device__ __forceinline__ void ld8(const float* p, float* o) {
     float4 a = ld4(p), b = ld4(p + 4);
@@ -122,7 +164,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static inline size_t dtype_size(int dt) { return dt == VS_BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dt) { return dt == VS_F32 ? 4 : 2; }
+
+// One launcher body per storage type.  VS_F16 is the inference precision: the operators of an evaluation-mode forward pass
+// dispatch through VS_FOR_T; the training-only operators keep their two-way dispatch behind VS_NO_F16.
+#define VS_FOR_T(dtype, ...)                                          \
+    do {                                                                   \
+        if ((dtype) == VS_BF16) { typedef bf16_t T; __VA_ARGS__; }         \
+        else if ((dtype) == VS_F16) { typedef f16_t T; __VA_ARGS__; }      \
+        else { typedef float T; __VA_ARGS__; }                             \
+    } while (0)
+#define VS_NO_F16(dtype, what) VS_REQUIRE((dtype) != VS_F16, "%s: fp16 is the inference precision - this operator is built for fp32 / bf16", what)
 
 // ---- internal op launchers (one per .hip file) ------------------------------------------------------
 struct ConvParams {

@@ -1,23 +1,31 @@
 // Pieces shared by the convolution kernels of conv_igemm.hip (tile kernel, direct kernel, head kernel).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 template <typename T> struct CT;
 template <> struct CT<bf16_t> { static constexpr int CK = 32, EPS = 8; };
+template <> struct CT<f16_t> { static constexpr int CK = 32, EPS = 8; };
 template <> struct CT<float> { static constexpr int CK = 16, EPS = 4; };
 
 // value as it reads back after being stored in T
 template <typename T>
 __device__ __forceinline__ float4 ld4_roundtrip(const float (&v)[4]) {
-    if constexpr (sizeof(T) == 2)
-        return make_float4(bf16_to_f32(f32_to_bf16(v[0])), bf16_to_f32(f32_to_bf16(v[1])), bf16_to_f32(f32_to_bf16(v[2])), bf16_to_f32(f32_to_bf16(v[3])));
-    else
+    if constexpr (sizeof(T) == 2) {
+        const float a[4] = {v[0], v[1], v[2], v[3]};
+        T t[4];
+        for (int i = 0; i < 4; ++i) Elem<T>::st(t + i, a[i]);
+        return make_float4(Elem<T>::ld(t), Elem<T>::ld(t + 1), Elem<T>::ld(t + 2), Elem<T>::ld(t + 3));
+    } else
         return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 template <typename T>
 __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, f16_t>::value) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    } else if constexpr (sizeof(T) == 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                       acc, 0, 0, 0);
     } else {

@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                     const int off = (live && (h & 1)) ? ooff[j] : kOob;
                     uint2 pk;
                     if constexpr (sizeof(T) == 2) {
-                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        pk.x = pack2<T>(v[0], v[1]);
+                        pk.y = pack2<T>(v[2], v[3]);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, off, (h >> 1) * orow, 0);
                     } else {
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, (h >> 1) * orow, 0);
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                         const int off = live ? ooff[j] : kOob;
                         if constexpr (sizeof(T) == 2) {
                             uint2 pk;
-                            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                            pk.x = pack2<T>(v[0], v[1]);
+                            pk.y = pack2<T>(v[2], v[3]);
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, off, h * orow, 0);
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, h * orow, 0);
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 4) void conv_head_kernel(ConvParams p, DirectG
 
 // geometry the direct kernel covers
 static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = fp32 store, bit 1 = NCHW layout
-    const int CK = dtype == VS_BF16 ? 32 : 16;
+    const int CK = dtype == VS_F32 ? 16 : 32;
     const bool nchw = (p.out_f32 >> 1) != 0, f32 = (p.out_f32 & 1) != 0;
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
@@ -780,7 +780,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
         const int rm = ring_mode(VS_BF16, p, out_nchw);
         if (rm) {
             const long groups = rm == 3 ? p.N / 2 : (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
@@ -849,6 +849,10 @@ int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s) {
     q.out_f32 = p.out_f32 & 1;
     if (dtype == VS_BF16) return dispatch<bf16_t>(q, nchw, s);
     if (dtype == VS_F32) return dispatch<float>(q, nchw, s);
+    if (dtype == VS_F16) {
+        VS_REQUIRE(!q.bz && !q.stats_partial && !q.pool0, "conv_igemm: fp16 is the inference precision (no training epilogues)");
+        return dispatch<f16_t>(q, nchw, s);
+    }
     vs_set_error("conv_igemm: bad dtype %d", dtype);
     return VS_ERR_INVALID;
 }

@@ -257,8 +257,7 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64
 
 #define VS_LAUNCH_T(kernel, grid, lds, s, ...)                                                                          \
     do {                                                                                                                \
-        if (dtype == VS_BF16) { typedef bf16_t T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); } \
-        else { typedef float T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); }                   \
+        VS_FOR_T(dtype, { hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); });                   \
         VS_LAUNCH_CHECK();                                                                                              \
     } while (0)
 

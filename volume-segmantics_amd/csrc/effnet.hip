@@ -671,8 +671,7 @@ inline int bn2_blocks(int64_t rows, int c) {
 
 #define VS_LAUNCH_T(kernel, grid, lds, s, ...)                                                                          \
     do {                                                                                                                \
-        if (dtype == VS_BF16) { typedef bf16_t T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); } \
-        else { typedef float T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); }                   \
+        VS_FOR_T(dtype, { hipLaunchKernelGGL((kernel<T>), grid, dim3(256), lds, s, __VA_ARGS__); });                   \
         VS_LAUNCH_CHECK();                                                                                              \
     } while (0)
 
@@ -685,10 +684,7 @@ extern "C" int vs_bn2_stats(int dtype, const void* x, int64_t rows, int c, float
     const int nb = bn2_blocks(rows, c), slabs = (c / kVec + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
     VS_LAUNCH_T(bn2_stats_partial, dim3(nb, slabs), 0, s, (const T*)x, rows, c, workspace);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(bn2_stats_finalize<bf16_t>, dim3(c), dim3(64), 0, s, workspace, (const bf16_t*)x, nb, c, rows, eps, momentum, mean, invstd, running_mean, running_var);
-    else
-        hipLaunchKernelGGL(bn2_stats_finalize<float>, dim3(c), dim3(64), 0, s, workspace, (const float*)x, nb, c, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(bn2_stats_finalize<T>, dim3(c), dim3(64), 0, s, workspace, (const T*)x, nb, c, rows, eps, momentum, mean, invstd, running_mean, running_var));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -728,17 +724,14 @@ extern "C" int vs_dwconv2d(int dtype, const void* x, const float* w, void* y, in
     hipStream_t s = (hipStream_t)stream;
     const bool strip_ok = k != 2 && (dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3))));
     if (!x_single_channel && strip_ok) {      // four outputs per lane, every input row of the window loaded once
-        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
-        else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s);
+        VS_FOR_T(dtype, launch_dw_strip<T>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, s));
         VS_LAUNCH_CHECK();
         return VS_OK;
     }
     if (x_single_channel) {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
-        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
+        VS_FOR_T(dtype, hipLaunchKernelGGL((dwconv2d_fwd_kernel<T, float, true>), grid, dim3(256), lds, s, (const float*)x, w, (T*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo));
     } else {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_fwd_kernel<bf16_t, bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, w, (bf16_t*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
-        else hipLaunchKernelGGL((dwconv2d_fwd_kernel<float, float, false>), grid, dim3(256), lds, s, (const float*)x, w, (float*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo);
+        VS_FOR_T(dtype, hipLaunchKernelGGL((dwconv2d_fwd_kernel<T, T, false>), grid, dim3(256), lds, s, (const T*)x, w, (T*)y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo));
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -749,8 +742,7 @@ extern "C" int vs_dwconv2d_bwd_data(int dtype, const void* dy, const float* w, v
                "dwconv2d_bwd_data: kernel 3 / 5, stride 1 / 2, channels a multiple of 8");
     const bool strip_ok = k != 2 && (dilation == 1 || dilation == 2 || (dilation == 4 && k == 3));
     if (stride == 1 && strip_ok && 2 * pad_lo == (k - 1) * dilation && ho == h && wo == wd) {   // a stride-1 "same" layer: the forward sweep with the taps reversed
-        if (dtype == VS_BF16) launch_dw_strip<bf16_t>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
-        else launch_dw_strip<float>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream);
+        VS_FOR_T(dtype, launch_dw_strip<T>(dy, w, dx, n, h, wd, c, k, 1, pad_lo, dilation, h, wd, 1, accumulate, (hipStream_t)stream));
         VS_LAUNCH_CHECK();
         return VS_OK;
     }
@@ -773,18 +765,14 @@ extern "C" int vs_dwconv2d_wgrad(int dtype, const void* x, const void* dy, float
     hipStream_t s = (hipStream_t)stream;
     if (!x_single_channel && dilation == 1) {
 #define VS_WSTRIP(T_, K_, S_) hipLaunchKernelGGL((dwconv2d_wgrad_strip<T_, K_, S_>), grid, dim3(256), 0, s, (const T_*)x, (const T_*)dy, n, h, wd, c, pad_lo, ho, wo, workspace)
-        if (dtype == VS_BF16) {
-            if (k == 3 && stride == 1) VS_WSTRIP(bf16_t, 3, 1); else if (k == 3) VS_WSTRIP(bf16_t, 3, 2); else if (stride == 1) VS_WSTRIP(bf16_t, 5, 1); else VS_WSTRIP(bf16_t, 5, 2);
-        } else {
-            if (k == 3 && stride == 1) VS_WSTRIP(float, 3, 1); else if (k == 3) VS_WSTRIP(float, 3, 2); else if (stride == 1) VS_WSTRIP(float, 5, 1); else VS_WSTRIP(float, 5, 2);
-        }
+        VS_FOR_T(dtype, {
+            if (k == 3 && stride == 1) VS_WSTRIP(T, 3, 1); else if (k == 3) VS_WSTRIP(T, 3, 2); else if (stride == 1) VS_WSTRIP(T, 5, 1); else VS_WSTRIP(T, 5, 2);
+        });
 #undef VS_WSTRIP
     } else if (x_single_channel) {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, float, true>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
-        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, true>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
+        VS_FOR_T(dtype, hipLaunchKernelGGL((dwconv2d_wgrad_partial<T, float, true>), grid, dim3(256), 0, s, (const float*)x, (const T*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace));
     } else {
-        if (dtype == VS_BF16) hipLaunchKernelGGL((dwconv2d_wgrad_partial<bf16_t, bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
-        else hipLaunchKernelGGL((dwconv2d_wgrad_partial<float, float, false>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace);
+        VS_FOR_T(dtype, hipLaunchKernelGGL((dwconv2d_wgrad_partial<T, T, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, workspace));
     }
     VS_LAUNCH_CHECK();
     const int total = c * k * k;
@@ -803,12 +791,8 @@ extern "C" int vs_sample_scale_add(int dtype, const void* x, const float* mask, 
 // out [n][c] = scale * sum over hw of a[n][hw][c] (* b[n][hw][c] when b is given), any c that is a multiple of 8
 extern "C" int vs_sample_rowsum(int dtype, const void* a, const void* b, void* out, int n, int64_t hw, int c, float scale, void* stream) {
     VS_REQUIRE(a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "sample_rowsum: channels must be a multiple of 8");
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(sample_rowsum_kernel<bf16_t>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
-                           (bf16_t*)out, hw, c, scale);
-    else
-        hipLaunchKernelGGL(sample_rowsum_kernel<float>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
-                           (float*)out, hw, c, scale);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(sample_rowsum_kernel<T>, dim3(n, (c / kVec + 255) / 256), dim3(1024), 0, (hipStream_t)stream, (const T*)a, (const T*)b,
+                           (T*)out, hw, c, scale));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -845,8 +829,7 @@ extern "C" int vs_dwconv2d_affine(int dtype, const void* x, const float* w, cons
                "dwconv2d_affine: bad arguments");
     VS_REQUIRE(dilation == 1 || (stride == 1 && (dilation == 2 || (dilation == 4 && k == 3))), "dwconv2d_affine: dilation %d at stride %d, kernel %d is not taken", dilation, stride, k);
     VS_REQUIRE(ho > 0 && wo > 0 && (ho - 1) * stride - pad_lo < h && (wo - 1) * stride - pad_lo < wd, "dwconv2d_affine: output %dx%d does not fit input %dx%d", ho, wo, h, wd);
-    if (dtype == VS_BF16) launch_dw_strip<bf16_t>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, (hipStream_t)stream, scale, shift, act);
-    else launch_dw_strip<float>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, (hipStream_t)stream, scale, shift, act);
+    VS_FOR_T(dtype, launch_dw_strip<T>(x, w, y, n, h, wd, c, k, stride, pad_lo, dilation, ho, wo, 0, 0, (hipStream_t)stream, scale, shift, act));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -365,8 +365,7 @@ bool gn_shape_ok(int c, int G) {
 
 #define VS_LAUNCH_T(kernel, grid, s, ...)                                                                  \
     do {                                                                                                    \
-        if (dtype == VS_BF16) { typedef bf16_t T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); } \
-        else { typedef float T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); }          \
+        VS_FOR_T(dtype, { hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); });          \
         VS_LAUNCH_CHECK();                                                                                  \
     } while (0)
 

@@ -664,12 +664,8 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_apply: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     const size_t lds = 2 * (size_t)c * sizeof(float);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(bn_apply_inline_kernel<bf16_t>, dim3(m.nblocks), dim3(256), lds, s, (const bf16_t*)x, partial, nparts, eps,
-                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const bf16_t*)residual, relu, (bf16_t*)y, rows, c, m);
-    else
-        hipLaunchKernelGGL(bn_apply_inline_kernel<float>, dim3(m.nblocks), dim3(256), lds, s, (const float*)x, partial, nparts, eps,
-                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const float*)residual, relu, (float*)y, rows, c, m);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(bn_apply_inline_kernel<T>, dim3(m.nblocks), dim3(256), lds, s, (const T*)x, partial, nparts, eps,
+                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const T*)residual, relu, (T*)y, rows, c, m));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -690,25 +686,16 @@ int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const f
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     if (nparts <= vs_option("bn_inline_rows") && c <= 512 && 256 % ((2 * c) / 4) == 0) {   // few rows: finalise inside the apply sweep
-        if (dtype == VS_BF16)
-            hipLaunchKernelGGL((bn_bwd_apply<bf16_t, false, true>), dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr,
-                               (const bf16_t*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (bf16_t*)dx, (bf16_t*)dres, rows, c, m,
-                               partial, nparts);
-        else
-            hipLaunchKernelGGL((bn_bwd_apply<float, false, true>), dim3(m.nblocks), dim3(256), 0, s, (const float*)g, (const float*)nullptr,
-                               (const float*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (float*)dx, (float*)dres, rows, c, m,
-                               partial, nparts);
+        VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false, true>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
+                               (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m,
+                               partial, nparts));
         VS_LAUNCH_CHECK();
         return VS_OK;
     }
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, partial, nparts, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply<bf16_t, false>), dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr,
-                           (const bf16_t*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (bf16_t*)dx, (bf16_t*)dres, rows, c, m);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply<float, false>), dim3(m.nblocks), dim3(256), 0, s, (const float*)g, (const float*)nullptr,
-                           (const float*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (float*)dx, (float*)dres, rows, c, m);
+    VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
+                           (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -724,9 +711,7 @@ extern "C" int vs_bn_stats(int dtype, const void* x, int64_t rows, int c, float 
     VS_REQUIRE(c % kVec == 0 && c <= 2048,
                "bn_stats: unsupported channel count %d", c);
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_stats: workspace too small");
-    if (dtype == VS_BF16)
-        return stats_t<bf16_t>(x, rows, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, (hipStream_t)stream);
-    return stats_t<float>(x, rows, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, (hipStream_t)stream);
+    VS_FOR_T(dtype, return stats_t<T>(x, rows, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, (hipStream_t)stream));
 }
 
 extern "C" int vs_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma,
@@ -735,12 +720,8 @@ extern "C" int vs_bn_apply(int dtype, const void* x, const float* mean, const fl
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_apply: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(m.nblocks), dim3(256), 0, s, (const bf16_t*)x, mean, invstd, gamma,
-                           beta, (const bf16_t*)residual, relu, (bf16_t*)y, rows, c, m);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(m.nblocks), dim3(256), 0, s, (const float*)x, mean, invstd, gamma,
-                           beta, (const float*)residual, relu, (float*)y, rows, c, m);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(m.nblocks), dim3(256), 0, s, (const T*)x, mean, invstd, gamma,
+                           beta, (const T*)residual, relu, (T*)y, rows, c, m));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -756,7 +737,7 @@ extern "C" int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x
 // whether the one-launch form applies, and its grid (0 = no)
 static int bn_bwd_fused_blocks(int dtype, int64_t rows, int c) {
     if (!vs_option("bn_bwd_fused") || c > 512 || (c & 7) || 256 % ((2 * c) / 4) != 0) return 0;
-    const double bytes = (double)rows * c * (dtype == VS_BF16 ? 2.0 : 4.0);
+    const double bytes = (double)rows * c * (double)dtype_size(dtype);
     if (bytes > 9.0e6 || bytes < 2.0e5) return 0;            // a few MB: 32 x 32 maps and smaller at batch 32
     int nb = (int)(bytes / 65536.0);
     if (vs_option("bn_fused_blocks") > 0) return vs_option("bn_fused_blocks");
@@ -773,8 +754,7 @@ int launch_bn_bwd_fused(int dtype, const void* dy, const void* y, const void* x,
     relu |= vs_option("bn_fused_dbg") << 8;      // diagnostics (tools/convlab): 1 = do not wait at the barrier, 2 = stop after the row sums
 #define VS_BWD_FUSED(T, R) hipLaunchKernelGGL((bn_bwd_fused_kernel<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, (const T*)x, mean, \
                                               invstd, gamma, beta, relu, (T*)dx, (T*)dres, dgamma, dbeta, rows, c, m, workspace, ctl)
-    if (dtype == VS_BF16) { if (rc) VS_BWD_FUSED(bf16_t, true); else VS_BWD_FUSED(bf16_t, false); }
-    else { if (rc) VS_BWD_FUSED(float, true); else VS_BWD_FUSED(float, false); }
+    VS_FOR_T(dtype, { if (rc) VS_BWD_FUSED(T, true); else VS_BWD_FUSED(T, false); });
 #undef VS_BWD_FUSED
     VS_LAUNCH_CHECK();
     return VS_OK;
@@ -809,13 +789,11 @@ int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, con
                                                 (const T*)x, mean, invstd, gamma, beta, relu, rows, c, m, workspace)
 #define VS_BWD_APPLY(T, R) hipLaunchKernelGGL((bn_bwd_apply<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \
                                               (const T*)x, mean, invstd, gamma, beta, dgamma, dbeta, relu, (T*)dx, (T*)dres, rows, c, m)
-    if (dtype == VS_BF16) { if (rc) VS_BWD_PARTIAL(bf16_t, true); else VS_BWD_PARTIAL(bf16_t, false); }
-    else { if (rc) VS_BWD_PARTIAL(float, true); else VS_BWD_PARTIAL(float, false); }
+    VS_FOR_T(dtype, { if (rc) VS_BWD_PARTIAL(T, true); else VS_BWD_PARTIAL(T, false); });
     VS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
-    if (dtype == VS_BF16) { if (rc) VS_BWD_APPLY(bf16_t, true); else VS_BWD_APPLY(bf16_t, false); }
-    else { if (rc) VS_BWD_APPLY(float, true); else VS_BWD_APPLY(float, false); }
+    VS_FOR_T(dtype, { if (rc) VS_BWD_APPLY(T, true); else VS_BWD_APPLY(T, false); });
     VS_LAUNCH_CHECK();
 #undef VS_BWD_PARTIAL
 #undef VS_BWD_APPLY

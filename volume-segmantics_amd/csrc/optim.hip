@@ -270,22 +270,15 @@ extern "C" int vs_train_hyper_set(float* hyper, float lr, float beta1, float bet
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad,
                           hipStream_t s) {
     dim3 grid(cdiv(cin, 32), cdiv(cout_pad > cout ? cout_pad : cout, 32), taps);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cout, taps,
-                           cin, cout_pad, 0);
-    else
-        hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cin,
-                           cout_pad, 0);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(weight_prepare_kernel<T>, grid, dim3(32, 8), 0, s, w, (T*)wc, (T*)wt, cout, taps,
+                           cin, cout_pad, 0));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
 
 int launch_convt_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cin, int cout, hipStream_t s) {
     const int blocks = grid_for((int64_t)4 * cout * 9 * cin);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(convt_weight_prepare_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cin, cout);
-    else
-        hipLaunchKernelGGL(convt_weight_prepare_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wc, (float*)wt, cin, cout);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(convt_weight_prepare_kernel<T>, dim3(blocks), dim3(256), 0, s, w, (T*)wc, (T*)wt, cin, cout));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -303,10 +296,7 @@ int launch_convt_wgrad_gather(const float* dense, float* dw, int cin, int cout, 
 int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cg, hipStream_t s) {
     VS_REQUIRE(cout % 32 == 0 && cg >= 4 && cg <= 32 && 32 % cg == 0, "weight_prepare_grouped: %d channels in groups of %d", cout, cg);
     dim3 grid(cout / 32, 1, taps);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, (bf16_t*)wc, (bf16_t*)wt, cout, taps, cout, cout, cg);
-    else
-        hipLaunchKernelGGL(weight_prepare_kernel<float>, grid, dim3(32, 8), 0, s, w, (float*)wc, (float*)wt, cout, taps, cout, cout, cg);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(weight_prepare_kernel<T>, grid, dim3(32, 8), 0, s, w, (T*)wc, (T*)wt, cout, taps, cout, cout, cg));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -326,10 +316,7 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
         blocks += cdiv(cin[i], 32) * ((t.cg[i] && t.cg[i] != 255) ? 1 : cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32)) * taps[i];
     }
     t.first_block[n] = blocks;
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(weight_prepare_all_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t);
-    else
-        hipLaunchKernelGGL(weight_prepare_all_kernel<float>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(weight_prepare_all_kernel<T>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -340,10 +327,7 @@ int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, i
     VS_REQUIRE(k >= 1 && k <= 16, "segmentation head: classes must be <= 16 (got %d)", k);
     VS_REQUIRE(!db || partial, "segmentation head: the bias gradient needs a partial buffer");
     const int blocks = db ? kHeadBlocks : grid_for((int64_t)n * hw);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d, (bf16_t*)o, n, k, hw, db ? partial : nullptr);
-    else
-        hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<float>, dim3(blocks), dim3(256), 0, s, d, (float*)o, n, k, hw, db ? partial : nullptr);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<T>, dim3(blocks), dim3(256), 0, s, d, (T*)o, n, k, hw, db ? partial : nullptr));
     VS_LAUNCH_CHECK();
     if (db) {
         hipLaunchKernelGGL(bias_grad_final, dim3(k), dim3(64), 0, s, partial, db, kHeadBlocks, k);

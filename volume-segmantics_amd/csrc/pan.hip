@@ -483,8 +483,7 @@ __global__ void fold_bias_kernel(const float* __restrict__ scale, const float* _
 
 #define VS_LAUNCH_T(kernel, grid, s, ...)                                                                                \
     do {                                                                                                                  \
-        if (dtype == VS_BF16) { typedef bf16_t T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); }   \
-        else { typedef float T; hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); }                     \
+        VS_FOR_T(dtype, { hipLaunchKernelGGL((kernel<T>), grid, dim3(256), 0, s, __VA_ARGS__); });                     \
         VS_LAUNCH_CHECK();                                                                                                \
     } while (0)
 

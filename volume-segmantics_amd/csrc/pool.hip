@@ -278,22 +278,16 @@ inline int grid_for(int64_t total) {
 
 #define VS_DISPATCH_T(kern, total, ...)                                                                      \
     do {                                                                                                     \
-        if (dtype == VS_BF16)                                                                                \
-            hipLaunchKernelGGL(kern<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-        else                                                                                                 \
-            hipLaunchKernelGGL(kern<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+        VS_FOR_T(dtype, \
+            hipLaunchKernelGGL(kern<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__));  \
         VS_LAUNCH_CHECK();                                                                                   \
     } while (0)
 
 extern "C" int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, void* stream) {
     VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0, "maxpool_fwd: bad shape");
     const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, idx, n, h, w, c);
-    else
-        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)x, (float*)y, idx, n, h, w, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)y, idx, n, h, w, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -302,12 +296,8 @@ extern "C" int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, voi
                               int w, int c, void* stream) {
     VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0 && idx, "maxpool_bwd: bad arguments");
     const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)dy, idx, (bf16_t*)dx, accumulate, n, h, w, c);
-    else
-        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)dy, idx, (float*)dx, accumulate, n, h, w, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dy, idx, (T*)dx, accumulate, n, h, w, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -315,12 +305,8 @@ extern "C" int vs_maxpool_bwd(int dtype, const void* dy, const uint8_t* idx, voi
 int launch_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, hipStream_t stream) {
     VS_REQUIRE(c % kVec == 0, "upsample2x_bwd: channels must be a multiple of 8");
     const int64_t total = (int64_t)n * h * w * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
-                           (const bf16_t*)dy, (bf16_t*)dx, n, h, w, c, accumulate);
-    else
-        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                           (const float*)dy, (float*)dx, n, h, w, c, accumulate);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const T*)dy, (T*)dx, n, h, w, c, accumulate));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -335,12 +321,8 @@ extern "C" int vs_channel_slice(int dtype, const void* src, int c_src, int src_o
                src_off + c <= c_src && dst_off + c <= c_dst && rows >= 0,
                "channel_slice: channel counts / offsets must be multiples of 8 and inside their tensors");
     const int64_t total = rows * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(channel_slice_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, c_src,
-                           src_off, (bf16_t*)dst, c_dst, dst_off, c, rows, accumulate);
-    else
-        hipLaunchKernelGGL(channel_slice_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, c_src,
-                           src_off, (float*)dst, c_dst, dst_off, c, rows, accumulate);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(channel_slice_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)src, c_src,
+                           src_off, (T*)dst, c_dst, dst_off, c, rows, accumulate));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -348,12 +330,8 @@ extern "C" int vs_channel_slice(int dtype, const void* src, int c_src, int src_o
 extern "C" int vs_zero_stuff2x(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream) {
     VS_REQUIRE(c % kVec == 0, "zero_stuff2x: channels must be a multiple of 8");
     const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(zero_stuff2x_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, n, h, w, c);
-    else
-        hipLaunchKernelGGL(zero_stuff2x_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)x, (float*)y, n, h, w, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(zero_stuff2x_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)y, n, h, w, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -362,12 +340,8 @@ extern "C" int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int 
                                   const float* shift, int relu, void* stream) {
     VS_REQUIRE(x && y && c > 0 && c % kVec == 0 && (!scale == !shift), "depth_to_space2: channels must be a multiple of 8, scale and shift come together");
     const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(depth_to_space2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           (bf16_t*)y, n, h, w, c, bias, scale, shift, relu);
-    else
-        hipLaunchKernelGGL(depth_to_space2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                           (float*)y, n, h, w, c, bias, scale, shift, relu);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(depth_to_space2_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                           (T*)y, n, h, w, c, bias, scale, shift, relu));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -375,12 +349,8 @@ extern "C" int vs_depth_to_space2(int dtype, const void* x, void* y, int n, int 
 extern "C" int vs_space_to_depth2(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream) {
     VS_REQUIRE(x && y && c > 0 && c % kVec == 0, "space_to_depth2: channels must be a multiple of 8");
     const int64_t total = (int64_t)n * 4 * h * w * (c / kVec);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(space_to_depth2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           (bf16_t*)y, n, h, w, c);
-    else
-        hipLaunchKernelGGL(space_to_depth2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                           (float*)y, n, h, w, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(space_to_depth2_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                           (T*)y, n, h, w, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -395,10 +365,7 @@ extern "C" int vs_colsum(int dtype, const void* x, int64_t rows, int c, float* o
     const int rl = 256 / (cs / kVec);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kColsumBlocks, (rows + rl - 1) / rl));
     const dim3 grid(blocks, (c + 255) / 256);
-    if (dtype == VS_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, cs, workspace);
-    else
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, c, cs, workspace);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, rows, c, cs, workspace));
     VS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, workspace, out, blocks, c);
     VS_LAUNCH_CHECK();

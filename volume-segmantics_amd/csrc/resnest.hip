@@ -83,16 +83,14 @@ __global__ void radix2_gated_sum_bwd_kernel(const T* __restrict__ dout, const T*
 extern "C" int vs_radix2_softmax(int dtype, const void* z, void* a, int n, int c, void* stream) {
     VS_REQUIRE(z && a && n > 0 && c > 0, "radix2_softmax: bad arguments");
     const int blocks = (n * c + 255) / 256;
-    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_softmax_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)a, n, c);
-    else hipLaunchKernelGGL(radix2_softmax_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)a, n, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(radix2_softmax_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)z, (T*)a, n, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
 extern "C" int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, void* dz, int n, int c, void* stream) {
     VS_REQUIRE(da && a && dz && n > 0 && c > 0, "radix2_softmax_bwd: bad arguments");
     const int blocks = (n * c + 255) / 256;
-    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_softmax_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, (const bf16_t*)a, (bf16_t*)dz, n, c);
-    else hipLaunchKernelGGL(radix2_softmax_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)da, (const float*)a, (float*)dz, n, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(radix2_softmax_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)da, (const T*)a, (T*)dz, n, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -102,16 +100,14 @@ extern "C" int vs_radix2_softmax_bwd(int dtype, const void* da, const void* a, v
 extern "C" int vs_radix2_gated_sum(int dtype, const void* x, const void* a, void* out, int n, int64_t hw, int c, void* stream) {
     VS_REQUIRE(x && a && out && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "radix2_gated_sum: channels must be a multiple of 8");
     const dim3 grid(grid_for((int64_t)n * hw * (c / kVec)));
-    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_gated_sum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)a, (bf16_t*)out, n, hw, c);
-    else hipLaunchKernelGGL(radix2_gated_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)a, (float*)out, n, hw, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(radix2_gated_sum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)a, (T*)out, n, hw, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
 extern "C" int vs_radix2_gated_sum_bwd(int dtype, const void* dout, const void* a, void* dx, int n, int64_t hw, int c, void* stream) {
     VS_REQUIRE(dout && a && dx && n > 0 && hw > 0 && c > 0 && c % kVec == 0, "radix2_gated_sum_bwd: channels must be a multiple of 8");
     const dim3 grid(grid_for((int64_t)n * hw * (c / kVec)));
-    if (dtype == VS_BF16) hipLaunchKernelGGL(radix2_gated_sum_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)a, (bf16_t*)dx, n, hw, c);
-    else hipLaunchKernelGGL(radix2_gated_sum_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, (const float*)a, (float*)dx, n, hw, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL(radix2_gated_sum_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout, (const T*)a, (T*)dx, n, hw, c));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

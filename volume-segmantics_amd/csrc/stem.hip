@@ -403,6 +403,9 @@ extern "C" int vs_stem_fwd(int dtype, const float* x, const float* w, const floa
     else if (dtype == VS_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (bf16_t*)y, n, h, w_);
+    else if (dtype == VS_F16)       // fp32 arithmetic on the fp32 slices (one input channel: 0.5 % of the network's FLOPs), fp16 store
+        hipLaunchKernelGGL(stem_fwd_kernel<f16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
+                           (f16_t*)y, n, h, w_);
     else
         hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (float*)y, n, h, w_);
@@ -417,6 +420,7 @@ extern "C" size_t vs_stem_wgrad_workspace(int n, int h, int w_) {
 
 extern "C" int vs_stem_wgrad(int dtype, const float* x, const void* dy, float* dw, float* workspace,
                              size_t workspace_bytes, int n, int h, int w_, void* stream) {
+    VS_NO_F16(dtype, "stem_wgrad");
     VS_REQUIRE(h % 2 == 0 && w_ % 2 == 0 && x && dy && dw, "stem_wgrad: bad arguments");
     VS_REQUIRE(workspace && workspace_bytes >= vs_stem_wgrad_workspace(n, h, w_), "stem_wgrad: workspace too small");
     const int total = n * cdiv(h / 2, TPH) * cdiv(w_ / 2, TPW);

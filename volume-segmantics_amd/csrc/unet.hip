@@ -1284,7 +1284,7 @@ extern "C" int vs_unet_create_ex(vs_unet_t** out, int dtype, int classes, int ma
     VS_REQUIRE((encoder != 150 && encoder != 201) || (topology != 4 && topology != 5 && topology != 7),
                "unet_create: the ResNeSt encoders do not support the dilating decoders (DeepLabV3 / DeepLabV3+ / PAN) - smp's ResNestEncoder.make_dilated "
                "raises for them as well (their parameter-free average pools would stay at stride 2)");
-    VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16, "unet_create: bad dtype %d", dtype);
+    VS_REQUIRE(dtype == VS_F32 || dtype == VS_BF16 || dtype == VS_F16, "unet_create: bad dtype %d", dtype);
     VS_REQUIRE(classes >= 1 && classes <= 16, "unet_create: classes must be in [1,16], got %d", classes);
     VS_REQUIRE(max_batch >= 1 && h >= 32 && w >= 32 && h % 32 == 0 && w % 32 == 0,
                "unet_create: batch %d, %dx%d - spatial dims must be positive multiples of 32", max_batch, h, w);
@@ -1322,7 +1322,7 @@ extern "C" int vs_unet_prepare(vs_unet_t* net, const float* params, const float*
         };
         for (auto& u : net->units) {
             if (u.kind != U_CONV && u.kind != U_HEAD) continue;
-            const bool wc = net->dtype == VS_BF16 || u.cg || u.g2, wt = training != 0;
+            const bool wc = net->dtype != VS_F32 || u.cg || u.g2, wt = training != 0;
             if (!wc && !wt) continue;
             cgs[nl] = u.g2 ? 255 : u.cg;
             w_off[nl] = c.t(u.w_idx).offset;
@@ -1381,7 +1381,7 @@ extern "C" int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* 
         if (v.kind != U_CONV && v.kind != U_HEAD) continue;
         VS_REQUIRE(nl < 64, "unet_prepare_range: too many layers in one range");
         w_off[nl] = net->layout.tensors[v.w_idx].offset;
-        wc_off[nl] = (net->dtype == VS_BF16 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
+        wc_off[nl] = (net->dtype != VS_F32 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
         wt_off[nl] = (long)Ctx::wt_off(v, other);
         cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
         cgs[nl] = v.g2 ? 255 : v.cg;
@@ -1462,6 +1462,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                         float* logits, void* workspace, void* stream, const VolScatter* scatter) {
     VS_REQUIRE(net && params && bnstate && x && logits && workspace, "unet_forward: null pointer");
     VS_REQUIRE(n >= 1 && n <= net->max_batch, "unet_forward: batch %d exceeds the plan's max_batch %d", n, net->max_batch);
+    VS_REQUIRE(!(training && net->dtype == VS_F16), "unet_forward: fp16 is the inference precision (batch statistics, the backward pass and the optimiser are built for fp32 / bf16)");
     Ctx c{net, (char*)workspace, params, bnstate, (hipStream_t)stream, n};
     const int dt = net->dtype;
     int rc;
@@ -1856,7 +1857,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (v.bias_idx >= 0 && aux_on) push(v.bias_idx);
         if (v.kind == U_CONV || v.kind == U_HEAD) {
             w_off[nl] = c.t(v.w_idx).offset;
-            wc_off[nl] = (dt == VS_BF16 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
+            wc_off[nl] = (dt != VS_F32 || v.cg || v.g2) ? (long)Ctx::wc_off(v, other) : -1;
             wt_off[nl] = (long)Ctx::wt_off(v, other);
             cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
             cgs[nl] = v.g2 ? 255 : v.cg;
@@ -1877,6 +1878,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                int need_encoder_wgrad, float* grads, void* workspace, void* stream, int unit_lo, int unit_hi,
                                const vs_adamw_args* opt, int role) {
     VS_REQUIRE(net && params && x && dlogits && grads && workspace, "unet_backward: null pointer");
+    VS_NO_F16(net->dtype, "unet_backward");
     const bool do_main = role != ROLE_SIDE, do_side = role != ROLE_MAIN;
     VS_REQUIRE(n == net->last_n, "unet_backward: batch %d does not match the last training forward (%d)", n, net->last_n);
     Ctx c{net, (char*)workspace, params, nullptr, (hipStream_t)stream, n};

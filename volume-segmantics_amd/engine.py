@@ -90,11 +90,11 @@ class VolSegUnet(nn.Module):
         self.encoder_name, self.topology = encoder, topology
         self._enc = self.TOPOLOGIES[topology] * 1000 + self.ENCODERS[encoder]     # the C ABI's encoder code
         precision = precision or default_precision()
-        if precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16' (inference only), got {precision!r}")
         self.classes = int(classes)
         self.precision = precision
-        self._dtype_code = _lib.VS_F32 if precision == "fp32" else _lib.VS_BF16
+        self._dtype_code = {"fp32": _lib.VS_F32, "bf16": _lib.VS_BF16, "fp16": _lib.VS_F16}[precision]
         self._table = _lib.unet_tensor_table(self.classes, self._enc)
         dev = torch.device(device if device is not None else "cpu")
         if dev.type == "cuda" and dev.index is None:
@@ -699,6 +699,10 @@ class VolSegUnet(nn.Module):
 
     def forward(self, x):
         x = self._check_input(x)
+        if self.training and self.precision == "fp16":
+            # fp16 activations and weights (BASELINE configs[4]) are the INFERENCE precision: batch statistics, the backward pass
+            # and the optimiser are built for fp32 / bf16 (no loss scaling here) - train in bf16 and predict in fp16
+            raise RuntimeError("precision 'fp16' is inference only: call model.eval(), or train with precision 'bf16' / 'fp32'")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if self._anchor is None or self._anchor.device != self.device:
                 self._anchor = torch.zeros((), device=self.device, requires_grad=True)

@@ -1,7 +1,8 @@
 """The drop-in seam: ``create_model_on_device`` / ``create_model_from_file``
-(volume_segmantics/model/model_2d.py:10-57).  For U_NET / U_NET_PLUS_PLUS / LINKNET / FPN / DEEPLABV3 / DEEPLABV3_PLUS / MA_NET / PAN over the ResNet-family encoders the
-returned ``nn.Module`` is the HIP engine (engine.VolSegUnet); the other smp topologies / encoders of the reference are rows of
-SURVEY.md section 8f ("next") and are refused loudly rather than routed through a fallback."""
+(volume_segmantics/model/model_2d.py:10-57).  For every model type of the reference (U_NET / U_NET_PLUS_PLUS / LINKNET / FPN / DEEPLABV3 / DEEPLABV3_PLUS / MA_NET / PAN) over
+the encoders of its list (resnet34 / resnet50 / resnext50_32x4d / efficientnet-b3 / -b4 / timm-resnest50d / -101e, + resnet18) the
+returned ``nn.Module`` is the HIP engine (engine.VolSegUnet); the few pairs the engine does not build (Linknet over EfficientNet,
+ResNeSt under the dilated topologies) are refused loudly by ``vs_unet_create_ex`` rather than routed through a fallback."""
 from __future__ import annotations
 
 import logging
@@ -90,7 +91,7 @@ def load_pretrained_encoder(model: VolSegUnet, sd: dict) -> None:
 load_torchvision_resnet34 = load_pretrained_encoder   # earlier name
 
 
-def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int = 0) -> Tuple[torch.nn.Module, int, dict]:
+def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int = 0, precision: str | None = None) -> Tuple[torch.nn.Module, int, dict]:
     """Checkpoint -> (model, number of labels, label codes).  The checkpoint pickles the ModelType enum under the
     reference's module path, so ``weights_only=False`` and an importable ``volume_segmantics.utilities.base_data_utils``
     (or this package's alias, see checkpoint_compat) are needed for files written by the reference."""
@@ -102,6 +103,8 @@ def create_model_from_file(weights_fn: Path, gpu: bool = True, device_num: int =
     struct = dict(model_dict["model_struc_dict"])
     struct.update(model_dict.get("engine_settings", {}))   # keys only this engine knows (compute precision)
     struct["encoder_weights"] = None  # weights come from the file; never touch the network
+    if precision:                      # the prediction settings' own `precision:` key (e.g. fp16 - inference only) wins over the
+        struct["precision"] = precision    # precision the checkpoint was trained in
     model = create_model_on_device(device_num, struct)
     logging.info("Loading in the saved weights.")
     model.load_state_dict(model_dict["model_state_dict"])

@@ -128,7 +128,7 @@ class VolSeg2dPredictor:
         self.settings = settings
         self.model_device_num = int(settings.cuda_device)
         self.model, self.num_labels, self.label_codes = create_model_from_file(
-            self.model_file_path, device_num=self.model_device_num)
+            self.model_file_path, device_num=self.model_device_num, precision=getattr(settings, "precision", None))
 
     def _get_model_from_trainer(self, trainer):
         self.model = trainer.model
