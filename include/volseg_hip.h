@@ -57,6 +57,10 @@ typedef struct vs_conv_desc {
 int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void* src1, const void* w,
                   const float* scale, const float* shift, const void* residual,
                   void* y, void* y1, void* stream);
+/* Which kernel instantiation vs_conv2d_fwd picks for a descriptor: cout tile * 1000 + pixel tiles per wave * 100 + taps * 10 + kind
+ * (1 tile kernel, 2 stride 2, 4 direct shallow-layer kernel, 6 LDS-DMA ring, 7 persistent LDS-DMA ring, 8 eight-wave tiles).  No
+ * reference counterpart: a test / tooling query (tests assert which path a parity case exercised). */
+int vs_conv2d_variant(const vs_conv_desc* d);
 
 /* dw[cout][kh*kw][cin] (fp32) = sum_pixels dy (x) x.  torch: conv weight gradient of loss.backward()
  * (vol_seg_2d_trainer.py:429).  workspace >= vs_conv2d_wgrad_workspace(d). */

@@ -329,6 +329,55 @@ def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
     assert torch.allclose(from_nhwc(dx), x.grad, **tol(code, x.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize("case", [(24, 128, 128, 64, 0, 64, "res"), (17, 112, 144, 64, 0, 64, "affine"), (36, 64, 64, 128, 0, 128, "res"),
+                                  (64, 32, 32, 256, 0, 256, "plain"), (36, 64, 64, 256, 128, 128, "affine"), (17, 128, 128, 128, 64, 64, "affine"),
+                                  (4, 256, 256, 64, 64, 32, "affine"), (36, 96, 80, 64, 0, 32, "swish"), (128, 16, 16, 512, 0, 512, "res")])
+def test_persistent_stream_conv_equals_the_tile_kernel_bit_for_bit(case):
+    """conv_stream_kernel (csrc/conv_stream.h) - the persistent LDS-DMA form that serves the evaluation-mode 3x3 layers of large
+    launches (prediction batches) - against conv_igemm_kernel on the same operands: EVERY output bit equal (same accumulation
+    order, same epilogue arithmetic), so a slice's prediction cannot depend on which kernel its batch size selected; and
+    against torch CPU within the bf16 tolerance.  Covers resident (64 input channels) and streamed weights, residual + ReLU,
+    folded-BatchNorm scale / shift, swish, the decoder form (x2-upsampled tensor + skip tensor), ragged image sizes, 32- and
+    64-wide cout tiles, and grids that do not divide by the workgroup count."""
+    L = lib()
+    code = 1
+    n, h, w, c0, c1, cout, kind = case
+    g = torch.Generator().manual_seed(23)
+    up = 1 if c1 else 0
+    x0 = rounded(torch.randn(n, c0, h >> up, w >> up, generator=g), code)
+    x1 = rounded(torch.randn(n, c1, h, w, generator=g), code) if c1 else None
+    xin = x0 if not c1 else torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1)
+    wt = rounded(torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5, code)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = rounded(torch.randn(n, cout, h, w, generator=g), code) if kind == "res" else None
+    ref = F.conv2d(xin, wt, padding=1)
+    if kind != "plain":
+        ref = ref * scale[None, :, None, None] + shift[None, :, None, None]
+    if res is not None:
+        ref = ref + res
+    ref = ref * torch.sigmoid(ref) if kind == "swish" else (F.relu(ref) if kind != "plain" else ref)
+    relu = 2 if kind == "swish" else (0 if kind == "plain" else 1)
+    d = conv_desc(L, code, n, h, w, c0, cout, 3, 1, 1, c1=c1, up0=up, relu=relu)
+    x0d, x1d, wd = to_nhwc(x0, code), (to_nhwc(x1, code) if c1 else None), w_krsc(wt, code)
+    scd, shd = (scale.to(DEV), shift.to(DEV)) if kind != "plain" else (None, None)
+    rd = to_nhwc(res, code) if res is not None else None
+    outs = {}
+    try:
+        for stream in (1, 0):
+            L.set_option("conv_stream", stream)
+            yd = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+            L.check(L.lib.vs_conv2d_fwd(d, L.ptr(x0d), L.ptr(x1d) if c1 else None, L.ptr(wd), L.ptr(scd) if scd is not None else None,
+                                        L.ptr(shd) if shd is not None else None, L.ptr(rd) if rd is not None else None, L.ptr(yd), None, None))
+            sync()
+            outs[stream] = yd
+            if stream:
+                assert L.lib.vs_conv2d_variant(d) % 10 == 7, "the persistent kernel was not selected for this launch"
+    finally:
+        L.set_option("conv_stream", 1)
+    assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16))
+    assert torch.allclose(from_nhwc(outs[1]), ref, **tol(code, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1, 1, 0, 1), (3, 20, 28, 40, 48, 3, 1, 1, 0, 1), (2, 32, 32, 64, 128, 3, 2, 1, 0, 1),
                                   (2, 16, 16, 96, 32, 1, 1, 0, 0, 1), (1, 64, 64, 16, 16, 3, 1, 1, 0, 1), (2, 16, 16, 128, 64, 3, 1, 2, 0, 2),
                                   (2, 8, 8, 256, 128, 3, 1, 1, 64, 1), (8, 64, 64, 64, 64, 3, 1, 1, 0, 1), (2, 128, 128, 32, 16, 3, 1, 1, 0, 1)])

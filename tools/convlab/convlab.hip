@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "../../volume-segmantics_amd/csrc/conv_ring.h"
+#include "../../volume-segmantics_amd/csrc/conv_stream.h"
 
 void vs_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
@@ -61,6 +61,19 @@ static void print_probe(const char* what, unsigned long long* dbuf, size_t cap) 
     std::vector<unsigned long long> h(cap * 8);
     CK(hipMemcpy(h.data(), dbuf, cap * 64, hipMemcpyDeviceToHost));
     double ph[4] = {0, 0, 0, 0}, life = 0; size_t n = 0; unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+    {   // conv_stream_kernel's own record: begin, loop start, summed tap-7 waits, summed epilogues, end, tiles
+        double lf = 0, pro = 0, wt = 0, ep = 0, nt = 0; size_t m = 0;
+        for (size_t i = 0; i < cap; ++i) {
+            const unsigned long long* o = &h[i * 8];
+            if (!o[0] || o[7] != 0x53) continue;
+            ++m; lf += (o[4] - o[0]) * 0.01; pro += (o[1] - o[0]) * 0.01; wt += o[2] * 0.01; ep += o[3] * 0.01; nt += (double)o[5];
+        }
+        if (m) {
+            printf("      [probe] %s: %zu WGs, life %.1f us, prologue %.2f us, %.1f tiles per WG: per tile %.2f us = waits at the chunk barriers %.2f + epilogue %.2f + rest %.2f\n",
+                   what, m, lf / m, pro / m, nt / m, (lf - pro) / nt, wt / nt, ep / nt, (lf - pro - wt - ep) / nt);
+            return;
+        }
+    }
     for (size_t i = 0; i < cap; ++i) {
         const unsigned long long* o = &h[i * 8];
         if (!o[0]) continue;
@@ -81,6 +94,9 @@ template <int BN, int PT, int NW, int TWS, int IMGS, int WPS, int PIN = 0>
 static int run_ring(const ConvParams& p, hipStream_t s) { return ring::launch_ring<BN, PT, NW, TWS, IMGS, WPS, PIN>(p, 0, g_probe, s); }
 template <int PT, int NW, int TWS, int IMGS>
 static bool ok_ring(const ConvParams& p) { return ring::ring_geom_ok<PT, NW, TWS, IMGS>(p) && (IMGS > 1 || (p.Hout >= 8 && p.Wout >= (1 << TWS))); }
+template <int BN, int PT, int NW, int TWS, int WPS, int PIN = 2>
+static int run_stream(const ConvParams& p, hipStream_t s) { return ring::launch_stream<BN, PT, NW, TWS, WPS, PIN>(p, g_probe, s); }
+static bool ok_stream(const ConvParams& p) { return ring::stream_ok(p, 0); }
 static int run_lib(const ConvParams& p, hipStream_t s) {
     vs_conv_desc d{};
     d.dtype = VS_BF16; d.n = p.N; d.hin = p.Hin; d.win = p.Win; d.c0 = p.C0; d.c1 = p.C1; d.up0 = p.up0; d.cout = p.Cout;
@@ -93,6 +109,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 30;
     const int rounds = argc > 2 ? atoi(argv[2]) : 3;
     const bool do_probe = argc > 3 && atoi(argv[3]) != 0, do_wgrad = argc > 4 && atoi(argv[4]) != 0, do_conv = !(argc > 5 && atoi(argv[5]) == 0), do_chain = argc > 6 && atoi(argv[6]) != 0, do_bn = argc > 7 && atoi(argv[7]) != 0;
+    const bool pred_shapes = argc > 8 && atoi(argv[8]) != 0;     // the layers of a 512^2 prediction forward at batch 64 instead
     std::vector<Shape> shapes = {
         {"layer1 64->64 @64", 32, 64, 64, 0, 0, 64},
         {"layer2 128->128 @32", 32, 32, 128, 0, 0, 128},
@@ -107,8 +124,23 @@ int main(int argc, char** argv) {
         {"dec4.c1 up32->16 @256", 32, 256, 32, 0, 1, 16},
         {"ragged 40->48 @24 (n=3)", 3, 24, 40, 0, 0, 48},
     };
+    if (pred_shapes)
+        shapes = {
+            {"P layer1 64->64 @128", 64, 128, 64, 0, 0, 64},
+            {"P layer2 128->128 @64", 64, 64, 128, 0, 0, 128},
+            {"P layer3 256->256 @32", 64, 32, 256, 0, 0, 256},
+            {"P layer4 512->512 @16", 64, 16, 512, 0, 0, 512},
+            {"P dec0.c1 up512+256->256 @32", 64, 32, 512, 256, 1, 256},
+            {"P dec1.c1 up256+128->128 @64", 64, 64, 256, 128, 1, 128},
+            {"P dec2.c1 up128+64->64 @128", 64, 128, 128, 64, 1, 64},
+            {"P dec3.c1 up64+64->32 @256", 64, 256, 64, 64, 1, 32},
+            {"P dec3.c2 32->32 @256", 64, 256, 32, 0, 0, 32},
+        };
     std::vector<Variant> vars = {
         {"lib (conv_igemm)", run_lib, ok_any},
+        {"stream BN64 PT2 NW8 16x16 pin2", run_stream<64, 2, 8, 4, 2, 2>, ok_stream},
+        {"stream BN64 PT2 NW8 16x16 pin0", run_stream<64, 2, 8, 4, 2, 0>, ok_stream},
+        {"stream BN32 PT2 NW8 16x16 pin2", run_stream<32, 2, 8, 4, 2, 2>, ok_stream},
         {"ring BN64 PT2 NW4 16x8  1w pin0", run_ring<64, 2, 4, 4, 1, 1, 0>, ok_ring<2, 4, 4, 1>},
         {"ring BN64 PT2 NW4 16x8  1w pin1", run_ring<64, 2, 4, 4, 1, 1, 1>, ok_ring<2, 4, 4, 1>},
         {"ring BN64 PT2 NW4 16x8  1w pin2", run_ring<64, 2, 4, 4, 1, 1, 2>, ok_ring<2, 4, 4, 1>},
@@ -127,6 +159,11 @@ int main(int argc, char** argv) {
         {"ring BN32 PT2 NW8 8x8 x4img pin2", run_ring<32, 2, 8, 3, 4, 2, 2>, ok_ring<2, 8, 3, 4>},
     };
     if (!do_conv) vars.resize(1);
+    if (const char* only = getenv("CONVLAB_ONLY")) {      // keep the library path and the variants whose name contains the string
+        std::vector<Variant> keep;
+        for (auto& v : vars) if (v.fn == run_lib || v.name.find(only) != std::string::npos) keep.push_back(v);
+        vars = keep;
+    }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     srand(1234);

@@ -55,6 +55,7 @@ _SIGS = {
     "vs_last_error": (C.c_char_p, []),
     "vs_version": (I, []),
     "vs_conv2d_fwd": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
+    "vs_conv2d_variant": (I, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),

@@ -49,6 +49,18 @@ extern "C" int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void
     return launch_conv_igemm(d->dtype, p, (hipStream_t)stream);
 }
 
+// which kernel instantiation vs_conv2d_fwd picks for this descriptor (with an affine epilogue where the descriptor allows one):
+// cout tile * 1000 + pixel tiles per wave * 100 + taps * 10 + kind (1 = stride-1 tile kernel, 2 = stride 2, 4 = direct shallow-layer
+// kernel, 6 = LDS-DMA ring, 7 = persistent LDS-DMA ring, 8 = 8-wave 256-pixel tiles); negative = error.  For tests and tools.
+extern "C" int vs_conv2d_variant(const vs_conv_desc* d) {
+    ConvParams p;
+    int rc = desc_to_params(d, p);
+    if (rc) return rc;
+    p.src0 = (const void*)16; p.src1 = d->c1 ? (const void*)16 : nullptr; p.w = (const void*)16; p.out = (void*)16;
+    p.out1 = d->split_c > 0 ? (void*)16 : nullptr;
+    return conv_igemm_variant(d->dtype, p);
+}
+
 static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
     VS_REQUIRE(d, "conv: null descriptor");
     p = WgradParams{};

@@ -30,7 +30,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
-#include "conv_ring.h"
+#include "conv_stream.h"
 #include "prof.h"
 
 namespace {
@@ -724,6 +724,16 @@ Pick pick_cfg(const ConvParams& p) {
 // workgroup per CU with its staging off the registers beats two that stage through them (tools/convlab: layer2 / layer3 /
 // layer4 / dec0 / dec1 shapes of the batch-32 step 12 - 22 % faster, the short-K 64- and 32-channel layers slower).
 // 0 = no; 1 = 256-pixel tiles x 64 couts; 2 = 256-pixel tiles x 32 couts; 3 = pairs of 8 x 8 images x 32 couts
+// conv_stream_kernel (conv_stream.h), the persistent form, takes the evaluation-mode stride-1 3x3 layers of LARGE launches
+// (prediction: batches of 512 x 512 slices) - at least `conv_stream_min_tiles` tile jobs per CU-resident workgroup, so that
+// the per-tile latencies it removes are what the launch consists of.  0 = no, else the cout tile (64 / 32)
+static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
+    if (dtype != VS_BF16 || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512) return 0;
+    const int bn = (p.Cout % 64 == 0) ? 64 : 32;
+    const long jobs = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * (p.Cout / bn);
+    return jobs >= 256L * vs_option("conv_stream_min_tiles") ? bn : 0;
+}
+
 static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
         out_nchw || (p.Cout & 3) || p.out_f32) return 0;
@@ -781,6 +791,10 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
     if constexpr (std::is_same<T, bf16_t>::value) {
+        if (const int sm = stream_mode(VS_BF16, p, out_nchw)) {
+            unsigned long long* probe = vs_probe_buffer(256);
+            return sm == 64 ? ring::launch_stream<64, 2, 8, 4, 2, 2>(p, probe, s) : ring::launch_stream<32, 2, 8, 4, 2, 2>(p, probe, s);
+        }
         const int rm = ring_mode(VS_BF16, p, out_nchw);
         if (rm) {
             const long groups = rm == 3 ? p.N / 2 : (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
@@ -828,6 +842,7 @@ bool conv_igemm_can_pool(const ConvParams& p) {
 // (code 1 = stride 1, 2 = stride 2, 4 = direct (LDS-free) shallow-layer kernel, 8 = 8-wave 256-pixel tiles)
 int conv_igemm_variant(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return 16 * 1000 + 2 * 100 + 9 * 10 + 4;
+    if (const int sm = stream_mode(dtype, p, p.out_f32 >> 1)) return sm * 1000 + 2 * 100 + 9 * 10 + 7;                    // 7 = persistent LDS-DMA ring
     if (const int rm = ring_mode(dtype, p, p.out_f32 >> 1)) return (rm == 1 ? 64 : 32) * 1000 + 2 * 100 + 9 * 10 + 6;   // 6 = LDS-DMA ring
     const Pick c = pick_cfg(p);
     return c.BN * 1000 + c.PT * 100 + (p.KH * p.KW) * 10 + (c.NW == 8 ? 8 : (p.stride == 2 ? 2 : 1));
