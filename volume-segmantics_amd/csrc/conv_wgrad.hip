@@ -32,6 +32,7 @@ struct WGeom {
     unsigned pw_magic, tw_magic, th_magic;          // x / PW, x / tiles_w, x / tiles_h by umulhi (bf16 fast path)
     int fast;                                        // bf16 fast path (conv_wgrad_bf16_kernel) applies
     int ring;                                        // 1 / 2: conv_wgrad_ring_kernel on 16 x 8 tiles / on pairs of 8 x 8 images
+    int xmode, ppx;                                  // workgroup -> (pair, split) assignment (ring::wg_assign), bf16 kernels
     unsigned long long* probe;                       // phase timestamps (tools/convlab); null in normal operation
 };
 
@@ -267,10 +268,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     char* dyl = smem + P * kXP;
     const int dummy = P * kXP + BM * DYP;                  // 16 spare bytes: target of the stores of idle staging items
 
-    const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x - ct * g.cchunks;
+    int pair, split;
+    if (!ring::wg_assign(g.xmode, g.ctiles * g.cchunks, g.nsplit, g.ppx, pair, split)) return;
+    const int ct = pair / g.cchunks, cc = pair - ct * g.cchunks;
     const int co0 = ct * BNO, c0 = p.cg ? co0 : cc * 32;    // grouped (MO = 2): the cout tile's own super-group
     const int Cw = p.cg ? 32 : (p.C0 + p.C1), cwb = p.cg ? co0 : 0;
-    const int split = blockIdx.y;
     const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
     const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
     const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
@@ -493,6 +495,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     const double dw_bytes = (double)p.Cout * p.KH * p.KW * (p.cg ? 32 : Cin) * 4.0;
     // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
     g.probe = nullptr;
+    g.xmode = 0; g.ppx = 0;
     g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
     g.ring = 0;
@@ -518,6 +521,17 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
         int ns = std::max(cdiv(target, base), std::min(cdiv(4 * target, base), by_slab));
         ns = std::min(ns, g.total_tiles);
         g.nsplit = cdiv(g.total_tiles, cdiv(g.total_tiles, ns));
+        // XCD-aware assignment (ring::wg_assign): whole K splits per XCD from 8 splits on; 1 / 2 / 4 splits span 8 / 4 / 2 XCDs
+        g.xmode = 0; g.ppx = 0;
+        if (vs_option("wgrad_xcd")) {
+            int want = g.nsplit;
+            if (want == 3) want = 4;
+            else if (want >= 5) want = (want + 7) / 8 * 8;
+            want = std::min(want, g.total_tiles);
+            const int got = cdiv(g.total_tiles, cdiv(g.total_tiles, want));
+            if (got >= 8) { g.nsplit = got; g.xmode = 1; }
+            else if (got == 1 || got == 2 || got == 4) { g.nsplit = got; g.xmode = 2; g.ppx = cdiv(base, 8 / got); }
+        }
         g.dys = 0;
         return VS_OK;
     }
@@ -562,7 +576,8 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
     WGeom gg = g;
     gg.probe = vs_probe_buffer((size_t)g.ctiles * g.cchunks * g.nsplit);
-    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, gg);
+    const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, g.ctiles * g.cchunks, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gg);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
@@ -583,8 +598,10 @@ int launch_ring_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
     ring::WGeomR gr{};
     gr.tiles_h = g.tiles_h; gr.tiles_w = g.tiles_w; gr.total_tiles = g.total_tiles; gr.cchunks = g.cchunks; gr.nsplit = g.nsplit;
     gr.tw_magic = g.tw_magic; gr.th_magic = g.th_magic;
+    gr.xmode = g.xmode; gr.npairs = g.ctiles * g.cchunks; gr.ppx = g.ppx;
     gr.probe = vs_probe_buffer((size_t)g.ctiles * g.cchunks * g.nsplit);
-    hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, gr);
+    const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, gr.npairs, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gr);
     VS_LAUNCH_CHECK();
     if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * 9 * (p.C0 + p.C1), g.nsplit, s);

@@ -21,8 +21,36 @@
 
 namespace ring {
 
+// (cout tile x cin chunk pair, K split) of a workgroup.  xmode 0: 2-D grid (pair = blockIdx.x, split = blockIdx.y).  Otherwise a
+// 1-D grid, whose consecutive ids the hardware deals round-robin to the 8 XCDs (id & 7):
+//   1 (8 or more splits): a K split lives on ONE XCD - every (cout tile, cin chunk) workgroup of a pixel range shares that L2,
+//     so a pixel tile's input patches and dy tiles leave HBM once, not once per XCD that happens to hold one of their readers
+//     (the step is HBM-bound: PMC traffic 13.6 GB per step at ~2.9 TB/s, of which the weight gradients were 3.6 GB - 1.8x
+//     what they read algorithmically);
+//   2 (1 / 2 / 4 splits): a split spans 8 / nsplit XCDs, each takes a contiguous cout-major range of `ppx` pairs (whole cout
+//     tiles where they divide: dy once per split, an input chunk once per XCD of the split).
+// false: this workgroup has nothing to do (ragged tail of the 1-D grid)
+__device__ __forceinline__ bool wg_assign(int xmode, int npairs, int nsplit, int ppx, int& pair, int& split) {
+    if (xmode == 0) { pair = blockIdx.x; split = blockIdx.y; return true; }
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (xmode == 1) {
+        const int sl = j / npairs;
+        pair = j - sl * npairs;
+        split = sl * 8 + xcd;
+        return split < nsplit;
+    }
+    const int X = 8 / nsplit;
+    split = xcd / X;
+    pair = (xcd - split * X) * ppx + j;
+    return j < ppx && pair < npairs;
+}
+inline unsigned wg_grid(int xmode, int npairs, int nsplit, int ppx) {
+    return xmode == 0 ? 0u : (xmode == 1 ? 8u * ((nsplit + 7) / 8) * npairs : 8u * ppx);
+}
+
 struct WGeomR {
     int tiles_h, tiles_w, total_tiles, cchunks, nsplit;
+    int xmode, npairs, ppx;
     unsigned tw_magic, th_magic;
     unsigned long long* probe;
 };
@@ -49,10 +77,11 @@ __global__ __launch_bounds__(256, WPS) void conv_wgrad_ring_kernel(WgradParams p
     unsigned long long tprobe[5];
     if (g.probe) tprobe[0] = wall_clock64();
 
-    const int ct = blockIdx.x / g.cchunks, cc = blockIdx.x - ct * g.cchunks;
+    int pair, split;
+    if (!wg_assign(g.xmode, g.npairs, g.nsplit, g.ppx, pair, split)) return;
+    const int ct = pair / g.cchunks, cc = pair - ct * g.cchunks;
     const int co0 = ct * BNO, c0 = cc * 32;
     const int Cin = p.C0 + p.C1;
-    const int split = blockIdx.y;
     const int per = (g.total_tiles + g.nsplit - 1) / g.nsplit;
     const int t0 = split * per, t1 = min(g.total_tiles, t0 + per);
     const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
