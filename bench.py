@@ -284,6 +284,8 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
             code = dv % 10
             name = (f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, 1, 8, 1>" if code == 8 else
                     f"conv_direct_kernel<{tname}, 16, 0>" if code == 4 else
+                    f"ring::conv_stream_kernel<{dv // 1000}, 2, 8, 4, 2, 2, " if code == 7 else      # (its three epilogue modes share the prefix)
+                    f"ring::conv_ring_kernel<{dv // 1000}, " if code == 6 else
                     f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, {code}, 4, 1>")
             ach = dfl / (dms * 1e-3) / 1e12
             tr = load_traffic(name, "predict")
@@ -292,7 +294,7 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
                     "avg_launch_ms": round(dms / dn, 5), "launches_per_direction": dn,
                     "algorithmic_gflop_per_launch": round(dfl / dn / 1e9, 3), "share_of_kernel_time": round(dms / total_ms, 3),
                     "all_conv_tflops": round(sum(v[1] for v in byvar.values()) / (sum(v[0] for v in byvar.values()) * 1e-3) / 1e12, 1),
-                    "note": "one direction (512 slices, batch 64) with HIP events around every launch; flops = 2 x MACs of the layers this instantiation serves"}
+                    "note": f"one direction (512 slices, batch {batch}) with HIP events around every launch; flops = 2 x MACs of the layers this instantiation serves"}
     n_slices = n_dirs * cube
     flop = {(256, 2): 15.44e9, (512, 4): 61.92e9}.get((cube, classes), 0.0) * n_slices
     return {"seconds": round(dt, 4), "slices": n_slices, "slices_per_s": round(n_slices / dt, 1),
@@ -531,7 +533,7 @@ def main():
         log("predict: 256^3 single axis")
         predict["predict_256cube_low_2class"] = predict_bench(dev, world, args.precision, 256, 2, 1, 32)
         log("predict: 512^3 12 directions")
-        predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 64)   # eval mode: the batch size does not change the result
+        predict["predict_512cube_12way_4class"] = predict_bench(dev, world, args.precision, 512, 4, 12, 128)   # eval mode: the batch size does not change the result (128: enough pixel tiles per CU for the persistent convolution kernel)
         log("predict done")
         if rank == 0:
             predict["merge_512cube"] = merge_bench(dev)

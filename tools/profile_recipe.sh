@@ -12,7 +12,7 @@ mkdir -p $out profiles
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TRAIN="python3 bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-predict --step-mode eager"
 SHORT="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-predict --step-mode eager"
-PRED="python3 tools/predict_once.py 64"
+PRED="python3 tools/predict_once.py 128"
 echo "[recipe] train kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $out/train -o t -- $TRAIN > $out/train_bench.json 2> $out/train.err
 cp $out/train/t_kernel_stats.csv profiles/${tag}_train_kernel_stats.csv && cp $out/train_bench.json profiles/${tag}_train_kernel_stats.bench.json
 echo "[recipe] train FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $SHORT > /dev/null 2> $out/fetch.err
