@@ -79,6 +79,28 @@ def load_traffic_class(prefixes):
     return None
 
 
+def load_step_traffic():
+    """HBM bytes of ONE training step summed over every kernel of the newest committed PMC passes (profiles/r*_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-predict`), or None.  Steps in that run = launches of the stem
+    kernel (one per step); the GEMM / MFMA-loop cross-check kernels of the bench are left out."""
+    for f in sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        steps = (d.get("stem_fwd_bf16_kernel") or {}).get("launches")
+        if not steps:
+            continue
+        rows = {k: v for k, v in d.items() if isinstance(v, dict) and v.get("launches") and not k.startswith(("Cijk", "debug_mfma", "at::", "void at::"))}
+        rd = sum(v["read_bytes_per_launch"] * v["launches"] for v in rows.values()) / steps
+        wr = sum(v["write_bytes_per_launch"] * v["launches"] for v in rows.values()) / steps
+        top = sorted(rows.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:6]
+        return {"bytes_per_step": int(rd + wr), "read_bytes_per_step": int(rd), "write_bytes_per_step": int(wr), "steps_in_the_counter_run": steps,
+                "largest": [{"kernel": k[:60], "mb_per_step": round(v["bytes_per_launch"] * v["launches"] / steps / 1e6, 1)} for k, v in top],
+                "source": f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run)"}
+    return None
+
+
 def dice_loss(output, target, eps=1e-6):
     """DiceLoss(normalization='none') of the reference (data/pytorch3dunet_losses.py:15-41,89-135)."""
     inter = (output * target).sum((0, 2, 3))
@@ -618,6 +640,14 @@ def main():
             "share_of_kernel_time": round(bms / sum(v["ms"] for v in prof.values()), 3),
             "traffic": (load_traffic_class(big_prefix) or {}).get("bytes_per_launch"), "traffic_detail": load_traffic_class(big_prefix)}
         out["peak_crosscheck"] = gemm_crosscheck(dev)
+        if headline and args.precision == "bf16":
+            # the whole step against the HBM roof (average over the step: ~half of what streaming kernels sustain on this part)
+            st = load_step_traffic()
+            if st:
+                tbs = st["bytes_per_step"] / (ms_per_step * 1e-3) / 1e12
+                out["whole_step_hbm"] = dict(st, achieved_tbs=round(tbs, 3), peak_tbs=HBM_PEAK_GBS / 1e3, frac=round(tbs / (HBM_PEAK_GBS / 1e3), 4),
+                                             note="committed counter bytes of one step / this run's step time; 1 GiB streaming kernels on this part sustain "
+                                                  "5.5 TB/s (1 read : 1 write copy), 6.0 (2 : 1 add), 6.6 (fill) - tools/hbm_probe.py; vs_merge_maxprob 5.5")
         if headline:
             step_tflops = slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12
             loop = out["peak_crosscheck"].get("mfma_only_loop", {}).get("tflops")

@@ -99,8 +99,8 @@ def merge(fetch_csv, write_csv, seq_json, out_md):
                 rows.append((int(r["Dispatch_Id"]), re.sub(r"^void ", "", name).split("(")[0], float(r["Counter_Value"])))
         rows.sort()
         return rows
-    fam_main = ("conv_igemm_kernel", "conv_direct_kernel", "conv_head_kernel")
-    fam_w = ("conv_wgrad_bf16_kernel", "conv_wgrad_kernel")
+    fam_main = ("conv_igemm_kernel", "conv_direct_kernel", "conv_head_kernel", "ring::conv_ring_kernel", "ring::conv_stream_kernel")
+    fam_w = ("conv_wgrad_bf16_kernel", "conv_wgrad_kernel", "ring::conv_wgrad_ring_kernel")
     def last_step(rows, fam, n):
         sel = [r for r in rows if r[1].startswith(fam)]
         return sel[-n:]
