@@ -332,7 +332,8 @@ def test_grouped_conv_fwd_dgrad_wgrad(code, shape):
 @pytest.mark.parametrize("case", [(24, 128, 128, 64, 0, 64, "res"), (17, 112, 144, 64, 0, 64, "affine"), (36, 64, 64, 128, 0, 128, "res"),
                                   (64, 32, 32, 256, 0, 256, "plain"), (36, 64, 64, 256, 128, 128, "affine"), (17, 128, 128, 128, 64, 64, "affine"),
                                   (4, 256, 256, 64, 64, 32, "affine"), (36, 96, 80, 64, 0, 32, "swish"), (128, 16, 16, 512, 0, 512, "res")])
-def test_persistent_stream_conv_equals_the_tile_kernel_bit_for_bit(case):
+@pytest.mark.parametrize("code", [1, 2])
+def test_persistent_stream_conv_equals_the_tile_kernel_bit_for_bit(case, code):
     """conv_stream_kernel (csrc/conv_stream.h) - the persistent LDS-DMA form that serves the evaluation-mode 3x3 layers of large
     launches (prediction batches) - against conv_igemm_kernel on the same operands: EVERY output bit equal (same accumulation
     order, same epilogue arithmetic), so a slice's prediction cannot depend on which kernel its batch size selected; and
@@ -340,8 +341,7 @@ def test_persistent_stream_conv_equals_the_tile_kernel_bit_for_bit(case):
     folded-BatchNorm scale / shift, swish, the decoder form (x2-upsampled tensor + skip tensor), ragged image sizes, 32- and
     64-wide cout tiles, and grids that do not divide by the workgroup count."""
     L = lib()
-    code = 1
-    n, h, w, c0, c1, cout, kind = case
+    n, h, w, c0, c1, cout, kind = case           # code 1: bf16; 2: fp16 (the inference precision runs on the same kernel)
     g = torch.Generator().manual_seed(23)
     up = 1 if c1 else 0
     x0 = rounded(torch.randn(n, c0, h >> up, w >> up, generator=g), code)
@@ -365,7 +365,7 @@ def test_persistent_stream_conv_equals_the_tile_kernel_bit_for_bit(case):
     try:
         for stream in (1, 0):
             L.set_option("conv_stream", stream)
-            yd = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+            yd = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
             L.check(L.lib.vs_conv2d_fwd(d, L.ptr(x0d), L.ptr(x1d) if c1 else None, L.ptr(wd), L.ptr(scd) if scd is not None else None,
                                         L.ptr(shd) if shd is not None else None, L.ptr(rd) if rd is not None else None, L.ptr(yd), None, None))
             sync()

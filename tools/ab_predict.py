@@ -20,8 +20,9 @@ def main():
     opt, v0, v1 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+    precision = sys.argv[6] if len(sys.argv) > 6 else "bf16"
     dev = torch.device("cuda:0")
-    model = VolSegUnet(4, device=dev, precision="bf16", seed=1)
+    model = VolSegUnet(4, device=dev, precision=precision, seed=1)
     model.eval()
     pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
     pred.model, pred.num_labels, pred.label_codes = model, 4, {}

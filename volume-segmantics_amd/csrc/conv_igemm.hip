@@ -728,7 +728,7 @@ Pick pick_cfg(const ConvParams& p) {
 // (prediction: batches of 512 x 512 slices) - at least `conv_stream_min_tiles` tile jobs per CU-resident workgroup, so that
 // the per-tile latencies it removes are what the launch consists of.  0 = no, else the cout tile (64 / 32)
 static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
-    if (dtype != VS_BF16 || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512) return 0;
+    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512) return 0;
     const int bn = (p.Cout % 64 == 0) ? 64 : 32;
     const long jobs = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * (p.Cout / bn);
     return jobs >= 256L * vs_option("conv_stream_min_tiles") ? bn : 0;
@@ -790,11 +790,13 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
-    if constexpr (std::is_same<T, bf16_t>::value) {
-        if (const int sm = stream_mode(VS_BF16, p, out_nchw)) {
+    if constexpr (sizeof(T) == 2) {
+        if (const int sm = stream_mode(Elem<T>::kDtype, p, out_nchw)) {
             unsigned long long* probe = vs_probe_buffer(256);
-            return sm == 64 ? ring::launch_stream<64, 2, 8, 4, 2, 2>(p, probe, s) : ring::launch_stream<32, 2, 8, 4, 2, 2>(p, probe, s);
+            return sm == 64 ? ring::launch_stream<T, 64, 2, 8, 4, 2, 2>(p, probe, s) : ring::launch_stream<T, 32, 2, 8, 4, 2, 2>(p, probe, s);
         }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
         const int rm = ring_mode(VS_BF16, p, out_nchw);
         if (rm) {
             const long groups = rm == 3 ? p.N / 2 : (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);

@@ -25,7 +25,7 @@
 // Measured (tools/convlab, prediction shapes at batch 64, same process as the tile kernel): 64 -> 64 @128^2 1.05x (that
 // layer moves 268 MB for 77 GFLOP - the HBM read + write stream bounds it), 128 -> 128 @64^2 1.17x, 256 -> 256 @32^2 1.24x,
 // 512 -> 512 @16^2 1.12x, up64+64 -> 32 @256^2 1.25x; the 512^3 12-direction prediction 0.587 -> 0.512 s (tools/ab_predict.py).
-// Evaluation-mode epilogue only (folded BatchNorm scale / shift, residual, ReLU / swish, bf16 NHWC store): the layers this
+// Evaluation-mode epilogue only (folded BatchNorm scale / shift, residual, ReLU / swish, 16-bit NHWC store; T = bf16_t or f16_t): the layers this
 // kernel is chosen for are the prediction forward's (conv_igemm.hip: stream_mode); everything else stays on
 // conv_igemm_kernel / conv_ring_kernel.  Accumulation order (chunk-major, taps 0..8) and the epilogue's arithmetic are those
 // of conv_igemm_kernel: the outputs are bit-identical (tests/test_hip_ops.py), so a slice's prediction does not depend on
@@ -54,9 +54,9 @@ struct SGeom {
 
 // MODE: 0 = one input tensor, no residual; 1 = one input tensor + residual in the epilogue (the second convolution of a ResNet
 // block); 2 = two input tensors (decoder: x2-upsampled features + skip), no residual.  Each keeps only its own registers.
-template <int BN, int PT, int NW, int TWS, int WPS, int PIN, int MODE, bool PROBE = false>
+template <typename T, int BN, int PT, int NW, int TWS, int WPS, int PIN, int MODE, bool PROBE = false>
 __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p, SGeom g) {
-    typedef bf16_t T;
+    static_assert(sizeof(T) == 2, "conv_stream_kernel: 16-bit storage (bf16_t or f16_t)");
     constexpr int NT = NW * 64, NJ = BN / 16, BM = NW * PT * 16, TW = 1 << TWS, TH = BM / TW;
     constexpr int PH = TH + 2, PW = TW + 2, PP = PH * PW;
     constexpr int PIT = cdivc(PP * 4, NT);
@@ -329,7 +329,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
                 if (emode & 1) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
                 else if (emode & 2) { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
                 if constexpr (MODE == 1) {
-                    const float4 rv = unpack4(make_uint2(rres[i][j].x, rres[i][j].y));
+                    typename Raw4<T>::type rq;
+                    if constexpr (std::is_same<T, bf16_t>::value) rq = make_uint2(rres[i][j].x, rres[i][j].y);
+                    else rq = f16raw4{make_uint2(rres[i][j].x, rres[i][j].y)};
+                    const float4 rv = unpack4(rq);
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                 }
                 if (erelu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -396,14 +399,14 @@ inline bool stream_ok(const ConvParams& p, int out_nchw) {
            (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < lim && (double)p.Cout * 9 * (p.C0 + p.C1) * 2.0 < lim;
 }
 
-template <int BN, int PT, int NW, int TWS, int WPS, int PIN = 2>
+template <typename T, int BN, int PT, int NW, int TWS, int WPS, int PIN = 2>
 int launch_stream(const ConvParams& p, unsigned long long* probe, hipStream_t s, int workgroups = 256) {
     static bool attr_set[6] = {false, false, false, false, false, false};
     const int mode = p.C1 ? 2 : (p.residual ? 1 : 0);
     VS_REQUIRE(!(p.C1 && p.residual), "conv_stream: a two-tensor input and a residual do not occur together");
-    auto kern = mode == 2 ? (probe ? conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 2, true> : conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 2, false>)
-              : mode == 1 ? (probe ? conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 1, true> : conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 1, false>)
-                          : (probe ? conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 0, true> : conv_stream_kernel<BN, PT, NW, TWS, WPS, PIN, 0, false>);
+    auto kern = mode == 2 ? (probe ? conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 2, true> : conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 2, false>)
+              : mode == 1 ? (probe ? conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 1, true> : conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 1, false>)
+                          : (probe ? conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 0, true> : conv_stream_kernel<T, BN, PT, NW, TWS, WPS, PIN, 0, false>);
     constexpr size_t lds = stream_lds_bytes<BN, PT, NW, TWS>();
     static_assert(lds <= 160 * 1024, "conv_stream: LDS ring too large");
     constexpr int BM = NW * PT * 16, TW = 1 << TWS, TH = BM / TW;
