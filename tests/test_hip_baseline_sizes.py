@@ -158,3 +158,49 @@ def test_deeplabv3plus_efficientnet_b4_1024_one_slice_eval():
         else:
             assert ((got - ref).norm() / ref.norm()).item() < 0.1
         del model
+
+
+@pytest.mark.parametrize("option,value,exact", [("wgrad_ring", 0, False), ("wgrad_xcd", 0, False), ("conv_ring", 0, False), ("conv_ring", 2, False),
+                                                ("conv_stream", 0, True), ("bn_bwd_fused", 1, False), ("fuse_bn_bwd", 0, False),
+                                                ("wgrad_pair_join", 1, True)])
+def test_every_kernel_choice_option_gives_the_same_training_step(option, value, exact):
+    """The runtime options that pick between kernels / schedules of the SAME arithmetic (round 3 added several: ring and
+    persistent convolution kernels, the ring weight-gradient kernel, its XCD-aware K-split assignment, the one-launch BatchNorm
+    backward, the fused first BN-backward sweep, per-unit joins of the weight-gradient stream): one headline-sized training step
+    (U-Net / ResNet-34, 256 x 256, batch 32, bf16) under the non-default value against the default.  `exact`: the option only
+    changes WHERE the same sums are computed - gradients bit-equal; otherwise summation order / K-split counts / rounding points differ - loss
+    within 1e-4 and the gradients within bf16 noise of the default's (relative L2 < 2e-2, cosine > 0.999; `conv_ring` 0 changes the
+    tile shapes of the FORWARD convolutions and with them the grouping of the BatchNorm statistics' partial sums: last-bit
+    differences in mean / variance become 1-ulp bf16 differences in activations - measured 5.5e-2 / 0.9985, allowed 0.1 / 0.995)."""
+    import bench
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    x, t = bench.synth_batch(32, 256, 2, seed=3)
+    x, t = x.to(DEV), torch.nn.functional.one_hot(t.long(), 2).permute(0, 3, 1, 2).float().contiguous().to(DEV)
+
+    def run():
+        model = VolSegUnet(2, device=DEV, precision="bf16", seed=5)
+        model.train()
+        loss = HipDiceLoss()(model(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), model._flat_grad.clone(), [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+
+    old = L.lib.vs_get_option(option.encode())
+    base = run()
+    try:
+        L.set_option(option, value)
+        other = run()
+    finally:
+        L.set_option(option, old)
+    assert torch.isfinite(other[1]).all()
+    if exact:
+        assert base[0] == other[0] and torch.equal(base[1], other[1]), (option, (base[1] - other[1]).abs().max().item())
+        return
+    assert abs(base[0] - other[0]) < 1e-4, (option, base[0], other[0])
+    g0, g1 = base[1].double(), other[1].double()
+    rel = ((g0 - g1).norm() / g0.norm()).item()
+    cos = (torch.dot(g0, g1) / (g0.norm() * g1.norm())).item()
+    print(f"[options] {option}={value}: loss {other[0]:.6f} vs {base[0]:.6f}; all gradients: relative L2 {rel:.2e}, cosine {cos:.6f}")
+    assert (rel < 0.1 and cos > 0.995) if option == "conv_ring" else (rel < 2e-2 and cos > 0.999), (option, rel, cos)
