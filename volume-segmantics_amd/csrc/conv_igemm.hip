@@ -603,7 +603,10 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
 static DirectGeom direct_geom(const ConvParams& p) {
     DirectGeom g{};
     g.strips_w = cdiv(p.Wout, 16);
-    g.RH = std::max(2, vs_option("conv_direct_rows") & ~1);
+    // rows per wave: every wave pays a 2-row warm-up of its input ring; with >= 4 Mi output pixels per launch (prediction batches
+    // of 512 x 512 slices) there are waves to spare and longer strips win (512^3 x 12 prediction: 32 rows 0.507 s, 128 rows 0.499 s)
+    const bool big = (long)p.N * p.Hout * p.Wout >= (4L << 20) * 4;
+    g.RH = std::max(2, vs_option(big ? "conv_direct_rows_big" : "conv_direct_rows") & ~1);
     g.chunks_h = cdiv(p.Hout, g.RH);
     g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
     g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;

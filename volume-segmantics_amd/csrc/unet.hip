@@ -1909,7 +1909,12 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     if (use_side) {
         for (int i = 0; i < vs_unet::kSide; ++i) {
             if (net->side[i]) continue;
-            VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+            // the weight gradients are off the critical path: with `side_low_priority` their stream gets the lowest priority the
+            // device offers, so that the dispatcher prefers the caller's chain whenever both have workgroups ready
+            int prio_lo = 0, prio_hi = 0;
+            VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            if (vs_option("side_low_priority")) VS_CHECK_HIP(hipStreamCreateWithPriority(&net->side[i], hipStreamNonBlocking, prio_lo));
+            else VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
             VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
         }
         while (net->fork_events.size() < net->units.size()) {
