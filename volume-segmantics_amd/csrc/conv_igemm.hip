@@ -628,20 +628,33 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
         VS_REQUIRE(!p.up0 && !p.relu && !p.scale && !p.stats_partial, "conv_head: plain 3x3 head only");
     }
     const dim3 grid(cdiv(g.nwaves, 4));
+    // `conv_direct_occ` (0 = the kernel's own limit of 4): workgroups per CU, enforced with unused dynamic LDS.  Every wave keeps
+    // rows of its strip in flight; past some point more waves per CU only thrash L1 / L2 (counter reads of the head kernel at
+    // batch 128: 2.6x its input) - tools/ab_predict.py
+    const int occ = vs_option("conv_direct_occ");
+    const size_t pad = (occ >= 1 && occ < 4) ? std::min((size_t)(160 * 1024) / occ - 12 * 1024, (size_t)128 * 1024) : 0;
+    static bool attr_set = false;
+    if (pad && !attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_direct_kernel<T, BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_direct_kernel<T, BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
     VolScatter sc{};
     if (p.scatter) {
         sc = *p.scatter;
         ConvParams q = p;
         q.scatter = nullptr;
-        hipLaunchKernelGGL((conv_head_kernel<T, 3>), grid, dim3(256), 0, s, q, g, sc);
+        hipLaunchKernelGGL((conv_head_kernel<T, 3>), grid, dim3(256), pad, s, q, g, sc);
     } else if (head) {
         VS_REQUIRE(out_nchw && p.Cout <= 4 && BN == 16 && !p.pool0 && !p.scale, "conv_direct: unsupported ragged output");
-        hipLaunchKernelGGL((conv_head_kernel<T, 2>), grid, dim3(256), 0, s, p, g, sc);
+        hipLaunchKernelGGL((conv_head_kernel<T, 2>), grid, dim3(256), pad, s, p, g, sc);
     } else if (p.pool0) {
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), 0, s, p, g);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 1>), grid, dim3(256), pad, s, p, g);
     } else {
         VS_REQUIRE(!p.out_f32, "conv_direct: fp32 NHWC output is not supported");
-        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), 0, s, p, g);
+        hipLaunchKernelGGL((conv_direct_kernel<T, BN, 0>), grid, dim3(256), pad, s, p, g);
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
