@@ -556,6 +556,11 @@ size_t vs_volume_sum_workspace(int64_t n);
 int vs_volume_sum(int vtype, const void* data, int64_t n, int op, double avg, void* workspace, size_t workspace_bytes,
                   double* out, void* stream);
 
+/* 2 x 2 x 2 block mean of an INTEGER volume [d][h][w] into float64 [(d+1)/2][(h+1)/2][(w+1)/2], odd edges zero padded and still
+ * divided by 8: `downsample_data` = skimage.measure.block_reduce(data, (2, 2, 2), np.nanmean) - utilities/base_data_utils.py:161-163
+ * (called from data/base_data_manager.py:36-38 when `downsample: True`).  Exact (block sums of integers are exact in float64). */
+int vs_downsample2x_mean(int vtype, const void* data, double* out, int d, int h, int w, void* stream);
+
 /* out[i] = uint8(clip((clip(x, lower, upper) - lower) / (upper - lower), 0, 1) * 255), NaN -> nan_fill first, every step
  * rounded in the volume's float type (float32 volumes) or in float64 (float64 and integer volumes) as NumPy's in-place
  * ufuncs do (base_data_utils.py:270-287).  counts (optional, 2 x uint64 on the device, accumulated): voxels above upper /

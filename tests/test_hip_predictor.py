@@ -225,6 +225,29 @@ def test_prediction_manager_qualities_and_outputs(tmp_path):
     assert mgr.predict_volume_to_path(None).shape == (4,) + vol.shape   # quality from settings ("low")... one_hot
 
 
+def test_prediction_manager_reads_and_writes_hdf5_like_the_reference(tmp_path):
+    """The reference's own file format end to end on the box (vol_seg_prediction_manager.py:90-99, base_data_utils.py:179-214,
+    351-356): the volume comes from an HDF5 file (internal path `data_hdf5_path`), labels and fp16 probabilities go to
+    chunked, gzip-compressed HDF5 files - through h5py where installed, through utilities/hdf5_lite.py (libhdf5) here."""
+    from volume_segmantics_amd.model.operations.vol_seg_prediction_manager import VolSeg2DPredictionManager
+    from volume_segmantics_amd.utilities import base_data_utils as utils, hdf5_lite
+    if utils._h5py() is None and not hdf5_lite.available():
+        pytest.skip("neither h5py nor libhdf5 on this machine")
+    _, path = _ckpt(tmp_path, 4)
+    vol = np.random.default_rng(4).integers(0, 4000, size=(18, 40, 36)).astype(np.uint16)
+    utils.save_data_to_hdf5(vol, tmp_path / "scan.h5", internal_path="/entry/data")
+    mgr = VolSeg2DPredictionManager(str(path), tmp_path / "scan.h5", _settings(clip_data=True, output_probs=True, data_hdf5_path="/entry/data"))
+    assert mgr.data_vol.dtype == np.uint8 and mgr.data_vol.shape == vol.shape
+    out = tmp_path / "seg.h5"
+    pred = mgr.predict_volume_to_path(out, Quality.MEDIUM)
+    lab, chunks = utils.numpy_from_hdf5(out, "/data")
+    prb, _ = utils.numpy_from_hdf5(tmp_path / "seg_probs.h5", "/data")
+    assert np.array_equal(lab, pred) and lab.dtype == np.uint8 and chunks is not None
+    assert prb.dtype == np.float16 and prb.shape == vol.shape and (prb > 0.25).all() and (prb <= 1).all()
+    mgr2 = VolSeg2DPredictionManager(str(path), vol, _settings(clip_data=True, output_probs=True))      # the same volume as an array
+    assert np.array_equal(mgr2.predict_volume_to_path(None, Quality.MEDIUM), pred)
+
+
 @pytest.mark.parametrize("mtype,encoder", [("U_Net", "resnet34"), ("U_Net_Plus_Plus", "resnet34"), ("Linknet", "resnet34"), ("FPN", "resnet34"),
                                            ("DeepLabV3", "resnet34"), ("DeepLabV3_Plus", "resnet34"), ("MA_Net", "resnet34"),
                                            ("U_Net", "resnext50_32x4d"), ("U_Net", "efficientnet-b4"), ("DeepLabV3_Plus", "efficientnet-b3"), ("U_Net", "timm-resnest50d")])

@@ -115,3 +115,26 @@ def test_preprocess_like_reference_suite(rand_size):
     dm = BaseDataManager(nan_vol.copy(), _settings(clip_data=True))             # test_preprocess_replace_nan_clip
     host = BaseDataManager(nan_vol.copy(), _settings(clip_data=True, device_preprocess=False))
     assert dm.data_vol.dtype == np.uint8 and np.array_equal(dm.data_vol, host.data_vol)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.int32, np.int8])
+def test_downsample_on_device_equals_block_reduce_nanmean(dtype):
+    """`downsample: True` (data/base_data_manager.py:36-38 -> utilities/base_data_utils.py:161-163: skimage block_reduce with
+    np.nanmean over 2 x 2 x 2 blocks, odd edges zero padded): vs_downsample2x_mean gives the host restatement's float64 values bit
+    for bit for integer volumes (even, odd and size-1 dimensions), and BaseDataManager takes that path with a GPU present."""
+    from volume_segmantics_amd.data.base_data_manager import BaseDataManager
+    from volume_segmantics_amd.utilities import base_data_utils as U
+    rng = np.random.default_rng(9)
+    info = np.iinfo(dtype)
+    for shape in [(8, 10, 12), (9, 11, 13), (1, 7, 2), (33, 64, 65), (2, 2, 2)]:
+        vol = rng.integers(max(info.min, -30000), min(info.max, 30000) + 1, shape).astype(dtype)
+        ref = U.downsample_data(vol)
+        got = U.downsample_data_device(vol, DEV)
+        assert got.dtype == np.float64 and got.shape == ref.shape == tuple((s + 1) // 2 for s in shape)
+        assert np.array_equal(got, ref), (dtype, shape)
+    vol = rng.integers(0, 200, (40, 50, 61)).astype(dtype) if dtype != np.int8 else rng.integers(-100, 100, (40, 50, 61)).astype(dtype)
+    s = SimpleNamespace(st_dev_factor=2.575, downsample=True, clip_data=True, data_hdf5_path="/data", cuda_device=0)
+    on_device = BaseDataManager(vol.copy(), s)
+    on_host = BaseDataManager(vol.copy(), SimpleNamespace(**{**vars(s), "device_preprocess": False}))
+    assert on_device.data_vol.shape == (20, 25, 31) and on_device.data_mean == on_host.data_mean
+    assert on_device.data_vol.dtype == np.uint8 and np.array_equal(on_device.data_vol, on_host.data_vol)

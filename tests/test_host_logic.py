@@ -359,3 +359,47 @@ def test_get_batch_size_follows_the_reference_memory_rule_with_two_documented_ch
     assert utils.get_batch_size(SimpleNamespace(cuda_device=0, prediction_batch_size=cfg.BIG_CUDA_PRED_BATCH),
                                 prediction=True) == 4
     assert utils.get_batch_size(SimpleNamespace(cuda_device=0, batch_size=32)) == 32
+
+
+def test_hdf5_volumes_round_trip_through_the_c_library_without_h5py(tmp_path):
+    """utilities/base_data_utils.py:179-214, 351-356 do their HDF5 I/O with h5py; this image has libhdf5 but no h5py for the torch
+    interpreter, so `utilities/hdf5_lite.py` binds the two calls to the C library.  Round trips for every dtype the path meets
+    (uint8 volumes and labels, uint16 / float32 tomograms, float16 probabilities), nested internal paths, the NeXus candidates,
+    chunked + gzip layout like `create_dataset(..., chunks=True, compression="gzip")` - and the files are read back by an
+    INDEPENDENT program where the image has one (conda's `h5dump`): datatype, dataspace and values."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    from volume_segmantics_amd.utilities import hdf5_lite
+    if utils._h5py() is None and not hdf5_lite.available():
+        pytest.skip("neither h5py nor libhdf5 on this machine")
+    rng = np.random.default_rng(3)
+    for dt in ("uint8", "uint16", "int16", "int32", "float32", "float64", "float16"):
+        a = (rng.random((7, 33, 18)) * 200 - 40).astype(dt)
+        path = tmp_path / f"vol_{dt}.h5"
+        utils.save_data_to_hdf5(a, path, internal_path="/data", chunking=True)
+        assert hdf5_lite.is_hdf5(path)
+        b, chunks = utils.get_numpy_from_path(path, internal_path="/data")
+        assert b.dtype == a.dtype and np.array_equal(a, b) and chunks is not None and len(chunks) == 3
+    big = rng.integers(0, 255, (96, 128, 128), dtype=np.uint8)           # 1.5 MiB: several chunks, compressed
+    utils.save_data_to_hdf5(big, tmp_path / "big.h5")
+    back, chunks = utils.numpy_from_hdf5(tmp_path / "big.h5")
+    assert np.array_equal(big, back) and np.prod(chunks) <= 512 * 1024 and (tmp_path / "big.h5").stat().st_size < big.size * 1.1
+    nested = np.arange(2 * 3 * 4, dtype=np.uint16).reshape(2, 3, 4)
+    if utils._h5py() is None:
+        hdf5_lite.write_dataset(tmp_path / "scan.nxs", "/entry/final_result_tomo/data", nested)
+        got, _ = utils.get_numpy_from_path(tmp_path / "scan.nxs")                     # NeXus: the reference's two candidate paths
+        assert np.array_equal(got, nested)
+        assert hdf5_lite.exists(tmp_path / "scan.nxs", "/entry/final_result_tomo") and not hdf5_lite.exists(tmp_path / "scan.nxs", "/processed/result/data")
+        with pytest.raises(KeyError):
+            hdf5_lite.read_dataset(tmp_path / "scan.nxs", "/data")
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if Path("/opt/conda/bin/h5dump").exists() else None)
+    if h5dump:
+        head = subprocess.run([h5dump, "-H", str(tmp_path / "vol_float16.h5")], capture_output=True, text=True).stdout
+        assert "16-bit little-endian floating-point" in head and "( 7, 33, 18 )" in head, head
+        head = subprocess.run([h5dump, "-H", "-p", str(tmp_path / "big.h5")], capture_output=True, text=True).stdout
+        assert "H5T_STD_U8LE" in head and "CHUNKED" in head and "DEFLATE" in head, head
+        small = np.arange(12, dtype=np.int32).reshape(1, 3, 4)
+        utils.save_data_to_hdf5(small, tmp_path / "small.h5", internal_path="/seg/labels")
+        body = subprocess.run([h5dump, "-d", "/seg/labels", str(tmp_path / "small.h5")], capture_output=True, text=True).stdout
+        assert "(0,2,0): 8, 9, 10, 11" in body, body

@@ -215,6 +215,7 @@ _SIGS = {
     "vs_volume_sum_workspace": (SZ, [I64]),
     "vs_volume_sum": (I, [I, P, I64, I, C.c_double, P, SZ, P, P]),
     "vs_clip_to_uint8": (I, [I, P, I64, C.c_double, C.c_double, C.c_double, P, P, P]),
+    "vs_downsample2x_mean": (I, [I, P, P, I, I, I, P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

@@ -225,6 +225,40 @@ int run_clip(const TIn* data, int64_t n, double nan_fill, double lower, double u
     return VS_OK;
 }
 
+// 2 x 2 x 2 block mean with zero padding at odd edges (skimage.measure.block_reduce(data, (2, 2, 2), np.nanmean) as the reference
+// calls it, utilities/base_data_utils.py:161-163): out[z][y][x] = (sum of the block's 8 voxels, missing ones = 0) / 8 in float64.
+// Integer volumes only: their block sums are exact in float64 in any order and no voxel is NaN, so this IS NumPy's result.
+template <typename TIn, typename C>
+__global__ void downsample2x_kernel(const TIn* __restrict__ in, double* __restrict__ out, int D, int H, int W, int d2, int h2, int w2) {
+    const int64_t total = (int64_t)d2 * h2 * w2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w2);
+        const int64_t r = i / w2;
+        const int y = (int)(r % h2), z = (int)(r / h2);
+        double acc = 0.0;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int zz = 2 * z + dz, yy = 2 * y + dy, xx = 2 * x + dx;
+                    if (zz < D && yy < H && xx < W) acc += (double)in[((int64_t)zz * H + yy) * W + xx];
+                }
+        out[i] = acc / 8.0;
+    }
+}
+
+template <typename TIn, typename C>
+int run_downsample(const TIn* data, double* out, int D, int H, int W, hipStream_t s) {
+    const int d2 = (D + 1) / 2, h2 = (H + 1) / 2, w2 = (W + 1) / 2;
+    int64_t g = ((int64_t)d2 * h2 * w2 + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL((downsample2x_kernel<TIn, C>), dim3((unsigned)g), dim3(256), 0, s, data, out, D, H, W, d2, h2, w2);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
 }  // namespace
 
 extern "C" size_t vs_volume_sum_workspace(int64_t n) {
@@ -263,4 +297,11 @@ extern "C" int vs_clip_to_uint8(int vtype, const void* data, int64_t n, double n
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* cnt = (unsigned long long*)counts;
     VS_VOLUME_DISPATCH(run_clip, n, nan_fill, lower, upper, out, cnt, s)
+}
+
+extern "C" int vs_downsample2x_mean(int vtype, const void* data, double* out, int d, int h, int w, void* stream) {
+    VS_REQUIRE(data && out && d >= 1 && h >= 1 && w >= 1, "downsample2x_mean: bad arguments");
+    VS_REQUIRE(vtype != VS_VOL_F32 && vtype != VS_VOL_F64, "downsample2x_mean: integer volumes only (float block means depend on NumPy's summation order and NaN handling: host path)");
+    hipStream_t s = (hipStream_t)stream;
+    VS_VOLUME_DISPATCH(run_downsample, out, d, h, w, s)
 }

@@ -39,7 +39,11 @@ class BaseDataManager:
 
     def _preprocess_data(self):
         if self.downsample:
-            self.data_vol = utils.downsample_data(self.data_vol)
+            device = self._preprocess_device()
+            if device is not None and self.data_vol.ndim == 3 and np.issubdtype(self.data_vol.dtype, np.integer):
+                self.data_vol = utils.downsample_data_device(self.data_vol, device)      # exact for integer volumes (csrc/preprocess.hip)
+            else:
+                self.data_vol = utils.downsample_data(self.data_vol)
         self.data_vol_shape = self.data_vol.shape
         device = self._preprocess_device()
         if device is not None:   # statistics and the uint8 map on the GPU: the same numbers, bit for bit (csrc/preprocess.hip)

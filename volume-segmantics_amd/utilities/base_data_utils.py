@@ -1,6 +1,6 @@
 """Enums and small helpers of the hot path, mirroring volume_segmantics/utilities/base_data_utils.py
 (the reference lines each item follows are cited inline).  Disk I/O helpers import their third-party
-library lazily: HDF5 needs h5py, which this image does not ship for the torch interpreter."""
+library lazily: HDF5 goes through h5py where it is installed and through `hdf5_lite` (ctypes on libhdf5) where it is not."""
 from __future__ import annotations
 
 import logging
@@ -247,6 +247,17 @@ def nanmean_device(data: np.ndarray, device="cuda:0"):
     return device_nanmean_nanstd(dev, vtype, data.size, want_std=False)[0]
 
 
+def downsample_data_device(data: np.ndarray, device="cuda:0") -> np.ndarray:
+    """`downsample_data` for integer volumes on the GPU (vs_downsample2x_mean): the same float64 values, bit for bit."""
+    import torch
+    from .. import _lib
+    dev, vtype = volume_to_device(data, device)
+    d, h, w = data.shape
+    out = torch.empty(((d + 1) // 2, (h + 1) // 2, (w + 1) // 2), dtype=torch.float64, device=dev.device)
+    _lib.check(_lib.lib.vs_downsample2x_mean(vtype, _lib.ptr(dev), _lib.ptr(out), d, h, w, _lib.stream_ptr()))
+    return out.cpu().numpy()
+
+
 def downsample_data(data: np.ndarray, factor: int = 2) -> np.ndarray:
     """:161-163 - block nan-mean (skimage.measure.block_reduce semantics: edge blocks are zero padded)."""
     pads = [(0, (-s) % factor) for s in data.shape]
@@ -275,16 +286,35 @@ def sequential_labels(unique_labels: np.ndarray) -> bool:
 
 # ---- disk I/O (outside the hot path; third-party libraries imported lazily) -----------------------------
 def _h5py():
+    """h5py when this interpreter has it, else None (then `hdf5_lite`, a ctypes binding to libhdf5, does the same two jobs)."""
     try:
         import h5py
         return h5py
-    except ImportError as e:
-        raise ImportError("HDF5 input/output needs h5py, which is not installed for this interpreter; "
-                          "pass a numpy array / .npy file instead") from e
+    except ImportError:
+        return None
+
+
+def _h5lite():
+    from . import hdf5_lite
+    if not hdf5_lite.available():
+        raise ImportError("HDF5 input/output needs h5py or the HDF5 C library (libhdf5; set VOLSEG_LIBHDF5): neither was found - "
+                          "pass a numpy array / .npy file instead")
+    return hdf5_lite
 
 
 def numpy_from_hdf5(path, hdf5_path="/data", nexus=False):
     h5 = _h5py()
+    if h5 is None:
+        lite = _h5lite()
+        if nexus:
+            for cand in ("processed/result/data", "entry/final_result_tomo/data"):
+                if lite.exists(path, cand):
+                    hdf5_path = cand
+                    break
+            else:
+                logging.error("NXS file: could not find a data entry, exiting!")
+                sys.exit(1)
+        return lite.read_dataset(path, hdf5_path)
     with h5.File(path, "r") as f:
         if nexus:
             for cand in ("processed/result/data", "entry/final_result_tomo/data"):
@@ -325,6 +355,9 @@ def save_data_to_hdf5(data, file_path, internal_path="/data", chunking=True):
         np.save(file_path, data)
         return
     h5 = _h5py()
+    if h5 is None:
+        _h5lite().write_dataset(file_path, internal_path, np.asarray(data), chunks=chunking, compression=cfg.HDF5_COMPRESSION)
+        return
     with h5.File(file_path, "w") as f:
         f.create_dataset(internal_path, data=data, chunks=chunking, compression=cfg.HDF5_COMPRESSION)
 
