@@ -407,3 +407,27 @@ def test_model_train_2d_flow_from_volumes_to_prediction(tmp_path):
     mgr = VolSeg2DPredictionManager(str(out), data, psettings)
     pred = mgr.predict_volume_to_path(tmp_path / "pred.npy")
     assert pred.shape == data.shape and pred.dtype == np.uint8 and pred.max() <= 1 and mgr.predictor.model.precision == "bf16"
+
+
+def test_resident_slice_feed_yields_the_data_loader_batches(tmp_path):
+    """data/datasets.py: ResidentSliceLoader (PNG pairs decoded once, kept as uint8 in HBM, batches gathered on the device) against
+    the DataLoader over the same dataset and the same ShardedBatchSampler: identical uint8 batches in identical order, over two
+    epochs (reshuffled by set_epoch), also the last, partial validation batch."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from volume_segmantics_amd.data.datasets import ResidentSliceLoader, ShardedBatchSampler, VolSeg2dDataset
+    rng = np.random.default_rng(2)
+    (tmp_path / "d").mkdir(); (tmp_path / "s").mkdir()
+    for i in range(21):
+        Image.fromarray(rng.integers(0, 255, (64, 48), dtype=np.uint8)).save(tmp_path / "d" / f"data_z_stack_{i}.png")
+        Image.fromarray(rng.integers(0, 3, (64, 48), dtype=np.uint8)).save(tmp_path / "s" / f"seg_z_stack_{i}.png")
+    ds = VolSeg2dDataset(tmp_path / "d", tmp_path / "s", 64, augment="device")
+    for shuffle, drop_last in ((True, True), (False, False)):
+        a = ShardedBatchSampler(len(ds), 4, shuffle=shuffle, drop_last=drop_last, seed=5)
+        b = ShardedBatchSampler(len(ds), 4, shuffle=shuffle, drop_last=drop_last, seed=5)
+        resident, loader = ResidentSliceLoader(ds, a, DEV), DataLoader(ds, batch_sampler=b)
+        assert len(resident) == len(loader) == (5 if drop_last else 6)
+        for epoch in range(2):
+            a.set_epoch(epoch); b.set_epoch(epoch)
+            for (xr, mr), (xl, ml) in zip(resident, loader):
+                assert xr.is_cuda and xr.dtype == torch.uint8 and xr.shape == xl.shape and torch.equal(xr.cpu(), xl) and torch.equal(mr.cpu(), ml)

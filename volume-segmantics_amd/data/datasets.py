@@ -155,6 +155,37 @@ def make_training_loaders(train_ds, valid_ds, batch_size: int, rank: int = 0, wo
             DataLoader(valid_ds, batch_sampler=vs, collate_fn=_collate_maybe_empty, **loader_kw))
 
 
+class ResidentSliceLoader:
+    """The training feed without the per-step PNG decode: every slice pair of the subset is decoded ONCE (the reference decodes
+    each PNG again in every epoch, in 4 loader workers - data/datasets.py:42-60, utilities/config.py:33: ~1 ms per 256 x 256 pair
+    and worker, i.e. at most ~4 000 slices/s against a training step that consumes 7 000), kept as uint8 in HBM, and a batch
+    is an index gather on the device.  Iterates like the DataLoader it replaces: the same ShardedBatchSampler decides the
+    batches (`batch_sampler`, `set_epoch`), it yields (images (b, 1, s, s) uint8, masks (b, s, s) uint8) on the device - what
+    `prepare_training_batch` takes for device-side augmentation / normalisation - or None for an empty validation share."""
+
+    def __init__(self, dataset, batch_sampler, device, decode_threads: int = 8):
+        from concurrent.futures import ThreadPoolExecutor
+        self.batch_sampler, self.device = batch_sampler, torch.device(device)
+        n = len(dataset)
+        with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:      # PIL releases the GIL while it decodes
+            pairs = list(pool.map(dataset.__getitem__, range(n)))
+        if n and pairs[0][0].dtype != torch.uint8:
+            raise ValueError("ResidentSliceLoader needs raw uint8 pairs (VolSeg2dDataset(augment='device'))")
+        self.images = torch.stack([p[0] for p in pairs]).to(self.device) if n else torch.empty((0, 1, 0, 0), dtype=torch.uint8, device=self.device)
+        self.masks = torch.stack([p[1] for p in pairs]).to(self.device) if n else torch.empty((0, 0, 0), dtype=torch.uint8, device=self.device)
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def __iter__(self):
+        for idx in self.batch_sampler:
+            if not idx:
+                yield None
+                continue
+            i = torch.as_tensor(idx, dtype=torch.int64, device=self.device)
+            yield self.images.index_select(0, i), self.masks.index_select(0, i)
+
+
 def shared_seed(rank: int, world: int) -> int:
     """A random seed that is the same on every rank: rank 0 draws it (the reference's split is unseeded), the others receive it."""
     seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
@@ -178,5 +209,16 @@ def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings, rank
     indices = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
     cut = int(n * settings.training_set_proportion)
     workers = int(getattr(settings, "num_workers", cfg.NUM_WORKERS))
+    resident = getattr(settings, "resident_feed", None)
+    if resident is None:      # default: on whenever the batches are augmented on the device anyway
+        resident = mode == "device" and torch.cuda.is_available()
+    if resident:
+        if mode != "device":
+            raise ValueError("resident_feed needs device-side augmentation (a GPU and an image_size that is a multiple of 8)")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        valid_raw = VolSeg2dDataset(image_dir, label_dir, settings.image_size, augment="device")      # raw pairs: normalised on the device
+        ts = ShardedBatchSampler(cut, batch_size, rank, world, shuffle=True, drop_last=True, seed=seed + 1)
+        vs = ShardedBatchSampler(n - cut, batch_size, rank, world, shuffle=False, drop_last=False)
+        return (ResidentSliceLoader(Subset(train_full, indices[:cut]), ts, dev), ResidentSliceLoader(Subset(valid_raw, indices[cut:]), vs, dev))
     return make_training_loaders(Subset(train_full, indices[:cut]), Subset(valid_full, indices[cut:]), batch_size, rank, world,
                                  seed=seed + 1, num_workers=workers, pin_memory=cfg.PIN_CUDA_MEMORY and torch.cuda.is_available())

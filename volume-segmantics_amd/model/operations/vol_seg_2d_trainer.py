@@ -223,7 +223,10 @@ class VolSeg2dTrainer:
             tic = time.perf_counter()
             self._set_epoch(self._epochs_run)
             for batch in self.training_loader:
-                train_losses.append(self._train_one_batch(lr_scheduler, batch).item())
+                # (the reference calls loss.item() here, one host-device sync per step; the values are only used as the epoch's
+                # average, so they stay on the device until the epoch ends and the host keeps enqueueing ahead of the GPU)
+                train_losses.append(self._train_one_batch(lr_scheduler, batch).detach())
+            train_losses = torch.stack(train_losses).double().cpu().tolist() if train_losses else []
             self.model.eval()
             with torch.no_grad():
                 for batch in self.validation_loader:
