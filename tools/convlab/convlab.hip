@@ -95,7 +95,7 @@ static int run_ring(const ConvParams& p, hipStream_t s) { return ring::launch_ri
 template <int PT, int NW, int TWS, int IMGS>
 static bool ok_ring(const ConvParams& p) { return ring::ring_geom_ok<PT, NW, TWS, IMGS>(p) && (IMGS > 1 || (p.Hout >= 8 && p.Wout >= (1 << TWS))); }
 template <int BN, int PT, int NW, int TWS, int WPS, int PIN = 2>
-static int run_stream(const ConvParams& p, hipStream_t s) { return ring::launch_stream<bf16_t, BN, PT, NW, TWS, WPS, PIN>(p, g_probe, s); }
+static int run_stream(const ConvParams& p, hipStream_t s) { return ring::launch_stream<bf16_t, BN, PT, NW, TWS, WPS, PIN>(p, g_probe, s, 256, getenv("STREAM_STAGGER") ? atoi(getenv("STREAM_STAGGER")) : 0); }
 static bool ok_stream(const ConvParams& p) { return ring::stream_ok(p, 0); }
 static int run_lib(const ConvParams& p, hipStream_t s) {
     vs_conv_desc d{};

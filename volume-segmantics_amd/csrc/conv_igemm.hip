@@ -809,7 +809,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (const int sm = stream_mode(Elem<T>::kDtype, p, out_nchw)) {
             unsigned long long* probe = vs_probe_buffer(256);
-            return sm == 64 ? ring::launch_stream<T, 64, 2, 8, 4, 2, 2>(p, probe, s) : ring::launch_stream<T, 32, 2, 8, 4, 2, 2>(p, probe, s);
+            const int stg = vs_option("conv_stream_stagger");
+            return sm == 64 ? ring::launch_stream<T, 64, 2, 8, 4, 2, 2>(p, probe, s, 256, stg) : ring::launch_stream<T, 32, 2, 8, 4, 2, 2>(p, probe, s, 256, stg);
         }
     }
     if constexpr (std::is_same<T, bf16_t>::value) {

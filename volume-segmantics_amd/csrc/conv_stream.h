@@ -50,6 +50,7 @@ struct SGeom {
     int groups, ctiles, lanes;       // pixel tiles over the batch; cout tiles; tile sequences per XCD and cout tile
     unsigned ct_magic, ti_magic, tw_magic;
     unsigned long long* probe;       // per-workgroup stamps (tools/convlab); null in normal operation
+    int stagger;                     // start delay, in steps of 512 clocks x ((workgroup >> 3) & 7): spreads the tile-boundary store bursts
 };
 
 // MODE: 0 = one input tensor, no residual; 1 = one input tensor + residual in the epilogue (the second convolution of a ResNet
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
     const int gstep = g.lanes * 8;
     int grp = seq * 8 + xcd;
     if (grp >= g.groups) return;
+    if (g.stagger) {
+        for (int k = ((blockIdx.x >> 3) & 7) * g.stagger; k > 0; --k) __builtin_amdgcn_s_sleep(8);      // 512 clocks (~0.2 us) each
+    }
     const int n0 = ytile * BN;
     const int Cin = p.C0 + p.C1;
     const int ush = p.up0 ? 1 : 0;
@@ -400,7 +404,7 @@ inline bool stream_ok(const ConvParams& p, int out_nchw) {
 }
 
 template <typename T, int BN, int PT, int NW, int TWS, int WPS, int PIN = 2>
-int launch_stream(const ConvParams& p, unsigned long long* probe, hipStream_t s, int workgroups = 256) {
+int launch_stream(const ConvParams& p, unsigned long long* probe, hipStream_t s, int workgroups = 256, int stagger = 0) {
     static bool attr_set[6] = {false, false, false, false, false, false};
     const int mode = p.C1 ? 2 : (p.residual ? 1 : 0);
     VS_REQUIRE(!(p.C1 && p.residual), "conv_stream: a two-tensor input and a residual do not occur together");
@@ -425,6 +429,7 @@ int launch_stream(const ConvParams& p, unsigned long long* probe, hipStream_t s,
     g.ti_magic = 0xffffffffu / (unsigned)(g.tiles_h * g.tiles_w) + 1u;
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;
     g.probe = probe;
+    g.stagger = stagger;
     VS_REQUIRE(g.tiles_h * g.tiles_w < 65536 && p.N < 65536 && g.groups < (1 << 24), "conv_stream: tile grid too large");
     const int nwg = 8 * g.lanes * g.ctiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, s, p, g);
