@@ -243,6 +243,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
     read_frags(smem + W0_B, smem + P0_B, 1, wf[1], xf[1]);
 
     int qw = 0, qp = 0;                                  // weight slot (chunk index & 1) and patch slot (chunk index % 3) of the current chunk
+    // (Tried and measured slower end to end, 512^3 x 12 prediction on one box: transposing the finished tile through LDS - the patch
+    // slot its last chunk vacated - so that a lane stores 16 bytes and a wave instruction covers whole 128-byte rows halves the
+    // stores and cut the epilogue from 1.8 to 1.1 us per tile in tools/convlab, but the next tile's first patch pieces then
+    // have to wait for that slot: 0.559 s against 0.538 s.  A start delay staggered by workgroup: neutral.)
     // (Spreading a finished tile's stores over the next tile's first chunk instead of issuing them back to back was tried:
     // the time only moves from the store issue to the chunk barriers - on the 64 -> 64 layers the sum of input and output
     // traffic, 3.3 TB/s of mixed reads and writes, is what bounds the tile rate - and with streamed weights the stores
