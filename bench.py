@@ -306,7 +306,7 @@ def predict_bench(dev, world, precision, cube: int, classes: int, n_dirs: int, b
             code = dv % 10
             name = (f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, 1, 8, 1>" if code == 8 else
                     f"conv_direct_kernel<{tname}, 16, 0>" if code == 4 else
-                    f"ring::conv_stream_kernel<{dv // 1000}, 2, 8, 4, 2, 2, " if code == 7 else      # (its three epilogue modes share the prefix)
+                    f"ring::conv_stream_kernel<{tname}, {dv // 1000}, 2, 8, 4, 2, 2, " if code == 7 else      # (its three epilogue modes share the prefix)
                     f"ring::conv_ring_kernel<{dv // 1000}, " if code == 6 else
                     f"conv_igemm_kernel<{tname}, {dv // 1000}, {dv // 100 % 10}, {dv // 10 % 10}, {code}, 4, 1>")
             ach = dfl / (dms * 1e-3) / 1e12
@@ -366,6 +366,9 @@ def main():
                          "during the untimed set-up and keep the faster one on this box")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-predict", action="store_true", help="skip the 512^3 12-direction / 256^3 predict measurements")
+    ap.add_argument("--grad-transport", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="dtype of the gradient buckets on the wire at N > 1 (auto: the compute precision - bf16 halves the bytes per "
+                         "xGMI link, SURVEY.md section 8e; the sum carries <= 2 * N * 2^-8 * max|g| of rounding, tests/test_dist_gloo.py)")
     ap.add_argument("--encoder", default="resnet34", choices=["resnet18", "resnet34", "resnet50", "resnext50_32x4d", "efficientnet-b3", "efficientnet-b4", "timm-resnest50d", "timm-resnest101e"])
     ap.add_argument("--topology", default="unet", choices=["unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "deeplabv3", "manet", "pan"],
                     help="with --encoder / --size / --classes: other rows of the model matrix, e.g. BASELINE configs[3] = "
@@ -406,6 +409,8 @@ def main():
         dist.broadcast(model._flat, 0)
         dist.broadcast(model._bnstate, 0)
         model.dp_group = dist.group.WORLD
+        if args.grad_transport == "bf16" or (args.grad_transport == "auto" and args.precision == "bf16"):
+            model.dp_grad_dtype = torch.bfloat16
         model.dropout_seed += 1000003 * rank
     x, lab = synth_batch(args.batch, args.size, args.classes, seed=1234 + rank)   # every rank: its own shard of the global batch
     x = x.to(dev)
@@ -575,6 +580,7 @@ def main():
         code = dvar % 10
         dom_name = (f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, 1, 8, 1>" if code == 8 else
                     f"ring::conv_ring_kernel<{dvar // 1000}, " if code == 6 else
+                    f"ring::conv_stream_kernel<{tname}, {dvar // 1000}, 2, 8, 4, 2, 2, " if code == 7 else
                     f"conv_igemm_kernel<{tname}, {dvar // 1000}, {dvar // 100 % 10}, {dvar // 10 % 10}, {code}, 4, 1>")
         dom_ms, dom_fl, dom_calls = byvar[dvar]
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -596,7 +602,8 @@ def main():
                                    (f"synthetic 1-ch slices, {args.classes}-class, {args.topology}/{args.encoder}, batch {args.batch} per GPU, "
                                     "train step (fwd + DiceLoss + bwd + AdamW + OneCycleLR)"),
                        "global_batch": args.batch * world, "slice": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
-                       "master_weights": "fp32", "final_loss": round(final_loss, 5)},
+                       "master_weights": "fp32", "final_loss": round(final_loss, 5),
+                       **({"grad_allreduce": str(model.dp_grad_dtype).replace("torch.", "") + " buckets inside backward"} if world > 1 else {})},
             "whole_step_mfma_frac": round(slices_per_s / world * FLOP_PER_SLICE_FWD_BWD_256 / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4) if headline else None,
             # where a step's wall time goes: a host- or gap-bound run shows ms_per_step well above the kernel sums
             "step_timing": {
@@ -631,8 +638,8 @@ def main():
         big_name = {"conv_wgrad": "conv_wgrad_ring_kernel / conv_wgrad_bf16_kernel (+ slab_reduce4_kernel)",
                     "conv_fwd": "conv_igemm_kernel (forward launches)", "conv_dgrad": "conv_igemm_kernel (data-gradient launches)"}[big]
         big_prefix = {"conv_wgrad": ("ring::conv_wgrad_ring_kernel", "conv_wgrad_bf16_kernel", "conv_wgrad_kernel"),
-                      "conv_fwd": ("conv_igemm_kernel", "ring::conv_ring_kernel", "conv_direct_kernel"),
-                      "conv_dgrad": ("conv_igemm_kernel", "ring::conv_ring_kernel", "conv_direct_kernel")}[big]
+                      "conv_fwd": ("conv_igemm_kernel", "ring::conv_ring_kernel", "ring::conv_stream_kernel", "conv_direct_kernel"),
+                      "conv_dgrad": ("conv_igemm_kernel", "ring::conv_ring_kernel", "ring::conv_stream_kernel", "conv_direct_kernel")}[big]
         out["roofline_largest_class"] = {
             "bound": "mfma", "class": big, "kernel": big_name, "achieved": round(bfl / (bms * 1e-3) / 1e12, 2) if bms else 0.0,
             "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bfl / (bms * 1e-3) / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4) if bms else 0.0,
