@@ -156,6 +156,17 @@ __device__ __forceinline__ uint4 bload(__amdgpu_buffer_rsrc_t r, int voff, int s
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Workgroup index with XCD locality: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (id & 7), each with
+// its own L2.  Kernels whose neighbouring workgroups share input halos (strips of a convolution, pooling windows) take this
+// index instead of blockIdx.x: XCD k then works on the k-th contiguous eighth of the grid, so a halo is fetched into one L2
+// instead of two.  Bijective for every grid size (the first n % 8 XCDs take one workgroup more).  `on` = 0: identity.
+__device__ __forceinline__ int xcd_block(int on) {
+    const int b = blockIdx.x, n = gridDim.x;
+    if (!on || n < 16) return b;
+    const int xcd = b & 7, j = b >> 3, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -272,6 +272,7 @@ struct DirectGeom {
     int strips_w, chunks_h, RH;      // column strips per row, row chunks per image, rows per chunk
     unsigned sw_magic, ch_magic;     // x / strips_w, x / chunks_h by umulhi
     int nwaves, out_nchw;
+    int xcd;                         // XCD-local strip order (common.h: xcd_block)
 };
 
 // MODE 0: NHWC store in T (optional per-channel affine + ReLU, optional statistics); 1: 2x2 sum-pooled NHWC store (dgrad
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
         }
     }
     __syncthreads();
-    const int gw = blockIdx.x * 4 + wave;                   // this wave's strip
+    const int gw = xcd_block(g.xcd) * 4 + wave;             // this wave's strip
     if (gw >= g.nwaves) return;
     const int q = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
     const int ws = gw - q * g.strips_w;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, 4) void conv_head_kernel(ConvParams p, DirectG
         }
     }
     __syncthreads();
-    const int gw = blockIdx.x * 4 + wave;                   // this wave's strip
+    const int gw = xcd_block(g.xcd) * 4 + wave;             // this wave's strip
     if (gw >= g.nwaves) return;
     const int q = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
     const int ws = gw - q * g.strips_w;
@@ -611,6 +612,7 @@ static DirectGeom direct_geom(const ConvParams& p) {
     g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
     g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
     g.nwaves = p.N * g.strips_w * g.chunks_h;
+    g.xcd = vs_option("xcd_blocks");
     return g;
 }
 

@@ -4,6 +4,7 @@
 //  * backward of the decoder's nearest x2 upsampling (2x2 sum);
 //  * zero stuffing used to express the dgrad of the stride-2 convolutions as a stride-1 convolution.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -11,10 +12,11 @@ constexpr int kVec = 8;
 
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int n,
-                                   int h, int w, int c) {
+                                   int h, int w, int c, int xcd) {
     const int ho_n = h / 2, wo_n = w / 2, cv = c / kVec;
     const int64_t total = (int64_t)n * ho_n * wo_n * cv;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // (overlapping 3x3 windows: XCD-local block order keeps a row's second reader on the same L2 - common.h: xcd_block)
+    for (int64_t i = (int64_t)xcd_block(xcd) * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = i;
         const int cg = t % cv; t /= cv;
         const int wo = t % wo_n; t /= wo_n;
@@ -287,7 +289,7 @@ extern "C" int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, i
     VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0, "maxpool_fwd: bad shape");
     const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
     VS_FOR_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)x, (T*)y, idx, n, h, w, c));
+                           (const T*)x, (T*)y, idx, n, h, w, c, vs_option("xcd_blocks")));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
