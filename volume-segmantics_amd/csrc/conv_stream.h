@@ -64,8 +64,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
     constexpr int WROWS = 9 * BN, TS = NT / 4 / BN;
     static_assert((NT / 4) % BN == 0, "cout tile must divide the rows of a piece pass");
     constexpr int WIT = cdivc(WROWS * 4, NT);
-    constexpr int PATCH_B = PIT * NT * 16, WGT_B = WIT * NT * 16, STAGE_B = PATCH_B + WGT_B;
-    constexpr int D = PIT + WIT, NG = 4, DG = cdivc(D, NG);
+    constexpr int PATCH_B = PIT * NT * 16, WGT_B = WIT * NT * 16;
     constexpr int NST = PT * NJ;                         // buffer stores per lane and tile (the counted wait relies on it)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
 
     // LDS: two weight slots, three patch slots, the affine table.  Patch pieces [LO, HI) of the chunk whose first channel is
     // c0 - of the current tile, or (nx) of the one after it - into patch slot `slot`; weight pieces likewise
-    constexpr int W0_B = 0, P0_B = 2 * WGT_B, AFF_B = P0_B + 3 * PATCH_B;
+    constexpr int W0_B = 0, P0_B = 2 * WGT_B, AFF_B = P0_B + 3 * PATCH_B;      // byte offsets of the two rings and the affine table
     auto issue_p = [&](auto lo_, auto hi_, int c0, int slot, bool nx) {
         constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
         const bool from0 = MODE != 2 || c0 < p.C0;
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_stream_kernel(ConvParams p,
     // wait for it with a vmcnt that also drains the LDS-DMA pieces in flight).  Cout is a multiple of BN (launcher).
     const int emode = (p.scale ? 1 : 0) | (p.shift ? 2 : 0);
     const int erelu = p.relu;
-    float* eaff = reinterpret_cast<float*>(smem + 2 * WGT_B + 3 * PATCH_B);   // [2][BN]: this cout tile's scale and shift, behind the rings
+    float* eaff = reinterpret_cast<float*>(smem + AFF_B);                     // [2][BN]: this cout tile's scale and shift, behind the rings
     if (tid < 2 * BN) {
         const float* src = tid < BN ? p.scale : p.shift;
         eaff[tid] = src ? src[n0 + (tid & (BN - 1))] : (tid < BN ? 1.f : 0.f);
