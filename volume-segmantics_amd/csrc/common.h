@@ -214,6 +214,11 @@ struct ConvParams {
     int brelu;
     int dil;                             // 0 / 1 = none; 2 = dilation 2 of a stride-1 3x3 kernel (pad 2)
     int gc;                              // 0 = dense; 32 = grouped convolution on 32-channel super-groups (C0 == Cout, C1 == 0)
+    // Optional, instead of stats_partial's one row per tile: the per-tile sums go, as 64-bit FIXED-POINT integers, into
+    // stats_nb (power of two) rows of bins by atomic add (row = tile & (stats_nb - 1); layout [row][2][Cout]; sum x scaled by
+    // 2^24, sum x^2 by 2^16).  Integer adds commute: the totals are bit-reproducible whatever order the workgroups arrive in,
+    // and the consumer finalises stats_nb rows inline instead of waiting for a finalize launch over hundreds (norm.hip).
+    unsigned long long* stats_bins; int stats_nb;
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
@@ -227,7 +232,8 @@ struct VolScatter {
 // stage[n][hp][wp] packed keys -> cropped, max-merged into the key volume with the slice index as the fastest-moving lane
 // index: for directions whose slices are the volume's contiguous axis the head's own scatter would touch one line per voxel
 int launch_keys_stage_scatter(const uint32_t* stage, int nb, const vs_dirmap& m, int s0, uint32_t* keys, hipStream_t s);
-bool conv_head_scatter_ok(int dtype, const ConvParams& p);   // whether launch_conv_igemm can honour p.scatter for this layer
+bool conv_head_scatter_ok(int dtype, const ConvParams& p);
+bool conv_igemm_bins_ok(int dtype, const ConvParams& p);     // whether p's kernel honours ConvParams::stats_bins   // whether launch_conv_igemm can honour p.scatter for this layer
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
@@ -240,6 +246,12 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
                                   const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
 int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t rows, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t s);
+// train-mode BatchNorm whose sums sit in fixed-point bins (ConvParams::stats_bins): finalise the nb rows inline, normalise
+constexpr double kStatScale1 = 16777216.0, kStatScale2 = 65536.0;     // 2^24, 2^16
+int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long* bins, int nb, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
+int launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s);
 
 // BatchNorm backward (dx, dres, dgamma, dbeta): three launches, or ONE with a grid barrier for tensors of a few MB (norm.hip).
 // ctl: 16 zeroed bytes of barrier counters that re-arm themselves (null: the end of `workspace`, zeroed by a memset first)

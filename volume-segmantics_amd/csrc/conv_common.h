@@ -55,7 +55,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
     // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
     const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
     // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
-    if (p.stats_partial) {
+    if (p.stats_partial || p.stats_bins) {
         float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][BN]
         __syncthreads();                               // staged tiles are dead
 #pragma unroll
@@ -87,12 +87,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
         __syncthreads();
         if (tid < 2 * BN) {
             const int k = tid / BN, cc = tid % BN;
-            if (n0 + cc < p.Cout)
-                p.stats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] =
-                    [&] { float a = 0.f;
+            if (n0 + cc < p.Cout) {
+                float a = 0.f;
 #pragma unroll
-                          for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
-                          return a; }();
+                for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
+                if (p.stats_bins)      // fixed point: the order the workgroups arrive in cannot change the total
+                    atomicAdd(p.stats_bins + ((size_t)(tile & (p.stats_nb - 1)) * 2 + k) * p.Cout + n0 + cc,
+                              (unsigned long long)__double2ll_rn((double)a * (k ? kStatScale2 : kStatScale1)));
+                else
+                    p.stats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] = a;
+            }
         }
     }
     // (1b) dgrad that completes the gradient of a conv+BN(+ReLU) unit's activation: mask, store g, BN-backward partials

@@ -621,6 +621,7 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     DirectGeom g = direct_geom(p);
     g.out_nchw = out_nchw;
     VS_REQUIRE((double)p.Hin * p.Win * p.C0 * sizeof(T) < 2.0e9 && (long)g.nwaves * 16 < (1L << 32), "conv_direct: tensor too large");
+    VS_REQUIRE(!p.stats_bins, "conv_direct: statistics go to partial rows here (check conv_igemm_bins_ok first)");
     const bool head = p.scatter || (p.Cout & 3) != 0 || out_nchw;
     if (head) {   // four output rows per accumulator tile: strips start at multiples of 4
         g.RH = std::max(4, g.RH & ~3);
@@ -870,6 +871,10 @@ int conv_igemm_variant(int dtype, const ConvParams& p) {
 }
 
 bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && direct_ok(dtype, p); }
+
+// whether the kernel launch_conv_igemm picks for p can put its statistics into fixed-point bins (ConvParams::stats_bins): the
+// kernels that end in conv_epilogue (tile and ring kernels); the direct shallow-layer kernel keeps its partial rows per wave
+bool conv_igemm_bins_ok(int dtype, const ConvParams& p) { return dtype == VS_BF16 && !direct_ok(dtype, p); }
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave

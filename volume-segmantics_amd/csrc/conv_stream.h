@@ -396,7 +396,7 @@ constexpr size_t stream_lds_bytes() {
 // whether conv_stream_kernel's restrictions hold for this layer (the caller adds its own policy: grid size, option)
 inline bool stream_ok(const ConvParams& p, int out_nchw) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter || out_nchw || p.out_f32 || p.out1 ||
-        p.pool0 || p.stats_partial || p.bz || (p.Cout & 31) || p.up0 > 1 || (p.scale && !p.shift))
+        p.pool0 || p.stats_partial || p.stats_bins || p.bz || (p.Cout & 31) || p.up0 > 1 || (p.scale && !p.shift))
         return false;
     if ((p.C0 & 31) || (p.C1 & 31) || p.C0 + p.C1 < 64) return false;
     if (p.Hout < 16 || p.Wout < 16) return false;

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 // (<= 64: the 16x16 / 8x8-pixel layers), every workgroup sums them itself (fp64, rows in order) instead of waiting for a
 // separate finalise launch - ~1.5 us of redundant work per workgroup against ~7 us of launch + drain on the critical path.
 // Workgroup 0 also publishes mean / invstd for the backward pass and updates the running statistics.
-template <typename T>
+// FIXED: `partial` holds nparts rows of 64-bit fixed-point bins ([row][2][c]: sum x * 2^24, sum x^2 * 2^16, accumulated by atomic adds
+// in the producing convolution's epilogue - ConvParams::stats_bins) instead of fp32 partial rows
+template <typename T, bool FIXED = false>
 __global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restrict__ x, const float* __restrict__ partial, int nparts,
                                                             float eps, float momentum, float* __restrict__ mean,
                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
@@ -221,7 +223,38 @@ __global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restric
         }
     };
     const int cols = (2 * c) / 4;
-    if (c <= 512 && 256 % cols == 0) {
+    if constexpr (FIXED) {
+        // integer sums: any summation order gives the same bits, so all 256 threads share the rows - thread (value column, row
+        // group) adds its rows with the loads independent of each other, the row groups meet in LDS
+        const long long* bins = reinterpret_cast<const long long*>(partial);
+        const int nv = 2 * c;                           // values per bin row: [2][c]
+        long long* isum = reinterpret_cast<long long*>(s_stat + 2 * c);     // max(256, nv) entries behind the statistics (dynamic LDS:
+                                                                             // a static 32 KB array would cap the sweep's occupancy)
+        if (nv <= 256) {
+            const int RG = 256 / nv, col = tid % nv, rg = tid / nv;
+            long long acc = 0;
+            if (rg < RG) {
+#pragma unroll 8
+                for (int r = rg; r < nparts; r += RG) acc += bins[(size_t)r * nv + col];
+                isum[rg * nv + col] = acc;
+            }
+            __syncthreads();
+            for (int ch = tid; ch < c; ch += 256) {
+                long long sv = 0, qv = 0;
+                for (int g2 = 0; g2 < RG; ++g2) { sv += isum[g2 * nv + ch]; qv += isum[g2 * nv + c + ch]; }
+                finish(ch, (double)sv * (1.0 / kStatScale1), (double)qv * (1.0 / kStatScale2));
+            }
+        } else {
+            for (int col = tid; col < nv; col += 256) {
+                long long acc = 0;
+#pragma unroll 8
+                for (int r = 0; r < nparts; ++r) acc += bins[(size_t)r * nv + col];
+                isum[col] = acc;
+            }
+            __syncthreads();
+            for (int ch = tid; ch < c; ch += 256) finish(ch, (double)isum[ch] * (1.0 / kStatScale1), (double)isum[c + ch] * (1.0 / kStatScale2));
+        }
+    } else if (c <= 512 && 256 % cols == 0) {
         // all 256 threads: thread (column of four statistics, row group) sums its rows with 16-byte loads, four in flight;
         // the row groups meet in LDS in a fixed order (fp64 throughout: every workgroup forms the same numbers)
         __shared__ double dsum[4096];                                  // [RG][2 c]
@@ -666,6 +699,31 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
     const size_t lds = 2 * (size_t)c * sizeof(float);
     VS_FOR_T(dtype, hipLaunchKernelGGL(bn_apply_inline_kernel<T>, dim3(m.nblocks), dim3(256), lds, s, (const T*)x, partial, nparts, eps,
                            momentum, mean, invstd, running_mean, running_var, gamma, beta, (const T*)residual, relu, (T*)y, rows, c, m));
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long* bins, int nb, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s) {
+    VS_REQUIRE(c % kVec == 0 && c <= 2048 && nb >= 1, "bn_apply: unsupported channel count %d", c);
+    RowMap m = make_rowmap(rows, c);
+    const size_t lds = 2 * (size_t)c * sizeof(float) + (size_t)std::max(256, 2 * c) * sizeof(long long);
+    VS_FOR_T(dtype, hipLaunchKernelGGL((bn_apply_inline_kernel<T, true>), dim3(m.nblocks), dim3(256), lds, s, (const T*)x, (const float*)bins, nb, eps,
+                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const T*)residual, relu, (T*)y, rows, c, m));
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+namespace {
+__global__ void zero_u64_kernel(unsigned long long* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0ull;
+}
+}  // namespace
+// (a kernel, not hipMemsetAsync: a recorded step stays a linear graph of kernel nodes)
+int launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s) {
+    if (!n) return VS_OK;
+    hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, p, n);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
