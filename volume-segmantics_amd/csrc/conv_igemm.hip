@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
             const bool live = h >= h0;                         // (h < h1 always: hi <= h1)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (MODE == 0 && p.stats_partial && live && inw) {
+                if (MODE == 0 && (p.stats_partial || p.stats_bins) && live && inw) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { s1[j][r] += a0[j][r]; s2[j][r] += a0[j][r] * a0[j][r]; }
                 }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
             for (int j = 0; j < NJ; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; a2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
     }
-    if (MODE == 0 && p.stats_partial) {   // one partial row per wave: sum / sum of squares over the strip's pixels
+    if (MODE == 0 && (p.stats_partial || p.stats_bins)) {   // one partial row per wave: sum / sum of squares over the strip's pixels (or fixed-point bins)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -455,8 +455,14 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
                 for (int o = 1; o < 16; o <<= 1) { s1[j][r] += __shfl_xor(s1[j][r], o, 64); s2[j][r] += __shfl_xor(s2[j][r], o, 64); }
                 const int c = j * 16 + lq * 4 + r;
                 if (lr == 0 && c < p.Cout) {
-                    p.stats_partial[((size_t)gw * 2 + 0) * p.Cout + c] = s1[j][r];
-                    p.stats_partial[((size_t)gw * 2 + 1) * p.Cout + c] = s2[j][r];
+                    if (p.stats_bins) {
+                        unsigned long long* b = p.stats_bins + (size_t)(gw & (p.stats_nb - 1)) * 2 * p.Cout + c;
+                        atomicAdd(b, (unsigned long long)__double2ll_rn((double)s1[j][r] * kStatScale1));
+                        atomicAdd(b + p.Cout, (unsigned long long)__double2ll_rn((double)s2[j][r] * kStatScale2));
+                    } else {
+                        p.stats_partial[((size_t)gw * 2 + 0) * p.Cout + c] = s1[j][r];
+                        p.stats_partial[((size_t)gw * 2 + 1) * p.Cout + c] = s2[j][r];
+                    }
                 }
             }
     }
@@ -621,7 +627,6 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     DirectGeom g = direct_geom(p);
     g.out_nchw = out_nchw;
     VS_REQUIRE((double)p.Hin * p.Win * p.C0 * sizeof(T) < 2.0e9 && (long)g.nwaves * 16 < (1L << 32), "conv_direct: tensor too large");
-    VS_REQUIRE(!p.stats_bins, "conv_direct: statistics go to partial rows here (check conv_igemm_bins_ok first)");
     const bool head = p.scatter || (p.Cout & 3) != 0 || out_nchw;
     if (head) {   // four output rows per accumulator tile: strips start at multiples of 4
         g.RH = std::max(4, g.RH & ~3);
@@ -873,8 +878,8 @@ int conv_igemm_variant(int dtype, const ConvParams& p) {
 bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && direct_ok(dtype, p); }
 
 // whether the kernel launch_conv_igemm picks for p can put its statistics into fixed-point bins (ConvParams::stats_bins): the
-// kernels that end in conv_epilogue (tile and ring kernels); the direct shallow-layer kernel keeps its partial rows per wave
-bool conv_igemm_bins_ok(int dtype, const ConvParams& p) { return dtype == VS_BF16 && !direct_ok(dtype, p); }
+// kernels that end in conv_epilogue (tile and ring kernels) and the direct shallow-layer kernel (one atomic pair per wave and cout)
+bool conv_igemm_bins_ok(int dtype, const ConvParams& p) { return dtype == VS_BF16; }
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave

@@ -119,7 +119,9 @@ struct Act {  // one activation tensor (per-sample element count = c*h*w)
     size_t off_a = 0, off_z = 0, off_da = 0, off_dz = 0;
 };
 
-constexpr int kStatBins = 16;     // rows of fixed-point statistics bins per unit (ConvParams::stats_bins): 16 atomics per address at 256 tiles
+// rows of fixed-point statistics bins of a unit (ConvParams::stats_bins): enough rows that an address takes ~16 - 32 atomic adds per
+// launch (16 rows for the tile kernels' 256 - 512 tiles; 256 for the <= 16-channel layers, whose direct kernel adds once per WAVE)
+static inline int stat_bins_rows(int cout) { return cout <= 16 ? 256 : 16; }
 
 struct Unit {
     UnitKind kind;
@@ -148,7 +150,7 @@ struct Unit {
                     // compute copies are block-expanded to 32-channel super-groups (vs_weights_prepare_grouped)
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
-    size_t off_bins = 0;                         // kStatBins rows of fixed-point statistics bins ([row][2][cout] 64-bit), training plans
+    size_t off_bins = 0;                         // stat_bins_rows(cout) rows of fixed-point statistics bins ([row][2][cout] 64-bit), training plans
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
     std::vector<int> tens;                       // U_FPA: parameter tensor indices
     size_t off_fpa_pool = 0, off_fpa_arena = 0, off_fpa_plane = 0;   // U_FPA: pooled input, pyramid arena (fp32), attention plane (fp32)
@@ -1092,12 +1094,12 @@ size_t plan_workspace(vs_unet* net) {
     {   // fixed-point statistics bins of every convolution + BatchNorm unit (ConvParams::stats_bins): one contiguous block
         size_t total = 0;
         for (auto& u : net->units)
-            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) total += (size_t)kStatBins * 2 * u.cout * sizeof(unsigned long long);
+            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) total += (size_t)stat_bins_rows(u.cout) * 2 * u.cout * sizeof(unsigned long long);
         net->bins_bytes = total;
         net->off_bins0 = take(total);
         size_t at = net->off_bins0;
         for (auto& u : net->units)
-            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) { u.off_bins = at; at += (size_t)kStatBins * 2 * u.cout * sizeof(unsigned long long); }
+            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) { u.off_bins = at; at += (size_t)stat_bins_rows(u.cout) * 2 * u.cout * sizeof(unsigned long long); }
     }
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
@@ -1713,10 +1715,10 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 if (dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     if (u.bn_idx >= 0 && rows_needed > vs_option("bn_inline_rows") && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p)) {
-                        // many tiles: their sums go into kStatBins rows of fixed-point bins, finalised inside the apply sweep -
+                        // many tiles: their sums go into a few rows of fixed-point bins, finalised inside the apply sweep -
                         // no finalize launch between the convolution and its normalisation (0.34 ms of a 4.76 ms step)
                         p.stats_bins = (unsigned long long*)(c.ws + u.off_bins);
-                        p.stats_nb = kStatBins;
+                        p.stats_nb = stat_bins_rows(u.cout);
                         fused_bins = true;
                     } else if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
@@ -1781,7 +1783,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
             if (fused_bins) {
                 ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
-                if ((rc = launch_bn_apply_from_bins(dt, c.z(u.out), (const unsigned long long*)(c.ws + u.off_bins), kStatBins, 1e-5f, 0.1f,
+                if ((rc = launch_bn_apply_from_bins(dt, c.z(u.out), (const unsigned long long*)(c.ws + u.off_bins), stat_bins_rows(u.cout), 1e-5f, 0.1f,
                                                     c.bnc(u, 2), c.bnc(u, 3), rm, rv, c.P(u.bn_idx), c.P(u.bn_idx + 1),
                                                     u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, c.s))) return rc;
                 continue;
