@@ -1,5 +1,5 @@
 """BASELINE configs[4]'s network (DeepLabV3+ / efficientnet-b4) on 1024 x 1024 slices, for rocprofv3 --kernel-trace --stats (needs a GPU):
-   python tools/predict_config5_probe.py [slices] [batch]"""
+   python tools/predict_config5_probe.py [slices] [batch] [bf16|fp16]"""
 import sys, time, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 from types import SimpleNamespace
@@ -12,8 +12,9 @@ from volume_segmantics_amd.utilities.base_data_utils import Axis
 
 slices = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 dev = torch.device("cuda:0")
-model = VolSegUnet(2, device=dev, precision="bf16", seed=1, encoder="efficientnet-b4", topology="deeplabv3plus")
+model = VolSegUnet(2, device=dev, precision=precision, seed=1, encoder="efficientnet-b4", topology="deeplabv3plus")
 model.eval()
 pred = VolSeg2dPredictor.__new__(VolSeg2dPredictor)
 pred.model, pred.num_labels, pred.label_codes = model, 2, {}
