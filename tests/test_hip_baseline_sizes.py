@@ -162,7 +162,7 @@ def test_deeplabv3plus_efficientnet_b4_1024_one_slice_eval():
 
 @pytest.mark.parametrize("option,value,exact", [("wgrad_ring", 0, False), ("wgrad_xcd", 0, False), ("conv_ring", 0, False), ("conv_ring", 2, False),
                                                 ("conv_stream", 0, True), ("stats_bins", 0, False), ("bn_bwd_fused", 1, False), ("fuse_bn_bwd", 0, False),
-                                                ("wgrad_pair_join", 1, True)])
+                                                ("wgrad_pair_join", 1, True), ("nl_fwd", 1, False)])
 def test_every_kernel_choice_option_gives_the_same_training_step(option, value, exact):
     """The runtime options that pick between kernels / schedules of the SAME arithmetic (round 3 added several: ring and
     persistent convolution kernels, the ring weight-gradient kernel, its XCD-aware K-split assignment, the one-launch BatchNorm
@@ -206,5 +206,46 @@ def test_every_kernel_choice_option_gives_the_same_training_step(option, value, 
     print(f"[options] {option}={value}: loss {other[0]:.6f} vs {base[0]:.6f}; all gradients: relative L2 {rel:.2e}, cosine {cos:.6f}")
     # (`conv_ring` and `stats_bins` change how the BatchNorm statistics of the FORWARD pass are summed - tile shapes / fp32 partial
     # rows vs fixed-point bins: the sums agree to ~1e-7, which is enough to move bf16 activations by an ulp here and there)
-    loose = option in ("conv_ring", "stats_bins")
+    loose = option in ("conv_ring", "stats_bins", "nl_fwd")    # (`nl_fwd` 1 takes the deep layers off the ring kernels and off partial rows)
     assert (rel < 0.2 and cos > 0.99) if loose else (rel < 2e-2 and cos > 0.999), (option, rel, cos)
+
+
+def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep():
+    """Round 3 (second half): a conv -> BN -> ReLU unit whose output has ONE reader (a BasicBlock's conv1, the decoder's
+    convolutions) no longer runs a normalisation sweep in training - its convolution finalises the batch statistics behind a
+    ticket, and the reader (forward convolution AND weight gradient) normalises the pre-norm tensor while staging it
+    (`nl_fwd`, ConvParams::nl_*).  With the kernel families pinned (tile kernels, register-staged weight gradients, statistics in
+    bins for every layer) the two forms do the same arithmetic on the same values: one headline-sized training step must give
+    the same loss and the same gradients BIT FOR BIT, and the BatchNorm running statistics must agree bit for bit as well."""
+    import bench
+    from volume_segmantics_amd import _lib as L
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+    from volume_segmantics_amd.engine import VolSegUnet
+    x, t = bench.synth_batch(32, 256, 2, seed=3)
+    x, t = x.to(DEV), torch.nn.functional.one_hot(t.long(), 2).permute(0, 3, 1, 2).float().contiguous().to(DEV)
+
+    def run():
+        model = VolSegUnet(2, device=DEV, precision="bf16", seed=5)
+        model.train()
+        loss = HipDiceLoss()(model(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        bn = torch.cat([b.detach().float().flatten() for n, b in model.named_buffers() if "running" in n])
+        return loss.item(), model._flat_grad.clone(), bn.clone()
+
+    pinned = {"conv_ring": 0, "wgrad_ring": 0, "bn_inline_rows": 0}
+    old = {k: L.lib.vs_get_option(k.encode()) for k in list(pinned) + ["nl_fwd"]}
+    try:
+        for k, v in pinned.items():
+            L.set_option(k, v)
+        L.set_option("nl_fwd", 1)
+        on = run()
+        L.set_option("nl_fwd", 0)
+        off = run()
+    finally:
+        for k, v in old.items():
+            L.set_option(k, v)
+    assert torch.isfinite(on[1]).all()
+    assert on[0] == off[0], (on[0], off[0])
+    assert torch.equal(on[2], off[2]), (on[2] - off[2]).abs().max().item()
+    assert torch.equal(on[1], off[1]), (on[1] - off[1]).abs().max().item()

@@ -183,6 +183,7 @@ _SIGS = {
     "vs_train_hyper_set": (I, [P, F, F, F, F, F, I, P, I, P]),
     "vs_unet_unit_param_offset": (I64, [P, I]),
     "vs_unet_num_units": (I, [P]),
+    "vs_unet_nl_plan": (I, [P, I, C.POINTER(I), I]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),
                                C.POINTER(SZ), C.POINTER(SZ)]),
     "vs_profile_enable": (I, [I]),

@@ -144,6 +144,20 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
     st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
 }
 
+// normalise-on-load of one 16-byte item (8 bf16 channels): the arithmetic of bn_apply_kernel, element for element
+__device__ __forceinline__ uint4 nl_apply8(const uint4 v, const bool live, const float (&m)[8], const float (&a)[8], const float (&b)[8]) {
+    float x[8];
+    x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+    x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+    x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
+    x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = fmaxf((x[k] - m[k]) * a[k] + b[k], 0.f);
+    uint4 r;
+    r.x = pack2<bf16_t>(x[0], x[1]); r.y = pack2<bf16_t>(x[2], x[3]); r.z = pack2<bf16_t>(x[4], x[5]); r.w = pack2<bf16_t>(x[6], x[7]);
+    return live ? r : make_uint4(0u, 0u, 0u, 0u);   // padding / ragged edges stay zero
+}
+
 // ---- raw buffer loads ---------------------------------------------------------------------------------
 // 16-byte load through a buffer descriptor: `voff` is a per-lane byte offset, `soff` a uniform one; an offset outside
 // [0, bytes) - use -1 - returns zeros, so padding and ragged edges need no branches.
@@ -219,6 +233,19 @@ struct ConvParams {
     // 2^24, sum x^2 by 2^16).  Integer adds commute: the totals are bit-reproducible whatever order the workgroups arrive in,
     // and the consumer finalises stats_nb rows inline instead of waiting for a finalize launch over hundreds (norm.hip).
     unsigned long long* stats_bins; int stats_nb;
+    // Optional, with stats_bins: every workgroup (direct kernel: wave) takes a ticket once its sums are in the bins; the one that
+    // takes the LAST ticket finalises the statistics itself (fp64, the arithmetic of bn_apply_inline_kernel: mean / invstd for the
+    // backward pass, running statistics).  The consumer can then normalise this tensor while it LOADS it (nl_* below) and no
+    // normalisation sweep - no launch at all - sits between the two convolutions on the caller's stream.
+    unsigned* fin_ticket;                // one zeroed counter (lives behind the unit's bins: cleared by the same launch)
+    int fin_tickets;                     // tickets a launch takes
+    long long fin_rows;                  // N * Hout * Wout
+    float fin_eps, fin_mom;
+    float* fin_mean; float* fin_invstd; float* fin_rm; float* fin_rv;   // outputs ([Cout] each; rm / rv may be null)
+    // Normalise-on-load of src0 (training forward of a conv -> BN -> ReLU -> conv pair): src0 holds the producer's PRE-norm
+    // output z; the loader applies y = max((z - mean) * (invstd * gamma) + beta, 0), rounded to the storage type exactly as the
+    // normalisation sweep would have stored it, before the chunk goes to LDS (zero padding stays zero).  null = off.
+    const float* nl_mean; const float* nl_invstd; const float* nl_gamma; const float* nl_beta;
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
@@ -234,6 +261,8 @@ struct VolScatter {
 int launch_keys_stage_scatter(const uint32_t* stage, int nb, const vs_dirmap& m, int s0, uint32_t* keys, hipStream_t s);
 bool conv_head_scatter_ok(int dtype, const ConvParams& p);
 bool conv_igemm_bins_ok(int dtype, const ConvParams& p);     // whether p's kernel honours ConvParams::stats_bins   // whether launch_conv_igemm can honour p.scatter for this layer
+int conv_igemm_tickets(int dtype, const ConvParams& p);      // tickets p's launch takes (ConvParams::fin_ticket); 0 = kernel without tickets
+bool conv_igemm_nl_ok(int dtype, const ConvParams& p);       // whether launch_conv_igemm can honour p.nl_* (normalise src0 on load)
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
@@ -252,6 +281,8 @@ int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long
                               float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
                               const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
 int launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s);
+bool stem_fwd_bins_ok(int dtype);
+int launch_stem_fwd_bins(const float* x, const float* w, void* z, int n, int h, int w_, unsigned long long* bins, int nb, hipStream_t s);
 
 // BatchNorm backward (dx, dres, dgamma, dbeta): three launches, or ONE with a grid barrier for tensors of a few MB (norm.hip).
 // ctl: 16 zeroed bytes of barrier counters that re-arm themselves (null: the end of `workspace`, zeroed by a memset first)
@@ -270,9 +301,12 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
+    // src0 holds the pre-norm output z of a conv -> BN -> ReLU unit: normalise while staging (see ConvParams::nl_*); null = off
+    const float* nl_mean; const float* nl_invstd; const float* nl_gamma; const float* nl_beta;
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
+bool conv_wgrad_nl_ok(int dtype, const WgradParams& p);      // whether launch_conv_wgrad can honour p.nl_* (normalise src0 on load)
 // dw[i] = sum_k partials[k*n + i], fixed summation order
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);
 

@@ -62,7 +62,10 @@ constexpr int patch_items(int pt, int stride, int nw = 4) {
 
 // DIL: dilation of a 3x3 kernel (1 or 2; torchvision / smp "replace stride with dilation" stages).  Dilated variants take their
 // tile geometry from the launch like the stride-2 ones and use the same staging budget (the patch is (tile + 2 DIL) wide).
-template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1>
+// NLOAD: src0 is the PRE-norm output z of the conv -> BN -> ReLU unit in front (ConvParams::nl_*): its chunks are normalised in
+// registers on their way to LDS - y = max((z - mean) * (invstd * gamma) + beta, 0) rounded to bf16, the value the normalisation
+// sweep would have stored, zero padding left zero - so that sweep, its launch and the y tensor do not exist.
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1, bool NLOAD = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(ConvParams p, TileGeom g) {
     constexpr int NT = NW * 64;
     constexpr int CK = CT<T>::CK, EPS = CT<T>::EPS;
@@ -132,6 +135,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     const int CinW = p.gc ? p.gc : Cin;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * NTAPS * CinW * (int)sizeof(T), 0x00020000);
     const int dummy = (P + NTAPS * BN) * kPS;    // 64 spare bytes behind the staged tiles: target of the stores of idle items
+    // NLOAD: [3][C0 rounded up to 32] floats behind them - mean, invstd * gamma, beta of src0's channels
+    float* cst = reinterpret_cast<float*>(smem + dummy + 64);
+    const int C0r = (p.C0 + 31) & ~31;
+    if constexpr (NLOAD) {
+        for (int ch = tid; ch < p.C0; ch += NT) {
+            cst[ch] = p.nl_mean[ch];
+            cst[C0r + ch] = p.nl_invstd[ch] * p.nl_gamma[ch];
+            cst[2 * C0r + ch] = p.nl_beta[ch];
+        }   // visible to every wave behind the first barrier of the chunk loop
+    }
 
     // ---- chunk-invariant staging addresses (byte offsets; -1 = zero fill) ----
     int poff0[PITEMS], poff1[PITEMS], pdst[PITEMS];
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
 
     // Prefetch depth: PF chunks are in flight (in registers) while one is being multiplied.  Kernels that run with one or
     // two workgroups per CU and have registers to spare use 2, so a staging load gets two chunk periods to land.
-    constexpr int PF = ((NW == 8 && BN <= 32) || (NW == 4 && PT == 1 && STRIDE == 1)) ? 2 : 1;
+    constexpr int PF = (((NW == 8 && BN <= 32) || (NW == 4 && PT == 1 && STRIDE == 1)) && !(NLOAD && NW == 8)) ? 2 : 1;   // (NLOAD, 8 waves: the second set spills)
     uint4 pregs[PF][PITEMS], wregs[PF][WITEMS];
     auto load_chunk = [&](int c0, uint4 (&preg)[PITEMS], uint4 (&wreg)[WITEMS]) {
         const bool from0 = c0 < p.C0;
@@ -204,6 +217,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
             const int c0 = cbase + s * CK;
             if (c0 >= kend) break;
             __syncthreads();  // every wave is done reading the previous chunk
+            if constexpr (NLOAD) {
+                if (c0 < p.C0) {   // (uniform) a chunk of src0: this thread's 8 channels are the same in all of its items
+                    const float* q = cst + c0 + (tid & 3) * EPS;
+                    float nm[8], na[8], nb[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(q + 4 * h), a4 = *reinterpret_cast<const float4*>(q + C0r + 4 * h),
+                                     b4 = *reinterpret_cast<const float4*>(q + 2 * C0r + 4 * h);
+                        nm[4 * h] = m4.x; nm[4 * h + 1] = m4.y; nm[4 * h + 2] = m4.z; nm[4 * h + 3] = m4.w;
+                        na[4 * h] = a4.x; na[4 * h + 1] = a4.y; na[4 * h + 2] = a4.z; na[4 * h + 3] = a4.w;
+                        nb[4 * h] = b4.x; nb[4 * h + 1] = b4.y; nb[4 * h + 2] = b4.z; nb[4 * h + 3] = b4.w;
+                    }
+                    const bool segok = (tid & 3) * EPS < p.C0 - c0;
+#pragma unroll
+                    for (int i = 0; i < PITEMS; ++i) pregs[s][i] = nl_apply8(pregs[s][i], segok && poff0[i] >= 0, nm, na, nb);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(patch + pdst[i]) = pregs[s][i];
 #pragma unroll
@@ -602,7 +632,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && !p.bz && !p.gc && p.dil <= 1 && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.nl_mean && !p.bz && !p.gc && p.dil <= 1 && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -668,11 +698,11 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     return VS_OK;
 }
 
-template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1>
+template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1, bool NLOAD = false>
 int launch_one(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW, DIL>;
-    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS + 64;
+    auto kern = conv_igemm_kernel<T, BN, PT, NTAPS, STRIDE, NW, DIL, NLOAD>;
+    const size_t lds = (size_t)g.PH * g.PW * kPS + (size_t)NTAPS * BN * kPS + 64 + (NLOAD ? (size_t)3 * ((p.C0 + 31) & ~31) * sizeof(float) : 0);
     VS_REQUIRE((double)p.Hin * p.Win * std::max(p.C0, p.C1) * sizeof(T) < 2.0e9 && (double)p.Cout * NTAPS * (p.C0 + p.C1) * sizeof(T) < 2.0e9,
                "conv_igemm: image or weight tensor exceeds the 32-bit staging offsets");
     VS_REQUIRE(lds <= 160 * 1024, "conv_igemm: LDS request %zu too large", lds);
@@ -707,6 +737,9 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
     }
     if constexpr (PT == 2 && BN == 64) {   // 8 x 16 output tiles of the stride-2 3x3 layers of a big batch
         if (p.stride == 2) return launch_one<T, 64, 2, 9, 2>(p, g, s);
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (p.nl_mean) return launch_one<T, BN, PT, 9, 1, 4, 1, true>(p, g, s);     // (dispatch checked: stride-1 3x3, no dilation)
     }
     return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
 }
@@ -752,7 +785,7 @@ Pick pick_cfg(const ConvParams& p) {
 // (prediction: batches of 512 x 512 slices) - at least `conv_stream_min_tiles` tile jobs per CU-resident workgroup, so that
 // the per-tile latencies it removes are what the launch consists of.  0 = no, else the cout tile (64 / 32)
 static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
-    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512) return 0;
+    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512 || p.nl_mean) return 0;
     const int bn = (p.Cout % 64 == 0) ? 64 : 32;
     const long jobs = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * (p.Cout / bn);
     return jobs >= 256L * vs_option("conv_stream_min_tiles") ? bn : 0;
@@ -760,7 +793,7 @@ static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
 
 static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
-        out_nchw || (p.Cout & 3) || p.out_f32) return 0;
+        out_nchw || (p.Cout & 3) || p.out_f32 || p.nl_mean) return 0;     // (normalise-on-load needs the register-staged tile kernel)
     const int Cin = p.C0 + p.C1;
     if (Cin < 128 || (Cin & 7) || (p.C1 && (p.C0 & 31))) return 0;
     if (p.out1 && (p.split_c & 31)) return 0;
@@ -812,6 +845,10 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     }
     ConvParams pd = p;
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
+    if (p.nl_mean) {
+        VS_REQUIRE(conv_igemm_nl_ok(Elem<T>::kDtype, pd) && p.nl_invstd && p.nl_gamma && p.nl_beta,
+                   "conv_igemm: normalise-on-load is built for the bf16 stride-1 3x3 layers (ask conv_igemm_nl_ok first)");
+    }
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
         return launch_direct<T, 16>(p, out_nchw, s);
     if constexpr (sizeof(T) == 2) {
@@ -844,6 +881,13 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     g.pw_magic = 0xffffffffu / (unsigned)g.PW + 1u;       // exact for x * PW < 2^32
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;
     g.probe = vs_probe_buffer((size_t)p.N * g.tiles_h * g.tiles_w * cdiv(p.Cout, BN));
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (NW == 8 && p.nl_mean) {
+#define VS_CONV8N(bn) if (BN == bn) return launch_one<T, bn, 2, 9, 1, 8, 1, true>(p, g, s)
+            VS_CONV8N(64); VS_CONV8N(32); VS_CONV8N(16);
+#undef VS_CONV8N
+        }
+    }
     if (NW == 8) {
         const bool t9 = p.KH * p.KW == 9;
 #define VS_CONV8(bn) if (BN == bn) return t9 ? launch_one<T, bn, 2, 9, 1, 8>(p, g, s) : launch_one<T, bn, 2, 1, 1, 8>(p, g, s)
@@ -880,6 +924,30 @@ bool conv_head_scatter_ok(int dtype, const ConvParams& p) { return p.scatter && 
 // whether the kernel launch_conv_igemm picks for p can put its statistics into fixed-point bins (ConvParams::stats_bins): the
 // kernels that end in conv_epilogue (tile and ring kernels) and the direct shallow-layer kernel (one atomic pair per wave and cout)
 bool conv_igemm_bins_ok(int dtype, const ConvParams& p) { return dtype == VS_BF16; }
+
+// whether launch_conv_igemm can normalise p.src0 while loading it (ConvParams::nl_*): the register-staged tile kernel's bf16
+// stride-1 3x3 instantiations (p as the layer will be launched, nl_* set or not)
+bool conv_igemm_nl_ok(int dtype, const ConvParams& p) {
+    ConvParams q = p;
+    q.nl_mean = nullptr;
+    if (dtype != VS_BF16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter || p.up0 == 2 || p.bz ||
+        (p.C0 & 7) || p.C0 > 2048) return false;
+    if (direct_ok(dtype, q)) return false;    // the strip kernels have no such loader (yet)
+    return true;
+}
+
+// tickets a launch of p takes when ConvParams::fin_ticket is set (= its workgroups that reach conv_epilogue); 0: the kernel
+// launch_conv_igemm picks has no ticket (direct / persistent kernels)
+int conv_igemm_tickets(int dtype, const ConvParams& p0) {
+    ConvParams p = p0;
+    static unsigned long long some_bins;
+    if (!p.stats_bins) p.stats_bins = &some_bins;     // tickets come with statistics bins: the kernel choice is the one made with them set
+    const int nchw = p.out_f32 >> 1;
+    if (dtype != VS_BF16 || direct_ok(dtype, p) || stream_mode(dtype, p, nchw)) return 0;
+    const int rm = ring_mode(dtype, p, nchw);
+    const int bn = rm ? (rm == 1 ? 64 : 32) : pick_cfg(p).BN;
+    return conv_igemm_stat_rows(dtype, p) * cdiv(p.Cout, bn);
+}
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {
     if (direct_ok(dtype, p)) return direct_geom(p).nwaves;   // one partial row per wave

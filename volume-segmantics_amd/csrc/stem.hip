@@ -197,9 +197,13 @@ __device__ __forceinline__ void load_stem_weights_bf16(const float* __restrict__
         }
 }
 
+// bins (training, optional): [nb rows][2][64] 64-bit fixed-point sums of the fp32 accumulators (sum x * 2^24, sum x^2 * 2^16), as the
+// convolution kernels leave them for their BatchNorm (ConvParams::stats_bins) - the workgroup's tiles are summed in registers and
+// added once, so the separate statistics sweep over the stored tensor (67 MB at batch 32 of 256 x 256) does not run.
 __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int relu, bf16_t* __restrict__ y, int n, int h, int wd) {
+                                                            int relu, bf16_t* __restrict__ y, int n, int h, int wd,
+                                                            unsigned long long* __restrict__ bins, int nb) {
     __shared__ __attribute__((aligned(16))) bf16_t patch[PHB * PWB];
     __shared__ __attribute__((aligned(16))) char otile[256 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
@@ -207,6 +211,11 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
     const int tiles_w = (wo_n + TPW - 1) / TPW, tiles_h = (ho_n + TPH - 1) / TPH;
     uint4 wa[4][2];
     load_stem_weights_bf16(w, lr, lq, wa);      // once per workgroup: it walks over tiles blockIdx.x, + gridDim.x, ..
+    float s1[4][4], s2[4][4];                   // [cout fragment j][r]: sums over this lane's pixels of every tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
     for (int tile = blockIdx.x; tile < n * tiles_h * tiles_w; tile += gridDim.x) {
     int b = tile;
     const int tx = b % tiles_w; b /= tiles_w;
@@ -232,6 +241,19 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[j][s]), __builtin_bit_cast(bf16x8, xb),
                                                                     acc[i][j], 0, 0, 0);
+        }
+    }
+    if (bins) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = h0 + 2 * wave + (i >> 1) < ho_n && w0 + (i & 1) * 16 + lr < wo_n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = ok ? acc[i][j][r] : 0.f;
+                    s1[j][r] += v; s2[j][r] += v * v;
+                }
         }
     }
     // Output through LDS: the accumulators hold 8-byte pieces (4 couts of one pixel); transposed through a [256 pixels][128 B]
@@ -266,6 +288,28 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
             *reinterpret_cast<uint4*>(y + (((size_t)img * ho_n + ho) * wo_n + wo) * 64 + slot * 8) =
                 *reinterpret_cast<const uint4*>(otile + pl * 128 + ((slot ^ (pl & 7)) << 4));
     }
+    }
+    if (bins) {     // the workgroup's sums: lanes of a 16-lane row, then the four waves (LDS), then one fixed-point add per channel and sum
+        float* red = reinterpret_cast<float*>(otile);            // [4 waves][2][64]
+        __syncthreads();                                         // the last tile's transposed reads are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[j][r] += __shfl_xor(s1[j][r], o, 64); s2[j][r] += __shfl_xor(s2[j][r], o, 64); }
+                if (lr == 0) {
+                    red[(wave * 2 + 0) * 64 + j * 16 + lq * 4 + r] = s1[j][r];
+                    red[(wave * 2 + 1) * 64 + j * 16 + lq * 4 + r] = s2[j][r];
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, cc = tid & 63;
+            const float a = (red[(0 * 2 + k) * 64 + cc] + red[(1 * 2 + k) * 64 + cc]) + (red[(2 * 2 + k) * 64 + cc] + red[(3 * 2 + k) * 64 + cc]);
+            atomicAdd(bins + ((size_t)(blockIdx.x & (nb - 1)) * 2 + k) * 64 + cc,
+                      (unsigned long long)__double2ll_rn((double)a * (k ? kStatScale2 : kStatScale1)));
+        }
     }
 }
 
@@ -399,7 +443,7 @@ extern "C" int vs_stem_fwd(int dtype, const float* x, const float* w, const floa
     const int tiles = n * cdiv(h / 2, TPH) * cdiv(w_ / 2, TPW);
     if (dtype == VS_BF16 && vs_option("stem_bf16"))
         hipLaunchKernelGGL(stem_fwd_bf16_kernel, dim3(std::min(tiles, 1024)), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift,
-                           relu, (bf16_t*)y, n, h, w_);
+                           relu, (bf16_t*)y, n, h, w_, (unsigned long long*)nullptr, 0);
     else if (dtype == VS_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (bf16_t*)y, n, h, w_);
@@ -409,6 +453,18 @@ extern "C" int vs_stem_fwd(int dtype, const float* x, const float* w, const floa
     else
         hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, relu,
                            (float*)y, n, h, w_);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// training forward of the bf16 stem with the batch statistics' sums left in fixed-point bins ([nb][2][64], zeroed by the caller; nb a
+// power of two); false: this dtype / option set has no such kernel (the caller runs its statistics sweep)
+bool stem_fwd_bins_ok(int dtype) { return dtype == VS_BF16 && vs_option("stem_bf16"); }
+int launch_stem_fwd_bins(const float* x, const float* w, void* z, int n, int h, int w_, unsigned long long* bins, int nb, hipStream_t s) {
+    VS_REQUIRE(h % 2 == 0 && w_ % 2 == 0 && x && w && z && bins && nb >= 1 && !(nb & (nb - 1)), "stem_fwd_bins: bad arguments");
+    const int tiles = n * cdiv(h / 2, TPH) * cdiv(w_ / 2, TPW);
+    hipLaunchKernelGGL(stem_fwd_bf16_kernel, dim3(std::min(tiles, 1024)), dim3(256), 0, s, x, w, (const float*)nullptr, (const float*)nullptr, 0,
+                       (bf16_t*)z, n, h, w_, bins, nb);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

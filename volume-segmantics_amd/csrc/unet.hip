@@ -122,6 +122,8 @@ struct Act {  // one activation tensor (per-sample element count = c*h*w)
 // rows of fixed-point statistics bins of a unit (ConvParams::stats_bins): enough rows that an address takes ~16 - 32 atomic adds per
 // launch (16 rows for the tile kernels' 256 - 512 tiles; 256 for the <= 16-channel layers, whose direct kernel adds once per WAVE)
 static inline int stat_bins_rows(int cout) { return cout <= 16 ? 256 : 16; }
+static inline size_t unit_bins_bytes(int cout) { return (size_t)stat_bins_rows(cout) * 2 * cout * sizeof(unsigned long long); }
+constexpr size_t kTicketBytes = 128;   // behind a unit's bins: the ticket counter of ConvParams::fin_ticket (cleared with the bins)
 
 struct Unit {
     UnitKind kind;
@@ -205,6 +207,9 @@ struct vs_unet {
     std::vector<char> group_first;  // optimiser groups of the fused backward (see unet_backward_range)
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
+    std::vector<int> sole_consumer;              // per activation: the ONE unit that reads it (-1: none / several readers)
+    std::vector<char> nl_act;                    // per activation, set by the last training forward: it was never materialised - its one
+                                                 // consumer normalises the producer's pre-norm output z while loading it (ConvParams::nl_*)
     size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
     int head_up = 1;                   // the head works at 1 / head_up resolution, nn.UpsamplingBilinear2d(head_up) follows (FPN: 4)
     uint32_t rng_seed = 0; const int64_t* rng_counter = nullptr;   // Dropout2d draws (vs_unet_set_rng)
@@ -1094,12 +1099,12 @@ size_t plan_workspace(vs_unet* net) {
     {   // fixed-point statistics bins of every convolution + BatchNorm unit (ConvParams::stats_bins): one contiguous block
         size_t total = 0;
         for (auto& u : net->units)
-            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) total += (size_t)stat_bins_rows(u.cout) * 2 * u.cout * sizeof(unsigned long long);
+            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) total += unit_bins_bytes(u.cout) + kTicketBytes;
         net->bins_bytes = total;
         net->off_bins0 = take(total);
         size_t at = net->off_bins0;
         for (auto& u : net->units)
-            if (u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) { u.off_bins = at; at += (size_t)stat_bins_rows(u.cout) * 2 * u.cout * sizeof(unsigned long long); }
+            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) { u.off_bins = at; at += unit_bins_bytes(u.cout) + kTicketBytes; }
     }
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
@@ -1147,7 +1152,12 @@ size_t plan_workspace(vs_unet* net) {
         if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
         p.cg = u.cg; p.dil = u.dil;
         if (u.colr) { p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
-        const size_t b = wgrad_workspace_bytes(net->dtype, p);
+        size_t b = wgrad_workspace_bytes(net->dtype, p);
+        if (u.kind == U_CONV && net->dtype == VS_BF16) {   // the normalise-on-load form runs on the register-staged kernel with its own K split
+            static const float one = 1.f;
+            p.nl_mean = &one;
+            b = std::max(b, wgrad_workspace_bytes(net->dtype, p));
+        }
         if (b > wg) wg = b;
     }
     for (auto& u : net->units) {
@@ -1224,6 +1234,62 @@ ConvParams conv_params(const Ctx& c, const Unit& u) {
         p.w = c.ws + Ctx::wc_off(u, c.net->wset);
     }
     return p;
+}
+
+// producer / consumer maps of the activation graph (built once)
+void ensure_graph_maps(vs_unet* net) {
+    if (!net->producer.empty()) return;
+    net->producer.assign(net->acts.size(), -1);
+    net->first_consumer.assign(net->acts.size(), 1 << 30);
+    net->sole_consumer.assign(net->acts.size(), -1);
+    std::vector<int> readers(net->acts.size(), 0);
+    for (int k = 0; k < (int)net->units.size(); ++k) {
+        const Unit& v = net->units[k];
+        if (v.out >= 0) net->producer[v.out] = k;
+        auto reads = [&](int a) {
+            if (a < 0) return;
+            if (k < net->first_consumer[a]) net->first_consumer[a] = k;
+            ++readers[a];
+            net->sole_consumer[a] = k;
+        };
+        for (int a : {v.src0, v.src1, v.res}) reads(a);
+        for (int a : v.members) reads(a);
+    }
+    for (size_t a = 0; a < readers.size(); ++a)
+        if (readers[a] != 1) net->sole_consumer[a] = -1;
+}
+
+// the weight-gradient launch of a convolution unit, without dy / dw / workspace
+WgradParams wgrad_params(const Ctx& c, const Unit& u) {
+    WgradParams p{};
+    p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
+    p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = c.n; p.Hin = u.hin; p.Win = u.win;
+    p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+    p.Cout = u.cout;
+    p.cg = u.cg; p.dil = u.dil;
+    if (u.colr) { p.src0 = c.ws + u.off_xs; p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
+    return p;
+}
+
+// Normalise-on-load (training, bf16): unit ui is a conv -> BN -> ReLU whose output has exactly ONE reader, a stride-1 3x3
+// convolution that takes it as src0 (a BasicBlock's conv1 -> conv2; a decoder block's conv1 -> conv2 -> next block's conv1).
+// Then ui's launch `pu` (statistics in fixed-point bins) finalises its own statistics behind a ticket, the reader - forward
+// convolution and weight gradient - applies the normalisation while staging ui's PRE-norm tensor, and neither the
+// normalisation sweep nor the activation tensor exist.  Returns the reader's unit index, or -1.
+int nl_consumer(const Ctx& c, int ui, const ConvParams& pu) {
+    vs_unet* net = c.net;
+    const int dt = net->dtype;
+    const Unit& u = net->units[ui];
+    if (dt != VS_BF16 || !vs_option("nl_fwd") || !vs_option("recompute_mask")) return -1;
+    if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0) return -1;
+    if (conv_igemm_tickets(dt, pu) <= 0) return -1;
+    ensure_graph_maps(net);
+    const int vi = net->sole_consumer[u.out];
+    if (vi <= ui) return -1;
+    const Unit& v = net->units[vi];
+    if (v.kind != U_CONV || v.src0 != u.out || v.src1 == u.out || v.res == u.out || v.colr || v.cg || v.g2) return -1;
+    if (!conv_igemm_nl_ok(dt, conv_params(c, v)) || !conv_wgrad_nl_ok(dt, wgrad_params(c, v))) return -1;
+    return vi;
 }
 
 }  // namespace
@@ -1487,6 +1553,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     int unit_index = -1;
     int carried_stat_rows = 0;     // partial statistic rows a plain convolution's epilogue left in bnws for the U_BN unit right behind it
     bool bn_folded_into_conv = false;   // evaluation: that U_BN's scale / shift / activation already ran in the convolution's epilogue
+    net->nl_act.assign(net->acts.size(), 0);
     if (training && dt == VS_BF16 && net->bins_bytes && vs_option("stats_bins") && vs_option("fuse_stats"))
         if ((rc = launch_zero_u64((unsigned long long*)(c.ws + net->off_bins0), net->bins_bytes / sizeof(unsigned long long), c.s))) return rc;
     for (auto& u : net->units) {
@@ -1498,7 +1565,12 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         switch (u.kind) {
         case U_STEM: {
             ProfScope prof(PK_STEM, 2.0 * n * u.hout * u.wout * 64 * 49, 4.0 * n * net->h * net->w + act_bytes(c, u, 1), c.s);
-            if (training) {
+            if (training && u.cout == 64 && net->bins_bytes && vs_option("stats_bins") && vs_option("fuse_stats") && stem_fwd_bins_ok(dt)) {
+                // batch statistics from the kernel's own accumulators (fixed-point bins, finalised inside the apply sweep)
+                if ((rc = launch_stem_fwd_bins(x, c.P(u.w_idx), c.z(u.out), n, net->h, net->w, (unsigned long long*)(c.ws + u.off_bins),
+                                               stat_bins_rows(u.cout), c.s))) return rc;
+                fused_bins = true;
+            } else if (training) {
                 if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), nullptr, nullptr, 0, c.z(u.out), n, net->h, net->w, stream))) return rc;
             } else {
                 if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), c.bnc(u, 0), c.bnc(u, 1), 1, c.a(u.out), n, net->h, net->w, stream))) return rc;
@@ -1677,6 +1749,11 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_CONV: {
             ConvParams p = conv_params(c, u);
+            if (training && u.src0 >= 0 && net->nl_act[u.src0]) {   // src0 was never normalised: its pre-norm tensor, normalised while it is staged
+                const Unit& q = net->units[net->producer[u.src0]];
+                p.src0 = c.z(u.src0);
+                p.nl_mean = c.bnc(q, 2); p.nl_invstd = c.bnc(q, 3); p.nl_gamma = c.P(q.bn_idx); p.nl_beta = c.P(q.bn_idx + 1);
+            }
             prof_set_variant(conv_igemm_variant(dt, p));
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
             prof_set_variant(0);
@@ -1714,12 +1791,21 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 if (u.bias_idx >= 0) p.shift = c.P(u.bias_idx);   // smp's ConvBnRelu keeps the convolution's bias: z includes it
                 if (dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
-                    if (u.bn_idx >= 0 && rows_needed > vs_option("bn_inline_rows") && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p)) {
+                    const bool bins_ok = u.bn_idx >= 0 && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p);
+                    const bool nl = bins_ok && nl_consumer(c, unit_index, p) >= 0;
+                    if (bins_ok && (nl || rows_needed > vs_option("bn_inline_rows"))) {
                         // many tiles: their sums go into a few rows of fixed-point bins, finalised inside the apply sweep -
                         // no finalize launch between the convolution and its normalisation (0.34 ms of a 4.76 ms step)
                         p.stats_bins = (unsigned long long*)(c.ws + u.off_bins);
                         p.stats_nb = stat_bins_rows(u.cout);
                         fused_bins = true;
+                        if (nl) {   // the last workgroup finalises; the one reader normalises on load
+                            p.fin_ticket = (unsigned*)(c.ws + u.off_bins + unit_bins_bytes(u.cout));
+                            p.fin_tickets = conv_igemm_tickets(dt, p);
+                            p.fin_rows = c.rows(u); p.fin_eps = 1e-5f; p.fin_mom = 0.1f;
+                            p.fin_mean = c.bnc(u, 2); p.fin_invstd = c.bnc(u, 3); p.fin_rm = rm; p.fin_rv = rv;
+                            net->nl_act[u.out] = 1;
+                        }
                     } else if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
                         fused_stat_rows = rows_needed;
@@ -1781,6 +1867,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         }
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
+            if (u.out >= 0 && net->nl_act[u.out]) continue;   // normalise-on-load: no sweep, no activation tensor
             if (fused_bins) {
                 ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
                 if ((rc = launch_bn_apply_from_bins(dt, c.z(u.out), (const unsigned long long*)(c.ws + u.off_bins), stat_bins_rows(u.cout), 1e-5f, 0.1f,
@@ -1917,18 +2004,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     const int dt = net->dtype;
     int rc;
     if (do_main && unit_hi == (int)net->units.size()) net->written.assign(net->acts.size(), 0);  // a new backward pass starts at the top
-    if (net->producer.empty()) {
-        net->producer.assign(net->acts.size(), -1);
-        net->first_consumer.assign(net->acts.size(), 1 << 30);
-        for (int k = 0; k < (int)net->units.size(); ++k) {
-            const Unit& v = net->units[k];
-            if (v.out >= 0) net->producer[v.out] = k;
-            for (int a : {v.src0, v.src1, v.res})
-                if (a >= 0 && k < net->first_consumer[a]) net->first_consumer[a] = k;
-            for (int a : v.members)
-                if (k < net->first_consumer[a]) net->first_consumer[a] = k;
-        }
-    }
+    ensure_graph_maps(net);
     if (do_main && unit_hi == (int)net->units.size()) net->bwd_stat_rows.assign(net->acts.size(), 0);
     VS_REQUIRE(net->written.size() == net->acts.size(), "unet_backward_range: ranges must start at the last unit");
     std::vector<char>& written = net->written;
@@ -2044,14 +2120,14 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         }
         if (want_w) {
             ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
-            WgradParams p{};
-            p.src0 = c.a(u.src0); p.src1 = u.src1 >= 0 ? c.a(u.src1) : nullptr;
-            p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = n; p.Hin = u.hin; p.Win = u.win;
-            p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k;
+            WgradParams p = wgrad_params(c, u);
             p.dy = dzp; p.Cout = dz_c;
-            p.cg = u.cg; p.dil = u.dil;
-            if (u.colr) { p.src0 = c.ws + u.off_xs; p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
+            if (u.kind == U_CONV && u.src0 >= 0 && !net->nl_act.empty() && net->nl_act[u.src0]) {   // as the forward read it: z, normalised on load
+                const Unit& q = net->units[net->producer[u.src0]];
+                p.src0 = c.z(u.src0);
+                p.nl_mean = c.bnc(q, 2); p.nl_invstd = c.bnc(q, 3); p.nl_gamma = c.P(q.bn_idx); p.nl_beta = c.P(q.bn_idx + 1);
+            }
             if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
                 p.Hout = u.hin; p.Wout = u.win;
                 const size_t k = ((const char*)wgws - (c.ws + net->off_wgws)) / net->wgws_bytes;
@@ -2562,6 +2638,27 @@ extern "C" int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const
 }
 
 // ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------
+// Which units' outputs a bf16 training forward at batch n would NOT materialise (normalise-on-load, see nl_consumer): flags[i] = 1
+// for such a unit i.  Host logic only - nothing is launched (tests, tools).  Returns the number of units.
+extern "C" int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap) {
+    VS_REQUIRE(net && flags && n >= 1 && n <= net->max_batch, "vs_unet_nl_plan: bad arguments");
+    Ctx c{net, reinterpret_cast<char*>(uintptr_t(1) << 20), nullptr, nullptr, nullptr, n};   // (addresses are never dereferenced)
+    std::vector<char> act(net->acts.size(), 0);
+    static const float one = 1.f;
+    for (int i = 0; i < (int)net->units.size(); ++i) {
+        const Unit& u = net->units[i];
+        if (i < cap) flags[i] = 0;
+        if (u.kind != U_CONV || net->dtype != VS_BF16 || u.bn_idx < 0 || u.gn_idx >= 0 || u.bias_idx >= 0) continue;
+        if (!vs_option("fuse_stats") || !vs_option("stats_bins") || !net->bins_bytes) continue;
+        ConvParams p = conv_params(c, u);
+        if (u.src0 >= 0 && act[u.src0]) p.nl_mean = &one;
+        if (!conv_igemm_bins_ok(net->dtype, p) || nl_consumer(c, i, p) < 0) continue;
+        act[u.out] = 1;
+        if (i < cap) flags[i] = 1;
+    }
+    return (int)net->units.size();
+}
+
 extern "C" int vs_unet_num_units(const vs_unet_t* net) { return (int)net->units.size(); }
 extern "C" int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* wname, int name_len, int* c, int* h, int* w,
                                   size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz) {
