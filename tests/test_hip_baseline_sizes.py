@@ -162,7 +162,7 @@ def test_deeplabv3plus_efficientnet_b4_1024_one_slice_eval():
 
 @pytest.mark.parametrize("option,value,exact", [("wgrad_ring", 0, False), ("wgrad_xcd", 0, False), ("conv_ring", 0, False), ("conv_ring", 2, False),
                                                 ("conv_stream", 0, True), ("stats_bins", 0, False), ("bn_bwd_fused", 1, False), ("fuse_bn_bwd", 0, False),
-                                                ("wgrad_pair_join", 1, True), ("nl_fwd", 1, False)])
+                                                ("wgrad_pair_join", 1, True), ("nl_fwd", 1, False), ("bwd_bins", 0, False)])
 def test_every_kernel_choice_option_gives_the_same_training_step(option, value, exact):
     """The runtime options that pick between kernels / schedules of the SAME arithmetic (round 3 added several: ring and
     persistent convolution kernels, the ring weight-gradient kernel, its XCD-aware K-split assignment, the one-launch BatchNorm

@@ -835,7 +835,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
     if (p.bz) {
         VS_REQUIRE(!p.pool0 && !p.out1 && !p.scale && !p.shift && !p.relu && !p.out_f32 && !out_nchw && !(p.Cout & 3) && !p.stats_partial &&
-                   p.bmean && p.binvstd && p.bstats_partial && (!p.brelu || p.by || (p.bgamma && p.bbeta)),
+                   p.bmean && p.binvstd && (p.bstats_partial || p.bstats_bins) && (!p.brelu || p.by || (p.bgamma && p.bbeta)),
                    "conv_igemm: the BN-backward epilogue takes a plain NHWC dgrad output");
     }
     if (p.pool0) {

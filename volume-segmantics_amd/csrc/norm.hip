@@ -414,7 +414,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
 
 // INLINE: the reduction's partial rows (few: <= 64) are summed by every workgroup itself (fp64, fixed order - the numbers
 // bn_bwd_finalize forms); workgroup 0 publishes dgamma / dbeta.  One launch and one dependent phase fewer per unit.
-template <typename T, bool RECOMPUTE, bool INLINE = false>
+// BINS (with INLINE): `partial` holds nparts rows of 64-bit fixed-point bins ([row][2][c], sums scaled by kBwdStatScale, added
+// atomically by the dgrad epilogue that completed the gradient - ConvParams::bstats_bins): integer sums, any order, same bits.
+template <typename T, bool RECOMPUTE, bool INLINE = false, bool BINS = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y,
                                                   const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -424,7 +426,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
                                                   const float* __restrict__ partial = nullptr, int nparts = 0) {
     const int tid = threadIdx.x;
     __shared__ float s_coef[INLINE ? 2 * 512 : 1];
-    if constexpr (INLINE) {
+    if constexpr (INLINE && BINS) {
+        __shared__ long long isum[256];
+        const long long* bins = reinterpret_cast<const long long*>(partial);
+        const int nv = 2 * c;                                          // values per bin row: [dbeta sums | dgamma sums]
+        if (nv <= 256) {
+            const int RG = 256 / nv, col = tid % nv, rg = tid / nv;
+            long long acc = 0;
+            if (rg < RG) {
+#pragma unroll 8
+                for (int r = rg; r < nparts; r += RG) acc += bins[(size_t)r * nv + col];
+                isum[rg * nv + col] = acc;
+            }
+            __syncthreads();
+            for (int ch = tid; ch < nv; ch += 256) {
+                long long t = 0;
+                for (int g2 = 0; g2 < RG; ++g2) t += isum[g2 * nv + ch];
+                const float f = (float)((double)t * (1.0 / kBwdStatScale));
+                s_coef[ch] = f;
+                if (blockIdx.x == 0) { if (ch < c) dbeta[ch] = f; else dgamma[ch - c] = f; }
+            }
+        } else {
+            for (int ch = tid; ch < nv; ch += 256) {
+                long long t = 0;
+#pragma unroll 8
+                for (int r = 0; r < nparts; ++r) t += bins[(size_t)r * nv + ch];
+                const float f = (float)((double)t * (1.0 / kBwdStatScale));
+                s_coef[ch] = f;
+                if (blockIdx.x == 0) { if (ch < c) dbeta[ch] = f; else dgamma[ch - c] = f; }
+            }
+        }
+        __syncthreads();
+    } else if constexpr (INLINE) {
         __shared__ double dsum[INLINE ? 4096 : 1];                     // [RG][2 c]
         const int cols = (2 * c) / 4, RG = 256 / cols, col = tid % cols, rg = tid / cols;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -754,6 +787,18 @@ int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const f
     VS_LAUNCH_CHECK();
     VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
                            (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m));
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+int launch_bn_bwd_from_bins(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
+                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const unsigned long long* bins,
+                            int nb, hipStream_t s) {
+    VS_REQUIRE(c % kVec == 0 && c <= 512, "bn_bwd (bins): unsupported channel count %d", c);
+    RowMap m = make_rowmap(rows, c);
+    VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false, true, true>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
+                           (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m,
+                           (const float*)bins, nb));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -153,6 +153,7 @@ struct Unit {
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
     size_t off_bins = 0;                         // stat_bins_rows(cout) rows of fixed-point statistics bins ([row][2][cout] 64-bit), training plans
+    size_t off_bbins = 0;                        // the same shape again for the BatchNorm-backward sums (ConvParams::bstats_bins); 0 = none
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
     std::vector<int> tens;                       // U_FPA: parameter tensor indices
     size_t off_fpa_pool = 0, off_fpa_arena = 0, off_fpa_plane = 0;   // U_FPA: pooled input, pyramid arena (fp32), attention plane (fp32)
@@ -208,6 +209,7 @@ struct vs_unet {
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
     std::vector<int> sole_consumer;              // per activation: the ONE unit that reads it (-1: none / several readers)
+    std::vector<char> bbins_dirty;               // per unit: its backward bins hold sums (the training forward's zero launch clears them all)
     std::vector<char> nl_act;                    // per activation, set by the last training forward: it was never materialised - its one
                                                  // consumer normalises the producer's pre-norm output z while loading it (ConvParams::nl_*)
     size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
@@ -1099,12 +1101,16 @@ size_t plan_workspace(vs_unet* net) {
     {   // fixed-point statistics bins of every convolution + BatchNorm unit (ConvParams::stats_bins): one contiguous block
         size_t total = 0;
         for (auto& u : net->units)
-            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) total += unit_bins_bytes(u.cout) + kTicketBytes;
+            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64))
+                total += unit_bins_bytes(u.cout) + kTicketBytes + (u.kind == U_CONV ? unit_bins_bytes(u.cout) : 0);
         net->bins_bytes = total;
         net->off_bins0 = take(total);
         size_t at = net->off_bins0;
         for (auto& u : net->units)
-            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) { u.off_bins = at; at += unit_bins_bytes(u.cout) + kTicketBytes; }
+            if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) {
+                u.off_bins = at; at += unit_bins_bytes(u.cout) + kTicketBytes;
+                if (u.kind == U_CONV) { u.off_bbins = at; at += unit_bins_bytes(u.cout); }
+            }
     }
     // activations (a for all, z for conv/stem outputs)
     for (auto& a : net->acts) {
@@ -1555,7 +1561,10 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     bool bn_folded_into_conv = false;   // evaluation: that U_BN's scale / shift / activation already ran in the convolution's epilogue
     net->nl_act.assign(net->acts.size(), 0);
     if (training && dt == VS_BF16 && net->bins_bytes && vs_option("stats_bins") && vs_option("fuse_stats"))
+    {
         if ((rc = launch_zero_u64((unsigned long long*)(c.ws + net->off_bins0), net->bins_bytes / sizeof(unsigned long long), c.s))) return rc;
+        net->bbins_dirty.assign(net->units.size(), 0);
+    }
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
         int fused_stat_rows = 0;
@@ -2417,7 +2426,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 dres = c.da(u.res);
                 written[u.res] = 1;
             }
-            if (net->bwd_stat_rows[u.out] > 0) {
+            if (net->bwd_stat_rows[u.out] < 0) {    // ... in fixed-point bins
+                ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
+                if ((rc = launch_bn_bwd_from_bins(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
+                                                  grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
+                                                  (const unsigned long long*)(c.ws + u.off_bbins), -net->bwd_stat_rows[u.out], c.s))) return rc;
+                net->bwd_stat_rows[u.out] = 0;
+            } else if (net->bwd_stat_rows[u.out] > 0) {
                 // the dgrad that completed da(u.out) left the masked gradient and the reduction's partial rows: one sweep
                 ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
                 if ((rc = launch_bn_bwd_from_partials(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
@@ -2532,7 +2547,22 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 net->units[pu].bn_idx >= 0 && !(p.Cout & 3) && conv_igemm_variant(dt, p) % 10 != 4) {
                 const Unit& q = net->units[pu];
                 const int rows_needed = conv_igemm_stat_rows(dt, p);
-                if ((size_t)rows_needed * 2 * q.cout * sizeof(float) <= net->bnws_bytes) {
+                // many tiles: the sums go into a few rows of fixed-point bins that the apply sweep adds up itself - no finalize launch
+                const bool bins = dt == VS_BF16 && vs_option("bwd_bins") && vs_option("stats_bins") && vs_option("fuse_stats") && q.off_bbins &&
+                                  q.cout <= 512 && rows_needed > vs_option("bn_inline_rows") && net->bbins_dirty.size() == net->units.size();
+                if (bins) {
+                    unsigned long long* bb = (unsigned long long*)(c.ws + q.off_bbins);
+                    if (net->bbins_dirty[pu] && (rc = launch_zero_u64(bb, unit_bins_bytes(q.cout) / sizeof(unsigned long long), c.s))) return rc;
+                    net->bbins_dirty[pu] = 1;
+                    const bool recompute = vs_option("recompute_mask") && q.relu && q.res < 0;
+                    p.bz = c.z(q.out);
+                    p.by = (q.relu && !recompute) ? c.a(q.out) : nullptr;
+                    p.bmean = c.bnc(q, 2); p.binvstd = c.bnc(q, 3);
+                    p.bgamma = c.P(q.bn_idx); p.bbeta = c.P(q.bn_idx + 1);
+                    p.bstats_bins = bb; p.bstats_nb = stat_bins_rows(q.cout);
+                    p.brelu = q.relu;
+                    net->bwd_stat_rows[pa] = -p.bstats_nb;
+                } else if ((size_t)rows_needed * 2 * q.cout * sizeof(float) <= net->bnws_bytes) {
                     const bool recompute = vs_option("recompute_mask") && q.relu && q.res < 0;
                     p.bz = c.z(q.out);
                     p.by = (q.relu && !recompute) ? c.a(q.out) : nullptr;
