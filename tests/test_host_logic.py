@@ -403,3 +403,43 @@ def test_hdf5_volumes_round_trip_through_the_c_library_without_h5py(tmp_path):
         utils.save_data_to_hdf5(small, tmp_path / "small.h5", internal_path="/seg/labels")
         body = subprocess.run([h5dump, "-d", "/seg/labels", str(tmp_path / "small.h5")], capture_output=True, text=True).stdout
         assert "(0,2,0): 8, 9, 10, 11" in body, body
+
+
+def test_normalise_on_load_plan_is_the_one_reader_rule():
+    """`vs_unet_nl_plan` (host logic, nothing is launched): with `nl_fwd` on, a bf16 training forward leaves exactly those conv +
+    BN + ReLU units un-normalised whose output has ONE reader, a stride-1 3x3 convolution on the register-staged kernels - for the
+    headline network at batch 32 of 256 x 256 the 16 BasicBlock conv1 units and 7 decoder convolutions (the last three decoder
+    outputs feed the strip kernels / the head: they keep their sweep), never a unit with a residual input, the stem, a downsample
+    1x1 or a unit whose output is a skip connection; none at all in fp32, or with the option off (the default)."""
+    import ctypes as C
+
+    from volume_segmantics_amd import _lib as L
+
+    def plan(dtype, topology_encoder=34, n=32, hw=256):
+        h = C.c_void_p()
+        L.check(L.lib.vs_unet_create_ex(C.byref(h), dtype, 2, n, hw, hw, topology_encoder))
+        try:
+            nu = L.lib.vs_unet_num_units(h)
+            flags = (C.c_int * nu)()
+            assert L.lib.vs_unet_nl_plan(h, n, flags, nu) == nu
+            return {name.split(" [")[0]: flags[i] for i, name in enumerate(L.unit_names(h))}
+        finally:
+            L.lib.vs_unet_destroy(h)
+
+    old = L.lib.vs_get_option(b"nl_fwd")
+    try:
+        L.set_option("nl_fwd", 0)
+        assert sum(plan(L.VS_BF16).values()) == 0
+        L.set_option("nl_fwd", 1)
+        on = plan(L.VS_BF16)
+        assert sum(plan(L.VS_F32).values()) == 0
+    finally:
+        L.set_option("nl_fwd", old)
+    chosen = sorted(k for k, v in on.items() if v)
+    assert len(chosen) == 23, chosen
+    assert sum(".conv1.weight" in k and k.startswith("encoder.layer") for k in chosen) == 16
+    assert all("conv2.weight" not in k and "downsample" not in k and k != "encoder.conv1.weight" for k in chosen if k.startswith("encoder"))
+    dec = [k for k in chosen if k.startswith("decoder")]
+    assert dec == sorted(["decoder.blocks.0.conv1.0.weight", "decoder.blocks.0.conv2.0.weight", "decoder.blocks.1.conv1.0.weight",
+                          "decoder.blocks.1.conv2.0.weight", "decoder.blocks.2.conv1.0.weight", "decoder.blocks.2.conv2.0.weight",
+                          "decoder.blocks.3.conv1.0.weight"]), dec
