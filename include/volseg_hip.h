@@ -206,6 +206,13 @@ int vs_unet_num_units(const vs_unet_t* net);
  * those units, torch's BatchNorm2d + ReLU modules between two convolutions (reference call site vol_seg_2d_trainer.py:424, the
  * model's forward).  Host logic only; returns the number of units. */
 int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap);
+/* SyncBatchNorm for data-parallel training (N ranks reproduce the reference's single BatchNorm batch - data/dataloaders.py:42-49, one
+ * loader feeding one model): `hook(user, values, count, kind, stream)` must sum `count` device values in place over the ranks,
+ * ordered on `stream` (kind 0: int64 - the fixed-point statistics sums, exact; kind 1: fp32), and return 0.  `world` ranks
+ * contribute equal shares of the global batch.  hook = NULL restores per-rank statistics.  bf16 plans whose BatchNorms all sit
+ * behind bias-free convolutions / the ResNet stem; others are refused. */
+typedef int (*vs_stats_hook_t)(void* user, void* values, int64_t count, int kind, void* stream);
+int vs_unet_set_stats_hook(vs_unet_t* net, vs_stats_hook_t hook, void* user, int world);
 int vs_unet_debug_unit(const vs_unet_t* net, int unit, char* weight_name, int name_len, int* c, int* h, int* w,
                        size_t* off_a, size_t* off_z, size_t* off_da, size_t* off_dz);
 

@@ -37,3 +37,12 @@ def test_two_rank_trainer_runs_through_an_early_stop_with_identical_weights(tmp_
     checkpoint, both ranks reload it and end with bit-identical parameters and running statistics."""
     r = _torchrun("dp_trainer_worker.py", str(tmp_path))
     assert r.returncode == 0 and "DP_TRAINER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("topology,encoder", [("unet", "resnet34"), ("unetplusplus", "resnet50")])
+def test_two_rank_sync_batchnorm_equals_one_rank_at_twice_the_batch(topology, encoder):
+    """SyncBatchNorm (`model.sync_bn`, vs_unet_set_stats_hook): two ranks with half the batch each reproduce ONE process running the
+    whole batch - training logits and running statistics bit for bit (the statistics are integer sums), gradients to bf16 noise
+    (tests/dp_syncbn_worker.py).  The headline network and BASELINE configs[3]'s (U-Net++ / ResNet-50 data-parallel training)."""
+    r = _torchrun("dp_syncbn_worker.py", topology, encoder)
+    assert r.returncode == 0 and "DP_SYNCBN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -443,3 +443,33 @@ def test_normalise_on_load_plan_is_the_one_reader_rule():
     assert dec == sorted(["decoder.blocks.0.conv1.0.weight", "decoder.blocks.0.conv2.0.weight", "decoder.blocks.1.conv1.0.weight",
                           "decoder.blocks.1.conv2.0.weight", "decoder.blocks.2.conv1.0.weight", "decoder.blocks.2.conv2.0.weight",
                           "decoder.blocks.3.conv1.0.weight"]), dec
+
+
+def test_sync_batchnorm_hook_is_accepted_only_where_it_is_built():
+    """vs_unet_set_stats_hook (host logic): bf16 plans whose BatchNorms all sit behind bias-free convolutions / the ResNet stem take
+    the cross-rank statistics hook (U-Net, U-Net++ / ResNet-50 = BASELINE configs[3], FPN); fp32 plans and networks with BatchNorm
+    elsewhere (Linknet's transposed convolutions, EfficientNet's standalone norms) are refused with a message, not silently run
+    with per-rank statistics."""
+    import ctypes as C
+
+    from volume_segmantics_amd import _lib as L
+
+    cb = L.STATS_HOOK(lambda user, values, count, kind, stream: 0)
+
+    def accepts(dtype, code):
+        h = C.c_void_p()
+        L.check(L.lib.vs_unet_create_ex(C.byref(h), dtype, 2, 2, 64, 64, code))
+        try:
+            rc = L.lib.vs_unet_set_stats_hook(h, C.cast(cb, C.c_void_p), None, 2)
+            if rc == 0:
+                assert L.lib.vs_unet_set_stats_hook(h, None, None, 1) == 0
+            return rc == 0, L.last_error()
+        finally:
+            L.lib.vs_unet_destroy(h)
+
+    assert accepts(L.VS_BF16, 34)[0] and accepts(L.VS_BF16, 1050)[0] and accepts(L.VS_BF16, 3034)[0]
+    ok, msg = accepts(L.VS_F32, 34)
+    assert not ok and "bf16" in msg
+    for code in (2034, 103):          # Linknet / resnet34, U-Net / efficientnet-b3
+        ok, msg = accepts(L.VS_BF16, code)
+        assert not ok and "SyncBatchNorm is not built" in msg, (code, msg)

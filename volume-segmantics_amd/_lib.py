@@ -184,6 +184,7 @@ _SIGS = {
     "vs_unet_unit_param_offset": (I64, [P, I]),
     "vs_unet_num_units": (I, [P]),
     "vs_unet_nl_plan": (I, [P, I, C.POINTER(I), I]),
+    "vs_unet_set_stats_hook": (I, [P, P, P, I]),
     "vs_unet_debug_unit": (I, [P, I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(SZ), C.POINTER(SZ),
                                C.POINTER(SZ), C.POINTER(SZ)]),
     "vs_profile_enable": (I, [I]),
@@ -287,6 +288,10 @@ def profile_read_raw(max_n: int = 1 << 16):
     if n < 0:
         raise RuntimeError("vs_profile_read_raw failed")
     return [(lib.vs_profile_kind_name(kind[i]).decode(), tag[i], ms[i], fl[i], by[i], var[i]) for i in range(n)]
+
+
+# SyncBatchNorm hook (include/volseg_hip.h: vs_stats_hook_t): int (*)(void* user, void* values, int64_t count, int kind, void* stream)
+STATS_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
 def set_option(name: str, value: int) -> None:

@@ -270,9 +270,14 @@ int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
 int conv_igemm_variant(int dtype, const ConvParams& p);      // BN*1000 + PT*100 + taps*10 + code of the chosen instantiation
+// Cross-rank BatchNorm statistics (SyncBatchNorm under data parallelism; vs_unet_set_stats_hook): `hook` sums `count` device values in
+// place over the ranks, stream-ordered on `stream` (kind 0: 64-bit integers - the fixed-point statistics bins, whose sum is exact and
+// the same bits on every rank; kind 1: fp32).  world = ranks contributing equal shares: the statistics then describe rows * world rows.
+typedef int (*vs_stats_hook_fn)(void* user, void* values, int64_t count, int kind, void* stream);
+struct BnSync { vs_stats_hook_fn hook; void* user; int world; float* scratch; };   // scratch: 2 * c device floats of the caller's
 int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
                                 void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
-                                int nparts, hipStream_t s);
+                                int nparts, hipStream_t s, const BnSync* sync = nullptr);
 int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial, int nparts, float eps, float momentum, float* mean,
                                   float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
                                   const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
@@ -286,7 +291,7 @@ int launch_bn_bwd_from_bins(int dtype, const void* g, const void* x, const float
                             int nb, hipStream_t s);
 int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long* bins, int nb, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
-                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s);
+                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s, int64_t stat_rows = 0);
 int launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s);
 bool stem_fwd_bins_ok(int dtype);
 int launch_stem_fwd_bins(const float* x, const float* w, void* z, int n, int h, int w_, unsigned long long* bins, int nb, hipStream_t s);
@@ -295,7 +300,7 @@ int launch_stem_fwd_bins(const float* x, const float* w, void* z, int n, int h, 
 // ctl: 16 zeroed bytes of barrier counters that re-arm themselves (null: the end of `workspace`, zeroed by a memset first)
 int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
-                    size_t workspace_bytes, unsigned* ctl, hipStream_t s);
+                    size_t workspace_bytes, unsigned* ctl, hipStream_t s, const BnSync* sync = nullptr);
 
 int launch_upsample2x_bwd(int dtype, const void* dy, void* dx, int n, int h, int w, int c, int accumulate, hipStream_t stream);
 

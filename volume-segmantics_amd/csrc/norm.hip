@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restric
                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ res, int relu,
-                                                            T* __restrict__ y, int64_t rows, int c, RowMap m) {
+                                                            T* __restrict__ y, int64_t rows, int c, RowMap m, int64_t stat_rows = 0) {
     extern __shared__ float s_stat[];   // [2][c]: mean, invstd
     const int tid = threadIdx.x;
+    if (stat_rows <= 0) stat_rows = rows;        // (the sums may describe more rows than this rank sweeps: cross-rank statistics)
     auto finish = [&](int ch, double s, double q) {
-        const double mu = s / (double)rows;
-        double var = q / (double)rows - mu * mu;
+        const double mu = s / (double)stat_rows;
+        double var = q / (double)stat_rows - mu * mu;
         if (var < 0.0) var = 0.0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
         s_stat[ch] = (float)mu;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_inline_kernel(const T* __restric
             mean[ch] = (float)mu;
             invstd[ch] = is;
             if (running_mean) {
-                const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                const double unbiased = stat_rows > 1 ? var * (double)stat_rows / (double)(stat_rows - 1) : var;
                 running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mu);
                 running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
             }
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
                                                   const float* __restrict__ beta, float* __restrict__ dgamma,
                                                   float* __restrict__ dbeta, int relu, T* __restrict__ dx,
                                                   T* __restrict__ dres, int64_t rows, int c, RowMap m,
-                                                  const float* __restrict__ partial = nullptr, int nparts = 0) {
+                                                  const float* __restrict__ partial = nullptr, int nparts = 0, int64_t stat_rows = 0) {
     const int tid = threadIdx.x;
     __shared__ float s_coef[INLINE ? 2 * 512 : 1];
     if constexpr (INLINE && BINS) {
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
     }
     const int cvi = tid % m.cv, rl = tid / m.cv;
     if (rl >= m.rpb) return;
-    const float inv_m = 1.0f / (float)rows;
+    const float inv_m = 1.0f / (float)(stat_rows > 0 ? stat_rows : rows);   // (stat_rows: the sums cover the rows of every rank)
     float mu[kVec], is[kVec], gi[kVec], db[kVec], dg[kVec], be[RECOMPUTE ? kVec : 1], ga[RECOMPUTE ? kVec : 1];
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
@@ -738,12 +739,12 @@ int launch_bn_apply_from_partials(int dtype, const void* x, const float* partial
 
 int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long* bins, int nb, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
-                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s) {
+                              const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s, int64_t stat_rows) {
     VS_REQUIRE(c % kVec == 0 && c <= 2048 && nb >= 1, "bn_apply: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
     const size_t lds = 2 * (size_t)c * sizeof(float) + (size_t)std::max(256, 2 * c) * sizeof(long long);
     VS_FOR_T(dtype, hipLaunchKernelGGL((bn_apply_inline_kernel<T, true>), dim3(m.nblocks), dim3(256), lds, s, (const T*)x, (const float*)bins, nb, eps,
-                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const T*)residual, relu, (T*)y, rows, c, m));
+                           momentum, mean, invstd, running_mean, running_var, gamma, beta, (const T*)residual, relu, (T*)y, rows, c, m, stat_rows));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }
@@ -771,11 +772,38 @@ int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t
 
 // BN backward whose reduction already happened in the producing dgrad's epilogue: `g` is the masked gradient, `partial` holds
 // nparts rows of per-channel (sum g, sum g * xhat).  Finalise (fp64, fixed order) and apply.
+namespace {
+__global__ void bn_sync_pack_kernel(const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ out, int c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < c) { out[i] = dbeta[i]; out[c + i] = dgamma[i]; }
+}
+}  // namespace
+// cross-rank sums for the BatchNorm-backward apply: this rank's (dbeta, dgamma) stay where the optimiser reads them (the gradient
+// all-reduce averages those like every other gradient), a copy is summed over the ranks and feeds dx
+static int bn_sync_sums(const BnSync& sy, const float* dgamma, const float* dbeta, int c, hipStream_t s) {
+    VS_REQUIRE(sy.hook && sy.scratch && sy.world >= 1, "bn_bwd: bad cross-rank statistics hook");
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3(cdiv(c, 256)), dim3(256), 0, s, dbeta, dgamma, sy.scratch, c);
+    VS_LAUNCH_CHECK();
+    const int rc = sy.hook(sy.user, sy.scratch, 2 * (int64_t)c, 1, (void*)s);
+    VS_REQUIRE(rc == 0, "bn_bwd: the cross-rank statistics hook failed (%d)", rc);
+    return VS_OK;
+}
+
 int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
                                 void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const float* partial,
-                                int nparts, hipStream_t s) {
+                                int nparts, hipStream_t s, const BnSync* sync) {
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     RowMap m = make_rowmap(rows, c);
+    if (sync) {      // finalise locally, sum the two vectors over the ranks, apply with the global sums and row count
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, partial, nparts, c, dgamma, dbeta);
+        VS_LAUNCH_CHECK();
+        if (const int rc = bn_sync_sums(*sync, dgamma, dbeta, c, s)) return rc;
+        VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
+                               (const T*)x, mean, invstd, gamma, (const float*)nullptr, sync->scratch + c, sync->scratch, 0, (T*)dx, (T*)dres, rows, c, m,
+                               (const float*)nullptr, 0, rows * sync->world));
+        VS_LAUNCH_CHECK();
+        return VS_OK;
+    }
     if (nparts <= vs_option("bn_inline_rows") && c <= 512 && 256 % ((2 * c) / 4) == 0) {   // few rows: finalise inside the apply sweep
         VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false, true>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
                                (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m,
@@ -875,11 +903,11 @@ extern "C" int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, con
 // workspace and zero them first (the stand-alone operator)
 int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
-                    size_t workspace_bytes, unsigned* ctl, hipStream_t s) {
+                    size_t workspace_bytes, unsigned* ctl, hipStream_t s, const BnSync* sync) {
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     VS_REQUIRE(!relu || y || beta, "bn_bwd: need y or beta for the ReLU mask");
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_bwd: workspace too small");
-    if (const int fb = bn_bwd_fused_blocks(dtype, rows, c)) {
+    if (const int fb = sync ? 0 : bn_bwd_fused_blocks(dtype, rows, c)) {
         if (!ctl) {
             ctl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + vs_bn_workspace(rows, c) - 16);
             VS_CHECK_HIP(hipMemsetAsync(ctl, 0, 16, s));
@@ -890,12 +918,19 @@ int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, con
     const bool rc = relu && !y;
 #define VS_BWD_PARTIAL(T, R) hipLaunchKernelGGL((bn_bwd_partial<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \
                                                 (const T*)x, mean, invstd, gamma, beta, relu, rows, c, m, workspace)
+    const float* sum_g = dgamma; const float* sum_b = dbeta;      // the sums the apply sweep reads (cross-rank: the summed copies)
+    const int64_t stat_rows = sync ? rows * sync->world : 0;
 #define VS_BWD_APPLY(T, R) hipLaunchKernelGGL((bn_bwd_apply<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \
-                                              (const T*)x, mean, invstd, gamma, beta, dgamma, dbeta, relu, (T*)dx, (T*)dres, rows, c, m)
+                                              (const T*)x, mean, invstd, gamma, beta, const_cast<float*>(sum_g), const_cast<float*>(sum_b), relu, \
+                                              (T*)dx, (T*)dres, rows, c, m, (const float*)nullptr, 0, stat_rows)
     VS_FOR_T(dtype, { if (rc) VS_BWD_PARTIAL(T, true); else VS_BWD_PARTIAL(T, false); });
     VS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(c), dim3(256), 0, s, workspace, m.nblocks, c, dgamma, dbeta);
     VS_LAUNCH_CHECK();
+    if (sync) {
+        if (const int rcs = bn_sync_sums(*sync, dgamma, dbeta, c, s)) return rcs;
+        sum_g = sync->scratch + c; sum_b = sync->scratch;
+    }
     VS_FOR_T(dtype, { if (rc) VS_BWD_APPLY(T, true); else VS_BWD_APPLY(T, false); });
     VS_LAUNCH_CHECK();
 #undef VS_BWD_PARTIAL

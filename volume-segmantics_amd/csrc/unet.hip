@@ -210,6 +210,9 @@ struct vs_unet {
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
     std::vector<int> sole_consumer;              // per activation: the ONE unit that reads it (-1: none / several readers)
     std::vector<char> bbins_dirty;               // per unit: its backward bins hold sums (the training forward's zero launch clears them all)
+    // SyncBatchNorm under data parallelism (vs_unet_set_stats_hook): the statistics of every BatchNorm are summed over the ranks
+    vs_stats_hook_fn stats_hook = nullptr; void* stats_user = nullptr; int stats_world = 1;
+    size_t off_syncsc = 0;                       // 2 * cmax floats: the summed copies of a unit's (dbeta, dgamma) for the backward apply
     std::vector<char> nl_act;                    // per activation, set by the last training forward: it was never materialised - its one
                                                  // consumer normalises the producer's pre-norm output z while loading it (ConvParams::nl_*)
     size_t off_gnz = 0, off_gnws = 0, gnws_bytes = 0, off_dropmask = 0, off_lsmall = 0, off_dlsmall = 0;   // smp.FPN (see plan_workspace)
@@ -1098,6 +1101,7 @@ size_t plan_workspace(vs_unet* net) {
     net->bnws_bytes = 4 * vs_bn_workspace(0, cmax);  // also receives the conv epilogue's per-tile statistics
     net->off_bnws = take(net->bnws_bytes);
     net->off_bncnt = take(256);                      // grid-barrier counters of the one-launch BatchNorm backward (zeroed by vs_unet_prepare)
+    net->off_syncsc = take((size_t)2 * cmax * sizeof(float));
     {   // fixed-point statistics bins of every convolution + BatchNorm unit (ConvParams::stats_bins): one contiguous block
         size_t total = 0;
         for (auto& u : net->units)
@@ -1286,7 +1290,7 @@ int nl_consumer(const Ctx& c, int ui, const ConvParams& pu) {
     vs_unet* net = c.net;
     const int dt = net->dtype;
     const Unit& u = net->units[ui];
-    if (dt != VS_BF16 || !vs_option("nl_fwd") || !vs_option("recompute_mask")) return -1;
+    if (dt != VS_BF16 || !vs_option("nl_fwd") || !vs_option("recompute_mask") || net->stats_hook) return -1;   // (cross-rank statistics: the sweep finalises)
     if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0) return -1;
     if (conv_igemm_tickets(dt, pu) <= 0) return -1;
     ensure_graph_maps(net);
@@ -1579,6 +1583,9 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 if ((rc = launch_stem_fwd_bins(x, c.P(u.w_idx), c.z(u.out), n, net->h, net->w, (unsigned long long*)(c.ws + u.off_bins),
                                                stat_bins_rows(u.cout), c.s))) return rc;
                 fused_bins = true;
+            } else if (training && net->stats_hook) {
+                vs_set_error("unet_forward: cross-rank BatchNorm statistics need the bf16 stem kernel and the statistics bins (options stem_bf16, stats_bins, fuse_stats)");
+                return VS_ERR_UNSUPPORTED;
             } else if (training) {
                 if ((rc = vs_stem_fwd(dt, x, c.P(u.w_idx), nullptr, nullptr, 0, c.z(u.out), n, net->h, net->w, stream))) return rc;
             } else {
@@ -1802,7 +1809,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     const bool bins_ok = u.bn_idx >= 0 && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p);
                     const bool nl = bins_ok && nl_consumer(c, unit_index, p) >= 0;
-                    if (bins_ok && (nl || rows_needed > vs_option("bn_inline_rows"))) {
+                    if (bins_ok && (nl || net->stats_hook || rows_needed > vs_option("bn_inline_rows"))) {
                         // many tiles: their sums go into a few rows of fixed-point bins, finalised inside the apply sweep -
                         // no finalize launch between the convolution and its normalisation (0.34 ms of a 4.76 ms step)
                         p.stats_bins = (unsigned long long*)(c.ws + u.off_bins);
@@ -1878,12 +1885,19 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         if (training) {  // batch statistics + normalise (+ residual) (+ ReLU)
             if (u.out >= 0 && net->nl_act[u.out]) continue;   // normalise-on-load: no sweep, no activation tensor
             if (fused_bins) {
+                int64_t stat_rows = 0;
+                if (net->stats_hook) {     // SyncBatchNorm: the integer sums of every rank, added in place (exact: the same bits everywhere)
+                    const int hrc = net->stats_hook(net->stats_user, c.ws + u.off_bins, (int64_t)stat_bins_rows(u.cout) * 2 * u.cout, 0, (void*)c.s);
+                    VS_REQUIRE(hrc == 0, "unet_forward: the cross-rank statistics hook failed (%d)", hrc);
+                    stat_rows = c.rows(u) * net->stats_world;
+                }
                 ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
                 if ((rc = launch_bn_apply_from_bins(dt, c.z(u.out), (const unsigned long long*)(c.ws + u.off_bins), stat_bins_rows(u.cout), 1e-5f, 0.1f,
                                                     c.bnc(u, 2), c.bnc(u, 3), rm, rv, c.P(u.bn_idx), c.P(u.bn_idx + 1),
-                                                    u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, c.s))) return rc;
+                                                    u.res >= 0 ? c.a(u.res) : nullptr, u.relu, c.a(u.out), c.rows(u), u.cout, c.s, stat_rows))) return rc;
                 continue;
             }
+            VS_REQUIRE(!net->stats_hook, "unet_forward: cross-rank BatchNorm statistics need the statistics bins for every unit (bf16, options stats_bins / fuse_stats)");
             if (fused_stat_rows && fused_stat_rows <= vs_option("bn_inline_rows")) {   // few partial rows: one launch does both
                 ProfScope prof(PK_BN_APPLY, 0, act_bytes(c, u, u.res >= 0 ? 3 : 2), c.s);
                 if ((rc = launch_bn_apply_from_partials(dt, c.z(u.out), (const float*)(c.ws + net->off_bnws), fused_stat_rows, 1e-5f, 0.1f,
@@ -2426,6 +2440,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 dres = c.da(u.res);
                 written[u.res] = 1;
             }
+            BnSync sy{net->stats_hook, net->stats_user, net->stats_world, (float*)(c.ws + net->off_syncsc)};
+            const BnSync* sync = net->stats_hook ? &sy : nullptr;
             if (net->bwd_stat_rows[u.out] < 0) {    // ... in fixed-point bins
                 ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
                 if ((rc = launch_bn_bwd_from_bins(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
@@ -2437,7 +2453,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
                 if ((rc = launch_bn_bwd_from_partials(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
                                                       grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
-                                                      (const float*)(c.ws + net->off_bnws), net->bwd_stat_rows[u.out], c.s))) return rc;
+                                                      (const float*)(c.ws + net->off_bnws), net->bwd_stat_rows[u.out], c.s, sync))) return rc;
                 net->bwd_stat_rows[u.out] = 0;
             } else {
             // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
@@ -2446,7 +2462,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             if ((rc = bn_bwd_dispatch(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
                                       c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
                                       grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
-                                      (float*)(c.ws + net->off_bnws), net->bnws_bytes, (unsigned*)(c.ws + net->off_bncnt), c.s))) return rc;
+                                      (float*)(c.ws + net->off_bnws), net->bnws_bytes, (unsigned*)(c.ws + net->off_bncnt), c.s, sync))) return rc;
             }
             dzp = c.dz(u.out); dz_c = u.cout;
             if (u.kind == U_CONV && u.bias_idx >= 0) {   // a biased convolution in front of BatchNorm (smp's ConvBnRelu): column sums of dz
@@ -2548,7 +2564,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 const Unit& q = net->units[pu];
                 const int rows_needed = conv_igemm_stat_rows(dt, p);
                 // many tiles: the sums go into a few rows of fixed-point bins that the apply sweep adds up itself - no finalize launch
-                const bool bins = dt == VS_BF16 && vs_option("bwd_bins") && vs_option("stats_bins") && vs_option("fuse_stats") && q.off_bbins &&
+                const bool bins = dt == VS_BF16 && !net->stats_hook && vs_option("bwd_bins") && vs_option("stats_bins") && vs_option("fuse_stats") && q.off_bbins &&
                                   q.cout <= 512 && rows_needed > vs_option("bn_inline_rows") && net->bbins_dirty.size() == net->units.size();
                 if (bins) {
                     unsigned long long* bb = (unsigned long long*)(c.ws + q.off_bbins);
@@ -2668,6 +2684,29 @@ extern "C" int vs_unet_adamw_range(vs_unet_t* net, int need_encoder_wgrad, const
 }
 
 // ---- debug: locate a unit's tensors inside the workspace (tests / diagnostics only) ----------------------
+// SyncBatchNorm for data-parallel training: `hook` sums device values in place over the ranks (stream-ordered; see BnSync in common.h),
+// `world` ranks contribute equal shares of the global batch.  With it every BatchNorm of a training forward normalises with the
+// statistics of the GLOBAL batch (the unit's fixed-point sums are added over the ranks before the normalisation sweep: integer
+// sums, so every rank forms the same bits and the result equals a single process running the whole batch), and the backward pass
+// sums (sum dy, sum dy xhat) over the ranks for dx.  hook = null: back to per-rank statistics.  Built for bf16 plans whose
+// BatchNorms all sit behind bias-free convolutions or the ResNet stem (U-Net / U-Net++ / FPN over the ResNet / ResNeXt encoders -
+// BASELINE configs[3]); other plans are refused here.  Replaces nothing in the reference (it is single-GPU: one loader, one
+// BatchNorm batch - data/dataloaders.py:42-49); it is what makes N ranks reproduce that single batch.
+extern "C" int vs_unet_set_stats_hook(vs_unet_t* net, vs_stats_hook_fn hook, void* user, int world) {
+    VS_REQUIRE(net && world >= 1, "vs_unet_set_stats_hook: bad arguments");
+    if (hook) {
+        VS_REQUIRE(net->dtype == VS_BF16, "vs_unet_set_stats_hook: cross-rank BatchNorm statistics are built for bf16 plans (fixed-point statistics bins)");
+        for (const Unit& u : net->units) {
+            const bool ok_bn = (u.kind == U_CONV && (u.bn_idx < 0 || (u.bias_idx < 0 && u.off_bins))) || (u.kind == U_STEM && u.off_bins) ||
+                               (u.kind != U_CONV && u.kind != U_STEM && u.kind != U_BN && u.kind != U_CONVT && u.kind != U_FPA);
+            VS_REQUIRE(ok_bn, "vs_unet_set_stats_hook: this network has BatchNorm layers outside bias-free convolution units (transposed convolutions, "
+                              "standalone norms, biased convolutions, the FPA block): SyncBatchNorm is not built for them");
+        }
+    }
+    net->stats_hook = hook; net->stats_user = user; net->stats_world = hook ? world : 1;
+    return VS_OK;
+}
+
 // Which units' outputs a bf16 training forward at batch n would NOT materialise (normalise-on-load, see nl_consumer): flags[i] = 1
 // for such a unit i.  Host logic only - nothing is launched (tests, tools).  Returns the number of units.
 extern "C" int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap) {

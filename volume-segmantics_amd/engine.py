@@ -115,6 +115,7 @@ class VolSegUnet(nn.Module):
         self.dp_group = None  # torch.distributed process group for data-parallel gradient all-reduce
         self.dp_grad_dtype = torch.float32
         self.dp_buckets = 4  # >1: bucketed, overlapped gradient all-reduce (decoder+head, layer4, layer3, rest)
+        self.sync_bn = False  # data parallel: BatchNorm statistics of the GLOBAL batch (SyncBatchNorm; see _sync_hook) instead of per rank
         self._wver = 0   # bumped when a HIP kernel (not a torch op) rewrites the parameters
         self._fused_optimizer = None   # FusedAdamW(fuse_step_into_backward=True) registers itself here
         self.dropout_seed = 0 if seed is None else int(seed)   # Dropout2d draws (smp.FPN); give every data-parallel rank its own
@@ -253,11 +254,52 @@ class VolSegUnet(nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             plan = {"handle": handle, "max_batch": max_batch, "training": train_ws, "ws": ws, "prep": None, "rng": None}
             self._plans[key] = plan
+        if training:
+            self._sync_hook(plan)
         if training and plan["rng"] != (self.dropout_seed, ptr(self._nbt)):
             # Dropout2d draws (smp.FPN): mask = f(seed, encoder.bn1.num_batches_tracked) - the counter every training step advances
             check(lib.vs_unet_set_rng(plan["handle"], self.dropout_seed & 0xFFFFFFFF, ptr(self._nbt)))
             plan["rng"] = (self.dropout_seed, ptr(self._nbt))
         return plan
+
+    def _sync_hook(self, plan):
+        """SyncBatchNorm (``model.sync_bn = True`` with a data-parallel group of more than one rank): the library calls back after every
+        convolution that feeds a BatchNorm, and in every BatchNorm backward, with a slice of the plan's workspace to be summed over
+        the ranks - 64-bit fixed-point statistics sums in the forward pass (integer adds: every rank ends with the same bits, and
+        with the bits a single process running the whole global batch would form), two fp32 vectors in the backward pass.  Every rank
+        must run the same batch size.  The reference has one loader and one BatchNorm batch (data/dataloaders.py:42-49); this is
+        what lets N ranks reproduce it.  Recorded steps (hipGraphs) cannot carry the callback: can_fuse_step is False."""
+        want = bool(self.sync_bn) and self.dp_group is not None and self._world() > 1
+        have = plan.get("sync")
+        if not want:
+            if have is not None:
+                check(lib.vs_unet_set_stats_hook(plan["handle"], None, None, 1))
+                plan["sync"] = None
+            return
+        key = (id(self.dp_group), self._world(), plan["ws"].data_ptr())
+        if have is not None and have[0] == key:
+            return
+        ws, group = plan["ws"], self.dp_group
+        base, nbytes = ws.data_ptr(), ws.numel()
+        state = {"error": None}
+
+        def hook(_user, values, count, kind, _stream):
+            try:
+                off = int(values) - base
+                width = 8 if kind == 0 else 4
+                if off < 0 or off + count * width > nbytes or off % width:
+                    raise RuntimeError("statistics hook called with a buffer outside the plan's workspace")
+                t = ws[off:off + count * width].view(torch.int64 if kind == 0 else torch.float32)
+                import torch.distributed as dist
+                dist.all_reduce(t, group=group)      # stream-ordered on the current stream (nccl = RCCL), synchronous under gloo
+                return 0
+            except Exception as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+                state["error"] = e
+                return -1
+
+        cb = _lib.STATS_HOOK(hook)
+        check(lib.vs_unet_set_stats_hook(plan["handle"], _lib.C.cast(cb, _lib.C.c_void_p), None, self._world()))
+        plan["sync"] = (key, cb, state)      # (the CFUNCTYPE object must outlive the registration)
 
     def _drop_steps(self):
         for st in self._steps.values():
@@ -395,7 +437,7 @@ class VolSegUnet(nn.Module):
             return False
         if not isinstance(opt, FusedAdamW) or opt.model is not self or self._fused_optimizer is not opt:
             return False
-        if self.dp_group is not None and self._world() > 1 and self.dp_grad_dtype != torch.float32:
+        if self.dp_group is not None and self._world() > 1 and (self.dp_grad_dtype != torch.float32 or self.sync_bn):
             return False
         if x.dim() != 4 or targets.dim() != 4 or targets.shape != (x.shape[0], self.classes, x.shape[2], x.shape[3]):
             return False

@@ -120,6 +120,9 @@ class VolSeg2dTrainer:
                 dist.broadcast(self.model._flat, 0)
                 dist.broadcast(self.model._bnstate, 0)
                 self.model.dp_group = dist.group.WORLD
+                # `sync_batchnorm: true`: BatchNorm statistics of the GLOBAL batch - N ranks reproduce the single-process batch the
+                # reference trains with (engine.VolSegUnet._sync_hook); default: per-rank statistics (torch DDP's default)
+                self.model.sync_bn = bool(getattr(self.settings, "sync_batchnorm", False))
                 self.model.dropout_seed += 1000003 * self.rank      # Dropout2d (FPN): every rank draws its own masks
             else:
                 vdist.broadcast_module(self.model)
