@@ -78,6 +78,26 @@ def main():
     rel = ((g0 - g1).norm() / g0.norm()).item()
     cos = (torch.dot(g0, g1) / (g0.norm() * g1.norm())).item()
     assert rel < 3e-2 and cos > 0.999, ("gradients", rel, cos)
+    # (d) the whole training step with the reference's loss: SyncBatchNorm + the Dice of the GLOBAL batch (HipDiceLoss(global_group))
+    # against one process on both shards - the same loss value, the same parameter gradients
+    from volume_segmantics_amd.data.losses import HipDiceLoss
+
+    def targets(r):
+        gt = torch.Generator().manual_seed(300 + r)
+        return torch.nn.functional.one_hot((torch.rand(B, HW, HW, generator=gt) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+
+    a2 = fresh(True, dist.group.WORLD)
+    loss_a = HipDiceLoss(global_group=dist.group.WORLD)(a2(x), targets(rank).to(dev))
+    loss_a.backward()
+    b2 = fresh(False, None)
+    loss_b = HipDiceLoss()(b2(torch.cat(xs).to(dev)), torch.cat([targets(r) for r in range(world)]).to(dev))
+    loss_b.backward()
+    torch.cuda.synchronize()
+    assert abs(loss_a.item() - loss_b.item()) < 1e-6, ("global Dice", loss_a.item(), loss_b.item())
+    h0, h1 = b2._flat_grad.double(), a2._flat_grad.double()        # (the factor `world` already rides in the loss gradient)
+    rel2 = ((h0 - h1).norm() / h0.norm()).item()
+    cos2 = (torch.dot(h0, h1) / (h0.norm() * h1.norm())).item()
+    assert rel2 < 3e-2 and cos2 > 0.999, ("gradients of the global Dice step", rel2, cos2)
     # (c) per-rank statistics (the default) are a different computation: the test above is not vacuous
     c = fresh(False, dist.group.WORLD)
     lc = c(x)
@@ -87,6 +107,7 @@ def main():
     dist.all_gather(both, torch.tensor([rel, cos]))
     if rank == 0:
         print(f"sync_bn: gradients vs the single process: relative L2 {[round(v[0].item(), 5) for v in both]}, cosine {[round(v[1].item(), 6) for v in both]}")
+        print(f"sync_bn + global Dice: loss {loss_a.item():.7f} vs {loss_b.item():.7f}, gradients relative L2 {rel2:.5f}, cosine {cos2:.6f}")
         print("DP_SYNCBN_OK")
     dist.barrier()
     dist.destroy_process_group()

@@ -43,7 +43,7 @@ class _FusedDiceFn(torch.autograd.Function):
     """DiceLoss(normalization="none") forward + gradient as two HIP sweeps (vs_dice_loss_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, logits, targets, eps):
+    def forward(ctx, logits, targets, eps, group=None):
         from .. import _lib
         n, k = logits.shape[:2]
         hw = logits[0, 0].numel()
@@ -56,34 +56,50 @@ class _FusedDiceFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         _lib.check(_lib.lib.vs_dice_loss_fwd(_lib.ptr(logits), _lib.ptr(targets), int(is_f32), n, k, hw, eps, _lib.ptr(loss),
                                             _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()))
+        world = 1
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+        if world > 1:
+            # the Dice of the GLOBAL batch (the reference's single loader sees all of it): the per-class sums I_c, D_c - the last 2 k
+            # floats of the workspace, which the gradient sweep reads - summed over the ranks; the loss from the global sums
+            stats = ws[ws.numel() - 2 * k:]
+            dist.all_reduce(stats, group=group)
+            inter, denom = stats.view(k, 2)[:, 0].double(), stats.view(k, 2)[:, 1].double()
+            loss = (1.0 - (2.0 * inter / denom.clamp(min=eps)).mean()).float()
         ctx.save_for_backward(logits, targets, ws)
-        ctx.meta = (n, k, hw, eps, is_f32)
+        ctx.meta = (n, k, hw, eps, is_f32, world)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         from .. import _lib
         logits, targets, ws = ctx.saved_tensors
-        n, k, hw, eps, is_f32 = ctx.meta
+        n, k, hw, eps, is_f32, world = ctx.meta
         dx = torch.empty_like(logits)
-        g = grad_out.contiguous().float()
+        # (global Dice: every rank holds d loss / d its own logits; the gradient all-reduce AVERAGES the ranks' parameter gradients,
+        # the global loss wants their SUM)
+        g = (grad_out * float(world)).contiguous().float()
         _lib.check(_lib.lib.vs_dice_loss_bwd(_lib.ptr(logits), _lib.ptr(targets), int(is_f32), _lib.ptr(g), n, k, hw, eps,
                                             _lib.ptr(ws), _lib.ptr(dx), _lib.stream_ptr()))
-        return dx, None, None
+        return dx, None, None, None
 
 
 class HipDiceLoss(nn.Module):
     """Drop-in for DiceLoss(normalization="none") on GPU tensors (falls through to the torch ops for anything else,
-    e.g. class weights or CPU tensors in the tests of the host logic)."""
+    e.g. class weights or CPU tensors in the tests of the host logic).  ``global_group``: a torch.distributed group - the loss is
+    then the Dice of the GLOBAL batch (per-class sums all-reduced; with SyncBatchNorm, N ranks train exactly the step one process
+    would run on the whole batch); default: every rank's own batch, as under a DistributedDataParallel wrap of the reference."""
 
-    def __init__(self, epsilon: float = 1e-6):
+    def __init__(self, epsilon: float = 1e-6, global_group=None):
         super().__init__()
         self.epsilon = epsilon
+        self.global_group = global_group
         self._torch = DiceLoss(normalization="none")
 
     def forward(self, input, target):
         if input.is_cuda and input.dtype == torch.float32 and input.dim() >= 3 and input.shape == target.shape:
-            return _FusedDiceFn.apply(input, target, self.epsilon)
+            return _FusedDiceFn.apply(input, target, self.epsilon, self.global_group)
         return self._torch(input, target)
 
 

@@ -93,6 +93,9 @@ class VolSeg2dTrainer:
         if name == "BCEDiceLoss":
             return HipSegLoss(name, self.settings.alpha, self.settings.beta) if gpu else BCEDiceLoss(self.settings.alpha, self.settings.beta)
         if name == "DiceLoss":
+            if gpu and self.world > 1 and bool(getattr(self.settings, "sync_batchnorm", False)):
+                import torch.distributed as dist
+                return HipDiceLoss(global_group=dist.group.WORLD)     # with SyncBatchNorm: the Dice of the global batch as well
             return HipDiceLoss() if gpu else DiceLoss(normalization="none")
         if name == "BCELoss":
             return HipSegLoss(name) if gpu else nn.BCEWithLogitsLoss()
