@@ -108,6 +108,29 @@ def test_config2_three_way_prediction_equals_reference_formulation_and_is_idempo
     assert np.array_equal(labels, l2) and np.array_equal(probs.view(np.uint16), p2.view(np.uint16))
 
 
+def test_twelve_way_prediction_without_the_repeated_directions_is_bit_identical():
+    """Four of the reference's twelve directions repeat earlier ones exactly (tests/test_host_logic.py pins the table) and the
+    first-wins merge can never take a repeat: the predictor's default (8 forward passes) must return the volume of all twelve
+    passes bit for bit - labels and fp16 probabilities - on an odd-shaped volume (pads, crops, non-cubic rotations) and for the
+    reference's own pairwise formulation of the twelve directions."""
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import REPEATED_DIRECTIONS, direction_views
+    from volume_segmantics_amd.utilities.base_data_utils import Axis
+    pred = _predictor(4, 16)
+    vol = bench.synth_volume(96, seed=77)[:61, 3:83, :72].copy()
+    pred.settings.dedup_directions = True
+    l8, p8 = pred._predict_12_ways_max_probs(vol)
+    assert pred.last_timings["directions_run"] == 8
+    pred.settings.dedup_directions = False
+    l12, p12 = pred._predict_12_ways_max_probs(vol)
+    assert pred.last_timings["directions_run"] == 12
+    assert len(np.unique(l12)) >= 3
+    assert np.array_equal(l8, l12) and np.array_equal(p8.view(np.uint16), p12.view(np.uint16))
+    # and the reason: a repeated direction predicts, voxel for voxel, what its earlier twin predicted
+    views = direction_views(np.arange(vol.size).reshape(vol.shape), 12)
+    for later, earlier in REPEATED_DIRECTIONS.items():
+        assert np.array_equal(views[later], views[earlier][::-1])
+
+
 def test_config3_twelve_way_shards_merge_to_the_unsharded_volume(monkeypatch):
     """Two ranks' work done one after the other on this GPU: each takes its contiguous half of every direction's slices
     into its own key volume; the elementwise max of the two (what all_reduce(MAX) computes) must equal the one-rank

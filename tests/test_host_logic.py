@@ -473,3 +473,22 @@ def test_sync_batchnorm_hook_is_accepted_only_where_it_is_built():
     for code in (2034, 103):          # Linknet / resnet34, U-Net / efficientnet-b3
         ok, msg = accepts(L.VS_BF16, code)
         assert not ok and "SyncBatchNorm is not built" in msg, (code, msg)
+
+
+def test_repeated_directions_are_exact_repeats_for_every_shape():
+    """Four of the reference's twelve prediction directions (vol_seg_2d_predictor.py:100-116: np.rot90 in the (0, 1) plane, then Z / Y / X
+    stacks) hold the SAME slices at the SAME voxel addresses as an earlier direction, in reversed order - the table the predictor
+    skips by in the max-probability merge (first-wins on ties, :90-98).  Address-valued volumes make the check exact; no other
+    pair of directions coincides."""
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import REPEATED_DIRECTIONS
+    for shape in ((5, 5, 5), (4, 6, 7), (29, 64, 40), (3, 3, 8)):
+        vol = np.arange(int(np.prod(shape))).reshape(shape)
+        views = direction_views(vol, 12)
+        found = {}
+        for a in range(12):
+            for b in range(a):
+                if views[a].shape == views[b].shape and (np.array_equal(views[a], views[b]) or np.array_equal(views[a], views[b][::-1])):
+                    found[a] = b
+        assert found == REPEATED_DIRECTIONS, (shape, found)
+        for later, earlier in REPEATED_DIRECTIONS.items():
+            assert later > earlier and np.array_equal(views[later], views[earlier][::-1])

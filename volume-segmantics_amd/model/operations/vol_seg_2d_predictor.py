@@ -37,6 +37,16 @@ def direction_views(vol: np.ndarray, n_dirs: int):
     return views
 
 
+# Four of the reference's twelve directions are EXACT repeats of earlier ones: a rotation by 90 degrees in the (0, 1) plane turns the
+# Z stack into the Y stack and back, so (rotation 1, Z) holds the slices of (rotation 0, Y), (rotation 2, Z) those of (rotation 1, Y),
+# (rotation 3, Z) those of (rotation 2, Y) and (rotation 3, Y) those of (rotation 0, Z) - the same images at the same voxel addresses,
+# in reversed slice order (np.array_equal(views[later], views[earlier][::-1]) for every shape; tests/test_host_logic.py).  A later
+# twin predicts what its earlier twin predicted, and the reference's merge keeps the earlier of two equal probabilities
+# (vol_seg_2d_predictor.py:90-98: np.argmax over (running, new) returns index 0 on a tie), so in the max-probability merge the
+# four later twins can never change a voxel: 8 forward passes give the reference's 12-direction result, bit for bit.
+REPEATED_DIRECTIONS = {3: 1, 6: 4, 9: 7, 10: 0}      # later twin -> the earlier direction it repeats (indices in call order)
+
+
 def dirmap_of(vol: np.ndarray, view: np.ndarray) -> _lib.DirMap:
     """vs_dirmap of a view: element strides and base offset are read off numpy's own view object."""
     item = vol.itemsize
@@ -159,8 +169,14 @@ class VolSeg2dPredictor:
         if hasattr(self.model, "eval"):
             self.model.eval()
         views = direction_views(vol, n_dirs) if n_dirs > 1 else [utils.rotate_array_to_axis(vol, first_axis)]
+        # max-probability merge over 12 directions: the four exact repeats are not run (`dedup_directions: false` runs them anyway -
+        # same result, 12 / 8 of the time); votes count every direction, repeats included, so the one-hot form runs all twelve
+        skip = REPEATED_DIRECTIONS if (n_dirs == 12 and mode == 1 and bool(getattr(self.settings, "dedup_directions", True))) else {}
         with torch.no_grad():
             for d, view in enumerate(views):
+                if d in skip:
+                    logging.info(f"Direction {d + 1}/{len(views)} repeats direction {skip[d] + 1}: not run (it cannot change the merge).")
+                    continue
                 dmap = dirmap_of(vol, view)
                 lo, hi = vdist.shard_range(dmap.depth, rank, world)
                 logging.info(f"Predicting direction {d + 1}/{len(views)}: slices [{lo}, {hi}) of stack {view.shape}.")
@@ -179,7 +195,8 @@ class VolSeg2dPredictor:
         else:
             out = backend.results(vol.shape, want_probs)
         t3 = time.perf_counter()
-        self.last_timings = {"upload_and_directions_s": t1 - t0, "exchange_s": t2 - t1, "unpack_download_s": t3 - t2}
+        self.last_timings = {"upload_and_directions_s": t1 - t0, "exchange_s": t2 - t1, "unpack_download_s": t3 - t2,
+                             "directions_run": len(views) - len(skip)}
         return out
 
     # ---- the reference's methods --------------------------------------------------------------------------------
