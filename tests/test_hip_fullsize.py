@@ -117,13 +117,16 @@ def test_twelve_way_prediction_without_the_repeated_directions_is_bit_identical(
     from volume_segmantics_amd.utilities.base_data_utils import Axis
     pred = _predictor(4, 16)
     vol = bench.synth_volume(96, seed=77)[:61, 3:83, :72].copy()
+    with torch.no_grad():   # centre the head on THIS volume's slices: a random-init network must use several classes for the test to bite
+        xs = torch.from_numpy(((vol[:8, :64, :64].astype(np.float32) / 255) - 0.449) / 0.226).unsqueeze(1).to(DEV)
+        dict(pred.model.named_parameters())["segmentation_head.0.bias"].sub_(pred.model(xs).mean(dim=(0, 2, 3)))
     pred.settings.dedup_directions = True
     l8, p8 = pred._predict_12_ways_max_probs(vol)
     assert pred.last_timings["directions_run"] == 8
     pred.settings.dedup_directions = False
     l12, p12 = pred._predict_12_ways_max_probs(vol)
     assert pred.last_timings["directions_run"] == 12
-    assert len(np.unique(l12)) >= 3
+    assert len(np.unique(l12)) >= 2 and 0.02 < (l12 == l12.flat[0]).mean() < 0.98
     assert np.array_equal(l8, l12) and np.array_equal(p8.view(np.uint16), p12.view(np.uint16))
     # and the reason: a repeated direction predicts, voxel for voxel, what its earlier twin predicted
     views = direction_views(np.arange(vol.size).reshape(vol.shape), 12)
