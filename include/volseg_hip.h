@@ -607,7 +607,8 @@ int vs_slices_gather_typed(int vtype, const void* vol, const vs_dirmap* m, int s
  * centre-cropped and scattered to voxel addresses (vol_seg_2d_predictor.py:45-64).
  * mode 0: labels[u8] and probs[f16] volumes (either may be null);
  * mode 1: keys[addr] = max(keys[addr], prob_bits<<16 | (15-dir)<<8 | label)  (packed-key merge);
- * mode 2: votes[label][addr] += 1 (one-hot variants, :118-136). */
+ * mode 2: votes[label][addr] += 1 (one-hot variants, :118-136); mode 3: += 2 - a direction of the 12-way scheme (:100-116) that a later
+ * one repeats exactly (same slices, same voxel addresses: the later one is then not run). */
 int vs_logits_to_volume(const float* logits, int classes, const vs_dirmap* m, int s0, int nb, int mode,
                         int direction, uint8_t* labels, uint16_t* probs, uint32_t* keys, uint8_t* votes,
                         int64_t nvox, void* stream);

@@ -28,7 +28,7 @@ class OracleBackend:
         s, h, w = np.meshgrid(np.arange(s0, s0 + nb), np.arange(m.h), np.arange(m.w), indexing="ij")
         return m.base + s * m.ss + h * m.sh + w * m.sw
 
-    def run_batch(self, m, direction, s0, nb):
+    def run_batch(self, m, direction, s0, nb, votes=1):
         self.calls.append((direction, s0, nb))
         addr = self._addr(m, s0, nb)
         slices = self.vol.ravel()[addr]
@@ -48,7 +48,7 @@ class OracleBackend:
         else:
             v = self.votes.numpy()
             for c in range(self.classes):
-                v[c][addr] += (lab == c).astype(np.uint8)
+                v[c][addr] += (lab == c).astype(np.uint8) * np.uint8(votes)
 
     @staticmethod
     def _unpack(keys_i32):

@@ -128,6 +128,13 @@ def test_twelve_way_prediction_without_the_repeated_directions_is_bit_identical(
     assert pred.last_timings["directions_run"] == 12
     assert len(np.unique(l12)) >= 2 and 0.02 < (l12 == l12.flat[0]).mean() < 0.98
     assert np.array_equal(l8, l12) and np.array_equal(p8.view(np.uint16), p12.view(np.uint16))
+    # the vote form (one-hot variants): a repeat is not run, its earlier twin votes twice
+    pred.settings.dedup_directions = True
+    v8 = pred._predict_12_ways_one_hot(vol)
+    assert pred.last_timings["directions_run"] == 8
+    pred.settings.dedup_directions = False
+    v12 = pred._predict_12_ways_one_hot(vol)
+    assert v12.shape == (4,) + vol.shape and (v12.sum(0) == 12).all() and np.array_equal(v8, v12)
     # and the reason: a repeated direction predicts, voxel for voxel, what its earlier twin predicted
     views = direction_views(np.arange(vol.size).reshape(vol.shape), 12)
     for later, earlier in REPEATED_DIRECTIONS.items():

@@ -79,7 +79,7 @@ __global__ void logits_to_volume_kernel(const float* __restrict__ logits, int cl
             const uint32_t old = keys[addr];
             if (key > old) keys[addr] = key;
         } else {
-            votes[(int64_t)lab * nvox + addr] += 1;
+            votes[(int64_t)lab * nvox + addr] += (MODE == 3 ? 2 : 1);    // (3: this direction stands for itself and its exact repeat)
         }
     }
 }
@@ -261,6 +261,10 @@ extern "C" int vs_logits_to_volume(const float* logits, int classes, const vs_di
     } else if (mode == 2) {
         VS_REQUIRE(votes && nvox > 0, "logits_to_volume: mode 2 needs a vote volume");
         hipLaunchKernelGGL(logits_to_volume_kernel<2>, dim3(grid_for(total)), dim3(256), 0, s, logits, classes, *m, s0, nb,
+                           direction, labels, probs, keys, votes, nvox);
+    } else if (mode == 3) {     // two votes: a direction of the 12-way scheme that another one repeats exactly (not run)
+        VS_REQUIRE(votes && nvox > 0, "logits_to_volume: mode 3 needs a vote volume");
+        hipLaunchKernelGGL(logits_to_volume_kernel<3>, dim3(grid_for(total)), dim3(256), 0, s, logits, classes, *m, s0, nb,
                            direction, labels, probs, keys, votes, nvox);
     } else {
         vs_set_error("logits_to_volume: bad mode %d", mode);

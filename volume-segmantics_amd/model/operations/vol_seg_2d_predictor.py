@@ -78,7 +78,8 @@ class HipBackend:
         self._x = None
         self._merged = None
 
-    def run_batch(self, dmap: _lib.DirMap, direction: int, s0: int, nb: int) -> None:
+    def run_batch(self, dmap: _lib.DirMap, direction: int, s0: int, nb: int, votes: int = 1) -> None:
+        """votes (vote mode only): 2 = the direction also stands for its exact repeat (REPEATED_DIRECTIONS), which is not run."""
         need = nb * dmap.hp * dmap.wp
         if self._x is None or self._x.numel() < need:
             self._x = torch.empty(need, dtype=torch.float32, device=self.model.device)
@@ -87,7 +88,8 @@ class HipBackend:
         check(lib.vs_slices_gather_typed(self.vtype, ptr(self.vol), dmap, s0, nb, ptr(x), st))
         # forward + softmax / arg-max / crop / scatter in one call: with <= 4 classes the head kernel writes labels /
         # probabilities / keys itself and no logits exist (identical results to vs_unet_forward + vs_logits_to_volume)
-        self.model._forward_to_volume(x, dmap, s0, self.mode, direction, self.labels, self.probs, self.keys, self.votes, self.nvox)
+        mode = 3 if (self.mode == 2 and votes == 2) else self.mode
+        self.model._forward_to_volume(x, dmap, s0, mode, direction, self.labels, self.probs, self.keys, self.votes, self.nvox)
 
     def _unpack(self, keys_i32: torch.Tensor, want_probs: bool = True):
         n = keys_i32.numel()
@@ -169,19 +171,23 @@ class VolSeg2dPredictor:
         if hasattr(self.model, "eval"):
             self.model.eval()
         views = direction_views(vol, n_dirs) if n_dirs > 1 else [utils.rotate_array_to_axis(vol, first_axis)]
-        # max-probability merge over 12 directions: the four exact repeats are not run (`dedup_directions: false` runs them anyway -
-        # same result, 12 / 8 of the time); votes count every direction, repeats included, so the one-hot form runs all twelve
-        skip = REPEATED_DIRECTIONS if (n_dirs == 12 and mode == 1 and bool(getattr(self.settings, "dedup_directions", True))) else {}
+        # 12 directions: the four exact repeats are not run (`dedup_directions: false` runs them anyway - same result, 12 / 8 of the
+        # time).  Max-probability merge: a repeat cannot change it.  Votes: its earlier twin votes twice.
+        skip = REPEATED_DIRECTIONS if (n_dirs == 12 and mode in (1, 2) and bool(getattr(self.settings, "dedup_directions", True))) else {}
+        twice = set(skip.values()) if mode == 2 else set()
         with torch.no_grad():
             for d, view in enumerate(views):
                 if d in skip:
-                    logging.info(f"Direction {d + 1}/{len(views)} repeats direction {skip[d] + 1}: not run (it cannot change the merge).")
+                    logging.info(f"Direction {d + 1}/{len(views)} repeats direction {skip[d] + 1}: not run.")
                     continue
                 dmap = dirmap_of(vol, view)
                 lo, hi = vdist.shard_range(dmap.depth, rank, world)
                 logging.info(f"Predicting direction {d + 1}/{len(views)}: slices [{lo}, {hi}) of stack {view.shape}.")
                 for s0 in range(lo, hi, batch):
-                    backend.run_batch(dmap, d, s0, min(batch, hi - s0))
+                    if d in twice:
+                        backend.run_batch(dmap, d, s0, min(batch, hi - s0), votes=2)
+                    else:
+                        backend.run_batch(dmap, d, s0, min(batch, hi - s0))
         profile = bool(getattr(self.settings, "profile_phases", False)) and torch.cuda.is_available()
         if profile:
             torch.cuda.synchronize()
