@@ -29,11 +29,19 @@ def main():
                                     rank, world, seed=7)
     settings = _trainer_settings()
     settings.precision = "bf16"
+    sync = len(sys.argv) > 2 and sys.argv[2] == "sync"
+    if sync:      # BatchNorm statistics and the Dice loss of the GLOBAL batch (settings key sync_batchnorm)
+        settings.sync_batchnorm = True
     torch.manual_seed(1000 + rank)        # different initial weights per rank: rank 0's must win through the broadcast
     tr = VolSeg2dTrainer(None, None, {"bg": 0, "fg": 1}, settings, loaders=loaders)
     out = Path(sys.argv[1]) / "dp_gpu.pytorch"
     tr.train_model(out, 10, 1, create=True, frozen=True)
     assert isinstance(tr.model, VolSegUnet) and tr.model.device.index == 0 and tr.model.precision == "bf16"
+    if sync:
+        from volume_segmantics_amd.data.losses import HipDiceLoss
+        assert tr.model.sync_bn and isinstance(tr.loss_criterion, HipDiceLoss) and tr.loss_criterion.global_group is not None
+        hooked = [p for p in tr.model._plans.values() if p.get("sync")]
+        assert hooked and all(p["sync"][2]["error"] is None for p in hooked)
     torch.cuda.synchronize()
     mine = torch.cat([tr.model._flat, tr.model._bnstate]).cpu()
     other = mine.clone()

@@ -31,11 +31,13 @@ def test_two_rank_data_parallel_fused_step_matches_plain_step(topology, encoder)
     assert r.returncode == 0 and "DP_REHEARSAL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_two_rank_trainer_runs_through_an_early_stop_with_identical_weights(tmp_path):
+@pytest.mark.parametrize("mode", ["per_rank", "sync"])
+def test_two_rank_trainer_runs_through_an_early_stop_with_identical_weights(tmp_path, mode):
     """VolSeg2dTrainer.train_model at world size 2 on the HIP engine (tests/dp_trainer_worker.py): disjoint shards of each
     global batch, the LR finder's learning rate and the early stop decided on all-reduced losses, rank 0 writes the
-    checkpoint, both ranks reload it and end with bit-identical parameters and running statistics."""
-    r = _torchrun("dp_trainer_worker.py", str(tmp_path))
+    checkpoint, both ranks reload it and end with bit-identical parameters and running statistics.  `sync`: the same run with
+    `sync_batchnorm: true` - SyncBatchNorm + the Dice of the global batch through the trainer's own settings surface."""
+    r = _torchrun("dp_trainer_worker.py", str(tmp_path), *(["sync"] if mode == "sync" else []))
     assert r.returncode == 0 and "DP_TRAINER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
