@@ -57,6 +57,10 @@ def _worker(rank, world, port, out_dir):
     for d, s0, nb in calls:
         per_dir.setdefault(d, []).append((s0, s0 + nb))
     shares = {d: (min(a for a, _ in v), max(b for _, b in v)) for d, v in per_dir.items()}
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import REPEATED_DIRECTIONS
+    assert sorted(shares) == [d for d in range(12) if d not in REPEATED_DIRECTIONS]     # the four exact repeats are not run
+    for d in REPEATED_DIRECTIONS:
+        shares[d] = (-1, -1)
     # data-parallel gradient averaging on the flat buffer
     m = VolSegUnet(2)
     m.dp_group = dist.group.WORLD
@@ -121,7 +125,11 @@ def test_sharded_prediction_and_grad_allreduce(tmp_path, world):
     # shares are disjoint and cover every direction's stack
     depths = [29, 32, 40] * 4
     depths[3:6] = [32, 29, 40]; depths[9:12] = [32, 29, 40]   # rot90 / rot270 volumes have shape (Y, Z, X)
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import REPEATED_DIRECTIONS
     for d in range(12):   # contiguous shares in rank order, from 0 to the direction's depth, sizes differing by at most one
+        if d in REPEATED_DIRECTIONS:    # not run: the merged result above equals the oracle's full twelve-direction reference all the same
+            assert all(int(r["shares"][d][0]) == -1 for r in rs)
+            continue
         edges = [0] + [int(r["shares"][d][1]) for r in rs]
         assert all(int(r["shares"][d][0]) == edges[i] for i, r in enumerate(rs)) and edges[-1] == depths[d]
         sizes = np.diff(edges)
