@@ -201,8 +201,8 @@ int64_t vs_unet_unit_param_offset(const vs_unet_t* net, int unit);
  * inside the workspace (byte offsets; NHWC, dtype of the plan).  Tests only. */
 int vs_unet_num_units(const vs_unet_t* net);
 /* Normalise-on-load plan of a bf16 TRAINING forward at batch n: flags[i] = 1 when unit i (a convolution + BatchNorm + ReLU whose
- * output has exactly one reader, a stride-1 3x3 convolution) will NOT run a normalisation sweep - its convolution finalises the batch
- * statistics itself and the reader (forward and weight gradient) normalises the pre-norm tensor while staging it.  Replaces, for
+ * output has exactly one reader, a stride-1 3x3 convolution) will NOT run a normalisation sweep - the reader sums the unit's statistics
+ * bins itself, normalises the pre-norm tensor while staging it and stores the activation as a by-product.  Replaces, for
  * those units, torch's BatchNorm2d + ReLU modules between two convolutions (reference call site vol_seg_2d_trainer.py:424, the
  * model's forward).  Host logic only; returns the number of units. */
 int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap);

@@ -219,9 +219,8 @@ def test_every_kernel_choice_option_gives_the_same_training_step(option, value, 
 
 def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep():
     """Round 3 (second half): a conv -> BN -> ReLU unit whose output has ONE reader (a BasicBlock's conv1, the decoder's
-    convolutions) no longer runs a normalisation sweep in training - its convolution finalises the batch statistics behind a
-    ticket, and the reader (forward convolution AND weight gradient) normalises the pre-norm tensor while staging it
-    (`nl_fwd`, ConvParams::nl_*).  With the kernel families pinned (tile kernels, register-staged weight gradients, statistics in
+    convolutions) runs no normalisation sweep in training under `nl_fwd` - the reader's workgroups sum the statistics bins
+    themselves, normalise the pre-norm tensor while staging it and store the activation as a by-product (ConvParams::nl_*).  With the kernel families pinned (tile kernels, register-staged weight gradients, statistics in
     bins for every layer) the two forms do the same arithmetic on the same values: one headline-sized training step must give
     the same loss and the same gradients BIT FOR BIT, and the BatchNorm running statistics must agree bit for bit as well."""
     import bench

@@ -407,7 +407,7 @@ def test_hdf5_volumes_round_trip_through_the_c_library_without_h5py(tmp_path):
 
 def test_normalise_on_load_plan_is_the_one_reader_rule():
     """`vs_unet_nl_plan` (host logic, nothing is launched): with `nl_fwd` on, a bf16 training forward leaves exactly those conv +
-    BN + ReLU units un-normalised whose output has ONE reader, a stride-1 3x3 convolution on the register-staged kernels - for the
+    BN + ReLU units without a normalisation sweep whose output has ONE reader, a stride-1 3x3 convolution on the register-staged kernels - for the
     headline network at batch 32 of 256 x 256 the 16 BasicBlock conv1 units and 7 decoder convolutions (the last three decoder
     outputs feed the strip kernels / the head: they keep their sweep), never a unit with a residual input, the stem, a downsample
     1x1 or a unit whose output is a skip connection; none at all in fp32, or with the option off (the default)."""

@@ -236,19 +236,19 @@ struct ConvParams {
     // 2^24, sum x^2 by 2^16).  Integer adds commute: the totals are bit-reproducible whatever order the workgroups arrive in,
     // and the consumer finalises stats_nb rows inline instead of waiting for a finalize launch over hundreds (norm.hip).
     unsigned long long* stats_bins; int stats_nb;
-    // Optional, with stats_bins: every workgroup (direct kernel: wave) takes a ticket once its sums are in the bins; the one that
-    // takes the LAST ticket finalises the statistics itself (fp64, the arithmetic of bn_apply_inline_kernel: mean / invstd for the
-    // backward pass, running statistics).  The consumer can then normalise this tensor while it LOADS it (nl_* below) and no
-    // normalisation sweep - no launch at all - sits between the two convolutions on the caller's stream.
-    unsigned* fin_ticket;                // one zeroed counter (lives behind the unit's bins: cleared by the same launch)
-    int fin_tickets;                     // tickets a launch takes
-    long long fin_rows;                  // N * Hout * Wout
-    float fin_eps, fin_mom;
-    float* fin_mean; float* fin_invstd; float* fin_rm; float* fin_rv;   // outputs ([Cout] each; rm / rv may be null)
-    // Normalise-on-load of src0 (training forward of a conv -> BN -> ReLU -> conv pair): src0 holds the producer's PRE-norm
-    // output z; the loader applies y = max((z - mean) * (invstd * gamma) + beta, 0), rounded to the storage type exactly as the
-    // normalisation sweep would have stored it, before the chunk goes to LDS (zero padding stays zero).  null = off.
-    const float* nl_mean; const float* nl_invstd; const float* nl_gamma; const float* nl_beta;
+    // Normalise-on-load of src0 (training forward of a conv -> BN -> ReLU -> conv pair; nl_bins != null = on): src0 holds the
+    // producer's PRE-norm output z and no normalisation sweep ran.  Every workgroup of THIS launch sums the producer's nl_nb rows of
+    // fixed-point statistics bins itself in its prologue (the arithmetic of bn_apply_inline_kernel: fp64 mean / variance; workgroup 0
+    // also publishes mean / invstd for the backward pass and updates the running statistics), then applies
+    // y = max((z - mean) * (invstd * gamma) + beta, 0), rounded to the storage type exactly as the sweep would have stored it, to
+    // every item between its buffer load and its LDS store (zero padding stays zero).  The workgroups of the first cout tile also
+    // store the normalised interior of their patch to nl_y - the activation tensor the weight gradient reads comes out as a
+    // by-product of the forward convolution, and the sweep (launch, one tensor read) is gone.
+    const unsigned long long* nl_bins; int nl_nb;
+    long long nl_rows; float nl_eps, nl_mom;
+    float* nl_mean; float* nl_invstd; float* nl_rm; float* nl_rv;   // outputs of workgroup 0 ([C0]; rm / rv may be null)
+    const float* nl_gamma; const float* nl_beta;
+    void* nl_y;                          // [N][Hin >> up0][Win >> up0][C0] in the storage type
     const struct VolScatter* scatter;    // HOST pointer, optional (segmentation head in prediction): instead of storing logits,
                                          // softmax -> arg-max -> (label, fp16 max-prob) goes straight to the volume (see predict.hip)
 };
@@ -264,7 +264,6 @@ struct VolScatter {
 int launch_keys_stage_scatter(const uint32_t* stage, int nb, const vs_dirmap& m, int s0, uint32_t* keys, hipStream_t s);
 bool conv_head_scatter_ok(int dtype, const ConvParams& p);
 bool conv_igemm_bins_ok(int dtype, const ConvParams& p);     // whether p's kernel honours ConvParams::stats_bins   // whether launch_conv_igemm can honour p.scatter for this layer
-int conv_igemm_tickets(int dtype, const ConvParams& p);      // tickets p's launch takes (ConvParams::fin_ticket); 0 = kernel without tickets
 bool conv_igemm_nl_ok(int dtype, const ConvParams& p);       // whether launch_conv_igemm can honour p.nl_* (normalise src0 on load)
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
@@ -313,12 +312,9 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
-    // src0 holds the pre-norm output z of a conv -> BN -> ReLU unit: normalise while staging (see ConvParams::nl_*); null = off
-    const float* nl_mean; const float* nl_invstd; const float* nl_gamma; const float* nl_beta;
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
-bool conv_wgrad_nl_ok(int dtype, const WgradParams& p);      // whether launch_conv_wgrad can honour p.nl_* (normalise src0 on load)
 // dw[i] = sum_k partials[k*n + i], fixed summation order
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);
 

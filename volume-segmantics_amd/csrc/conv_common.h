@@ -39,48 +39,6 @@ __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b
 }
 
 
-// ---- batch statistics finalised by the producing convolution itself (ConvParams::fin_*) ---------------------------------------
-// One channel's totals -> mean / invstd (and the running statistics): the arithmetic of bn_apply_inline_kernel<T, true>.
-__device__ __forceinline__ void bn_finish_channel(const ConvParams& p, int ch, long long sv, long long qv) {
-    const double rows = (double)p.fin_rows;
-    const double mu = ((double)sv * (1.0 / kStatScale1)) / rows;
-    double var = ((double)qv * (1.0 / kStatScale2)) / rows - mu * mu;
-    if (var < 0.0) var = 0.0;
-    p.fin_mean[ch] = (float)mu;
-    p.fin_invstd[ch] = (float)(1.0 / sqrt(var + (double)p.fin_eps));
-    if (p.fin_rm) {
-        const double unbiased = p.fin_rows > 1 ? var * rows / (double)(p.fin_rows - 1) : var;
-        p.fin_rm[ch] = (float)((1.0 - p.fin_mom) * (double)p.fin_rm[ch] + p.fin_mom * mu);
-        p.fin_rv[ch] = (float)((1.0 - p.fin_mom) * (double)p.fin_rv[ch] + p.fin_mom * unbiased);
-    }
-}
-// bins as the other workgroups' atomic adds left them: device-scope loads (another XCD's L2 never held these lines dirty - the
-// adds are performed at the memory side - but this XCD's may hold a stale clean copy)
-__device__ __forceinline__ long long bin_load(const unsigned long long* b) {
-    return (long long)__hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the workgroup (NT threads) that took the last ticket
-template <int NT>
-__device__ __forceinline__ void bn_finalize_bins(const ConvParams& p, int tid) {
-    const int c = p.Cout, nb = p.stats_nb;
-    for (int ch = tid; ch < c; ch += NT) {
-        long long s = 0, q = 0;
-#pragma unroll 8
-        for (int r = 0; r < nb; ++r) {
-            s += bin_load(p.stats_bins + ((size_t)r * 2 + 0) * c + ch);
-            q += bin_load(p.stats_bins + ((size_t)r * 2 + 1) * c + ch);
-        }
-        bn_finish_channel(p, ch, s, q);
-    }
-}
-// add to a bin; with tickets the RETURNING form: the value coming back (consumed by bin_adds_done in front of the ticket) is the
-// proof that the add has been performed
-__device__ __forceinline__ void bin_add(unsigned long long* b, unsigned long long v, bool ticketed, unsigned long long& back) {
-    if (ticketed) back += atomicAdd(b, v);
-    else atomicAdd(b, v);
-}
-__device__ __forceinline__ void bin_adds_done(unsigned long long back) { asm volatile("" ::"v"(back)); }
-
 // Epilogue of an implicit-GEMM tile: lane (lq, lr) of wave `wave` holds, for pixel tile i and cout tile j, the 4 output
 // channels n0 + 16j + 4lq .. +3 of pixel  wave*PT*16 + 16i + lr  of the TH x TW patch at (n, h0, w0).
 // Optional: per-channel sum / sum-of-squares partials of the raw accumulators (row `tile` of p.stats_partial), fused
@@ -96,7 +54,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
     struct { int tw_shift, out_nchw; } g{tw_shift, out_nchw};
     // ---- epilogue: lane holds pixel (lr) x couts 4*lq..4*lq+3 of each 16x16 tile ----
     const bool ragged = (p.Cout & 3) != 0 || g.out_nchw;  // segmentation head only
-    unsigned long long bin_back = 0;   // what this thread's (returning) bin adds brought back: see (3)
     // (1) optional per-channel statistics of the raw accumulators (train-mode BN of the bf16 path)
     if (p.stats_partial || p.stats_bins) {
         float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][BN]
@@ -135,8 +92,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
 #pragma unroll
                 for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
                 if (p.stats_bins)      // fixed point: the order the workgroups arrive in cannot change the total
-                    bin_add(p.stats_bins + ((size_t)(tile & (p.stats_nb - 1)) * 2 + k) * p.Cout + n0 + cc,
-                            (unsigned long long)__double2ll_rn((double)a * (k ? kStatScale2 : kStatScale1)), p.fin_ticket != nullptr, bin_back);
+                    atomicAdd(p.stats_bins + ((size_t)(tile & (p.stats_nb - 1)) * 2 + k) * p.Cout + n0 + cc,
+                              (unsigned long long)__double2ll_rn((double)a * (k ? kStatScale2 : kStatScale1)));
                 else
                     p.stats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] = a;
             }
@@ -308,15 +265,5 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
                 }
             }
         }
-    }
-    // (3) ticket: this workgroup's sums are in the bins (the returning adds above have come back); whoever takes the last ticket
-    // finalises the statistics - a few microseconds at the tail of ONE workgroup instead of a launch on the caller's stream
-    if (p.fin_ticket) {
-        int* flag = reinterpret_cast<int*>(smem);
-        bin_adds_done(bin_back);
-        __syncthreads();
-        if (tid == 0) *flag = __hip_atomic_fetch_add(p.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(p.fin_tickets - 1);
-        __syncthreads();
-        if (*flag) bn_finalize_bins<NW * 64>(p, tid);
     }
 }

@@ -62,9 +62,11 @@ constexpr int patch_items(int pt, int stride, int nw = 4) {
 
 // DIL: dilation of a 3x3 kernel (1 or 2; torchvision / smp "replace stride with dilation" stages).  Dilated variants take their
 // tile geometry from the launch like the stride-2 ones and use the same staging budget (the patch is (tile + 2 DIL) wide).
-// NLOAD: src0 is the PRE-norm output z of the conv -> BN -> ReLU unit in front (ConvParams::nl_*): its chunks are normalised in
-// registers on their way to LDS - y = max((z - mean) * (invstd * gamma) + beta, 0) rounded to bf16, the value the normalisation
-// sweep would have stored, zero padding left zero - so that sweep, its launch and the y tensor do not exist.
+// NLOAD: src0 is the PRE-norm output z of the conv -> BN -> ReLU unit in front (ConvParams::nl_*).  The prologue sums the unit's
+// statistics bins (every workgroup for itself; workgroup 0 publishes), the chunks are normalised in registers on their way to LDS -
+// y = max((z - mean) * (invstd * gamma) + beta, 0) rounded to bf16, the value the normalisation sweep would have stored, zero
+// padding left zero - and the workgroups of the first cout tile store the normalised interior of their patch (the activation the
+// weight gradient reads later): no normalisation sweep, no launch between the two convolutions.
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1, bool NLOAD = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(ConvParams p, TileGeom g) {
     constexpr int NT = NW * 64;
@@ -139,15 +141,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
     float* cst = reinterpret_cast<float*>(smem + dummy + 64);
     const int C0r = (p.C0 + 31) & ~31;
     if constexpr (NLOAD) {
+        const long long* bins = reinterpret_cast<const long long*>(p.nl_bins);     // [nl_nb][2][C0]: sum z * 2^24, sum z^2 * 2^16
+        const double rows = (double)p.nl_rows;
         for (int ch = tid; ch < p.C0; ch += NT) {
-            cst[ch] = p.nl_mean[ch];
-            cst[C0r + ch] = p.nl_invstd[ch] * p.nl_gamma[ch];
+            long long sv = 0, qv = 0;
+#pragma unroll 8
+            for (int r = 0; r < p.nl_nb; ++r) { sv += bins[((size_t)r * 2 + 0) * p.C0 + ch]; qv += bins[((size_t)r * 2 + 1) * p.C0 + ch]; }
+            // (the arithmetic of bn_apply_inline_kernel<T, true>: the same bits as the sweep's statistics)
+            const double mu = ((double)sv * (1.0 / kStatScale1)) / rows;
+            double var = ((double)qv * (1.0 / kStatScale2)) / rows - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)p.nl_eps));
+            cst[ch] = (float)mu;
+            cst[C0r + ch] = is * p.nl_gamma[ch];
             cst[2 * C0r + ch] = p.nl_beta[ch];
+            if (blockIdx.x == 0) {        // one workgroup publishes: statistics for the backward pass, running statistics
+                p.nl_mean[ch] = (float)mu;
+                p.nl_invstd[ch] = is;
+                if (p.nl_rm) {
+                    const double unbiased = p.nl_rows > 1 ? var * rows / (double)(p.nl_rows - 1) : var;
+                    p.nl_rm[ch] = (float)((1.0 - p.nl_mom) * (double)p.nl_rm[ch] + p.nl_mom * mu);
+                    p.nl_rv[ch] = (float)((1.0 - p.nl_mom) * (double)p.nl_rv[ch] + p.nl_mom * unbiased);
+                }
+            }
         }   // visible to every wave behind the first barrier of the chunk loop
     }
 
     // ---- chunk-invariant staging addresses (byte offsets; -1 = zero fill) ----
     int poff0[PITEMS], poff1[PITEMS], pdst[PITEMS];
+    unsigned ystore = 0;
 #pragma unroll
     for (int i = 0; i < PITEMS; ++i) {
         const int item = tid + i * NT;
@@ -158,6 +180,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
         poff0[i] = (ok && !(stuffed && ((hi | wi) & 1))) ? (((hi >> ush) * W0 + (wi >> ush)) * p.C0 + seg * EPS) * (int)sizeof(T) : -1;
         poff1[i] = ok ? ((hi * p.Win + wi) * p.C1 + seg * EPS) * (int)sizeof(T) : -1;
         pdst[i] = pp < P ? swz(pp, pw, seg) : dummy;
+        if constexpr (NLOAD) {   // items whose normalised value this workgroup stores to nl_y: the tile's own pixels (not the halo), once per source pixel
+            const bool mine = ok && hi >= h0 && hi < h0 + TH && wi >= w0 && wi < w0 + TW && !(ush && ((hi | wi) & 1));
+            ystore |= mine ? 1u << i : 0u;
+        }
     }
     // weight staging: pass i covers rows i*WROWS + (tid >> 2); row = tap*BN + nr, so a pass advances TS taps
     const int wrow0 = tid >> 2, wseg = tid & 3;
@@ -232,6 +258,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
                     const bool segok = (tid & 3) * EPS < p.C0 - c0;
 #pragma unroll
                     for (int i = 0; i < PITEMS; ++i) pregs[s][i] = nl_apply8(pregs[s][i], segok && poff0[i] >= 0, nm, na, nb);
+                    if (p.nl_y && ytile == 0) {     // (uniform) the activation tensor as a by-product; out-of-range offsets are dropped by the hardware
+                        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)((T*)p.nl_y + (size_t)n * H0 * W0 * p.C0), 0, H0 * W0 * p.C0 * (int)sizeof(T), 0x00020000);
+#pragma unroll
+                        for (int i = 0; i < PITEMS; ++i) {
+                            const uint4 v = pregs[s][i];
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, ry, (segok && ((ystore >> i) & 1u)) ? poff0[i] : (int)0x80000000,
+                                                                   c0 * (int)sizeof(T), 0);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -632,7 +668,7 @@ static bool direct_ok(int dtype, const ConvParams& p) {   // p.out_f32: bit 0 = 
     const bool head_ok = p.Cout <= 4 && !p.pool0 && !p.scale && !p.relu && !p.up0 && !p.stats_partial;   // conv_head_kernel
     const bool out_ok = p.scatter ? (head_ok && (p.scatter->mode == 0 || (p.scatter->mode == 1 && p.scatter->keys)))
                                   : nchw ? (f32 && head_ok) : (!f32 && !(p.Cout & 3));
-    return vs_option("conv_direct") && out_ok && !p.nl_mean && !p.bz && !p.gc && p.dil <= 1 && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
+    return vs_option("conv_direct") && out_ok && !p.nl_bins && !p.bz && !p.gc && p.dil <= 1 && p.up0 != 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.C0 <= CK &&
            p.Cout <= 16 && !p.residual && !p.out1 && (!p.pool0 || (!(p.Hout & 1) && !(p.Wout & 1) && p.Cout % 4 == 0)) &&
            (long)p.N * p.Hout * p.Wout >= (long)vs_option("conv_direct_min_px") &&
            (double)p.Hout * p.Wout * std::max(p.Cout, 4) * 4.0 < 2.0e9;
@@ -739,7 +775,7 @@ int launch_tk(const ConvParams& p, const TileGeom& g, hipStream_t s) {
         if (p.stride == 2) return launch_one<T, 64, 2, 9, 2>(p, g, s);
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
-        if (p.nl_mean) return launch_one<T, BN, PT, 9, 1, 4, 1, true>(p, g, s);     // (dispatch checked: stride-1 3x3, no dilation)
+        if (p.nl_bins) return launch_one<T, BN, PT, 9, 1, 4, 1, true>(p, g, s);     // (dispatch checked: stride-1 3x3, no dilation)
     }
     return nt == 9 ? launch_one<T, BN, PT, 9, 1>(p, g, s) : launch_one<T, BN, PT, 1, 1>(p, g, s);
 }
@@ -785,7 +821,7 @@ Pick pick_cfg(const ConvParams& p) {
 // (prediction: batches of 512 x 512 slices) - at least `conv_stream_min_tiles` tile jobs per CU-resident workgroup, so that
 // the per-tile latencies it removes are what the launch consists of.  0 = no, else the cout tile (64 / 32)
 static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
-    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512 || p.nl_mean) return 0;
+    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_stream") || !ring::stream_ok(p, out_nchw) || p.C0 + p.C1 > 512 || p.nl_bins) return 0;
     const int bn = (p.Cout % 64 == 0) ? 64 : 32;
     const long jobs = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * (p.Cout / bn);
     return jobs >= 256L * vs_option("conv_stream_min_tiles") ? bn : 0;
@@ -793,7 +829,7 @@ static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
 
 static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
-        out_nchw || (p.Cout & 3) || p.out_f32 || p.nl_mean) return 0;     // (normalise-on-load needs the register-staged tile kernel)
+        out_nchw || (p.Cout & 3) || p.out_f32 || p.nl_bins) return 0;     // (normalise-on-load needs the register-staged tile kernel)
     const int Cin = p.C0 + p.C1;
     if (Cin < 128 || (Cin & 7) || (p.C1 && (p.C0 & 31))) return 0;
     if (p.out1 && (p.split_c & 31)) return 0;
@@ -845,8 +881,8 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     }
     ConvParams pd = p;
     pd.out_f32 = p.out_f32 | (out_nchw << 1);
-    if (p.nl_mean) {
-        VS_REQUIRE(conv_igemm_nl_ok(Elem<T>::kDtype, pd) && p.nl_invstd && p.nl_gamma && p.nl_beta,
+    if (p.nl_bins) {
+        VS_REQUIRE(conv_igemm_nl_ok(Elem<T>::kDtype, pd) && p.nl_mean && p.nl_invstd && p.nl_gamma && p.nl_beta && p.nl_nb >= 1 && p.nl_rows >= 1,
                    "conv_igemm: normalise-on-load is built for the bf16 stride-1 3x3 layers (ask conv_igemm_nl_ok first)");
     }
     if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
@@ -882,7 +918,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;
     g.probe = vs_probe_buffer((size_t)p.N * g.tiles_h * g.tiles_w * cdiv(p.Cout, BN));
     if constexpr (std::is_same<T, bf16_t>::value) {
-        if (NW == 8 && p.nl_mean) {
+        if (NW == 8 && p.nl_bins) {
 #define VS_CONV8N(bn) if (BN == bn) return launch_one<T, bn, 2, 9, 1, 8, 1, true>(p, g, s)
             VS_CONV8N(64); VS_CONV8N(32); VS_CONV8N(16);
 #undef VS_CONV8N
@@ -929,24 +965,11 @@ bool conv_igemm_bins_ok(int dtype, const ConvParams& p) { return dtype == VS_BF1
 // stride-1 3x3 instantiations (p as the layer will be launched, nl_* set or not)
 bool conv_igemm_nl_ok(int dtype, const ConvParams& p) {
     ConvParams q = p;
-    q.nl_mean = nullptr;
+    q.nl_bins = nullptr;
     if (dtype != VS_BF16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter || p.up0 == 2 || p.bz ||
         (p.C0 & 7) || p.C0 > 2048) return false;
     if (direct_ok(dtype, q)) return false;    // the strip kernels have no such loader (yet)
     return true;
-}
-
-// tickets a launch of p takes when ConvParams::fin_ticket is set (= its workgroups that reach conv_epilogue); 0: the kernel
-// launch_conv_igemm picks has no ticket (direct / persistent kernels)
-int conv_igemm_tickets(int dtype, const ConvParams& p0) {
-    ConvParams p = p0;
-    static unsigned long long some_bins;
-    if (!p.stats_bins) p.stats_bins = &some_bins;     // tickets come with statistics bins: the kernel choice is the one made with them set
-    const int nchw = p.out_f32 >> 1;
-    if (dtype != VS_BF16 || direct_ok(dtype, p) || stream_mode(dtype, p, nchw)) return 0;
-    const int rm = ring_mode(dtype, p, nchw);
-    const int bn = rm ? (rm == 1 ? 64 : 32) : pick_cfg(p).BN;
-    return conv_igemm_stat_rows(dtype, p) * cdiv(p.Cout, bn);
 }
 
 int conv_igemm_stat_rows(int dtype, const ConvParams& p) {

@@ -233,9 +233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p, WGeom g)
 // the next tile.
 constexpr int kXP = 64;
 
-// NLOAD: src0 is the pre-norm output z of the conv -> BN -> ReLU unit in front (WgradParams::nl_*) - its items are normalised in
-// registers on their way to LDS, exactly as the forward convolution's loader did (conv_igemm_kernel)
-template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1, bool NLOAD = false>
+template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, WGeom g) {
     constexpr int KW = NTAPS == 9 ? 3 : 1, KH = KW;
     constexpr int BM = 64 * PT, KS = BM / 32;             // pixels / k-steps per tile
@@ -303,19 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     const int dco = co0 + dseg * 8 < p.Cout ? (co0 + dseg * 8) * 2 : -1;
     const int dth = r0 >> tw_shift, dtw = r0 & (TW - 1);
 
-    // NLOAD: this thread's 8 channels are the same in every item of every tile (one cin chunk per workgroup)
-    float nm[8], na[8], nb[8];
-    const bool nl = NLOAD && from0;
-    unsigned pmask = 0;                                    // items of the tile in flight that hold real pixels (not padding)
-    if constexpr (NLOAD) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ch = min(cb + (tid & 3) * 8 + k, cs - 1);
-            nm[k] = nl ? p.nl_mean[ch] : 0.f;
-            na[k] = nl ? p.nl_invstd[ch] * p.nl_gamma[ch] : 0.f;
-            nb[k] = nl ? p.nl_beta[ch] : 0.f;
-        }
-    }
     uint4 preg[PITEMS], dreg[DITEMS];
     auto load_tile = [&](int tile) {
         const int q = g.tiles_w == 1 ? tile : (int)__umulhi((unsigned)tile, g.tw_magic);
@@ -330,7 +315,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
             const bool ok = pco >= 0 && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
             const int off = ((n * Hs + (hi >> sh)) * Ws + (wi >> sh)) * cs * 2 + pco;
             preg[i] = bload(rx, ok ? off : -1, 0);
-            if constexpr (NLOAD) pmask = i == 0 ? (ok ? 1u : 0u) : (pmask | (ok ? 1u << i : 0u));
         }
         const int wo_ = w0 + dtw;
 #pragma unroll
@@ -367,12 +351,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradParams p, 
     if (g.probe) tprobe[1] = wall_clock64();
     for (int tile = t0; tile < t1; ++tile) {
         __syncthreads();
-        if constexpr (NLOAD) {
-            if (nl) {
-#pragma unroll
-                for (int i = 0; i < PITEMS; ++i) preg[i] = nl_apply8(preg[i], (pmask >> i) & 1u, nm, na, nb);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i) *reinterpret_cast<uint4*>(smem + pdst[i]) = preg[i];
 #pragma unroll
@@ -521,7 +499,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
     g.ring = 0;
-    if (g.fast && vs_option("wgrad_ring") && !p.nl_mean && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && (p.C0 % 32) == 0 && (p.C1 % 32) == 0) {
+    if (g.fast && vs_option("wgrad_ring") && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && (p.C0 % 32) == 0 && (p.C1 % 32) == 0) {
         if (PT == 2) g.ring = 1;
         else if (p.Hout == 8 && p.Wout == 8 && p.N % 2 == 0 && p.Cout >= 64) {   // 8 x 8 maps: two images per 128-pixel tile
             g.ring = 2;
@@ -582,10 +560,10 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     return VS_OK;
 }
 
-template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1, bool NLOAD = false>
+template <int MO, int NTAPS, int STRIDE, int PT, int DIL = 1>
 int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_wgrad_bf16_kernel<MO, NTAPS, STRIDE, PT, DIL, NLOAD>;
+    auto kern = conv_wgrad_bf16_kernel<MO, NTAPS, STRIDE, PT, DIL>;
     VS_REQUIRE(g.PH * g.PW * 4 <= wg_patch_items(PT, DIL > 1 ? 2 : STRIDE) * 256, "conv_wgrad: patch exceeds the staging budget");
     constexpr int BM = 64 * PT, DYP = 32 * MO < 64 ? 64 : 32 * MO;
     size_t lds = (size_t)g.PH * g.PW * kXP + (size_t)BM * DYP + 16;
@@ -682,13 +660,6 @@ int dispatch(const WgradParams& p, hipStream_t s) {
                 if (WO == 2) return launch_fast<2, 9, 1, 1, 4>(p, g, s);
                 return VS_ERR_UNSUPPORTED;
             }
-            if (p.nl_mean) {          // normalise-on-load: the register-staged kernel (geom kept it off the ring)
-                VS_REQUIRE(nt == 9 && p.stride == 1 && p.dil <= 1 && !p.cg && p.nl_invstd && p.nl_gamma && p.nl_beta,
-                           "conv_wgrad: normalise-on-load is built for the dense stride-1 3x3 layers");
-#define VS_WGN_CASE(mo) if (WO == mo) return g.PT == 2 ? launch_fast<mo, 9, 1, 2, 1, true>(p, g, s) : launch_fast<mo, 9, 1, 1, 1, true>(p, g, s)
-                VS_WGN_CASE(4); VS_WGN_CASE(2); VS_WGN_CASE(1);
-#undef VS_WGN_CASE
-            }
             if (g.ring == 1) {        // 16 x 8 tiles
                 if (WO == 4) return launch_ring_wgrad<4, 4, 1>(p, g, s);
                 if (WO == 2) return launch_ring_wgrad<2, 4, 1>(p, g, s);
@@ -784,16 +755,6 @@ size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {
     if (dtype == VS_BF16) { if (geom<bf16_t>(p, g, WO)) return 0; }
     else { if (geom<float>(p, g, WO)) return 0; }
     return ((size_t)g.nsplit + (p.cg && p.cg < 32 ? 1 : 0)) * p.Cout * p.KH * p.KW * (p.cg ? 32 : p.C0 + p.C1) * sizeof(float);
-}
-
-bool conv_wgrad_nl_ok(int dtype, const WgradParams& p) {
-    if (dtype != VS_BF16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.dil > 1 || p.cg || p.up0 > 1 || (p.C0 & 31)) return false;
-    WgradParams q = p;
-    static const float one = 1.f;
-    q.nl_mean = &one;
-    WGeom g; int WO;
-    if (geom<bf16_t>(q, g, WO)) return false;
-    return g.fast && !g.ring && (WO == 4 || WO == 2 || WO == 1);
 }
 
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s) {

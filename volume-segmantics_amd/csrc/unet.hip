@@ -1162,12 +1162,7 @@ size_t plan_workspace(vs_unet* net) {
         if (u.kind == U_CONVT) { p.Hout = u.hin; p.Wout = u.win; p.Cout = 4 * u.cout; }
         p.cg = u.cg; p.dil = u.dil;
         if (u.colr) { p.C0 = 9 * u.cin0; p.pad = 0; p.KH = p.KW = 1; }
-        size_t b = wgrad_workspace_bytes(net->dtype, p);
-        if (u.kind == U_CONV && net->dtype == VS_BF16) {   // the normalise-on-load form runs on the register-staged kernel with its own K split
-            static const float one = 1.f;
-            p.nl_mean = &one;
-            b = std::max(b, wgrad_workspace_bytes(net->dtype, p));
-        }
+        const size_t b = wgrad_workspace_bytes(net->dtype, p);
         if (b > wg) wg = b;
     }
     for (auto& u : net->units) {
@@ -1283,22 +1278,21 @@ WgradParams wgrad_params(const Ctx& c, const Unit& u) {
 
 // Normalise-on-load (training, bf16): unit ui is a conv -> BN -> ReLU whose output has exactly ONE reader, a stride-1 3x3
 // convolution that takes it as src0 (a BasicBlock's conv1 -> conv2; a decoder block's conv1 -> conv2 -> next block's conv1).
-// Then ui's launch `pu` (statistics in fixed-point bins) finalises its own statistics behind a ticket, the reader - forward
-// convolution and weight gradient - applies the normalisation while staging ui's PRE-norm tensor, and neither the
-// normalisation sweep nor the activation tensor exist.  Returns the reader's unit index, or -1.
-int nl_consumer(const Ctx& c, int ui, const ConvParams& pu) {
+// Then ui runs no normalisation sweep: its statistics stay in their fixed-point bins, the reader's workgroups sum them in their
+// prologue, normalise ui's PRE-norm tensor while staging it and leave the normalised activation behind as a by-product for the
+// weight gradient (ConvParams::nl_*).  Returns the reader's unit index, or -1.
+int nl_consumer(const Ctx& c, int ui) {
     vs_unet* net = c.net;
     const int dt = net->dtype;
     const Unit& u = net->units[ui];
-    if (dt != VS_BF16 || !vs_option("nl_fwd") || !vs_option("recompute_mask") || net->stats_hook) return -1;   // (cross-rank statistics: the sweep finalises)
-    if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0) return -1;
-    if (conv_igemm_tickets(dt, pu) <= 0) return -1;
+    if (dt != VS_BF16 || !vs_option("nl_fwd") || net->stats_hook) return -1;   // (cross-rank statistics: the sweep finalises)
+    if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0 || u.cout > 512) return -1;
     ensure_graph_maps(net);
     const int vi = net->sole_consumer[u.out];
     if (vi <= ui) return -1;
     const Unit& v = net->units[vi];
     if (v.kind != U_CONV || v.src0 != u.out || v.src1 == u.out || v.res == u.out || v.colr || v.cg || v.g2) return -1;
-    if (!conv_igemm_nl_ok(dt, conv_params(c, v)) || !conv_wgrad_nl_ok(dt, wgrad_params(c, v))) return -1;
+    if (!conv_igemm_nl_ok(dt, conv_params(c, v))) return -1;
     return vi;
 }
 
@@ -1765,10 +1759,15 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         }
         case U_CONV: {
             ConvParams p = conv_params(c, u);
-            if (training && u.src0 >= 0 && net->nl_act[u.src0]) {   // src0 was never normalised: its pre-norm tensor, normalised while it is staged
+            if (training && u.src0 >= 0 && net->nl_act[u.src0]) {   // src0 ran no normalisation sweep: its pre-norm tensor, normalised while it is staged
                 const Unit& q = net->units[net->producer[u.src0]];
                 p.src0 = c.z(u.src0);
-                p.nl_mean = c.bnc(q, 2); p.nl_invstd = c.bnc(q, 3); p.nl_gamma = c.P(q.bn_idx); p.nl_beta = c.P(q.bn_idx + 1);
+                p.nl_bins = (const unsigned long long*)(c.ws + q.off_bins); p.nl_nb = stat_bins_rows(q.cout);
+                p.nl_rows = c.rows(q); p.nl_eps = 1e-5f; p.nl_mom = 0.1f;
+                p.nl_mean = c.bnc(q, 2); p.nl_invstd = c.bnc(q, 3);
+                p.nl_rm = bnstate + c.t(q.bn_idx + 2).offset; p.nl_rv = bnstate + c.t(q.bn_idx + 3).offset;
+                p.nl_gamma = c.P(q.bn_idx); p.nl_beta = c.P(q.bn_idx + 1);
+                p.nl_y = c.a(u.src0);      // the activation the weight gradient reads: this launch's by-product
             }
             prof_set_variant(conv_igemm_variant(dt, p));
             ProfScope prof(PK_CONV_FWD, conv_flops(c, u), 0, c.s);
@@ -1808,20 +1807,14 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 if (dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     const bool bins_ok = u.bn_idx >= 0 && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p);
-                    const bool nl = bins_ok && nl_consumer(c, unit_index, p) >= 0;
+                    const bool nl = bins_ok && nl_consumer(c, unit_index) >= 0;
                     if (bins_ok && (nl || net->stats_hook || rows_needed > vs_option("bn_inline_rows"))) {
                         // many tiles: their sums go into a few rows of fixed-point bins, finalised inside the apply sweep -
                         // no finalize launch between the convolution and its normalisation (0.34 ms of a 4.76 ms step)
                         p.stats_bins = (unsigned long long*)(c.ws + u.off_bins);
                         p.stats_nb = stat_bins_rows(u.cout);
                         fused_bins = true;
-                        if (nl) {   // the last workgroup finalises; the one reader normalises on load
-                            p.fin_ticket = (unsigned*)(c.ws + u.off_bins + unit_bins_bytes(u.cout));
-                            p.fin_tickets = conv_igemm_tickets(dt, p);
-                            p.fin_rows = c.rows(u); p.fin_eps = 1e-5f; p.fin_mom = 0.1f;
-                            p.fin_mean = c.bnc(u, 2); p.fin_invstd = c.bnc(u, 3); p.fin_rm = rm; p.fin_rv = rv;
-                            net->nl_act[u.out] = 1;
-                        }
+                        if (nl) net->nl_act[u.out] = 1;   // no sweep: the one reader finalises the bins and normalises on load
                     } else if ((size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
                         p.stats_partial = (float*)(c.ws + net->off_bnws);
                         fused_stat_rows = rows_needed;
@@ -2146,11 +2139,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             WgradParams p = wgrad_params(c, u);
             p.dy = dzp; p.Cout = dz_c;
             p.partials = wgws; p.partial_bytes = net->wgws_bytes;
-            if (u.kind == U_CONV && u.src0 >= 0 && !net->nl_act.empty() && net->nl_act[u.src0]) {   // as the forward read it: z, normalised on load
-                const Unit& q = net->units[net->producer[u.src0]];
-                p.src0 = c.z(u.src0);
-                p.nl_mean = c.bnc(q, 2); p.nl_invstd = c.bnc(q, 3); p.nl_gamma = c.P(q.bn_idx); p.nl_beta = c.P(q.bn_idx + 1);
-            }
             if (u.kind == U_CONVT) {   // dense gradient of the 3x3 form, then its 16 real taps into torch's [in][out][4][4]
                 p.Hout = u.hin; p.Wout = u.win;
                 const size_t k = ((const char*)wgws - (c.ws + net->off_wgws)) / net->wgws_bytes;
@@ -2713,15 +2701,13 @@ extern "C" int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap) {
     VS_REQUIRE(net && flags && n >= 1 && n <= net->max_batch, "vs_unet_nl_plan: bad arguments");
     Ctx c{net, reinterpret_cast<char*>(uintptr_t(1) << 20), nullptr, nullptr, nullptr, n};   // (addresses are never dereferenced)
     std::vector<char> act(net->acts.size(), 0);
-    static const float one = 1.f;
     for (int i = 0; i < (int)net->units.size(); ++i) {
         const Unit& u = net->units[i];
         if (i < cap) flags[i] = 0;
         if (u.kind != U_CONV || net->dtype != VS_BF16 || u.bn_idx < 0 || u.gn_idx >= 0 || u.bias_idx >= 0) continue;
         if (!vs_option("fuse_stats") || !vs_option("stats_bins") || !net->bins_bytes) continue;
         ConvParams p = conv_params(c, u);
-        if (u.src0 >= 0 && act[u.src0]) p.nl_mean = &one;
-        if (!conv_igemm_bins_ok(net->dtype, p) || nl_consumer(c, i, p) < 0) continue;
+        if (!conv_igemm_bins_ok(net->dtype, p) || nl_consumer(c, i) < 0) continue;
         act[u.out] = 1;
         if (i < cap) flags[i] = 1;
     }
