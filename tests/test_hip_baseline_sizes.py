@@ -217,7 +217,8 @@ def test_every_kernel_choice_option_gives_the_same_training_step(option, value, 
     assert (rel < 0.2 and cos > 0.99) if loose else (rel < 2e-2 and cos > 0.999), (option, rel, cos)
 
 
-def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep():
+@pytest.mark.parametrize("kernels", ["tile", "ring"])
+def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep(kernels):
     """Round 3 (second half): a conv -> BN -> ReLU unit whose output has ONE reader (a BasicBlock's conv1, the decoder's
     convolutions) runs no normalisation sweep in training under `nl_fwd` - the reader's workgroups sum the statistics bins
     themselves, normalise the pre-norm tensor while staging it and store the activation as a by-product (ConvParams::nl_*).  With the kernel families pinned (tile kernels, register-staged weight gradients, statistics in
@@ -239,7 +240,9 @@ def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep():
         bn = torch.cat([b.detach().float().flatten() for n, b in model.named_buffers() if "running" in n])
         return loss.item(), model._flat_grad.clone(), bn.clone()
 
-    pinned = {"conv_ring": 0, "wgrad_ring": 0, "bn_inline_rows": 0}
+    # "tile": register-staged kernels throughout (conv_igemm_kernel<.., NLOAD>); "ring": the default LDS-DMA kernels, whose NLOAD form
+    # normalises the landed pieces in LDS (conv_ring_kernel<.., NLOAD>) - in both cases statistics in bins for every layer
+    pinned = {"conv_ring": 0, "wgrad_ring": 0, "bn_inline_rows": 0} if kernels == "tile" else {"bn_inline_rows": 0}
     old = {k: L.lib.vs_get_option(k.encode()) for k in list(pinned) + ["nl_fwd"]}
     try:
         for k, v in pinned.items():

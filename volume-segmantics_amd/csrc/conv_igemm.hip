@@ -258,7 +258,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv_igemm_kernel(Co
                     const bool segok = (tid & 3) * EPS < p.C0 - c0;
 #pragma unroll
                     for (int i = 0; i < PITEMS; ++i) pregs[s][i] = nl_apply8(pregs[s][i], segok && poff0[i] >= 0, nm, na, nb);
-                    if (p.nl_y && ytile == 0) {     // (uniform) the activation tensor as a by-product; out-of-range offsets are dropped by the hardware
+                    if (p.nl_y && ytile == (c0 / CK) % g.ctiles) {     // (uniform) the activation tensor as a by-product, the chunks dealt round-robin to the
+                                                                       // cout tiles of this pixel tile; out-of-range offsets are dropped by the hardware
                         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
                             (void*)((T*)p.nl_y + (size_t)n * H0 * W0 * p.C0), 0, H0 * W0 * p.C0 * (int)sizeof(T), 0x00020000);
 #pragma unroll
@@ -829,7 +830,8 @@ static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
 
 static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
-        out_nchw || (p.Cout & 3) || p.out_f32 || p.nl_bins) return 0;     // (normalise-on-load needs the register-staged tile kernel)
+        out_nchw || (p.Cout & 3) || p.out_f32) return 0;
+    if (p.nl_bins && (!vs_option("nl_ring") || (p.C0 & 31) || p.up0 == 2 || p.C0 > 1024)) return 0;   // normalise-on-load: whole chunks of src0, room for the table
     const int Cin = p.C0 + p.C1;
     if (Cin < 128 || (Cin & 7) || (p.C1 && (p.C0 & 31))) return 0;
     if (p.out1 && (p.split_c & 31)) return 0;
@@ -899,6 +901,11 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
         if (rm) {
             const long groups = rm == 3 ? p.N / 2 : (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
             unsigned long long* probe = vs_probe_buffer((size_t)(cdiv((int)groups, 8) * 8) * cdiv(p.Cout, rm == 1 ? 64 : 32));
+            if (p.nl_bins) {
+                if (rm == 1) return ring::launch_ring<64, 2, 8, 4, 1, 2, 2, true>(p, out_nchw, probe, s);
+                if (rm == 2) return ring::launch_ring<32, 2, 8, 4, 1, 4, 2, true>(p, out_nchw, probe, s);
+                return ring::launch_ring<32, 2, 4, 3, 2, 1, 2, true>(p, out_nchw, probe, s);
+            }
             if (rm == 1) return ring::launch_ring<64, 2, 8, 4, 1, 2, 2>(p, out_nchw, probe, s);
             if (rm == 2) return ring::launch_ring<32, 2, 8, 4, 1, 4, 2>(p, out_nchw, probe, s);
             return ring::launch_ring<32, 2, 4, 3, 2, 1, 2>(p, out_nchw, probe, s);

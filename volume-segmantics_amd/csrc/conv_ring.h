@@ -78,7 +78,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // BN: cout tile; PT: 16-pixel tiles per wave; NW: waves; TWS: log2 of the tile width; IMGS: images per pixel tile (> 1 only
 // when the tile height equals the image height: 8x8 maps)
-template <int BN, int PT, int NW, int TWS, int IMGS, int WPS, int PIN>
+// NLOAD (ConvParams::nl_*, see conv_igemm_kernel): src0 is a PRE-norm tensor.  The prologue sums the producer's statistics bins
+// into an LDS table while the first two chunks are in flight; the thread that issued a patch piece normalises it IN LDS behind the
+// wait that says its pieces have landed and in front of the chunk barrier (own pieces only: no extra barrier), and the workgroups
+// of the first cout tile store the normalised interior of their patch to nl_y from the same registers.
+template <int BN, int PT, int NW, int TWS, int IMGS, int WPS, int PIN, bool NLOAD = false>
 __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, Geom g) {
     typedef bf16_t T;
     constexpr int NT = NW * 64, NJ = BN / 16, BM = NW * PT * 16, TW = 1 << TWS, TH = BM / IMGS / TW;
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, G
     // ---- chunk-invariant piece addresses.  Piece i of this thread fills LDS slot (tid + i NT): pixel / row slot >> 2,
     // 16-byte position slot & 3, which holds channel segment (slot & 3) ^ key of the chunk ----
     int poff0[PIT], poff1[PIT];
+    unsigned nl_meta = 0;       // NLOAD, per piece i: bits 4i, 4i+1 = channel segment, bit 4i+2 = this workgroup stores it to nl_y
 #pragma unroll
     for (int i = 0; i < PIT; ++i) {
         const int it = tid + i * NT;
@@ -140,6 +145,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, G
         const bool ok = pp < P && img < nimg && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
         poff0[i] = (ok && !(stuffed && ((hi | wi) & 1))) ? (((img * H0 + (hi >> ush)) * W0 + (wi >> ush)) * p.C0 + seg * 8) * 2 : -1;
         poff1[i] = ok ? (((img * p.Hin + hi) * p.Win + wi) * p.C1 + seg * 8) * 2 : -1;
+        if constexpr (NLOAD) {    // the tile's own pixels (not the halo), once per source pixel
+            const bool mine = ok && ph >= 1 && ph <= TH && pw >= 1 && pw <= TW && !(ush && ((hi | wi) & 1));
+            nl_meta |= ((unsigned)seg | (mine ? 4u : 0u)) << (4 * i);
+        }
     }
     // weights: piece i covers rows i (NT / 4) + (tid >> 2); the rows advance by whole taps (TS per piece)
     const int wrow0 = tid >> 2;
@@ -202,9 +211,67 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, G
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nch = (Cin + 31) >> 5;
+    // NLOAD: [3][C0] floats behind the two stages - mean, invstd * gamma, beta of src0's channels (C0 a multiple of 32)
+    float* cst = reinterpret_cast<float*>(smem + 2 * STAGE_B);
+    __amdgpu_buffer_rsrc_t sry = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    // normalise this thread's own patch pieces of the chunk at c0 in place (they have landed: the caller waited), store the
+    // first cout tile's share of nl_y
+    auto nl_stage = [&](char* st, int c0) {
+        if (c0 >= p.C0) return;                      // (uniform) a chunk of the skip tensor: already an activation
+        static_for<0, PIT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            char* a = st + (tid + i * NT) * 16;
+            const unsigned m = nl_meta >> (4 * i);
+            const float* q = cst + c0 + (int)(m & 3u) * 8;
+            float nm[8], na[8], nb[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 m4 = *reinterpret_cast<const float4*>(q + 4 * h), a4 = *reinterpret_cast<const float4*>(q + p.C0 + 4 * h),
+                             b4 = *reinterpret_cast<const float4*>(q + 2 * p.C0 + 4 * h);
+                nm[4 * h] = m4.x; nm[4 * h + 1] = m4.y; nm[4 * h + 2] = m4.z; nm[4 * h + 3] = m4.w;
+                na[4 * h] = a4.x; na[4 * h + 1] = a4.y; na[4 * h + 2] = a4.z; na[4 * h + 3] = a4.w;
+                nb[4 * h] = b4.x; nb[4 * h + 1] = b4.y; nb[4 * h + 2] = b4.z; nb[4 * h + 3] = b4.w;
+            }
+            const uint4 v = nl_apply8(*reinterpret_cast<const uint4*>(a), poff0[i] >= 0, nm, na, nb);
+            *reinterpret_cast<uint4*>(a) = v;
+            if (ytile == (c0 >> 5) % g.ctiles)     // (uniform) the chunks' stores are dealt round-robin to the cout tiles of this pixel tile
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, sry, (m & 4u) ? poff0[i] : (int)0x80000000, c0 * 2, 0);
+        });
+    };
     issue(IC<0>{}, IC<D>{}, 0, lds0);
-    if (nch > 1) {
-        issue(IC<0>{}, IC<D>{}, 32, lds0 + STAGE_B);
+    if (nch > 1) issue(IC<0>{}, IC<D>{}, 32, lds0 + STAGE_B);
+    if constexpr (NLOAD) {
+        // the statistics of src0's channels from the producer's fixed-point bins (the arithmetic of bn_apply_inline_kernel<T, true>),
+        // summed while the first chunks are in flight; workgroup 0 publishes them
+        sry = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.nl_y + (size_t)n * H0 * W0 * p.C0), 0, nimg * H0 * W0 * p.C0 * 2, 0x00020000);
+        const long long* bins = reinterpret_cast<const long long*>(p.nl_bins);
+        const double rows = (double)p.nl_rows;
+        for (int ch = tid; ch < p.C0; ch += NT) {
+            long long sv = 0, qv = 0;
+#pragma unroll 8
+            for (int r = 0; r < p.nl_nb; ++r) { sv += bins[((size_t)r * 2 + 0) * p.C0 + ch]; qv += bins[((size_t)r * 2 + 1) * p.C0 + ch]; }
+            const double mu = ((double)sv * (1.0 / kStatScale1)) / rows;
+            double var = ((double)qv * (1.0 / kStatScale2)) / rows - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)p.nl_eps));
+            cst[ch] = (float)mu;
+            cst[p.C0 + ch] = is * p.nl_gamma[ch];
+            cst[2 * p.C0 + ch] = p.nl_beta[ch];
+            if (blockIdx.x == 0) {
+                p.nl_mean[ch] = (float)mu;
+                p.nl_invstd[ch] = is;
+                if (p.nl_rm) {
+                    const double unbiased = p.nl_rows > 1 ? var * rows / (double)(p.nl_rows - 1) : var;
+                    p.nl_rm[ch] = (float)((1.0 - p.nl_mom) * (double)p.nl_rm[ch] + p.nl_mom * mu);
+                    p.nl_rv[ch] = (float)((1.0 - p.nl_mom) * (double)p.nl_rv[ch] + p.nl_mom * unbiased);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // both chunks have landed, the table is written
+        __builtin_amdgcn_s_barrier();                                  // ... by every thread
+        nl_stage(smem, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (nch > 1) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");     // chunk 0 has landed (chunk 1 may still be in flight)
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -233,6 +300,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, G
             if constexpr (t == 7 && more) {
                 // all reads of chunk c are issued: wait for them and for this wave's pieces of chunk c+1, meet the others
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (NLOAD) {      // this thread's pieces of chunk c+1 are in LDS: normalise them before anyone reads them
+                    nl_stage(const_cast<char*>(nxt), (c + 1) * 32);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();
             }
             // pieces of the chunk after next, in NG groups at taps 7, 8, 0, 1: into the stage the barrier above freed
@@ -304,12 +375,14 @@ inline bool ring_geom_ok(const ConvParams& p) {
     return true;
 }
 
-template <int BN, int PT, int NW, int TWS, int IMGS, int WPS, int PIN = 0>
+template <int BN, int PT, int NW, int TWS, int IMGS, int WPS, int PIN = 0, bool NLOAD = false>
 int launch_ring(const ConvParams& p, int out_nchw, unsigned long long* probe, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_ring_kernel<BN, PT, NW, TWS, IMGS, WPS, PIN>;
-    constexpr size_t lds = ring_lds_bytes<BN, PT, NW, TWS, IMGS>();
-    static_assert(lds <= 160 * 1024, "conv_ring: LDS ring too large");
+    auto kern = conv_ring_kernel<BN, PT, NW, TWS, IMGS, WPS, PIN, NLOAD>;
+    constexpr size_t lds0 = ring_lds_bytes<BN, PT, NW, TWS, IMGS>();
+    static_assert(lds0 <= 160 * 1024, "conv_ring: LDS ring too large");
+    const size_t lds = lds0 + (NLOAD ? (size_t)3 * p.C0 * sizeof(float) : 0);
+    VS_REQUIRE(lds <= 160 * 1024 && (!NLOAD || (p.nl_bins && !(p.C0 & 31) && p.up0 != 2)), "conv_ring: normalise-on-load needs C0 in whole chunks and room for its table");
     constexpr int BM = NW * PT * 16, TW = 1 << TWS, TH = BM / IMGS / TW;
     VS_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.dil <= 1 && !p.gc, "conv_ring: stride-1 3x3 only");
     VS_REQUIRE((double)IMGS * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 4.0e9 && (double)p.Cout * 9 * (p.C0 + p.C1) * 2.0 < 4.0e9,
