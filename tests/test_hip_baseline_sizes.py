@@ -162,7 +162,7 @@ def test_deeplabv3plus_efficientnet_b4_1024_one_slice_eval():
 
 @pytest.mark.parametrize("option,value,exact", [("wgrad_ring", 0, False), ("wgrad_xcd", 0, False), ("conv_ring", 0, False), ("conv_ring", 2, False),
                                                 ("conv_stream", 0, True), ("stats_bins", 0, False), ("bn_bwd_fused", 1, False), ("fuse_bn_bwd", 0, False),
-                                                ("wgrad_pair_join", 1, True), ("nl_fwd", 1, False), ("bwd_bins", 1, False)])
+                                                ("wgrad_pair_join", 1, True), ("nl_fwd", 0, False), ("nl_max_c", 512, False), ("bwd_bins", 1, False)])
 def test_every_kernel_choice_option_gives_the_same_training_step(option, value, exact):
     """The runtime options that pick between kernels / schedules of the SAME arithmetic (round 3 added several: ring and
     persistent convolution kernels, the ring weight-gradient kernel, its XCD-aware K-split assignment, the one-launch BatchNorm
@@ -206,7 +206,7 @@ def test_every_kernel_choice_option_gives_the_same_training_step(option, value, 
     print(f"[options] {option}={value}: loss {other[0]:.6f} vs {base[0]:.6f}; all gradients: relative L2 {rel:.2e}, cosine {cos:.6f}")
     # (`conv_ring` and `stats_bins` change how the BatchNorm statistics of the FORWARD pass are summed - tile shapes / fp32 partial
     # rows vs fixed-point bins: the sums agree to ~1e-7, which is enough to move bf16 activations by an ulp here and there)
-    loose = option in ("conv_ring", "stats_bins", "nl_fwd")    # (`nl_fwd` 1 takes the deep layers off the ring kernels and off partial rows)
+    loose = option in ("conv_ring", "stats_bins", "nl_fwd", "nl_max_c")    # (normalise-on-load keeps its units' statistics in bins: rounding points move)
     if option == "stats_bins":
         # since the stem takes its statistics from its own fp32 accumulators (bins) too, `stats_bins` 0 changes the FIRST layer's batch
         # mean / variance by ~1e-4 sigma (test_stem_statistics_from_the_kernel_epilogue_match_the_sweep bounds it at 1e-3): a quarter of
@@ -243,11 +243,12 @@ def test_normalise_on_load_is_bit_identical_to_the_normalisation_sweep(kernels):
     # "tile": register-staged kernels throughout (conv_igemm_kernel<.., NLOAD>); "ring": the default LDS-DMA kernels, whose NLOAD form
     # normalises the landed pieces in LDS (conv_ring_kernel<.., NLOAD>) - in both cases statistics in bins for every layer
     pinned = {"conv_ring": 0, "wgrad_ring": 0, "bn_inline_rows": 0} if kernels == "tile" else {"bn_inline_rows": 0}
-    old = {k: L.lib.vs_get_option(k.encode()) for k in list(pinned) + ["nl_fwd"]}
+    old = {k: L.lib.vs_get_option(k.encode()) for k in list(pinned) + ["nl_fwd", "nl_max_c"]}
     try:
         for k, v in pinned.items():
             L.set_option(k, v)
         L.set_option("nl_fwd", 1)
+        L.set_option("nl_max_c", 512)          # every eligible unit, not only the default's six
         on = run()
         L.set_option("nl_fwd", 0)
         off = run()

@@ -410,7 +410,8 @@ def test_normalise_on_load_plan_is_the_one_reader_rule():
     BN + ReLU units without a normalisation sweep whose output has ONE reader, a stride-1 3x3 convolution on the register-staged kernels - for the
     headline network at batch 32 of 256 x 256 the 16 BasicBlock conv1 units and 7 decoder convolutions (the last three decoder
     outputs feed the strip kernels / the head: they keep their sweep), never a unit with a residual input, the stem, a downsample
-    1x1 or a unit whose output is a skip connection; none at all in fp32, or with the option off (the default)."""
+    1x1 or a unit whose output is a skip connection; none at all in fp32, or with the option off.  By default (`nl_max_c` 64) only
+    the six units of up to 64 channels among them."""
     import ctypes as C
 
     from volume_segmantics_amd import _lib as L
@@ -426,15 +427,21 @@ def test_normalise_on_load_plan_is_the_one_reader_rule():
         finally:
             L.lib.vs_unet_destroy(h)
 
-    old = L.lib.vs_get_option(b"nl_fwd")
+    old = L.lib.vs_get_option(b"nl_fwd"), L.lib.vs_get_option(b"nl_max_c")
+    assert old == (1, 64)       # the defaults: on, for producers of up to 64 channels (where it measures faster - DESIGN.md section 5)
     try:
         L.set_option("nl_fwd", 0)
         assert sum(plan(L.VS_BF16).values()) == 0
         L.set_option("nl_fwd", 1)
+        small = sorted(k for k, v in plan(L.VS_BF16).items() if v)
+        assert small == sorted(["encoder.layer1.0.conv1.weight", "encoder.layer1.1.conv1.weight", "encoder.layer1.2.conv1.weight",
+                                "decoder.blocks.2.conv1.0.weight", "decoder.blocks.2.conv2.0.weight", "decoder.blocks.3.conv1.0.weight"]), small
+        L.set_option("nl_max_c", 512)
         on = plan(L.VS_BF16)
         assert sum(plan(L.VS_F32).values()) == 0
     finally:
-        L.set_option("nl_fwd", old)
+        L.set_option("nl_fwd", old[0])
+        L.set_option("nl_max_c", old[1])
     chosen = sorted(k for k, v in on.items() if v)
     assert len(chosen) == 23, chosen
     assert sum(".conv1.weight" in k and k.startswith("encoder.layer") for k in chosen) == 16

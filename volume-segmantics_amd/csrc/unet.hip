@@ -1286,7 +1286,8 @@ int nl_consumer(const Ctx& c, int ui) {
     const int dt = net->dtype;
     const Unit& u = net->units[ui];
     if (dt != VS_BF16 || !vs_option("nl_fwd") || net->stats_hook) return -1;   // (cross-rank statistics: the sweep finalises)
-    if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0 || u.cout > 512) return -1;
+    if (u.kind != U_CONV || u.relu != 1 || u.res >= 0 || u.colr || u.gn_idx >= 0 || u.bias_idx >= 0 || u.bn_idx < 0 || u.cout > 512 ||
+        u.cout > vs_option("nl_max_c")) return -1;    // (the reader's table and per-chunk work grow with the channel count: per-unit table in DESIGN.md)
     ensure_graph_maps(net);
     const int vi = net->sole_consumer[u.out];
     if (vi <= ui) return -1;
