@@ -25,6 +25,11 @@ if not LIB_PATH.exists():
         f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         f"(or `make -C {_HERE / 'csrc'}`); there is no CPU fallback for the HIP path")
 
+# torch first: PyTorch-ROCm ships its own HIP runtime, and the library's dependency on libamdhip64 must resolve to THAT copy - loaded
+# the other way round (this module before torch, e.g. build() and smoke() in one process) the process holds two runtimes and the
+# second one finds "no ROCm-capable device"
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(str(LIB_PATH))
 
 
