@@ -52,11 +52,20 @@ def load_traffic(kernel_name: str, workload: str = "train"):
     for f in sorted((REPO / "profiles").glob(f"r*_pmc_traffic{'' if workload == 'train' else '_' + workload}.json"), reverse=True):
         try:
             d = json.loads(f.read_text())
-            t = d.get(kernel_name) or next((v for k, v in sorted(d.items()) if k.startswith(kernel_name)), None)   # (a name prefix: ring kernels)
+            t = d.get(kernel_name)
         except Exception:
-            t = None
+            continue
         if t:
             return dict(t, source=f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run)")
+        # a name PREFIX (the ring kernels: one variant code covers several instantiations, and `roofline.achieved` sums the
+        # time and the FLOPs of ALL their launches): launch-weighted mean over the same set of kernels
+        rows = [v for k, v in d.items() if isinstance(v, dict) and k.startswith(kernel_name) and v.get("launches")]
+        if rows:
+            n = sum(v["launches"] for v in rows)
+            out = {key: int(sum(v[key] * v["launches"] for v in rows) / n) for key in ("bytes_per_launch", "read_bytes_per_launch", "write_bytes_per_launch")
+                   if all(key in v for v in rows)}
+            return dict(out, kernels=len(rows), launches=n, correction=rows[0].get("correction"),
+                        source=f"profiles/{f.name} (committed rocprofv3 --pmc passes, not this run; launch-weighted over {len(rows)} instantiations)")
     return None
 
 

@@ -62,6 +62,37 @@ int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void* src1, con
  * reference counterpart: a test / tooling query (tests assert which path a parity case exercised). */
 int vs_conv2d_variant(const vs_conv_desc* d);
 
+/* The TRAINING forms of the same convolution launch - what the network plan (vs_unet_forward / vs_unet_backward) asks of it around a
+ * train-mode BatchNorm2d; exposed as one operator so that every kernel the batch-32 step selects (LDS-DMA ring tiles of 64 / 32
+ * couts, pairs of 8 x 8 images) can be held against torch with its training epilogue, at the launch sizes that select it.
+ * Every group is optional (NULL / 0 = off):
+ *  (a) statistics: the per-channel sum / sum of squares of the raw fp32 accumulators - F.batch_norm(training=True)'s batch
+ *      statistics inside smp.Unet.forward (vol_seg_2d_trainer.py:424) - either as 64-bit fixed-point bins ([stats_nb][2][cout], sums
+ *      scaled by vs_stat_scale(0) / (1), added atomically to what the caller zeroed; stats_nb a power of two) or as fp32 partial rows
+ *      ([vs_conv2d_stat_rows][2][cout]);
+ *  (b) pool0: the data gradient through nearest x2 upsampling (F.interpolate's backward, :429): channels < (y1 ? split_c : cout)
+ *      are summed over 2 x 2 pixel blocks and stored to y at half resolution;
+ *  (c) the first sweep of BatchNorm backward in the epilogue of the data gradient that completes a unit's activation gradient
+ *      (autograd's batch-norm + ReLU backward, :429): g = (acc + residual) masked by (by > 0) - or, by == NULL, by the recomputed
+ *      (bz - bmean) * binvstd * bgamma + bbeta > 0 - when brelu; y = g; bstats_partial [vs_conv2d_stat_rows][2][cout] = per-tile
+ *      sum g, sum g * (bz - bmean) * binvstd;
+ *  (d) normalise on load: src0 is the PRE-norm output of the producing unit whose statistics sit in nl_bins ([nl_nb][2][c0], nl_rows
+ *      rows each); the launch finalises them (nl_mean / nl_invstd out, running statistics nl_rm / nl_rv updated when given),
+ *      convolves relu((src0 - mean) * invstd * nl_gamma + nl_beta) rounded to the storage type, and leaves that activation in nl_y. */
+typedef struct vs_conv_train {
+    uint64_t* stats_bins; int32_t stats_nb; float* stats_partial;
+    int32_t pool0;
+    const void* bz; const void* by; const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta;
+    float* bstats_partial; int32_t brelu;
+    const uint64_t* nl_bins; int32_t nl_nb; int64_t nl_rows; float nl_eps, nl_mom;
+    float* nl_mean; float* nl_invstd; float* nl_rm; float* nl_rv; const float* nl_gamma; const float* nl_beta; void* nl_y;
+} vs_conv_train;
+int vs_conv2d_train(const vs_conv_desc* d, const void* src0, const void* src1, const void* w, const void* residual, void* y, void* y1,
+                    const vs_conv_train* t, void* stream);
+int vs_conv2d_train_variant(const vs_conv_desc* d, const vs_conv_train* t);   /* vs_conv2d_variant's code for that launch */
+int vs_conv2d_stat_rows(const vs_conv_desc* d, const vs_conv_train* t);      /* partial rows that launch writes (one per tile) */
+double vs_stat_scale(int which);   /* fixed-point scale of the bins: 0 = sum, 1 = sum of squares */
+
 /* dw[cout][kh*kw][cin] (fp32) = sum_pixels dy (x) x.  torch: conv weight gradient of loss.backward()
  * (vol_seg_2d_trainer.py:429).  workspace >= vs_conv2d_wgrad_workspace(d). */
 size_t vs_conv2d_wgrad_workspace(const vs_conv_desc* d);

@@ -24,12 +24,15 @@ def main():
     from volume_segmantics_amd.data.datasets import ArraySliceDataset, make_training_loaders
     from volume_segmantics_amd.engine import VolSegUnet
     from volume_segmantics_amd.model.operations.vol_seg_2d_trainer import VolSeg2dTrainer
-    imgs, masks, cut = _trainer_data(size=64)
+    sync = len(sys.argv) > 2 and sys.argv[2] == "sync"
+    # sync: 17 validation slices = two global batches of 8 + ONE slice - rank 1's share of the last global batch is empty, so the
+    # ranks run different numbers of validation batches: nothing in the validation loop may be a collective (the global Dice of
+    # `sync_batchnorm` is a training construct; HipDiceLoss drops the group under torch.no_grad())
+    imgs, masks, cut = _trainer_data(n_valid=17 if sync else 21, size=64)
     loaders = make_training_loaders(ArraySliceDataset(imgs[:cut], masks[:cut]), ArraySliceDataset(imgs[cut:], masks[cut:]), 4,
                                     rank, world, seed=7)
     settings = _trainer_settings()
     settings.precision = "bf16"
-    sync = len(sys.argv) > 2 and sys.argv[2] == "sync"
     if sync:      # BatchNorm statistics and the Dice loss of the GLOBAL batch (settings key sync_batchnorm)
         settings.sync_batchnorm = True
     torch.manual_seed(1000 + rank)        # different initial weights per rank: rank 0's must win through the broadcast

@@ -146,6 +146,60 @@ def test_prediction_does_not_depend_on_the_batch_size(predictor_and_golden, tmp_
         assert np.array_equal(out[bs][1].view(np.uint16), out[7][1].view(np.uint16)), bs
 
 
+def _blurred_volume(shape, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(shape).astype(np.float32)
+    for ax in range(3):      # cheap separable smoothing: the slices then look like images, not noise
+        v = (np.roll(v, 1, ax) + 2 * v + np.roll(v, -1, ax)) / 4
+    return np.clip(128 + 160 * v, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("precision,depth,batches", [("bf16", 131, (1, 3, 32, 128)), ("fp16", 131, (1, 32, 128)), ("fp32", 35, (1, 3, 32))])
+def test_prediction_at_512_does_not_depend_on_the_batch_size_across_the_kernel_thresholds(tmp_path, precision, depth, batches):
+    """The premise of leaving out the repeated directions (a repeat predicts what its twin predicted) and of every claim that the
+    batch size is a free parameter: a slice's label and fp16 probability bits do not depend on how many slices share its forward
+    pass.  The kernel chosen for a layer DOES depend on the launch size (csrc/conv_igemm.hip: `conv_direct_min_px`,
+    `conv_nw8_min_wgs`, `conv_min_wgs`, `conv_stream_min_tiles`, the persistent kernel's grid), so this runs 512 x 512 slices - where
+    batches of 1, 3, 32 and 128 land on different sides of every one of those thresholds - with a ragged last batch each (131 = 4 x 32
+    + 3 = 128 + 3), and compares every voxel bit for bit.  Reference: the batch loop of _predict_single_axis,
+    vol_seg_2d_predictor.py:38-58."""
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    _, path = _ckpt(tmp_path, 4)
+    pred = VolSeg2dPredictor(str(path), _settings(precision=precision))
+    assert pred.model.precision == precision
+    vol = _blurred_volume((depth, 512, 512), 77)
+    out = {}
+    for bs in batches:
+        pred.settings.prediction_batch_size = bs
+        out[bs] = pred._predict_single_axis(vol, axis=Axis.Z)
+    ref = out[batches[0]]
+    assert len(np.unique(ref[0])) >= 2
+    for bs in batches[1:]:
+        dl = int((out[bs][0] != ref[0]).sum())
+        dp = int((out[bs][1].view(np.uint16) != ref[1].view(np.uint16)).sum())
+        assert dl == 0 and dp == 0, f"batch {bs} vs batch {batches[0]}: {dl} labels, {dp} probabilities differ"
+
+
+def test_twelve_way_without_the_repeats_equals_all_twelve_when_twins_fall_into_ragged_batches(tmp_path):
+    """dedup_directions at 512-pixel slices with a batch size that does not divide the stacks: a repeated direction visits its twin's
+    slices in REVERSED order, so a slice that sat in a full batch in the twin lands in the ragged tail of the repeat (another
+    launch size, possibly another kernel).  Labels, fp16 probabilities and the vote volume must still be identical with and without
+    the four repeats.  Reference: _predict_12_ways_max_probs / _predict_12_ways_one_hot, vol_seg_2d_predictor.py:100-136."""
+    from volume_segmantics_amd.model.operations.vol_seg_2d_predictor import VolSeg2dPredictor
+    _, path = _ckpt(tmp_path, 4)
+    pred = VolSeg2dPredictor(str(path), _settings(precision="bf16", prediction_batch_size=27))
+    vol = _blurred_volume((45, 512, 480), 78)          # stacks of 45, 512 and 480 slices; 512 = 18 x 27 + 26, 480 = 17 x 27 + 21
+    res = {}
+    for dedup in (True, False):
+        pred.settings.dedup_directions = dedup
+        res[dedup] = (pred._predict_12_ways_max_probs(vol), pred._predict_12_ways_one_hot(vol))
+        assert pred.last_timings["directions_run"] == (8 if dedup else 12)
+    (l1, p1), v1 = res[True]
+    (l0, p0), v0 = res[False]
+    assert np.array_equal(l1, l0) and np.array_equal(p1.view(np.uint16), p0.view(np.uint16))
+    assert np.array_equal(v1, v0) and (v1.sum(0) == 12).all()
+
+
 def test_prediction_settings_precision_fp16_overrides_the_checkpoint(predictor_and_golden, tmp_path):
     """`precision: fp16` in the PREDICTION settings (BASELINE configs[4]) loads a checkpoint trained in any precision into the fp16
     inference engine: labels equal the reference golden's wherever the oracle's margin clears fp16's error, the fp16 probabilities
@@ -221,7 +275,7 @@ def test_prediction_manager_qualities_and_outputs(tmp_path):
         pred = mgr.predict_volume_to_path(out, q)
         assert pred.dtype == np.uint8 and out.exists()
         assert pred.shape == ((4,) + vol.shape if one_hot else vol.shape)
-        assert (tmp_path / f"out_{q.name}_{one_hot}_probs.npy").exists() == (not one_hot)
+        assert (tmp_path / f"out_{q.name}_{one_hot}_probs.h5").exists() == (not one_hot)     # the reference's hard-coded name (:94-98)
     assert mgr.predict_volume_to_path(None).shape == (4,) + vol.shape   # quality from settings ("low")... one_hot
 
 

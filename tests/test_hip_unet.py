@@ -155,10 +155,25 @@ def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
     """Every backward kernel, in the network, at the network's own shapes: recompute BN-backward, one dgrad
     per block and EVERY weight gradient in fp64 on the CPU from the engine's own saved tensors (so ReLU masks
     are identical by construction) and compare.  fp32: exact to rounding; bf16: to bf16 storage rounding."""
+    _backward_self_consistency(precision, 4, 64, torch.float64)
+
+
+def test_backward_self_consistency_at_the_headline_batch32_256():
+    """The same per-layer recomputation AT THE SIZE bench.py TIMES - U-Net / ResNet-34, 256 x 256, batch 32, bf16, the library's default
+    options - so the kernels held to account are the ones the step launches there: ring::conv_ring_kernel (64- and 32-cout tiles,
+    pairs of 8 x 8 images) with statistics bins and the fused BatchNorm-backward epilogue, conv_wgrad_ring_kernel with its split-K
+    slabs, the 8-wave and direct kernels of the shallow layers, normalise-on-load for the narrow units.  All 46 BatchNorm backward
+    passes, all 46 weight gradients and 21 data gradients against a CPU recomputation (fp32 here: the comparison is at bf16 storage
+    rounding, 2e-2) from the engine's own tensors.  Reference: loss.backward() of _train_one_batch (vol_seg_2d_trainer.py:429)."""
+    from volume_segmantics_amd import _lib as L
+    assert L.lib.vs_get_option(b"conv_ring") == 1 and L.lib.vs_get_option(b"wgrad_ring") == 1 and L.lib.vs_get_option(b"fuse_bn_bwd") == 1
+    _backward_self_consistency("bf16", 32, 256, torch.float32)
+
+
+def _backward_self_consistency(precision, B, hw, cpu_dtype):
     import ctypes as C
     import torch.nn.functional as F
     from volume_segmantics_amd import _lib as L
-    B, hw = 4, 64
     oracle, model, x, *_ = _train_pair(precision, B, hw)
     tight = precision == "fp32"
     plan = model._plans[(hw, hw)]
@@ -174,12 +189,12 @@ def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
         L.check(L.lib.vs_unet_debug_unit(plan["handle"], u, name, 128, C.byref(c), C.byref(h), C.byref(w), *[C.byref(o) for o in offs]))
         n_el = B * c.value * h.value * w.value
         def get(off, n_el=n_el, c=c.value, h=h.value, w=w.value):
-            return ws[off:off + n_el * esz].view(dt).view(B, h, w, c).cpu().double().permute(0, 3, 1, 2).contiguous()
+            return ws[off:off + n_el * esz].view(dt).view(B, h, w, c).cpu().to(cpu_dtype).permute(0, 3, 1, 2).contiguous()
         wn = name.value.decode()
         units[wn] = dict(a=get(offs[0].value), z=get(offs[1].value), da=get(offs[2].value), dz=get(offs[3].value)) if wn != "segmentation_head.0.weight" else {}
         order.append(wn)
-    sd = {k: v.double().cpu() for k, v in model.state_dict().items()}
-    grads = {n: p.grad.double().cpu() for n, p in model.named_parameters()}
+    sd = {k: v.to(cpu_dtype).cpu() for k, v in model.state_dict().items() if v.is_floating_point()}
+    grads = {n: p.grad.to(cpu_dtype).cpu() for n, p in model.named_parameters()}
     tol_op = 2e-5 if tight else 2e-2
     feats = {"f1": "encoder.conv1.weight", "f2": "encoder.layer1.2.conv2.weight", "f3": "encoder.layer2.3.conv2.weight",
              "f4": "encoder.layer3.5.conv2.weight", "f5": "encoder.layer4.2.conv2.weight"}
@@ -214,7 +229,7 @@ def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
         stride = 2 if (W.shape[0] != W.shape[1] and wn.startswith("encoder.layer") and "conv2" not in wn) else 1
         pad = W.shape[2] // 2
         if wn == "encoder.conv1.weight":
-            xin, stride, pad = x.double(), 2, 3
+            xin, stride, pad = x.to(cpu_dtype), 2, 3
         else:
             xin = conv_input(wn)
         if wn == "segmentation_head.0.weight":
@@ -226,11 +241,12 @@ def test_backward_self_consistency_in_network(precision, bn_bwd_fusion):
         relu = "downsample" not in wn
         dzm = t["da"] * (t["a"] > 0) if relu else t["da"]
         z = t["z"]
-        mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+        mean = z.double().mean((0, 2, 3), keepdim=True).to(cpu_dtype)
+        var = z.double().var((0, 2, 3), unbiased=False, keepdim=True).to(cpu_dtype)
         invstd = 1 / torch.sqrt(var + 1e-5)
         xh = (z - mean) * invstd
         M = z.numel() / z.shape[1]
-        db, dg = dzm.sum((0, 2, 3)), (dzm * xh).sum((0, 2, 3))
+        db, dg = dzm.double().sum((0, 2, 3)).to(cpu_dtype), (dzm * xh).double().sum((0, 2, 3)).to(cpu_dtype)
         ref_dz = sd[bn + ".weight"].view(1, -1, 1, 1) * invstd * (dzm - db.view(1, -1, 1, 1) / M - xh * dg.view(1, -1, 1, 1) / M)
         assert rel(t["dz"], ref_dz) < tol_op, ("bn_bwd", wn, rel(t["dz"], ref_dz))
         assert rel(grads[bn + ".bias"], db) < tol_op and rel(grads[bn + ".weight"], dg) < tol_op, ("bn grads", wn)

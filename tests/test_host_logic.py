@@ -499,3 +499,55 @@ def test_repeated_directions_are_exact_repeats_for_every_shape():
         assert found == REPEATED_DIRECTIONS, (shape, found)
         for later, earlier in REPEATED_DIRECTIONS.items():
             assert later > earlier and np.array_equal(views[later], views[earlier][::-1])
+
+
+def test_resident_feed_keeps_the_reference_label_range_error(tmp_path):
+    """utilities/base_data_utils.py:150-158 of the reference: F.one_hot raises "Class values must be smaller than num_classes" on the
+    first batch whose mask holds a value >= the label count (the classic 0 / 255 PNG with 2 labels).  The resident feed's masks
+    already live on the device, where prepare_training_batch's host check does not look: the loader checks its whole subset once
+    and raises the same error when iterated; in-range masks pass and the batches equal the DataLoader's."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from volume_segmantics_amd.data.datasets import ResidentSliceLoader, ShardedBatchSampler, VolSeg2dDataset
+    rng = np.random.default_rng(3)
+    for sub, top in (("bad", 255), ("ok", 1)):
+        (tmp_path / sub / "d").mkdir(parents=True); (tmp_path / sub / "s").mkdir()
+        for i in range(9):
+            Image.fromarray(rng.integers(0, 255, (32, 32), dtype=np.uint8)).save(tmp_path / sub / "d" / f"data_z_stack_{i}.png")
+            Image.fromarray((rng.integers(0, 2, (32, 32)) * top).astype(np.uint8)).save(tmp_path / sub / "s" / f"seg_z_stack_{i}.png")
+    for sub in ("bad", "ok"):
+        ds = VolSeg2dDataset(tmp_path / sub / "d", tmp_path / sub / "s", 32, augment="device")
+        loader = ResidentSliceLoader(ds, ShardedBatchSampler(len(ds), 4, shuffle=False, drop_last=False), "cpu")
+        assert loader.max_label == (255 if sub == "bad" else 1)
+        assert len(list(loader)) == 3          # no label count known yet: nothing to check against
+        loader.num_labels = 2                  # what VolSeg2dTrainer.__init__ sets
+        if sub == "bad":
+            with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
+                next(iter(loader))
+        else:
+            ref = DataLoader(ds, batch_sampler=ShardedBatchSampler(len(ds), 4, shuffle=False, drop_last=False))
+            for (xr, mr), (xl, ml) in zip(loader, ref):
+                assert torch.equal(xr, xl) and torch.equal(mr, ml)
+    assert ResidentSliceLoader.bytes_needed(768, 256) == 768 * 256 * 256 * 2
+
+
+def test_global_dice_is_a_training_construct_only():
+    """`sync_batchnorm` pairs SyncBatchNorm with the Dice of the GLOBAL batch (HipDiceLoss(global_group=...): one all-reduce inside the
+    loss).  In the validation loop the ranks run different numbers of batches when the last global batch is partial (a rank whose
+    share is empty skips it, data/datasets.py: ShardedBatchSampler), so the criterion must not communicate there: under
+    torch.no_grad() - and for logits that carry no gradient - the group is dropped."""
+    from types import SimpleNamespace as NS
+    from volume_segmantics_amd.data import losses
+    seen = []
+    orig = losses._FusedDiceFn.apply
+    losses._FusedDiceFn.apply = staticmethod(lambda i, t, e, g=None: seen.append(g) or 0.0)
+    try:
+        crit = losses.HipDiceLoss(global_group="WORLD")
+        fake = lambda rg: NS(is_cuda=True, dtype=torch.float32, dim=lambda: 4, shape=(2, 2, 8, 8), requires_grad=rg)
+        crit(fake(True), fake(False))
+        with torch.no_grad():
+            crit(fake(True), fake(False))
+        crit(fake(False), fake(False))
+    finally:
+        losses._FusedDiceFn.apply = orig
+    assert seen == ["WORLD", None, None]

@@ -38,6 +38,16 @@ class ConvDesc(C.Structure):
         "dtype", "n", "hin", "win", "c0", "c1", "up0", "cout", "kh", "kw", "stride", "pad", "relu", "out_f32", "split_c", "groups", "dilation")]
 
 
+class ConvTrain(C.Structure):
+    """vs_conv_train: the training forms of a convolution launch (statistics epilogue, pooled / masked data gradients, normalise on load)"""
+    _fields_ = [("stats_bins", C.c_void_p), ("stats_nb", C.c_int32), ("stats_partial", C.c_void_p), ("pool0", C.c_int32),
+                ("bz", C.c_void_p), ("by", C.c_void_p), ("bmean", C.c_void_p), ("binvstd", C.c_void_p), ("bgamma", C.c_void_p),
+                ("bbeta", C.c_void_p), ("bstats_partial", C.c_void_p), ("brelu", C.c_int32),
+                ("nl_bins", C.c_void_p), ("nl_nb", C.c_int32), ("nl_rows", C.c_int64), ("nl_eps", C.c_float), ("nl_mom", C.c_float),
+                ("nl_mean", C.c_void_p), ("nl_invstd", C.c_void_p), ("nl_rm", C.c_void_p), ("nl_rv", C.c_void_p),
+                ("nl_gamma", C.c_void_p), ("nl_beta", C.c_void_p), ("nl_y", C.c_void_p)]
+
+
 class DirMap(C.Structure):
     _fields_ = [("base", C.c_int64), ("ss", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)] + [
         (n, C.c_int32) for n in ("depth", "h", "w", "hp", "wp", "pad_top", "pad_left", "crop_top", "crop_left")]
@@ -61,6 +71,10 @@ _SIGS = {
     "vs_version": (I, []),
     "vs_conv2d_fwd": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "vs_conv2d_variant": (I, [C.POINTER(ConvDesc)]),
+    "vs_conv2d_train": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, C.POINTER(ConvTrain), P]),
+    "vs_conv2d_train_variant": (I, [C.POINTER(ConvDesc), C.POINTER(ConvTrain)]),
+    "vs_conv2d_stat_rows": (I, [C.POINTER(ConvDesc), C.POINTER(ConvTrain)]),
+    "vs_stat_scale": (C.c_double, [I]),
     "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),

@@ -61,6 +61,62 @@ extern "C" int vs_conv2d_variant(const vs_conv_desc* d) {
     return conv_igemm_variant(d->dtype, p);
 }
 
+// the training forms of the launch (statistics epilogue, pooled / masked data gradients, normalise on load): ConvParams as the
+// network plan fills it, from the flat C structure
+static int train_to_params(const vs_conv_desc* d, const vs_conv_train* t, ConvParams& p) {
+    int rc = desc_to_params(d, p);
+    if (rc) return rc;
+    VS_REQUIRE(t, "conv_train: null training block");
+    VS_REQUIRE(!(t->stats_bins && t->stats_partial), "conv_train: statistics go to bins OR partial rows");
+    VS_REQUIRE(!t->stats_bins || (t->stats_nb >= 1 && (t->stats_nb & (t->stats_nb - 1)) == 0), "conv_train: stats_nb must be a power of two");
+    p.stats_bins = (unsigned long long*)t->stats_bins; p.stats_nb = t->stats_nb; p.stats_partial = t->stats_partial;
+    p.pool0 = t->pool0;
+    p.bz = t->bz; p.by = t->by; p.bmean = t->bmean; p.binvstd = t->binvstd; p.bgamma = t->bgamma; p.bbeta = t->bbeta;
+    p.bstats_partial = t->bstats_partial; p.brelu = t->brelu;
+    if (t->nl_bins) {
+        VS_REQUIRE(t->nl_nb >= 1 && t->nl_rows >= 1 && t->nl_mean && t->nl_invstd && t->nl_gamma && t->nl_beta && t->nl_y,
+                   "conv_train: normalise-on-load needs its bins, row count, affine parameters and outputs");
+        p.nl_bins = (const unsigned long long*)t->nl_bins; p.nl_nb = t->nl_nb; p.nl_rows = t->nl_rows; p.nl_eps = t->nl_eps; p.nl_mom = t->nl_mom;
+        p.nl_mean = t->nl_mean; p.nl_invstd = t->nl_invstd; p.nl_rm = t->nl_rm; p.nl_rv = t->nl_rv;
+        p.nl_gamma = t->nl_gamma; p.nl_beta = t->nl_beta; p.nl_y = t->nl_y;
+    }
+    return VS_OK;
+}
+
+extern "C" int vs_conv2d_train(const vs_conv_desc* d, const void* src0, const void* src1, const void* w, const void* residual, void* y,
+                               void* y1, const vs_conv_train* t, void* stream) {
+    ConvParams p;
+    int rc = train_to_params(d, t, p);
+    if (rc) return rc;
+    VS_REQUIRE((d->c1 == 0) == (src1 == nullptr), "conv: src1 / c1 mismatch");
+    VS_REQUIRE((d->split_c > 0) == (y1 != nullptr), "conv: y1 / split_c mismatch");
+    p.src0 = src0; p.src1 = src1; p.w = w; p.residual = residual; p.out = y; p.out1 = y1;
+    if (p.pool0) VS_REQUIRE(conv_igemm_can_pool(p), "conv_train: no pooled epilogue for this geometry");
+    if (p.nl_bins) VS_REQUIRE(conv_igemm_nl_ok(d->dtype, p), "conv_train: no normalise-on-load form for this layer");
+    if (p.stats_bins) VS_REQUIRE(conv_igemm_bins_ok(d->dtype, p), "conv_train: this layer's kernel has no statistics bins");
+    return launch_conv_igemm(d->dtype, p, (hipStream_t)stream);
+}
+
+static void fake_pointers(const vs_conv_desc* d, ConvParams& p) {
+    p.src0 = (const void*)16; p.src1 = d->c1 ? (const void*)16 : nullptr; p.w = (const void*)16; p.out = (void*)16;
+    p.out1 = d->split_c > 0 ? (void*)16 : nullptr;
+}
+extern "C" int vs_conv2d_train_variant(const vs_conv_desc* d, const vs_conv_train* t) {
+    ConvParams p;
+    int rc = train_to_params(d, t, p);
+    if (rc) return rc;
+    fake_pointers(d, p);
+    return conv_igemm_variant(d->dtype, p);
+}
+extern "C" int vs_conv2d_stat_rows(const vs_conv_desc* d, const vs_conv_train* t) {
+    ConvParams p;
+    int rc = train_to_params(d, t, p);
+    if (rc) return rc;
+    fake_pointers(d, p);
+    return conv_igemm_stat_rows(d->dtype, p);
+}
+extern "C" double vs_stat_scale(int which) { return which == 0 ? kStatScale1 : kStatScale2; }
+
 static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
     VS_REQUIRE(d, "conv: null descriptor");
     p = WgradParams{};

@@ -6,6 +6,7 @@ and the batch is augmented and normalised in HBM by csrc/augment.hip (prepare_tr
 sample goes through the NumPy form in the loader workers, as the reference does it."""
 from __future__ import annotations
 
+import logging
 import re
 from pathlib import Path
 
@@ -166,18 +167,44 @@ class ResidentSliceLoader:
     def __init__(self, dataset, batch_sampler, device, decode_threads: int = 8):
         from concurrent.futures import ThreadPoolExecutor
         self.batch_sampler, self.device = batch_sampler, torch.device(device)
+        self.num_labels = None      # set by the trainer: the label-range check of the reference's F.one_hot (see __iter__)
         n = len(dataset)
-        with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:      # PIL releases the GIL while it decodes
-            pairs = list(pool.map(dataset.__getitem__, range(n)))
-        if n and pairs[0][0].dtype != torch.uint8:
+        if not n:
+            self.images = torch.empty((0, 1, 0, 0), dtype=torch.uint8, device=self.device)
+            self.masks = torch.empty((0, 0, 0), dtype=torch.uint8, device=self.device)
+            self.max_label = -1
+            return
+        first = dataset[0]
+        if first[0].dtype != torch.uint8:
             raise ValueError("ResidentSliceLoader needs raw uint8 pairs (VolSeg2dDataset(augment='device'))")
-        self.images = torch.stack([p[0] for p in pairs]).to(self.device) if n else torch.empty((0, 1, 0, 0), dtype=torch.uint8, device=self.device)
-        self.masks = torch.stack([p[1] for p in pairs]).to(self.device) if n else torch.empty((0, 0, 0), dtype=torch.uint8, device=self.device)
+        # decoded straight into two preallocated (pinned, when a GPU is there) host buffers: no list of n tensors plus a stacked copy
+        pin = self.device.type == "cuda"
+        images = torch.empty((n,) + tuple(first[0].shape), dtype=torch.uint8, pin_memory=pin)
+        masks = torch.empty((n,) + tuple(first[1].shape), dtype=torch.uint8, pin_memory=pin)
+
+        def decode(i):
+            img, msk = dataset[i] if i else first
+            images[i].copy_(img)
+            masks[i].copy_(msk)
+        with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:      # PIL releases the GIL while it decodes
+            list(pool.map(decode, range(n)))
+        self.images, self.masks = images.to(self.device), masks.to(self.device)
+        self.max_label = int(self.masks.max())      # one device reduction per loader, nothing per step
+
+    @staticmethod
+    def bytes_needed(n: int, image_size: int) -> int:
+        """HBM the resident copy of n slice pairs takes (uint8 image + uint8 mask)."""
+        return int(n) * int(image_size) * int(image_size) * 2
 
     def __len__(self):
         return len(self.batch_sampler)
 
     def __iter__(self):
+        if self.num_labels is not None and self.max_label >= self.num_labels:
+            # torch.nn.functional.one_hot in the reference's prepare_training_batch (utilities/base_data_utils.py:150-158) raises on
+            # the first such batch (e.g. 0 / 255 PNG masks with 2 labels); the device one-hot kernel would silently give such
+            # pixels an all-zero target.  The masks live on the device here, so the check is made once, on the whole subset
+            raise RuntimeError("Class values must be smaller than num_classes.")
         for idx in self.batch_sampler:
             if not idx:
                 yield None
@@ -212,6 +239,15 @@ def get_2d_training_dataloaders(image_dir: Path, label_dir: Path, settings, rank
     resident = getattr(settings, "resident_feed", None)
     if resident is None:      # default: on whenever the batches are augmented on the device anyway
         resident = mode == "device" and torch.cuda.is_available()
+    if resident and mode == "device" and torch.cuda.is_available() and getattr(settings, "resident_feed", None) is None:
+        # default-on only while the decoded subsets fit comfortably next to the training workspace: a quarter of the free HBM at most;
+        # larger training sets stream through the DataLoader as in the reference
+        free, _total = torch.cuda.mem_get_info()
+        need = ResidentSliceLoader.bytes_needed(n, settings.image_size)
+        if need > free // 4:
+            logging.info(f"Training set of {n} slice pairs ({need / 2**30:.1f} GiB decoded) does not fit the resident feed's share of "
+                         f"free device memory ({free / 2**30:.1f} GiB free): streaming through the DataLoader instead.")
+            resident = False
     if resident:
         if mode != "device":
             raise ValueError("resident_feed needs device-side augmentation (a GPU and an image_size that is a multiple of 8)")

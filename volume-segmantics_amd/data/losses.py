@@ -99,7 +99,11 @@ class HipDiceLoss(nn.Module):
 
     def forward(self, input, target):
         if input.is_cuda and input.dtype == torch.float32 and input.dim() >= 3 and input.shape == target.shape:
-            return _FusedDiceFn.apply(input, target, self.epsilon, self.global_group)
+            # the cross-rank Dice is a TRAINING construct (it pairs with SyncBatchNorm's global batch): under torch.no_grad() - the
+            # validation loop - every rank evaluates its own batches, whose count can differ between ranks when the last global
+            # batch is partial (a rank with an empty share skips it), so a collective there would be mismatched across ranks
+            group = self.global_group if (torch.is_grad_enabled() and input.requires_grad) else None
+            return _FusedDiceFn.apply(input, target, self.epsilon, group)
         return self._torch(input, target)
 
 

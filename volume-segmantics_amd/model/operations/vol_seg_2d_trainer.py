@@ -49,6 +49,9 @@ class VolSeg2dTrainer:
             loaders = get_2d_training_dataloaders(image_dir_path, label_dir_path, settings, self.rank, self.world)
         self.training_loader, self.validation_loader = loaders
         self.label_no = labels if isinstance(labels, int) else len(labels)
+        for loader in loaders:      # device-resident feeds check their label range themselves (the reference's F.one_hot raises per batch)
+            if hasattr(loader, "max_label"):
+                loader.num_labels = self.label_no
         self.codes = labels if isinstance(labels, dict) else {}
         self.settings = settings
         self.starting_lr, self.end_lr = float(settings.starting_lr), float(settings.end_lr)

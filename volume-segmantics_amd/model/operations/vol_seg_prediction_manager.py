@@ -49,6 +49,6 @@ class VolSeg2DPredictionManager(BaseDataManager):
             output_path = Path(output_path)
             utils.save_data_to_hdf5(prediction, output_path, chunking=self.input_data_chunking)
             if probs is not None and self.settings.output_probs:
-                utils.save_data_to_hdf5(probs, output_path.parent / f"{output_path.stem}_probs{output_path.suffix}",
-                                        chunking=self.input_data_chunking)
+                # the reference hard-codes the name: "<stem>_probs.h5" whatever the label file's suffix (:94-98)
+                utils.save_data_to_hdf5(probs, f"{output_path.parent / output_path.stem}_probs.h5", chunking=self.input_data_chunking)
         return prediction
