@@ -312,11 +312,36 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
+    int defer_reduce;                     // 1: leave the split-K slabs in `partials` ([nsplit][|dw|] fp32) and do NOT sum them into dw - the
+                                          // caller sums them later in launch_slab_reduce's order (the fused optimiser launch of a parameter
+                                          // group, optim.hip: slab_sum_canonical); with ONE split the result still goes straight to dw
+    int* nsplit_out;                      // optional (host): the number of K splits this launch used
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 // dw[i] = sum_k partials[k*n + i], fixed summation order
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);
+// the lane-group count G of the slab_reduce4_kernel<G> launch_slab_reduce picks for (n, nparts) - 1, 4 or 16 - or 0 when it takes the
+// scalar kernel (n not a multiple of 4, unaligned buffers): what a caller that sums the slabs itself must reproduce
+int slab_reduce_groups(const float* partials, const float* dw, size_t n, int nparts);
+// One element's sum over nparts slabs of n floats in exactly slab_reduce4_kernel<G>'s association: group g adds slabs g, g + G, g + 2 G, ..
+// four at a time into two accumulators, the groups' totals are added in order.  Bit-identical to launch_slab_reduce for G from
+// slab_reduce_groups (every float4 component is summed independently there).
+__device__ __forceinline__ float slab_sum_canonical(const float* __restrict__ partials, size_t n, size_t i, int nparts, int G) {
+    float a = 0.f;
+    for (int g = 0; g < G; ++g) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = g; k < nparts; k += 4 * G) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k + u * G < nparts) ? partials[(size_t)(k + u * G) * n + i] : 0.f;
+            s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3];
+        }
+        const float t = s0 + s1;
+        a = g ? a + t : t;
+    }
+    return a;
+}
 
 // ---- optimiser pieces used by the fused backward (optim.hip) -------------------------------------------------------------
 struct AdamwRanges { int n; long off[160]; long len[160]; };   // passed to the kernel by value

@@ -23,6 +23,7 @@
 // upsample + concat and the zero-stuffed stride-2 gradients, all folded into the piece addresses.
 #pragma once
 #include "conv_common.h"
+#include "prof.h"
 
 namespace ring {
 
@@ -63,7 +64,8 @@ __device__ __forceinline__ A reload_first_kernarg() {
 struct Geom {
     int tiles_h, tiles_w;            // pixel tiles per image (1 x 1 when a tile spans IMGS whole images)
     int groups, ctiles;              // pixel tiles over the whole batch, cout tiles
-    unsigned ct_magic, ti_magic, tw_magic;
+    int xcs, xgn, ctl;               // the 8 XCDs as (8 >> xcs) pixel-tile partitions x (1 << xcs) cout partitions; ctl = cout tiles per partition
+    unsigned ct_magic, ti_magic, tw_magic;   // ct_magic divides by ctl
     int out_nchw;
     unsigned long long* probe;       // phase timestamps (tools/conv_probe.py); null in normal operation
 };
@@ -101,11 +103,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_ring_kernel(ConvParams p, G
     unsigned long long tprobe[5];
     if (g.probe) tprobe[0] = wall_clock64();
 
-    // workgroup -> tile, XCD-aware (see conv_igemm_kernel): the cout tiles of one pixel tile run back to back on one XCD
+    // workgroup -> tile, XCD-aware (see conv_igemm_kernel): the cout tiles of one pixel tile run back to back on one XCD.  An XCD is
+    // (pixel-tile partition xg, cout partition xc): it fetches 1 / xgn of the input and 1 / (1 << xcs) of the weights - the split that
+    // keeps an XCD's share inside its 4 MB L2 (launch_ring: layer4's 4.7 MB of weights against 2 MB of activations want 2 x 4, the
+    // shallow layers 8 x 1)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int gl = g.ctiles == 1 ? slot : (int)__umulhi((unsigned)slot, g.ct_magic);
-    const int ytile = slot - gl * g.ctiles;
-    const int grp = gl * 8 + xcd;
+    const int xc = xcd & ((1 << g.xcs) - 1), xg = xcd >> g.xcs;
+    const int gl = g.ctl == 1 ? slot : (int)__umulhi((unsigned)slot, g.ct_magic);
+    const int ytile = xc * g.ctl + (slot - gl * g.ctl);
+    const int grp = gl * g.xgn + xg;
     if (grp >= g.groups) return;
     int n, h0, w0, nimg;
     if constexpr (IMGS > 1) {
@@ -397,13 +403,28 @@ int launch_ring(const ConvParams& p, int out_nchw, unsigned long long* probe, hi
     g.tiles_w = IMGS > 1 ? 1 : cdiv(p.Wout, TW);
     g.groups = IMGS > 1 ? cdiv(p.N, IMGS) : p.N * g.tiles_h * g.tiles_w;
     g.ctiles = cdiv(p.Cout, BN);
-    g.ct_magic = 0xffffffffu / (unsigned)g.ctiles + 1u;
+    {   // XCD split: minimise the bytes ONE XCD pulls through its L2 = weights / cout partitions + input / pixel-tile partitions
+        const double wb = (double)p.Cout * 9 * (p.C0 + p.C1) * 2.0;
+        const double ib = (double)p.N * ((double)(p.Hin >> (p.up0 ? 1 : 0)) * (p.Win >> (p.up0 ? 1 : 0)) * p.C0 + (double)p.Hin * p.Win * p.C1) * 2.0;
+        const int forced = vs_option("conv_ring_xc");      // 0 = choose; 1 / 2 / 4 / 8 = that many cout partitions (A / B runs)
+        int best = 0;
+        double best_cost = 0;
+        for (int xcs = 0; xcs <= 3; ++xcs) {
+            const int xc = 1 << xcs;
+            if (g.ctiles % xc) continue;
+            if (forced && xc != forced) continue;
+            const double cost = wb / xc + ib * xc / 8.0;
+            if (xcs == 0 || !best_cost || cost < best_cost * 0.9) { best = xcs; best_cost = cost; }      // (a clear win only: the 8 x 1 map also shares the patch among neighbours in time)
+        }
+        g.xcs = best; g.xgn = 8 >> best; g.ctl = g.ctiles >> best;
+    }
+    g.ct_magic = 0xffffffffu / (unsigned)g.ctl + 1u;
     g.ti_magic = 0xffffffffu / (unsigned)(g.tiles_h * g.tiles_w) + 1u;
     g.tw_magic = 0xffffffffu / (unsigned)g.tiles_w + 1u;
     g.out_nchw = out_nchw;
     g.probe = probe;
     VS_REQUIRE(g.tiles_h * g.tiles_w < 65536 && p.N < 65536, "conv_ring: tile grid too large");
-    const long nwg = (long)cdiv(g.groups, 8) * 8 * g.ctiles;
+    const long nwg = (long)cdiv(g.groups, g.xgn) * g.ctl * 8;
     VS_REQUIRE(nwg < (1L << 31), "conv_ring: tile grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, s, p, g);
     VS_LAUNCH_CHECK();

@@ -579,7 +579,8 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, g.ctiles * g.cchunks, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gg);
     VS_LAUNCH_CHECK();
-    if (g.nsplit == 1) return VS_OK;
+    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
+    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
@@ -603,7 +604,8 @@ int launch_ring_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
     const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, gr.npairs, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gr);
     VS_LAUNCH_CHECK();
-    if (g.nsplit == 1) return VS_OK;
+    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
+    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * 9 * (p.C0 + p.C1), g.nsplit, s);
 }
 
@@ -623,7 +625,8 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
-    if (g.nsplit == 1) return VS_OK;
+    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
+    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
@@ -734,14 +737,23 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restr
     }
 }
 
+int slab_reduce_groups(const float* partials, const float* dw, size_t n, int nparts) {
+    if ((n & 3) || ((uintptr_t)partials & 15) || ((uintptr_t)dw & 15)) return 0;
+    const size_t n4 = n / 4;
+    if (n4 >= 131072 || nparts < 8) return 1;
+    if (n4 >= 32768 || nparts < 32) return 4;
+    return 16;
+}
+
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s) {
-    if ((n & 3) || ((uintptr_t)partials & 15) || ((uintptr_t)dw & 15)) {
+    const int G = slab_reduce_groups(partials, dw, n, nparts);
+    if (G == 0) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int)n, 64)), dim3(256), 0, s, partials, dw, n, nparts);
     } else {
         const size_t n4 = n / 4;
-        if (n4 >= 131072 || nparts < 8)
+        if (G == 1)
             hipLaunchKernelGGL(slab_reduce4_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);
-        else if (n4 >= 32768 || nparts < 32)
+        else if (G == 4)
             hipLaunchKernelGGL(slab_reduce4_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);
         else
             hipLaunchKernelGGL(slab_reduce4_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float4*)partials, (float4*)dw, n4, nparts);

@@ -9,53 +9,86 @@ namespace {
 
 // torch.optim.AdamW (single tensor path): p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+struct AdamwScalars { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
+__device__ __forceinline__ AdamwScalars adamw_scalars(float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                      const float* __restrict__ hyper) {
+    // hyper (optional): the step's scalars in device memory, written by vs_train_hyper_set - a captured graph replays the launch with a
+    // new learning rate / beta1 / bias correction every step
+    if (hyper) return AdamwScalars{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+    return AdamwScalars{lr, b1, b2, eps, wd, bc1, bc2_sqrt};
+}
+// ONE definition of the element update for every kernel that applies it (flat, ranged, fused with the weight copies): the same
+// expression tree, hence the same fused multiply-adds, hence bit-identical parameters whichever launch carried the step
+__device__ __forceinline__ float adamw_element(float pi, float gi, float& m, float& v, const AdamwScalars& a) {
+    pi = pi * (1.f - a.lr * a.wd);
+    const float mi = a.b1 * m + (1.f - a.b1) * gi;
+    const float vi = a.b2 * v + (1.f - a.b2) * gi * gi;
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    pi -= (a.lr / a.bc1) * (mi / denom);
+    return pi;
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ mask, int64_t n, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
-    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; }
+    const AdamwScalars a = adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
-        const float gi = g[i];
-        float pi = p[i] * (1.f - lr * wd);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float mi = m[i], vi = v[i];
+        p[i] = adamw_element(p[i], g[i], mi, vi, a);
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
-        p[i] = pi;
     }
 }
 
 __global__ void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                     float* __restrict__ v, AdamwRanges r, float lr, float b1, float b2, float eps, float wd,
                                     float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
-    // hyper (optional): the step's scalars in device memory, written by vs_train_hyper_set - a captured graph replays this
-    // launch with a new learning rate / beta1 / bias correction every step
-    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; }
+    const AdamwScalars a = adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper);
     const long off = r.off[blockIdx.y];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.len[blockIdx.y]; i += (long)gridDim.x * blockDim.x) {
         const long k = off + i;
-        const float gi = g[k];
-        float pi = p[k] * (1.f - lr * wd);
-        const float mi = b1 * m[k] + (1.f - b1) * gi;
-        const float vi = b2 * v[k] + (1.f - b2) * gi * gi;
+        float mi = m[k], vi = v[k];
+        p[k] = adamw_element(p[k], g[k], mi, vi, a);
         m[k] = mi;
         v[k] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
-        p[k] = pi;
     }
 }
+
+// What the fused optimiser launch does to ONE weight on its way into the copies (weight_prepare_tile's `upd`): its gradient is the
+// sum of the layer's split-K slabs in launch_slab_reduce's order (written to the flat gradient buffer as well, where the caller's
+// param.grad views live) or, with no slabs, read from that buffer; then the AdamW element update.  widx = element offset inside the
+// layer's weight tensor; all pointers already offset to the layer.
+struct NoUpdate {
+    __device__ __forceinline__ float operator()(long, float v) const { return v; }
+};
+struct AdamwUpdate {
+    float* p; float* g; float* m; float* v;          // the layer's slices of the flat parameter / gradient / moment buffers
+    const float* slabs; size_t n; int nparts, G;     // split-K slabs of its weight gradient ([nparts][n]); nparts == 0: g holds the gradient
+    AdamwScalars a;
+    __device__ __forceinline__ float operator()(long widx, float w) const {
+        float gi;
+        if (nparts) { gi = slab_sum_canonical(slabs, n, (size_t)widx, nparts, G); g[widx] = gi; }
+        else gi = g[widx];
+        float mi = m[widx], vi = v[widx];
+        const float pn = adamw_element(w, gi, mi, vi, a);
+        m[widx] = mi;
+        v[widx] = vi;
+        p[widx] = pn;
+        return pn;
+    }
+};
 
 // One 32 x 32 (cout x cin) tile of one tap: w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps
 // flipped][cout_pad], optional).  cg > 0: grouped convolution with cg channels per group (cin == cout) - w is
 // [cout][taps][cg]; the tile is the super-group bx's diagonal 32 x 32 block, wc / wt rows are 32 long, and a weight lands in
 // its group's cg x cg sub-block (zeros elsewhere).  Threads: tx 0..31, ty 0..7.
-template <typename T>
+template <typename T, typename Upd>
 __device__ __forceinline__ void weight_prepare_tile(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout, int taps,
                                                     int cin, int cout_pad, int cg, int bx, int by, int tap, int tx, int ty,
-                                                    float (&tile)[32][33]) {
+                                                    float (&tile)[32][33], const Upd& upd) {
     const bool two_groups = cg == 255;      // radix-2 split-attention convolution (ResNeSt): cin -> cout = 2 cin in TWO groups; w is
     if (two_groups) cg = 0;                 // [cout][taps][cin / 2], the copies are dense [cout][taps][cin] with the other group's half zero
     const int ci0 = bx * 32, co0 = (cg ? bx : by) * 32;
@@ -65,14 +98,15 @@ __device__ __forceinline__ void weight_prepare_tile(const float* __restrict__ w,
         if (two_groups) {
             if (co < cout && ci < cin) {
                 const int half = cin / 2, cl = ci - (co / (cout / 2)) * half;
-                if (cl >= 0 && cl < half) v = w[((size_t)co * taps + tap) * half + cl];
+                if (cl >= 0 && cl < half) { const long widx = ((long)co * taps + tap) * half + cl; v = upd(widx, w[widx]); }
                 if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
             }
         } else if (cg) {
-            if (co / cg == ci / cg) v = w[((size_t)co * taps + tap) * cg + ci % cg];
+            if (co / cg == ci / cg) { const long widx = ((long)co * taps + tap) * cg + ci % cg; v = upd(widx, w[widx]); }
             if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * 32 + tx, v);
         } else if (co < cout && ci < cin) {
-            v = w[((size_t)co * taps + tap) * cin + ci];
+            const long widx = ((long)co * taps + tap) * cin + ci;
+            v = upd(widx, w[widx]);
             if (wc) Elem<T>::st(wc + ((size_t)co * taps + tap) * cin + ci, v);
         }
         tile[r][tx] = v;
@@ -92,7 +126,7 @@ template <typename T>
 __global__ void weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ wc, T* __restrict__ wt, int cout,
                                       int taps, int cin, int cout_pad, int cg) {
     __shared__ float tile[32][33];
-    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, threadIdx.y, tile);
+    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, threadIdx.y, tile, NoUpdate{});
 }
 
 // ConvTranspose2d(kernel 4, stride 2, padding 1) as a 3x3 convolution onto 4 * cout channels + pixel shuffle: output parity
@@ -140,10 +174,18 @@ struct PrepTable {
     long w_off[64], wc_off[64], wt_off[64];  // element offset into params; BYTE offsets into the workspace (-1 = none)
     short cout[64], cin[64], cout_pad[64];
     unsigned char taps[64], cg[64];          // cg: channels per group of a grouped convolution (0 = dense)
+    // fused optimiser step (weight_prepare_all_kernel<T, true>): per layer, whether AdamW runs (0 = frozen: copies only), where its
+    // split-K slabs start in the workspace (bytes), how many there are (0 = the gradient already sits in the flat buffer) and the
+    // lane-group count of the reduction whose summation order is reproduced (slab_reduce_groups)
+    long slab_off[64];
+    short nparts[64];
+    unsigned char G[64], update[64];
 };
 
-template <typename T>
-__global__ void weight_prepare_all_kernel(const float* __restrict__ params, char* __restrict__ ws, PrepTable t) {
+template <typename T, bool FUSED>
+__global__ void weight_prepare_all_kernel(float* __restrict__ params, char* __restrict__ ws, PrepTable t, float* __restrict__ grads,
+                                          float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float lr, float b1, float b2, float eps,
+                                          float wd, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
     __shared__ float tile[32][33];
     int l = 0;
     while (l + 1 < t.n && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
@@ -153,10 +195,20 @@ __global__ void weight_prepare_all_kernel(const float* __restrict__ params, char
     const int bx = b % cib; b /= cib;
     const int by = b % cob;
     const int tap = b / cob;
-    const float* w = params + t.w_off[l];
+    float* w = params + t.w_off[l];
     T* wc = t.wc_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wc_off[l]) : nullptr;
     T* wt = t.wt_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wt_off[l]) : nullptr;
-    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile);
+    if constexpr (FUSED) {
+        if (t.update[l]) {
+            const int per_row = (cg == 255) ? cin / 2 : (cg ? cg : cin);
+            AdamwUpdate u{w, grads + t.w_off[l], exp_avg + t.w_off[l], exp_avg_sq + t.w_off[l],
+                          t.nparts[l] ? reinterpret_cast<const float*>(ws + t.slab_off[l]) : nullptr, (size_t)cout * taps * per_row,
+                          t.nparts[l], t.G[l], adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper)};
+            weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, u);
+            return;
+        }
+    }
+    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, NoUpdate{});
 }
 
 // dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels); the same sweep leaves per-class partial sums
@@ -301,11 +353,9 @@ int launch_weight_prepare_grouped(int dtype, const float* w, void* wc, void* wt,
     return VS_OK;
 }
 
-int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
-                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
-                              const int* cg, hipStream_t s) {
+static int fill_prep_table(PrepTable& t, int n, const long* w_off, const long* wc_off, const long* wt_off, const int* cout, const int* taps,
+                           const int* cin, const int* cout_pad, const int* cg) {
     VS_REQUIRE(n <= 64, "weight_prepare_all: too many layers (%d)", n);
-    PrepTable t{};
     t.n = n;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -316,7 +366,39 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
         blocks += cdiv(cin[i], 32) * ((t.cg[i] && t.cg[i] != 255) ? 1 : cdiv(cout_pad[i] > cout[i] ? cout_pad[i] : cout[i], 32)) * taps[i];
     }
     t.first_block[n] = blocks;
-    VS_FOR_T(dtype, hipLaunchKernelGGL(weight_prepare_all_kernel<T>, dim3(blocks), dim3(256), 0, s, params, (char*)ws, t));
+    return VS_OK;
+}
+
+int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
+                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
+                              const int* cg, hipStream_t s) {
+    PrepTable t{};
+    int rc = fill_prep_table(t, n, w_off, wc_off, wt_off, cout, taps, cin, cout_pad, cg);
+    if (rc) return rc;
+    VS_FOR_T(dtype, hipLaunchKernelGGL((weight_prepare_all_kernel<T, false>), dim3(t.first_block[n]), dim3(256), 0, s, const_cast<float*>(params), (char*)ws, t,
+                                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, (const float*)nullptr));
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// The optimiser step of a parameter group's convolution weights and the derivation of their copies for the next forward in ONE
+// launch: per weight  gradient = sum of the layer's split-K slabs (slab_off / nparts / G; nparts 0: read from `grads`)  ->  AdamW
+// element update  ->  fp32 master, low-precision copy, flipped / transposed copy.  update[i] == 0 (a frozen layer): copies only.
+// Replaces, per group, one slab-reduction launch per layer + the AdamW launch over the group's slice + the weight-copy launch.
+int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, float* grads, void* ws, int n, const long* w_off, const long* wc_off,
+                             const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad, const int* cg,
+                             const long* slab_off, const int* nparts, const int* G, const int* update, hipStream_t s) {
+    PrepTable t{};
+    int rc = fill_prep_table(t, n, w_off, wc_off, wt_off, cout, taps, cin, cout_pad, cg);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        VS_REQUIRE(nparts[i] >= 0 && nparts[i] < 32768 && (nparts[i] == 0 || (G[i] == 1 || G[i] == 4 || G[i] == 16)), "adamw_prepare_all: bad slab description");
+        t.slab_off[i] = slab_off[i]; t.nparts[i] = (short)nparts[i]; t.G[i] = (unsigned char)G[i]; t.update[i] = (unsigned char)update[i];
+    }
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step);
+    const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
+    VS_FOR_T(dtype, hipLaunchKernelGGL((weight_prepare_all_kernel<T, true>), dim3(t.first_block[n]), dim3(256), 0, s, a.params, (char*)ws, t, grads,
+                                       a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

@@ -69,6 +69,9 @@ extern "C" int vs_fpa_combine_bwd(int dtype, const void* dy, const float* plane,
 extern "C" int vs_sigmoid(int dtype, const void* x, void* y, int64_t elems, void* stream);
 extern "C" int vs_sigmoid_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t elems, void* stream);
 extern "C" int vs_bn_fold_bias(const float* scale, const float* bias, float* shift, int c, void* stream);
+int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, float* grads, void* ws, int n, const long* w_off, const long* wc_off,
+                             const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad, const int* cg,
+                             const long* slab_off, const int* nparts, const int* G, const int* update, hipStream_t s);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -155,6 +158,8 @@ struct Unit {
     size_t off_bins = 0;                         // stat_bins_rows(cout) rows of fixed-point statistics bins ([row][2][cout] 64-bit), training plans
     size_t off_bbins = 0;                        // the same shape again for the BatchNorm-backward sums (ConvParams::bstats_bins); 0 = none
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
+    size_t off_slab = 0, slab_bytes = 0;         // this unit's OWN split-K slab region (plain dense U_CONV of training plans): with the fused
+                                                 // optimiser step the slabs stay here until the group's one update launch sums them
     std::vector<int> tens;                       // U_FPA: parameter tensor indices
     size_t off_fpa_pool = 0, off_fpa_arena = 0, off_fpa_plane = 0;   // U_FPA: pooled input, pyramid arena (fp32), attention plane (fp32)
     std::vector<int> members;                    // U_CONCAT: the activations whose channels `out` strings together, in order
@@ -225,6 +230,8 @@ struct vs_unet {
     size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
+    std::vector<int> slab_parts;   // per unit: K splits its weight gradient left UNSUMMED in Unit::off_slab in the current backward
+                                   // (0: the gradient is complete in the flat buffer)
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
     static constexpr int kSide = 2;
@@ -1171,6 +1178,16 @@ size_t plan_workspace(vs_unet* net) {
     }
     net->wgws_bytes = wg;
     net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
+    // ... and a region of its own for every plain dense convolution: with the optimiser step fused into backward the split-K slabs
+    // of a whole parameter group stay unsummed until the group's ONE update launch reads them (unet_backward_range: group_update)
+    for (auto& u : net->units) {
+        if (u.kind != U_CONV || u.cg || u.g2 || u.colr || u.w_idx < 0) continue;
+        WgradParams p{};
+        p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = (int)N; p.Hin = u.hin; p.Win = u.win;
+        p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k; p.Cout = u.cout; p.dil = u.dil;
+        u.slab_bytes = wgrad_workspace_bytes(net->dtype, p);
+        u.off_slab = take(u.slab_bytes);
+    }
     {
         const Unit& hd = net->units.back();
         net->off_headdw = take((size_t)16 * hd.k * hd.k * hd.cin0 * sizeof(float));
@@ -1963,13 +1980,19 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     const int dt = net->dtype;
     const int other = net->wset ^ 1;
     AdamwRanges r{};
-    long w_off[64], wc_off[64], wt_off[64];
-    int cout[64], taps[64], cin[64], cpad[64], cgs[64], nl = 0;
+    long w_off[64], wc_off[64], wt_off[64], slab_off[64];
+    int cout[64], taps[64], cin[64], cpad[64], cgs[64], nparts[64], Gs[64], upd[64], nl = 0;
     int rc;
+    // The convolution weights of the range take their AdamW step INSIDE the launch that derives their copies (and sums their
+    // weight gradient's split-K slabs there too, where side_wgrad left them unsummed): one launch for the range's convolutions,
+    // one for everything else (BatchNorm affine parameters, biases, the stem, depthwise / attention tensors)
+    const bool fused_copy = vs_option("fuse_adamw_prepare") != 0;     // 0: AdamW over the convolution weights' ranges, then a plain copy launch
     auto flush = [&]() -> int {
         int rc2;
         if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
-        if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
+        if (nl && fused_copy && (rc2 = launch_adamw_prepare_all(dt, opt, const_cast<float*>(grads), c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad,
+                                                                cgs, slab_off, nparts, Gs, upd, s))) return rc2;
+        if (nl && !fused_copy && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
         r.n = 0; nl = 0;
         return VS_OK;
     };
@@ -1986,7 +2009,8 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
         if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
-        if (v.w_idx >= 0 && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
+        const bool conv_w = v.kind == U_CONV || v.kind == U_HEAD;          // its weight is updated by the fused copy launch below
+        if (v.w_idx >= 0 && !(conv_w && fused_copy) && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         const bool aux_on = !(v.aux_frozen && !need_encoder_wgrad);      // (ResNeSt: BatchNorms / biases named conv2.bn0, conv2.fc1, conv1.1 ..)
         if (v.bn_idx >= 0 && aux_on) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
@@ -1997,6 +2021,15 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
             wt_off[nl] = (long)Ctx::wt_off(v, other);
             cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
             cgs[nl] = v.g2 ? 255 : v.cg;
+            upd[nl] = !(v.frozen_candidate && !need_encoder_wgrad);
+            nparts[nl] = (upd[nl] && k < (int)net->slab_parts.size()) ? net->slab_parts[k] : 0;
+            slab_off[nl] = (long)v.off_slab;
+            Gs[nl] = 0;
+            if (nparts[nl]) {
+                const size_t nel = (size_t)v.cout * taps[nl] * cin[nl];
+                Gs[nl] = slab_reduce_groups((const float*)(c.ws + v.off_slab), grads + c.t(v.w_idx).offset, nel, nparts[nl]);
+                VS_REQUIRE(Gs[nl] > 0, "update_units: unit %d left slabs that launch_slab_reduce would sum with its scalar kernel", k);
+            }
             ++nl;
         }
     }
@@ -2095,6 +2128,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     const bool pair_sched = use_side && vs_option("wgrad_pair_join") == 2;
     int last_pair = -1;
     bool defer_group_update = pair_join || pair_sched;
+    const bool defer_slabs = opt != nullptr && do_side && vs_option("fuse_slab_sum") != 0 && vs_option("fuse_adamw_prepare") != 0;
+    if (net->slab_parts.size() != net->units.size()) net->slab_parts.assign(net->units.size(), 0);
     if (pair_join || pair_sched) {
         while (net->pair_events.size() < net->units.size()) {
             hipEvent_t e;
@@ -2158,7 +2193,17 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                                             hipMemcpyDeviceToDevice, ws_stream));
             } else {
                 p.dw = grads + c.t(u.w_idx).offset;
+                // fused optimiser step: the K splits stay unsummed in the unit's own slab region; the group's update launch sums
+                // them in launch_slab_reduce's order (no reduction launch, no write + re-read of the gradient in between)
+                int nsplit = 0;
+                const size_t nel = (size_t)dz_c * p.KH * p.KW * (p.C0 + p.C1);
+                if (defer_slabs && u.kind == U_CONV && u.slab_bytes && wgrad_workspace_bytes(dt, p) <= u.slab_bytes &&
+                    slab_reduce_groups((const float*)(c.ws + u.off_slab), p.dw, nel, 2) > 0) {
+                    p.partials = (float*)(c.ws + u.off_slab); p.partial_bytes = u.slab_bytes;
+                    p.defer_reduce = 1; p.nsplit_out = &nsplit;
+                }
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                net->slab_parts[ui] = (p.defer_reduce && nsplit > 1) ? nsplit : 0;
             }
         } else {
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
