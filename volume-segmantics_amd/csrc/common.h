@@ -313,8 +313,8 @@ struct WgradParams {
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
     int defer_reduce;                     // 1: leave the split-K slabs in `partials` ([nsplit][|dw|] fp32) and do NOT sum them into dw - the
-                                          // caller sums them later in launch_slab_reduce's order (the fused optimiser launch of a parameter
-                                          // group, optim.hip: slab_sum_canonical); with ONE split the result still goes straight to dw
+                                          // caller sums them later with launch_slab_reduce's own arithmetic (one launch for a whole parameter
+                                          // group, optim.hip: launch_group_reduce_adamw); with ONE split the result still goes straight to dw
     int* nsplit_out;                      // optional (host): the number of K splits this launch used
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
@@ -322,27 +322,44 @@ int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 // dw[i] = sum_k partials[k*n + i], fixed summation order
 int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, hipStream_t s);
 // the lane-group count G of the slab_reduce4_kernel<G> launch_slab_reduce picks for (n, nparts) - 1, 4 or 16 - or 0 when it takes the
-// scalar kernel (n not a multiple of 4, unaligned buffers): what a caller that sums the slabs itself must reproduce
+// scalar kernel (n not a multiple of 4, unaligned buffers): a launch that sums several layers' slabs at once uses the same body
 int slab_reduce_groups(const float* partials, const float* dw, size_t n, int nparts);
-// One element's sum over nparts slabs of n floats in exactly slab_reduce4_kernel<G>'s association: group g adds slabs g, g + G, g + 2 G, ..
-// four at a time into two accumulators, the groups' totals are added in order.  Bit-identical to launch_slab_reduce for G from
-// slab_reduce_groups (every float4 component is summed independently there).
-__device__ __forceinline__ float slab_sum_canonical(const float* __restrict__ partials, size_t n, size_t i, int nparts, int G) {
-    float a = 0.f;
-    for (int g = 0; g < G; ++g) {
-        float s0 = 0.f, s1 = 0.f;
+// dw = sum over the split-K slabs, 16 bytes per lane: thread (j, g) of a block sums slabs g, g + G, g + 2 G, .. of four
+// consecutive outputs (two accumulators, four loads in flight), the G groups of an output meet in LDS in a fixed order -
+// bitwise reproducible.  G widens the grid for the small tensors (64 x 9 x 64 outputs summed over 128 slabs).  `bid` = the block's
+// index among the cdiv(n4, 256 / G) blocks of this tensor (a per-layer launch passes blockIdx.x, the per-group launch its offset).
+template <int G>
+__device__ __forceinline__ void slab_reduce4_body(const float4* __restrict__ partials, float4* __restrict__ dw, size_t n4, int nparts, unsigned bid) {
+    constexpr int J = 256 / G;
+    __shared__ float4 red[G][J];
+    const int j = threadIdx.x % J, g = threadIdx.x / J;
+    const size_t i = (size_t)bid * J + j;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i < n4) {
         for (int k = g; k < nparts; k += 4 * G) {
-            float v[4];
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (k + u * G < nparts) ? partials[(size_t)(k + u * G) * n + i] : 0.f;
-            s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3];
+            for (int u = 0; u < 4; ++u) v[u] = (k + u * G < nparts) ? partials[(size_t)(k + u * G) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s0.x += v[0].x; s0.y += v[0].y; s0.z += v[0].z; s0.w += v[0].w;
+            s1.x += v[1].x; s1.y += v[1].y; s1.z += v[1].z; s1.w += v[1].w;
+            s0.x += v[2].x; s0.y += v[2].y; s0.z += v[2].z; s0.w += v[2].w;
+            s1.x += v[3].x; s1.y += v[3].y; s1.z += v[3].z; s1.w += v[3].w;
         }
-        const float t = s0 + s1;
-        a = g ? a + t : t;
     }
-    return a;
+    const float4 t = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    if constexpr (G == 1) {
+        if (i < n4) dw[i] = t;
+    } else {
+        red[g][j] = t;
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            float4 a = red[0][j];
+#pragma unroll
+            for (int q = 1; q < G; ++q) { a.x += red[q][j].x; a.y += red[q][j].y; a.z += red[q][j].z; a.w += red[q][j].w; }
+            dw[i] = a;
+        }
+    }
 }
-
 // ---- optimiser pieces used by the fused backward (optim.hip) -------------------------------------------------------------
 struct AdamwRanges { int n; long off[160]; long len[160]; };   // passed to the kernel by value
 int launch_adamw_slice(const vs_adamw_args& a, const float* grads, int64_t off, int64_t n, hipStream_t s);

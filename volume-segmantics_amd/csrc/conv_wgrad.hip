@@ -701,40 +701,10 @@ int dispatch(const WgradParams& p, hipStream_t s) {
 
 }  // namespace
 
-// dw = sum over the split-K slabs, 16 bytes per lane: thread (j, g) of a block sums slabs g, g + G, g + 2 G, .. of four
-// consecutive outputs (two accumulators, four loads in flight), the G groups of an output meet in LDS in a fixed order -
-// bitwise reproducible.  G widens the grid for the small tensors (64 x 9 x 64 outputs summed over 128 slabs).
+// (slab_reduce4_body<G> lives in common.h: the per-layer kernel below and the per-group launch of optim.hip share it)
 template <int G>
 __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restrict__ partials, float4* __restrict__ dw, size_t n4, int nparts) {
-    constexpr int J = 256 / G;
-    __shared__ float4 red[G][J];
-    const int j = threadIdx.x % J, g = threadIdx.x / J;
-    const size_t i = (size_t)blockIdx.x * J + j;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    if (i < n4) {
-        for (int k = g; k < nparts; k += 4 * G) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (k + u * G < nparts) ? partials[(size_t)(k + u * G) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s0.x += v[0].x; s0.y += v[0].y; s0.z += v[0].z; s0.w += v[0].w;
-            s1.x += v[1].x; s1.y += v[1].y; s1.z += v[1].z; s1.w += v[1].w;
-            s0.x += v[2].x; s0.y += v[2].y; s0.z += v[2].z; s0.w += v[2].w;
-            s1.x += v[3].x; s1.y += v[3].y; s1.z += v[3].z; s1.w += v[3].w;
-        }
-    }
-    const float4 t = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-    if constexpr (G == 1) {
-        if (i < n4) dw[i] = t;
-    } else {
-        red[g][j] = t;
-        __syncthreads();
-        if (g == 0 && i < n4) {
-            float4 a = red[0][j];
-#pragma unroll
-            for (int q = 1; q < G; ++q) { a.x += red[q][j].x; a.y += red[q][j].y; a.z += red[q][j].z; a.w += red[q][j].w; }
-            dw[i] = a;
-        }
-    }
+    slab_reduce4_body<G>(partials, dw, n4, nparts, blockIdx.x);
 }
 
 int slab_reduce_groups(const float* partials, const float* dw, size_t n, int nparts) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -57,29 +58,69 @@ __global__ void adamw_ranges_kernel(float* __restrict__ p, const float* __restri
     }
 }
 
-// What the fused optimiser launch does to ONE weight on its way into the copies (weight_prepare_tile's `upd`): its gradient is the
-// sum of the layer's split-K slabs in launch_slab_reduce's order (written to the flat gradient buffer as well, where the caller's
-// param.grad views live) or, with no slabs, read from that buffer; then the AdamW element update.  widx = element offset inside the
-// layer's weight tensor; all pointers already offset to the layer.
+// What the fused optimiser launch does to ONE weight on its way into the copies (weight_prepare_tile's `upd`): the AdamW element
+// update with the gradient from the flat buffer.  widx = element offset inside the layer's weight tensor; pointers offset to the layer.
 struct NoUpdate {
     __device__ __forceinline__ float operator()(long, float v) const { return v; }
 };
 struct AdamwUpdate {
-    float* p; float* g; float* m; float* v;          // the layer's slices of the flat parameter / gradient / moment buffers
-    const float* slabs; size_t n; int nparts, G;     // split-K slabs of its weight gradient ([nparts][n]); nparts == 0: g holds the gradient
+    float* p; const float* g; float* m; float* v;    // the layer's slices of the flat parameter / gradient / moment buffers
     AdamwScalars a;
     __device__ __forceinline__ float operator()(long widx, float w) const {
-        float gi;
-        if (nparts) { gi = slab_sum_canonical(slabs, n, (size_t)widx, nparts, G); g[widx] = gi; }
-        else gi = g[widx];
         float mi = m[widx], vi = v[widx];
-        const float pn = adamw_element(w, gi, mi, vi, a);
+        const float pn = adamw_element(w, g[widx], mi, vi, a);
         m[widx] = mi;
         v[widx] = vi;
         p[widx] = pn;
         return pn;
     }
 };
+
+// ONE launch in front of a parameter group's fused update: (a) the split-K slabs of every weight gradient of the group summed into the
+// flat gradient buffer - per layer exactly launch_slab_reduce's kernel body and lane-group count, so the bits do not depend on
+// whether a layer was reduced alone or with its group - and (b) the AdamW step of the group's SMALL tensors (BatchNorm affine
+// parameters, biases, the stem: ranges of the flat buffers), which depend on nothing in (a).  Replaces one reduction launch per
+// layer (42 per step for U-Net / ResNet-34) and the ranged AdamW launch.
+struct GroupTable {
+    int nred, nrng;
+    int first_block[49];                 // reduce role: first block of each layer; first_block[nred] = blocks of the role
+    long slab_off[48], dw_off[48];       // BYTE offset of the layer's slabs in the workspace; element offset of its gradient
+    int n4[48];                          // |dw| / 4
+    short nparts[48];
+    unsigned char G[48];
+    int rfirst[97];                      // range role: first block of each range, relative to the role's first block
+    long roff[96], rlen[96];
+};
+__global__ __launch_bounds__(256) void group_reduce_adamw_kernel(GroupTable t, const char* __restrict__ ws, float* __restrict__ grads,
+                                                               float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float lr,
+                                                               float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                               const float* __restrict__ hyper) {
+    const int nrb = t.first_block[t.nred];
+    if ((int)blockIdx.x < nrb) {
+        int l = 0;
+        while (l + 1 < t.nred && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
+        const float4* partials = reinterpret_cast<const float4*>(ws + t.slab_off[l]);
+        float4* dw = reinterpret_cast<float4*>(grads + t.dw_off[l]);
+        const unsigned bid = blockIdx.x - t.first_block[l];
+        if (t.G[l] == 1) slab_reduce4_body<1>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
+        else if (t.G[l] == 4) slab_reduce4_body<4>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
+        else slab_reduce4_body<16>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
+        return;
+    }
+    const int b = blockIdx.x - nrb;
+    int r = 0;
+    while (r + 1 < t.nrng && b >= t.rfirst[r + 1]) ++r;
+    const AdamwScalars a = adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper);
+    const int nb = t.rfirst[r + 1] - t.rfirst[r];
+    const long off = t.roff[r];
+    for (long i = (long)(b - t.rfirst[r]) * 256 + threadIdx.x; i < t.rlen[r]; i += (long)nb * 256) {
+        const long k = off + i;
+        float mi = m[k], vi = v[k];
+        p[k] = adamw_element(p[k], grads[k], mi, vi, a);
+        m[k] = mi;
+        v[k] = vi;
+    }
+}
 
 // One 32 x 32 (cout x cin) tile of one tap: w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps
 // flipped][cout_pad], optional).  cg > 0: grouped convolution with cg channels per group (cin == cout) - w is
@@ -174,41 +215,39 @@ struct PrepTable {
     long w_off[64], wc_off[64], wt_off[64];  // element offset into params; BYTE offsets into the workspace (-1 = none)
     short cout[64], cin[64], cout_pad[64];
     unsigned char taps[64], cg[64];          // cg: channels per group of a grouped convolution (0 = dense)
-    // fused optimiser step (weight_prepare_all_kernel<T, true>): per layer, whether AdamW runs (0 = frozen: copies only), where its
-    // split-K slabs start in the workspace (bytes), how many there are (0 = the gradient already sits in the flat buffer) and the
-    // lane-group count of the reduction whose summation order is reproduced (slab_reduce_groups)
-    long slab_off[64];
-    short nparts[64];
-    unsigned char G[64], update[64];
+    unsigned char update[64];                // fused optimiser step (weight_prepare_all_kernel<T, true>): AdamW runs on this layer (0 = frozen: copies only)
 };
 
 template <typename T, bool FUSED>
-__global__ void weight_prepare_all_kernel(float* __restrict__ params, char* __restrict__ ws, PrepTable t, float* __restrict__ grads,
+__global__ void weight_prepare_all_kernel(float* __restrict__ params, char* __restrict__ ws, PrepTable t, const float* __restrict__ grads,
                                           float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float lr, float b1, float b2, float eps,
                                           float wd, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
     __shared__ float tile[32][33];
+    // (the grid may be capped below the tile count - launch_adamw_prepare_all: a training step's optimiser launches share the chip with
+    // the backward pass and need not finish fast - so a block walks tiles blockIdx.x, + gridDim.x, ..)
     int l = 0;
-    while (l + 1 < t.n && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
-    const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l], cg = t.cg[l];
-    const int cib = (cin + 31) / 32, cob = (cg && cg != 255) ? 1 : ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
-    int b = blockIdx.x - t.first_block[l];
-    const int bx = b % cib; b /= cib;
-    const int by = b % cob;
-    const int tap = b / cob;
-    float* w = params + t.w_off[l];
-    T* wc = t.wc_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wc_off[l]) : nullptr;
-    T* wt = t.wt_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wt_off[l]) : nullptr;
-    if constexpr (FUSED) {
-        if (t.update[l]) {
-            const int per_row = (cg == 255) ? cin / 2 : (cg ? cg : cin);
-            AdamwUpdate u{w, grads + t.w_off[l], exp_avg + t.w_off[l], exp_avg_sq + t.w_off[l],
-                          t.nparts[l] ? reinterpret_cast<const float*>(ws + t.slab_off[l]) : nullptr, (size_t)cout * taps * per_row,
-                          t.nparts[l], t.G[l], adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper)};
-            weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, u);
-            return;
+    for (int tb = blockIdx.x; tb < t.first_block[t.n]; tb += gridDim.x) {
+        while (l + 1 < t.n && tb >= t.first_block[l + 1]) ++l;
+        const int cout = t.cout[l], cin = t.cin[l], cout_pad = t.cout_pad[l], taps = t.taps[l], cg = t.cg[l];
+        const int cib = (cin + 31) / 32, cob = (cg && cg != 255) ? 1 : ((cout_pad > cout ? cout_pad : cout) + 31) / 32;
+        int b = tb - t.first_block[l];
+        const int bx = b % cib; b /= cib;
+        const int by = b % cob;
+        const int tap = b / cob;
+        float* w = params + t.w_off[l];
+        T* wc = t.wc_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wc_off[l]) : nullptr;
+        T* wt = t.wt_off[l] >= 0 ? reinterpret_cast<T*>(ws + t.wt_off[l]) : nullptr;
+        if (tb != (int)blockIdx.x) __syncthreads();      // the previous tile's transposed reads are done
+        bool done = false;
+        if constexpr (FUSED) {
+            if (t.update[l]) {
+                AdamwUpdate u{w, grads + t.w_off[l], exp_avg + t.w_off[l], exp_avg_sq + t.w_off[l], adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper)};
+                weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, u);
+                done = true;
+            }
         }
+        if (!done) weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, NoUpdate{});
     }
-    weight_prepare_tile<T>(w, wc, wt, cout, taps, cin, cout_pad, cg, bx, by, tap, threadIdx.x & 31, threadIdx.x >> 5, tile, NoUpdate{});
 }
 
 // dlogits (n, K, h, w) fp32 NCHW -> [n*h*w][16] T (zero padded channels); the same sweep leaves per-class partial sums
@@ -382,23 +421,52 @@ int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, c
 }
 
 // The optimiser step of a parameter group's convolution weights and the derivation of their copies for the next forward in ONE
-// launch: per weight  gradient = sum of the layer's split-K slabs (slab_off / nparts / G; nparts 0: read from `grads`)  ->  AdamW
-// element update  ->  fp32 master, low-precision copy, flipped / transposed copy.  update[i] == 0 (a frozen layer): copies only.
-// Replaces, per group, one slab-reduction launch per layer + the AdamW launch over the group's slice + the weight-copy launch.
-int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, float* grads, void* ws, int n, const long* w_off, const long* wc_off,
+// launch: per weight  AdamW element update (gradient from the flat buffer)  ->  fp32 master, low-precision copy, flipped /
+// transposed copy.  update[i] == 0 (a frozen layer): copies only.  Replaces the AdamW launch over the group's slice + the copy launch.
+int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, const float* grads, void* ws, int n, const long* w_off, const long* wc_off,
                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad, const int* cg,
-                             const long* slab_off, const int* nparts, const int* G, const int* update, hipStream_t s) {
+                             const int* update, hipStream_t s) {
     PrepTable t{};
     int rc = fill_prep_table(t, n, w_off, wc_off, wt_off, cout, taps, cin, cout_pad, cg);
     if (rc) return rc;
-    for (int i = 0; i < n; ++i) {
-        VS_REQUIRE(nparts[i] >= 0 && nparts[i] < 32768 && (nparts[i] == 0 || (G[i] == 1 || G[i] == 4 || G[i] == 16)), "adamw_prepare_all: bad slab description");
-        t.slab_off[i] = slab_off[i]; t.nparts[i] = (short)nparts[i]; t.G[i] = (unsigned char)G[i]; t.update[i] = (unsigned char)update[i];
-    }
+    for (int i = 0; i < n; ++i) t.update[i] = (unsigned char)update[i];
     const float bc1 = 1.f - powf(a.beta1, (float)a.step);
     const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
-    VS_FOR_T(dtype, hipLaunchKernelGGL((weight_prepare_all_kernel<T, true>), dim3(t.first_block[n]), dim3(256), 0, s, a.params, (char*)ws, t, grads,
+    const int cap = vs_option("adamw_max_blocks");       // 0 = one block per tile
+    const int blocks = cap > 0 ? std::min(cap, t.first_block[n]) : t.first_block[n];
+    VS_FOR_T(dtype, hipLaunchKernelGGL((weight_prepare_all_kernel<T, true>), dim3(blocks), dim3(256), 0, s, a.params, (char*)ws, t, grads,
                                        a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper));
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
+// nred layers' slabs (slab_off: bytes into ws; dw_off: elements into grads; n: elements; nparts >= 2 slabs) + nrng AdamW ranges
+int launch_group_reduce_adamw(const vs_adamw_args& a, float* grads, const void* ws, int nred, const long* slab_off, const long* dw_off,
+                              const long* n, const int* nparts, int nrng, const long* roff, const long* rlen, hipStream_t s) {
+    VS_REQUIRE(nred >= 0 && nred <= 48 && nrng >= 0 && nrng <= 96, "group_reduce_adamw: %d layers / %d ranges exceed the table", nred, nrng);
+    if (nred == 0 && nrng == 0) return VS_OK;
+    GroupTable t{};
+    t.nred = nred; t.nrng = nrng;
+    int blocks = 0;
+    for (int i = 0; i < nred; ++i) {
+        const int G = slab_reduce_groups((const float*)((const char*)ws + slab_off[i]), grads + dw_off[i], (size_t)n[i], nparts[i]);
+        VS_REQUIRE(G > 0 && nparts[i] >= 2 && nparts[i] < 32768 && n[i] / 4 < (1L << 31), "group_reduce_adamw: layer %d is not one launch_slab_reduce sums with its float4 kernel", i);
+        t.first_block[i] = blocks;
+        t.slab_off[i] = slab_off[i]; t.dw_off[i] = dw_off[i]; t.n4[i] = (int)(n[i] / 4); t.nparts[i] = (short)nparts[i]; t.G[i] = (unsigned char)G;
+        blocks += (int)cdiv((long)(n[i] / 4), (long)(256 / G));
+    }
+    t.first_block[nred] = blocks;
+    int rb = 0;
+    for (int i = 0; i < nrng; ++i) {
+        t.rfirst[i] = rb;
+        t.roff[i] = roff[i]; t.rlen[i] = rlen[i];
+        rb += (int)std::min<long>(64, std::max<long>(1, (rlen[i] + 1023) / 1024));
+    }
+    t.rfirst[nrng] = rb;
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step);
+    const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
+    hipLaunchKernelGGL(group_reduce_adamw_kernel, dim3(blocks + rb), dim3(256), 0, s, t, (const char*)ws, grads, a.params, a.exp_avg, a.exp_avg_sq, a.lr,
+                       a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

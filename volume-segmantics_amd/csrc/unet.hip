@@ -69,9 +69,11 @@ extern "C" int vs_fpa_combine_bwd(int dtype, const void* dy, const float* plane,
 extern "C" int vs_sigmoid(int dtype, const void* x, void* y, int64_t elems, void* stream);
 extern "C" int vs_sigmoid_bwd(int dtype, const void* dy, const void* y, void* dx, int64_t elems, void* stream);
 extern "C" int vs_bn_fold_bias(const float* scale, const float* bias, float* shift, int c, void* stream);
-int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, float* grads, void* ws, int n, const long* w_off, const long* wc_off,
+int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, const float* grads, void* ws, int n, const long* w_off, const long* wc_off,
                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad, const int* cg,
-                             const long* slab_off, const int* nparts, const int* G, const int* update, hipStream_t s);
+                             const int* update, hipStream_t s);
+int launch_group_reduce_adamw(const vs_adamw_args& a, float* grads, const void* ws, int nred, const long* slab_off, const long* dw_off,
+                              const long* n, const int* nparts, int nrng, const long* roff, const long* rlen, hipStream_t s);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -1980,20 +1982,26 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     const int dt = net->dtype;
     const int other = net->wset ^ 1;
     AdamwRanges r{};
-    long w_off[64], wc_off[64], wt_off[64], slab_off[64];
-    int cout[64], taps[64], cin[64], cpad[64], cgs[64], nparts[64], Gs[64], upd[64], nl = 0;
+    long w_off[64], wc_off[64], wt_off[64];
+    int cout[64], taps[64], cin[64], cpad[64], cgs[64], upd[64], nl = 0;
+    long red_slab[48], red_dw[48], red_n[48];
+    int red_parts[48], nred = 0;
     int rc;
-    // The convolution weights of the range take their AdamW step INSIDE the launch that derives their copies (and sums their
-    // weight gradient's split-K slabs there too, where side_wgrad left them unsummed): one launch for the range's convolutions,
-    // one for everything else (BatchNorm affine parameters, biases, the stem, depthwise / attention tensors)
-    const bool fused_copy = vs_option("fuse_adamw_prepare") != 0;     // 0: AdamW over the convolution weights' ranges, then a plain copy launch
+    // Per range of units: ONE launch sums the split-K slabs side_wgrad left unsummed AND steps the small tensors (BatchNorm affine
+    // parameters, biases, the stem, depthwise / attention tensors), ONE launch steps the convolution weights inside the derivation of
+    // their copies.  `fuse_adamw_prepare` 0: the two-launch form it replaces (ranged AdamW over everything, then the plain copies)
+    const bool fused_copy = vs_option("fuse_adamw_prepare") != 0;
     auto flush = [&]() -> int {
         int rc2;
-        if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
-        if (nl && fused_copy && (rc2 = launch_adamw_prepare_all(dt, opt, const_cast<float*>(grads), c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad,
-                                                                cgs, slab_off, nparts, Gs, upd, s))) return rc2;
-        if (nl && !fused_copy && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
-        r.n = 0; nl = 0;
+        if (fused_copy) {
+            if ((r.n || nred) && (rc2 = launch_group_reduce_adamw(opt, const_cast<float*>(grads), c.ws, nred, red_slab, red_dw, red_n, red_parts, r.n,
+                                                                   r.off, r.len, s))) return rc2;
+            if (nl && (rc2 = launch_adamw_prepare_all(dt, opt, grads, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, upd, s))) return rc2;
+        } else {
+            if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
+            if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
+        }
+        r.n = 0; nl = 0; nred = 0;
         return VS_OK;
     };
     auto push = [&](int idx) {
@@ -2006,7 +2014,7 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     for (int k = lo; k < hi; ++k) {
         const Unit& v = net->units[k];
         if (v.w_idx < 0 && v.bn_idx < 0) continue;
-        if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
+        if (r.n > 64 || nl == 64 || nred == 48) { if ((rc = flush())) return rc; }
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
         const bool conv_w = v.kind == U_CONV || v.kind == U_HEAD;          // its weight is updated by the fused copy launch below
@@ -2022,13 +2030,12 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
             cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
             cgs[nl] = v.g2 ? 255 : v.cg;
             upd[nl] = !(v.frozen_candidate && !need_encoder_wgrad);
-            nparts[nl] = (upd[nl] && k < (int)net->slab_parts.size()) ? net->slab_parts[k] : 0;
-            slab_off[nl] = (long)v.off_slab;
-            Gs[nl] = 0;
-            if (nparts[nl]) {
-                const size_t nel = (size_t)v.cout * taps[nl] * cin[nl];
-                Gs[nl] = slab_reduce_groups((const float*)(c.ws + v.off_slab), grads + c.t(v.w_idx).offset, nel, nparts[nl]);
-                VS_REQUIRE(Gs[nl] > 0, "update_units: unit %d left slabs that launch_slab_reduce would sum with its scalar kernel", k);
+            if (upd[nl] && k < (int)net->slab_parts.size() && net->slab_parts[k] > 1) {      // its K splits are still unsummed
+                VS_REQUIRE(fused_copy, "update_units: unit %d left its slabs unsummed but the group launch is off", k);
+                red_slab[nred] = (long)v.off_slab; red_dw[nred] = c.t(v.w_idx).offset;
+                red_n[nred] = (long)v.cout * taps[nl] * cin[nl]; red_parts[nred] = net->slab_parts[k];
+                ++nred;
+                net->slab_parts[k] = 0;
             }
             ++nl;
         }
@@ -2101,15 +2108,16 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     // the group's parameter slice and ONE launch deriving its weight copies for the next forward follow on the side stream.
     auto group_update = [&](int ui) -> int {
         if (net->group_first.empty()) {   // unit index -> does an optimiser group start here
-            static const char* const kCuts[] = {"decoder.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0."};
-            net->group_first.assign(net->units.size(), 0);
+            static const char* const kCuts[] = {"decoder.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0.", "encoder.layer1.0."};
+            const int ncuts = vs_option("stem_group") ? 5 : 4;     // stem_group: the stem is a group of its own - layer1's update then runs
+            net->group_first.assign(net->units.size(), 0);        // under the max-pool / stem BatchNorm backward instead of behind the stem's gradient
             net->group_first[0] = 1;
             std::string prev;
             for (size_t k = 0; k < net->units.size(); ++k) {
                 if (net->units[k].w_idx < 0) continue;
                 const std::string& nm = net->layout.tensors[net->units[k].w_idx].name;
-                for (const char* cut : kCuts)
-                    if (nm.rfind(cut, 0) == 0 && prev.rfind(cut, 0) != 0) net->group_first[k] = 1;
+                for (int ci = 0; ci < ncuts; ++ci)
+                    if (nm.rfind(kCuts[ci], 0) == 0 && prev.rfind(kCuts[ci], 0) != 0) net->group_first[k] = 1;
                 prev = nm;
             }
         }
