@@ -104,6 +104,32 @@ def test_conv_direct_kernel(code, force_direct_kernel):
 
 
 @pytest.mark.parametrize("code", CODES)
+@pytest.mark.parametrize("cout", [16, 8])
+def test_conv_direct_kernel_pooled_data_gradient(code, cout, force_direct_kernel):
+    """The data gradient through nearest x2 upsampling on the strip kernel (MODE 1): a stride-1 convolution whose output is summed over
+    2 x 2 pixel blocks and stored at half resolution (F.interpolate's backward), 16 and 8 output channels.  Against autograd."""
+    import ctypes as C
+    L = lib()
+    g = torch.Generator().manual_seed(60 + cout)
+    n, h, w, cmid = 2, 32, 48, 16
+    x0 = rounded(torch.randn(n, cout, h // 2, w // 2, generator=g), code).requires_grad_()
+    wt = rounded(torch.randn(cmid, cout, 3, 3, generator=g) / (cout * 9) ** 0.5, code)
+    y = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), wt, padding=1)
+    dy = rounded(torch.randn(y.shape, generator=g), code)
+    y.backward(dy)
+    d = conv_desc(L, code, n, h, w, cmid, cout, 3, 1, 1)
+    t = L.ConvTrain()
+    t.pool0 = 1
+    assert L.lib.vs_conv2d_train_variant(d, t) == 16294
+    _, wtr = _prep_weights(L, code, wt)
+    dyd = to_nhwc(dy, code)
+    dx0 = torch.full((n, h // 2, w // 2, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_train(d, L.ptr(dyd), None, L.ptr(wtr), None, L.ptr(dx0), None, C.byref(t), None))
+    sync()
+    assert torch.allclose(from_nhwc(dx0), x0.grad, **tol(code, x0.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("code", CODES)
 def test_conv_direct_kernel_upsampled_input_and_head(code, force_direct_kernel):
     L = lib()
     g = torch.Generator().manual_seed(16)

@@ -887,7 +887,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
         VS_REQUIRE(conv_igemm_nl_ok(Elem<T>::kDtype, pd) && p.nl_mean && p.nl_invstd && p.nl_gamma && p.nl_beta && p.nl_nb >= 1 && p.nl_rows >= 1,
                    "conv_igemm: normalise-on-load is built for the bf16 stride-1 3x3 layers (ask conv_igemm_nl_ok first)");
     }
-    if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))
+    if (direct_ok(CT<T>::CK == 32 ? VS_BF16 : VS_F32, pd))      // (a 32-cout form was measured in round 4: 636 vs 426 us for the tile kernel on the 32 -> 32 layer of a 128 x 512^2 batch - not kept)
         return launch_direct<T, 16>(p, out_nchw, s);
     if constexpr (sizeof(T) == 2) {
         if (const int sm = stream_mode(Elem<T>::kDtype, p, out_nchw)) {

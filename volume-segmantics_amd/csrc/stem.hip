@@ -183,6 +183,32 @@ __device__ __forceinline__ void stage_patch_bf16(const float* __restrict__ x, bf
     }
 }
 
+// the same patch in two halves - loads into registers (issued early: the previous tile's epilogue runs under them), then the rounded
+// pairs into LDS
+constexpr int kStemPF = (PHB * PWB / 2 + 255) / 256;      // column pairs per thread
+__device__ __forceinline__ void patch_load_regs(const float* __restrict__ x, int img, int h, int wd, int h0, int w0, int tid, float2 (&r)[kStemPF]) {
+#pragma unroll
+    for (int k = 0; k < kStemPF; ++k) {
+        const int i = tid + k * 256;
+        const int ph = i / (PWB / 2), pw = (i - ph * (PWB / 2)) * 2;
+        const int hi = 2 * h0 - 3 + ph, wi = 2 * w0 - 3 + pw;
+        float a = 0.f, b = 0.f;
+        if (i < PHB * PWB / 2 && hi >= 0 && hi < h) {
+            const float* row = x + ((size_t)img * h + hi) * wd;
+            if (wi >= 0 && wi < wd) a = row[wi];
+            if (wi + 1 >= 0 && wi + 1 < wd) b = row[wi + 1];
+        }
+        r[k] = make_float2(a, b);
+    }
+}
+__device__ __forceinline__ void patch_store_regs(bf16_t* patch, int tid, const float2 (&r)[kStemPF]) {
+#pragma unroll
+    for (int k = 0; k < kStemPF; ++k) {
+        const int i = tid + k * 256;
+        if (i < PHB * PWB / 2) reinterpret_cast<uint32_t*>(patch)[i] = pack_bf16(r[k].x, r[k].y);
+    }
+}
+
 // this lane's weight fragments: A[row = cout 16j + lr][k = 8 * (4s + lq) + kw]
 __device__ __forceinline__ void load_stem_weights_bf16(const float* __restrict__ w, int lr, int lq, uint4 (&wa)[4][2]) {
 #pragma unroll
@@ -212,18 +238,38 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
     uint4 wa[4][2];
     load_stem_weights_bf16(w, lr, lq, wa);      // once per workgroup: it walks over tiles blockIdx.x, + gridDim.x, ..
     float s1[4][4], s2[4][4];                   // [cout fragment j][r]: sums over this lane's pixels of every tile
+    float sc[4][4], sh[4][4];                   // the folded-BatchNorm constants of this lane's 16 couts: once per workgroup, not per tile
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
-    for (int tile = blockIdx.x; tile < n * tiles_h * tiles_w; tile += gridDim.x) {
-    int b = tile;
-    const int tx = b % tiles_w; b /= tiles_w;
-    const int ty = b % tiles_h;
-    const int img = b / tiles_h;
-    const int h0 = ty * TPH, w0 = tx * TPW;
+        for (int r = 0; r < 4; ++r) {
+            s1[j][r] = s2[j][r] = 0.f;
+            sc[j][r] = scale ? scale[j * 16 + lq * 4 + r] : 1.f;
+            sh[j][r] = scale ? shift[j * 16 + lq * 4 + r] : 0.f;
+        }
+    const int ntiles = n * tiles_h * tiles_w;
+    auto tile_origin = [&](int tile, int& img, int& h0, int& w0) {
+        int b = tile;
+        const int tx = b % tiles_w; b /= tiles_w;
+        const int ty = b % tiles_h;
+        img = b / tiles_h; h0 = ty * TPH; w0 = tx * TPW;
+    };
+    float2 pf[kStemPF];                          // the NEXT tile's patch: in flight while this tile's MFMAs, transpose and stores run
+    {
+        int img, h0, w0;
+        tile_origin(min((int)blockIdx.x, ntiles - 1), img, h0, w0);
+        patch_load_regs(x, img, h, wd, h0, w0, tid, pf);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int img, h0, w0;
+    tile_origin(tile, img, h0, w0);
     __syncthreads();                            // the previous tile's fragment reads are done
-    stage_patch_bf16(x, patch, img, h, wd, h0, w0, tid);
+    patch_store_regs(patch, tid, pf);
+    if (tile + (int)gridDim.x < ntiles) {
+        int img2, h2, w2;
+        tile_origin(tile + gridDim.x, img2, h2, w2);
+        patch_load_regs(x, img2, h, wd, h2, w2, tid, pf);
+    }
     __syncthreads();
     f32x4 acc[4][4];
 #pragma unroll
@@ -267,7 +313,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const float* __restr
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (scale) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * scale[c + r] + shift[c + r];
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[j][r] + sh[j][r];
             }
             if (relu) {
 #pragma unroll
