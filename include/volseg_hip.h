@@ -261,8 +261,10 @@ int vs_profile_read_raw(int max_n, int* kind, int* tag, int* variant, double* ms
  * is set, convolution launches of at most cap_wgs workgroups record per-workgroup phase timestamps.  NULL disables. */
 int vs_debug_probe(void* buf, size_t cap_wgs);
 
-/* Runtime options: "side_stream" (1), "wgrad_target" (256), "conv_min_wgs" (512), "fuse_stats" (1),
- * "recompute_mask" (0); initial values can come from the environment as VS_<NAME>. */
+/* Runtime options (csrc/prof.hip holds the table): eleven kernel-family switches - "side_stream", "conv_direct", "conv_nw8", "conv_ring",
+ * "conv_stream", "wgrad_ring", "wgrad_xcd", "stats_bins", "fuse_bn_bwd", "nl_fwd", "stem_bf16" (all 1) - and thirteen launch-size
+ * thresholds / split sizes ("wgrad_target" 96, "conv_min_wgs" 512, "fork_every" 2, ...); initial values can come from the
+ * environment as VS_<NAME>.  No reference counterpart: tests and tooling. */
 int vs_set_option(const char* name, int value);
 int vs_get_option(const char* name);
 

@@ -331,6 +331,8 @@ def test_trainer_end_to_end_on_synthetic_slices(tmp_path, mtype, encoder):
                                loss_criterion="DiceLoss", alpha=0.75, beta=0.25, eval_metric="MeanIoU", pct_lr_inc=0.3,
                                plot_lr_graph=False, image_size=64, training_set_proportion=0.8,
                                model={"type": mtype, "encoder_name": encoder, "encoder_weights": None})
+    if encoder == "resnet34":      # the opt-in recorded step (`step_mode: graph`: replayed hipGraphs) for the ResNet-34 topologies; call by call otherwise
+        settings.step_mode = "graph"
     tr = VolSeg2dTrainer(None, None, {"bg": 0, "fg": 1}, settings, loaders=loaders)
     out = tmp_path / "trained.pytorch"
     tr.train_model(out, 1, 3, create=True, frozen=True)

@@ -225,9 +225,6 @@ struct ConvParams {
     const void* by;                      // its activation y for the mask (units with a residual input); null: recompute from z
     const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta;
     float* bstats_partial;               // [tiles][2][Cout]
-    unsigned long long* bstats_bins; int bstats_nb;   // instead: bstats_nb (power of two) rows of 64-bit fixed-point bins, sums scaled by
-                                                      // kBwdStatScale, added atomically (row = tile & (nb - 1)) - the apply sweep sums
-                                                      // the few rows itself and no finalize launch sits between the two (norm.hip)
     int brelu;
     int dil;                             // 0 / 1 = none; 2 = dilation 2 of a stride-1 3x3 kernel (pad 2)
     int gc;                              // 0 = dense; 32 = grouped convolution on 32-channel super-groups (C0 == Cout, C1 == 0)
@@ -285,9 +282,6 @@ int launch_bn_finalize_partials(const float* partial, int nparts, int c, int64_t
 // train-mode BatchNorm whose sums sit in fixed-point bins (ConvParams::stats_bins): finalise the nb rows inline, normalise
 constexpr double kStatScale1 = 16777216.0, kStatScale2 = 65536.0;     // 2^24, 2^16
 constexpr double kBwdStatScale = 68719476736.0;                        // 2^36: gradient sums (|sum| < 1.3e8, resolution 1.5e-11)
-int launch_bn_bwd_from_bins(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
-                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const unsigned long long* bins,
-                            int nb, hipStream_t s);
 int launch_bn_apply_from_bins(int dtype, const void* x, const unsigned long long* bins, int nb, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
                               const void* residual, int relu, void* y, int64_t rows, int c, hipStream_t s, int64_t stat_rows = 0);
@@ -312,10 +306,6 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
-    int defer_reduce;                     // 1: leave the split-K slabs in `partials` ([nsplit][|dw|] fp32) and do NOT sum them into dw - the
-                                          // caller sums them later with launch_slab_reduce's own arithmetic (one launch for a whole parameter
-                                          // group, optim.hip: launch_group_reduce_adamw); with ONE split the result still goes straight to dw
-    int* nsplit_out;                      // optional (host): the number of K splits this launch used
 };
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);

@@ -181,11 +181,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int tw_shift,
                 float a = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) a += red[(w * 2 + k) * BN + cc];
-                if (p.bstats_bins)
-                    atomicAdd(p.bstats_bins + ((size_t)(tile & (p.bstats_nb - 1)) * 2 + k) * p.Cout + n0 + cc,
-                              (unsigned long long)__double2ll_rn((double)a * kBwdStatScale));
-                else
-                    p.bstats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] = a;
+                p.bstats_partial[((size_t)tile * 2 + k) * p.Cout + n0 + cc] = a;
             }
         }
         return;

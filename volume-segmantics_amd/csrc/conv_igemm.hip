@@ -685,7 +685,7 @@ static DirectGeom direct_geom(const ConvParams& p) {
     g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
     g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
     g.nwaves = p.N * g.strips_w * g.chunks_h;
-    g.xcd = vs_option("xcd_blocks");
+    g.xcd = 0;      // (an XCD-local strip order was measured: 0.5207 vs 0.5212 s per 512^3 x 12 prediction - not kept)
     return g;
 }
 
@@ -703,19 +703,9 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
         VS_REQUIRE(!p.up0 && !p.relu && !p.scale && !p.stats_partial, "conv_head: plain 3x3 head only");
     }
     const dim3 grid(cdiv(g.nwaves, 4));
-    // `conv_direct_occ` (0 = the kernel's own limit of 4): workgroups per CU, enforced with unused dynamic LDS.  Every wave keeps
-    // rows of its strip in flight; past some point more waves per CU only thrash L1 / L2 (counter reads of the head kernel at
-    // batch 128: 2.6x its input) - tools/ab_predict.py
-    const int occ = vs_option("conv_direct_occ");
-    const size_t pad = (occ >= 1 && occ < 4) ? std::min((size_t)(160 * 1024) / occ - 12 * 1024, (size_t)128 * 1024) : 0;
-    static bool attr_set = false;
-    if (pad && !attr_set) {
-        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_direct_kernel<T, BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        VS_CHECK_HIP(hipFuncSetAttribute((const void*)conv_direct_kernel<T, BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    // (fewer workgroups per CU - enforced with unused dynamic LDS - were measured on the prediction: 2 / 3 per CU 0.559 / 0.542 s against
+    // 0.524 s at the kernel's own limit of 4: not kept)
+    const size_t pad = 0;
     VolScatter sc{};
     if (p.scatter) {
         sc = *p.scatter;
@@ -795,7 +785,7 @@ Pick pick_cfg(const ConvParams& p) {
     Pick c;
     c.NW = 4;
     c.PT = (p.stride == 1 && p.Hout * p.Wout >= 128 && p.Wout >= 16) ? 2 : 1;
-    if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && !p.gc && p.Wout >= 16 && p.Hout >= 8 && vs_option("conv_s2_pt2") &&
+    if (p.stride == 2 && p.KH == 3 && p.Cout >= 64 && !p.gc && p.Wout >= 16 && p.Hout >= 8 &&
         (long)p.N * cdiv(p.Hout, 8) * cdiv(p.Wout, 16) * cdiv(p.Cout, 64) >= vs_option("conv_min_wgs")) c.PT = 2;
     const bool can8 = vs_option("conv_nw8") && p.stride == 1 && p.dil <= 1 && p.Hout >= 16 && p.Wout >= 16;
     auto wgs = [&](int bn, int px) {
@@ -831,7 +821,7 @@ static int stream_mode(int dtype, const ConvParams& p, int out_nchw) {
 static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     if (dtype != VS_BF16 || !vs_option("conv_ring") || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1 || p.gc || p.scatter ||
         out_nchw || (p.Cout & 3) || p.out_f32) return 0;
-    if (p.nl_bins && (!vs_option("nl_ring") || (p.C0 & 31) || p.up0 == 2 || p.C0 > 1024)) return 0;   // normalise-on-load: whole chunks of src0, room for the table
+    if (p.nl_bins && ((p.C0 & 31) || p.up0 == 2 || p.C0 > 1024)) return 0;   // normalise-on-load: whole chunks of src0, room for the table
     const int Cin = p.C0 + p.C1;
     if (Cin < 128 || (Cin & 7) || (p.C1 && (p.C0 & 31))) return 0;
     if (p.out1 && (p.split_c & 31)) return 0;
@@ -844,7 +834,7 @@ static int ring_mode(int dtype, const ConvParams& p, int out_nchw) {
     const long tiles = (long)p.N * cdiv(p.Hout, 16) * cdiv(p.Wout, 16);
     const long w64 = tiles * cdiv(p.Cout, 64), w32 = tiles * cdiv(p.Cout, 32);
     const long maxw = vs_option("conv_ring_max_wgs");
-    if (vs_option("conv_ring") == 1 && p.Cout >= 64 && w64 >= 224 && w64 <= maxw && (!p.out1 || p.split_c % 64 == 0)) return 1;
+    if (p.Cout >= 64 && w64 >= 224 && w64 <= maxw && (!p.out1 || p.split_c % 64 == 0)) return 1;
     if (p.Cout >= 32 && w32 >= 128 && w32 <= maxw) return 2;
     return 0;
 }
@@ -873,7 +863,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if (p.out1) VS_REQUIRE(p.split_c % BN == 0, "conv_igemm: split_c %d not a multiple of the cout tile %d", p.split_c, BN);
     if (p.bz) {
         VS_REQUIRE(!p.pool0 && !p.out1 && !p.scale && !p.shift && !p.relu && !p.out_f32 && !out_nchw && !(p.Cout & 3) && !p.stats_partial &&
-                   p.bmean && p.binvstd && (p.bstats_partial || p.bstats_bins) && (!p.brelu || p.by || (p.bgamma && p.bbeta)),
+                   p.bmean && p.binvstd && p.bstats_partial && (!p.brelu || p.by || (p.bgamma && p.bbeta)),
                    "conv_igemm: the BN-backward epilogue takes a plain NHWC dgrad output");
     }
     if (p.pool0) {
@@ -892,7 +882,7 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (const int sm = stream_mode(Elem<T>::kDtype, p, out_nchw)) {
             unsigned long long* probe = vs_probe_buffer(256);
-            const int stg = vs_option("conv_stream_stagger");
+            const int stg = 0;      // (a start delay staggered by workgroup was measured neutral)
             return sm == 64 ? ring::launch_stream<T, 64, 2, 8, 4, 2, 2>(p, probe, s, 256, stg) : ring::launch_stream<T, 32, 2, 8, 4, 2, 2>(p, probe, s, 256, stg);
         }
     }

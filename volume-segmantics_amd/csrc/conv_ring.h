@@ -23,7 +23,6 @@
 // upsample + concat and the zero-stuffed stride-2 gradients, all folded into the piece addresses.
 #pragma once
 #include "conv_common.h"
-#include "prof.h"
 
 namespace ring {
 
@@ -406,13 +405,11 @@ int launch_ring(const ConvParams& p, int out_nchw, unsigned long long* probe, hi
     {   // XCD split: minimise the bytes ONE XCD pulls through its L2 = weights / cout partitions + input / pixel-tile partitions
         const double wb = (double)p.Cout * 9 * (p.C0 + p.C1) * 2.0;
         const double ib = (double)p.N * ((double)(p.Hin >> (p.up0 ? 1 : 0)) * (p.Win >> (p.up0 ? 1 : 0)) * p.C0 + (double)p.Hin * p.Win * p.C1) * 2.0;
-        const int forced = vs_option("conv_ring_xc");      // 0 = choose; 1 / 2 / 4 / 8 = that many cout partitions (A / B runs)
         int best = 0;
         double best_cost = 0;
         for (int xcs = 0; xcs <= 3; ++xcs) {
             const int xc = 1 << xcs;
             if (g.ctiles % xc) continue;
-            if (forced && xc != forced) continue;
             const double cost = wb / xc + ib * xc / 8.0;
             if (xcs == 0 || !best_cost || cost < best_cost * 0.9) { best = xcs; best_cost = cost; }      // (a clear win only: the 8 x 1 map also shares the patch among neighbours in time)
         }

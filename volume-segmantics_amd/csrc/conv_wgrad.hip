@@ -496,7 +496,7 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     // bf16 fast path: 16*MO couts per workgroup (all of them in every wave), K split across workgroups only
     g.probe = nullptr;
     g.xmode = 0; g.ppx = 0;
-    g.fast = sizeof(T) == 2 && vs_option("wgrad_fast") && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
+    g.fast = sizeof(T) == 2 && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
     g.ring = 0;
     if (g.fast && vs_option("wgrad_ring") && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && (p.C0 % 32) == 0 && (p.C1 % 32) == 0) {
@@ -579,8 +579,7 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, g.ctiles * g.cchunks, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gg);
     VS_LAUNCH_CHECK();
-    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
-    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
+    if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
@@ -604,8 +603,7 @@ int launch_ring_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
     const dim3 grid = g.xmode ? dim3(ring::wg_grid(g.xmode, gr.npairs, g.nsplit, g.ppx)) : dim3(g.ctiles * g.cchunks, g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, gr);
     VS_LAUNCH_CHECK();
-    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
-    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
+    if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * 9 * (p.C0 + p.C1), g.nsplit, s);
 }
 
@@ -625,8 +623,7 @@ int launch_one(const WgradParams& p, const WGeom& g, hipStream_t s) {
     if (g.nsplit == 1) q.partials = p.dw;  // no K split: the single slab IS the result
     hipLaunchKernelGGL(kern, dim3(g.ctiles * g.cchunks, g.nsplit), dim3(256), lds, s, q, g);
     VS_LAUNCH_CHECK();
-    if (p.nsplit_out) *p.nsplit_out = g.nsplit;
-    if (g.nsplit == 1 || p.defer_reduce) return VS_OK;
+    if (g.nsplit == 1) return VS_OK;
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 

@@ -531,176 +531,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
     }
 }
 
-// ---- backward, ONE launch (small tensors) ---------------------------------------------------------------------------
-// For the layers whose tensors are a few MB (32 x 32 maps and smaller at batch 32: 33 of the 46 units) the three launches
-// above are three launch latencies and two refetches of tensors the first sweep just had in its hands.  Here a grid of at
-// most 128 workgroups - all of them resident - does the whole thing: sweep 1 (masked gradient sums per workgroup, one
-// partial row each), a grid barrier, every workgroup sums the partial rows itself (fp64, rows in order: the same numbers
-// in every workgroup, bitwise reproducible), sweep 2 over ITS OWN rows again (dy and z now come from its L2) -> dz, dres.
-// The barrier is the placement-independent release / acquire form: plain row stores, every storing wave waits vmcnt(0),
-// workgroup barrier, one lane releases at agent scope and adds to the arrival counter; one lane polls it relaxed, then
-// acquires at agent scope, vmcnt(0), workgroup barrier, plain loads.  ctl = {arrivals, departures, -, gave-up flag}: the
-// workgroup that departs last zeroes the counters for the next launch (they start zeroed: vs_unet_prepare / the C entry).
-template <typename T, bool RECOMPUTE>
-__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
-                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                         T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int64_t rows, int c, RowMap m, float* partial,
-                                                         unsigned* ctl) {
-    __shared__ float red[2][256][kVec + 1];
-    __shared__ float coef[2][512];          // dbeta / rows, dgamma / rows per channel (c <= 512)
-    const int tid = threadIdx.x;
-    const int cvi = tid % m.cv, rl = tid / m.cv;
-    float mu[kVec], is[kVec], ga[kVec], be[kVec], gi[kVec];
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) {
-        const int ch = cvi * kVec + k;
-        mu[k] = mean[ch]; is[k] = invstd[ch];
-        gi[k] = gamma[ch] * invstd[ch]; ga[k] = gi[k];
-        be[k] = RECOMPUTE ? beta[ch] : 0.f;
-    }
-    const int64_t r0 = (int64_t)blockIdx.x * m.rows_per_block;
-    const int64_t r1 = min(rows, r0 + m.rows_per_block);
-    const int relu_dbg = relu;
-    relu &= 255;
-    {   // ---- sweep 1: per-workgroup sums of g and g * xhat ----
-        float s[kVec], q[kVec];
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) s[k] = q[k] = 0.f;
-        if (rl < m.rpb) {
-            for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
-                float g[kU][kVec], xv[kU][kVec], yv[RECOMPUTE ? 1 : kU][kVec];
-                bool ok[kU];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const int64_t r = rb + (int64_t)u * m.rpb;
-                    ok[u] = r < r1;
-                    const size_t o = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
-                    ld8(dy + o, g[u]);
-                    ld8(x + o, xv[u]);
-                    if constexpr (!RECOMPUTE) {
-                        if (relu) ld8(y + o, yv[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    if (!ok[u]) continue;
-                    if (relu) {
-                        if constexpr (!RECOMPUTE) {
-#pragma unroll
-                            for (int k = 0; k < kVec; ++k) g[u][k] = yv[u][k] > 0.f ? g[u][k] : 0.f;
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < kVec; ++k) g[u][k] = ((xv[u][k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[u][k] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) { s[k] += g[u][k]; q[k] += g[u][k] * (xv[u][k] - mu[k]) * is[k]; }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) { red[0][tid][k] = s[k]; red[1][tid][k] = q[k]; }
-        __syncthreads();
-        for (int ch = tid; ch < m.cv * kVec; ch += 256) {
-            const int g = ch / kVec, k = ch % kVec;
-            float a = 0.f, b = 0.f;
-            for (int j = 0; j < m.rpb; ++j) { a += red[0][j * m.cv + g][k]; b += red[1][j * m.cv + g][k]; }
-            partial[((size_t)blockIdx.x * 2 + 0) * c + ch] = a;
-            partial[((size_t)blockIdx.x * 2 + 1) * c + ch] = b;
-        }
-    }
-    // ---- grid barrier ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its partial-row stores are out
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (!(relu_dbg & 256) && __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { __hip_atomic_store(&ctl[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never in a healthy run
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // departure: the last workgroup through re-arms the counters (nobody polls them any more)
-        if (__hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    {   // ---- every workgroup: the same fixed-order fp64 sum of the partial rows ----
-        double* dsum = reinterpret_cast<double*>(&red[0][0][0]);      // [RG][2 c] doubles (<= 8 KB of the 18 KB array)
-        const int cols = (2 * c) / 4, RG = 256 / cols;                 // float4 columns of a row; row groups
-        const int col = tid % cols, rg = tid / cols;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (rg < RG) {
-            const int nb = (int)gridDim.x;
-            for (int r = rg; r < nb; r += 4 * RG) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    v[u] = (r + u * RG < nb) ? *reinterpret_cast<const float4*>(partial + (size_t)(r + u * RG) * 2 * c + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
-            }
-            double* d = dsum + (size_t)rg * 2 * c + col * 4;
-            d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
-        }
-        __syncthreads();
-        const double inv_m = 1.0 / (double)rows;
-        for (int ch = tid; ch < 2 * c; ch += 256) {
-            double t = 0.0;
-            for (int g2 = 0; g2 < RG; ++g2) t += dsum[(size_t)g2 * 2 * c + ch];
-            if (ch < c) { coef[0][ch] = (float)(t * inv_m); if (blockIdx.x == 0) dbeta[ch] = (float)t; }
-            else { coef[1][ch - c] = (float)(t * inv_m); if (blockIdx.x == 0) dgamma[ch - c] = (float)t; }
-        }
-        __syncthreads();
-    }
-    // ---- sweep 2: dz (and the masked gradient for the residual path) ----
-    if (rl >= m.rpb || (relu_dbg & 512)) return;
-    float db[kVec], dg[kVec];
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) { db[k] = coef[0][cvi * kVec + k]; dg[k] = coef[1][cvi * kVec + k]; }
-    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)kU * m.rpb) {
-        float g[kU][kVec], xv[kU][kVec], yv[RECOMPUTE ? 1 : kU][kVec];
-        size_t o[kU];
-        bool ok[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int64_t r = rb + (int64_t)u * m.rpb;
-            ok[u] = r < r1;
-            o[u] = (size_t)(ok[u] ? r : rb) * c + cvi * kVec;
-            ld8(dy + o[u], g[u]);
-            ld8(x + o[u], xv[u]);
-            if constexpr (!RECOMPUTE) {
-                if (relu) ld8(y + o[u], yv[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (!ok[u]) continue;
-            if (relu) {
-                if constexpr (!RECOMPUTE) {
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) g[u][k] = yv[u][k] > 0.f ? g[u][k] : 0.f;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) g[u][k] = ((xv[u][k] - mu[k]) * ga[k] + be[k]) > 0.f ? g[u][k] : 0.f;
-                }
-            }
-            if (dres) st8(dres + o[u], g[u]);
-            float o8[kVec];
-#pragma unroll
-            for (int k = 0; k < kVec; ++k) o8[k] = gi[k] * (g[u][k] - db[k] - (xv[u][k] - mu[k]) * is[k] * dg[k]);
-            st8(dx + o[u], o8);
-        }
-    }
-}
-
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                float* scale, float* shift, int c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -819,18 +649,6 @@ int launch_bn_bwd_from_partials(int dtype, const void* g, const void* x, const f
     return VS_OK;
 }
 
-int launch_bn_bwd_from_bins(int dtype, const void* g, const void* x, const float* mean, const float* invstd, const float* gamma,
-                            void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, const unsigned long long* bins,
-                            int nb, hipStream_t s) {
-    VS_REQUIRE(c % kVec == 0 && c <= 512, "bn_bwd (bins): unsupported channel count %d", c);
-    RowMap m = make_rowmap(rows, c);
-    VS_FOR_T(dtype, hipLaunchKernelGGL((bn_bwd_apply<T, false, true, true>), dim3(m.nblocks), dim3(256), 0, s, (const T*)g, (const T*)nullptr,
-                           (const T*)x, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, 0, (T*)dx, (T*)dres, rows, c, m,
-                           (const float*)bins, nb));
-    VS_LAUNCH_CHECK();
-    return VS_OK;
-}
-
 extern "C" size_t vs_bn_workspace(int64_t rows, int c) {
     (void)rows;
     return (size_t)kMaxBlocks * 2 * c * sizeof(float);
@@ -865,32 +683,6 @@ extern "C" int vs_bn_bwd(int dtype, const void* dy, const void* y, const void* x
                                workspace, workspace_bytes, stream);
 }
 
-// whether the one-launch form applies, and its grid (0 = no)
-static int bn_bwd_fused_blocks(int dtype, int64_t rows, int c) {
-    if (!vs_option("bn_bwd_fused") || c > 512 || (c & 7) || 256 % ((2 * c) / 4) != 0) return 0;
-    const double bytes = (double)rows * c * (double)dtype_size(dtype);
-    if (bytes > 9.0e6 || bytes < 2.0e5) return 0;            // a few MB: 32 x 32 maps and smaller at batch 32
-    int nb = (int)(bytes / 65536.0);
-    if (vs_option("bn_fused_blocks") > 0) return vs_option("bn_fused_blocks");
-    if (c >= 512 && nb > 32) nb = 32;                        // 256 float4 columns: one thread per column, <= 32 rows each
-    return std::max(16, std::min(128, nb));
-}
-
-// ctl: 4 zeroed words (arrival / departure counters; see bn_bwd_fused_kernel)
-int launch_bn_bwd_fused(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd, const float* gamma,
-                        const float* beta, int relu, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
-                        unsigned* ctl, int blocks, hipStream_t s) {
-    RowMap m = make_rowmap(rows, c, blocks);
-    const bool rc = relu && !y;
-    relu |= vs_option("bn_fused_dbg") << 8;      // diagnostics (tools/convlab): 1 = do not wait at the barrier, 2 = stop after the row sums
-#define VS_BWD_FUSED(T, R) hipLaunchKernelGGL((bn_bwd_fused_kernel<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, (const T*)x, mean, \
-                                              invstd, gamma, beta, relu, (T*)dx, (T*)dres, dgamma, dbeta, rows, c, m, workspace, ctl)
-    VS_FOR_T(dtype, { if (rc) VS_BWD_FUSED(T, true); else VS_BWD_FUSED(T, false); });
-#undef VS_BWD_FUSED
-    VS_LAUNCH_CHECK();
-    return VS_OK;
-}
-
 extern "C" int vs_bn_bwd_recompute(int dtype, const void* dy, const void* y, const void* x, const float* mean,
                                    const float* invstd, const float* gamma, const float* beta, int relu, void* dx,
                                    void* dres, float* dgamma, float* dbeta, int64_t rows, int c, float* workspace,
@@ -907,13 +699,7 @@ int bn_bwd_dispatch(int dtype, const void* dy, const void* y, const void* x, con
     VS_REQUIRE(c % kVec == 0 && c <= 2048, "bn_bwd: unsupported channel count %d", c);
     VS_REQUIRE(!relu || y || beta, "bn_bwd: need y or beta for the ReLU mask");
     VS_REQUIRE(workspace && workspace_bytes >= vs_bn_workspace(rows, c), "bn_bwd: workspace too small");
-    if (const int fb = sync ? 0 : bn_bwd_fused_blocks(dtype, rows, c)) {
-        if (!ctl) {
-            ctl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + vs_bn_workspace(rows, c) - 16);
-            VS_CHECK_HIP(hipMemsetAsync(ctl, 0, 16, s));
-        }
-        return launch_bn_bwd_fused(dtype, dy, y, x, mean, invstd, gamma, beta, relu, dx, dres, dgamma, dbeta, rows, c, workspace, ctl, fb, s);
-    }
+    (void)ctl;      // (a one-launch form with a grid barrier between the two sweeps was built in round 3 and measured slower: 5.47 vs 4.94 ms per step)
     RowMap m = make_rowmap(rows, c);
     const bool rc = relu && !y;
 #define VS_BWD_PARTIAL(T, R) hipLaunchKernelGGL((bn_bwd_partial<T, R>), dim3(m.nblocks), dim3(256), 0, s, (const T*)dy, (const T*)y, \

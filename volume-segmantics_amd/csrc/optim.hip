@@ -4,7 +4,6 @@
 #include <algorithm>
 
 #include "common.h"
-#include "prof.h"
 
 namespace {
 
@@ -75,52 +74,6 @@ struct AdamwUpdate {
         return pn;
     }
 };
-
-// ONE launch in front of a parameter group's fused update: (a) the split-K slabs of every weight gradient of the group summed into the
-// flat gradient buffer - per layer exactly launch_slab_reduce's kernel body and lane-group count, so the bits do not depend on
-// whether a layer was reduced alone or with its group - and (b) the AdamW step of the group's SMALL tensors (BatchNorm affine
-// parameters, biases, the stem: ranges of the flat buffers), which depend on nothing in (a).  Replaces one reduction launch per
-// layer (42 per step for U-Net / ResNet-34) and the ranged AdamW launch.
-struct GroupTable {
-    int nred, nrng;
-    int first_block[49];                 // reduce role: first block of each layer; first_block[nred] = blocks of the role
-    long slab_off[48], dw_off[48];       // BYTE offset of the layer's slabs in the workspace; element offset of its gradient
-    int n4[48];                          // |dw| / 4
-    short nparts[48];
-    unsigned char G[48];
-    int rfirst[97];                      // range role: first block of each range, relative to the role's first block
-    long roff[96], rlen[96];
-};
-__global__ __launch_bounds__(256) void group_reduce_adamw_kernel(GroupTable t, const char* __restrict__ ws, float* __restrict__ grads,
-                                                               float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float lr,
-                                                               float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                               const float* __restrict__ hyper) {
-    const int nrb = t.first_block[t.nred];
-    if ((int)blockIdx.x < nrb) {
-        int l = 0;
-        while (l + 1 < t.nred && (int)blockIdx.x >= t.first_block[l + 1]) ++l;
-        const float4* partials = reinterpret_cast<const float4*>(ws + t.slab_off[l]);
-        float4* dw = reinterpret_cast<float4*>(grads + t.dw_off[l]);
-        const unsigned bid = blockIdx.x - t.first_block[l];
-        if (t.G[l] == 1) slab_reduce4_body<1>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
-        else if (t.G[l] == 4) slab_reduce4_body<4>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
-        else slab_reduce4_body<16>(partials, dw, (size_t)t.n4[l], t.nparts[l], bid);
-        return;
-    }
-    const int b = blockIdx.x - nrb;
-    int r = 0;
-    while (r + 1 < t.nrng && b >= t.rfirst[r + 1]) ++r;
-    const AdamwScalars a = adamw_scalars(lr, b1, b2, eps, wd, bc1, bc2_sqrt, hyper);
-    const int nb = t.rfirst[r + 1] - t.rfirst[r];
-    const long off = t.roff[r];
-    for (long i = (long)(b - t.rfirst[r]) * 256 + threadIdx.x; i < t.rlen[r]; i += (long)nb * 256) {
-        const long k = off + i;
-        float mi = m[k], vi = v[k];
-        p[k] = adamw_element(p[k], grads[k], mi, vi, a);
-        m[k] = mi;
-        v[k] = vi;
-    }
-}
 
 // One 32 x 32 (cout x cin) tile of one tap: w fp32 [cout][taps][cin] -> wc (T, same layout, optional) and wt (T, [cin][taps
 // flipped][cout_pad], optional).  cg > 0: grouped convolution with cg channels per group (cin == cout) - w is
@@ -432,41 +385,10 @@ int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, const float* gra
     for (int i = 0; i < n; ++i) t.update[i] = (unsigned char)update[i];
     const float bc1 = 1.f - powf(a.beta1, (float)a.step);
     const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
-    const int cap = vs_option("adamw_max_blocks");       // 0 = one block per tile
-    const int blocks = cap > 0 ? std::min(cap, t.first_block[n]) : t.first_block[n];
+    const int blocks = t.first_block[n];      // (a capped grid - a slower optimiser that leaves the chip to the backward pass - was measured: 192
+                                              // blocks 4.87 vs 4.49 ms per step: the side stream's length IS the step's)
     VS_FOR_T(dtype, hipLaunchKernelGGL((weight_prepare_all_kernel<T, true>), dim3(blocks), dim3(256), 0, s, a.params, (char*)ws, t, grads,
                                        a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper));
-    VS_LAUNCH_CHECK();
-    return VS_OK;
-}
-
-// nred layers' slabs (slab_off: bytes into ws; dw_off: elements into grads; n: elements; nparts >= 2 slabs) + nrng AdamW ranges
-int launch_group_reduce_adamw(const vs_adamw_args& a, float* grads, const void* ws, int nred, const long* slab_off, const long* dw_off,
-                              const long* n, const int* nparts, int nrng, const long* roff, const long* rlen, hipStream_t s) {
-    VS_REQUIRE(nred >= 0 && nred <= 48 && nrng >= 0 && nrng <= 96, "group_reduce_adamw: %d layers / %d ranges exceed the table", nred, nrng);
-    if (nred == 0 && nrng == 0) return VS_OK;
-    GroupTable t{};
-    t.nred = nred; t.nrng = nrng;
-    int blocks = 0;
-    for (int i = 0; i < nred; ++i) {
-        const int G = slab_reduce_groups((const float*)((const char*)ws + slab_off[i]), grads + dw_off[i], (size_t)n[i], nparts[i]);
-        VS_REQUIRE(G > 0 && nparts[i] >= 2 && nparts[i] < 32768 && n[i] / 4 < (1L << 31), "group_reduce_adamw: layer %d is not one launch_slab_reduce sums with its float4 kernel", i);
-        t.first_block[i] = blocks;
-        t.slab_off[i] = slab_off[i]; t.dw_off[i] = dw_off[i]; t.n4[i] = (int)(n[i] / 4); t.nparts[i] = (short)nparts[i]; t.G[i] = (unsigned char)G;
-        blocks += (int)cdiv((long)(n[i] / 4), (long)(256 / G));
-    }
-    t.first_block[nred] = blocks;
-    int rb = 0;
-    for (int i = 0; i < nrng; ++i) {
-        t.rfirst[i] = rb;
-        t.roff[i] = roff[i]; t.rlen[i] = rlen[i];
-        rb += (int)std::min<long>(64, std::max<long>(1, (rlen[i] + 1023) / 1024));
-    }
-    t.rfirst[nrng] = rb;
-    const float bc1 = 1.f - powf(a.beta1, (float)a.step);
-    const float bc2s = sqrtf(1.f - powf(a.beta2, (float)a.step));
-    hipLaunchKernelGGL(group_reduce_adamw_kernel, dim3(blocks + rb), dim3(256), 0, s, t, (const char*)ws, grads, a.params, a.exp_avg, a.exp_avg_sq, a.lr,
-                       a.beta1, a.beta2, a.eps, a.weight_decay, bc1, bc2s, a.hyper);
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

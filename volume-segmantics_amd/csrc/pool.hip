@@ -289,7 +289,7 @@ extern "C" int vs_maxpool_fwd(int dtype, const void* x, void* y, uint8_t* idx, i
     VS_REQUIRE(c % kVec == 0 && h % 2 == 0 && w % 2 == 0, "maxpool_fwd: bad shape");
     const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / kVec);
     VS_FOR_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)x, (T*)y, idx, n, h, w, c, vs_option("xcd_blocks")));
+                           (const T*)x, (T*)y, idx, n, h, w, c, 0));
     VS_LAUNCH_CHECK();
     return VS_OK;
 }

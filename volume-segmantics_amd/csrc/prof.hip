@@ -74,8 +74,17 @@ extern "C" int vs_profile_read(double* ms, double* flops, double* bytes, int64_t
 // ---- runtime options (defaults can also come from the environment: VS_<NAME>) -----------------------------------------
 namespace {
 struct Opt { const char* name; int value; bool init; };
-Opt g_opts[] = {{"side_stream", 1, false},  {"wgrad_target", 96, false}, {"wgrad_target_plain", 256, false}, {"conv_min_wgs", 512, false},
-                {"fuse_stats", 1, false}, {"recompute_mask", 1, false}, {"conv_nw8", 1, false}, {"conv_nw8_min_wgs", 128, false}, {"wgrad_fast", 1, false}, {"wgrad_slab_mb", 16, false}, {"conv_direct", 1, false}, {"conv_direct_min_px", 262144, false}, {"conv_direct_rows_big", 128, false}, {"conv_direct_occ", 0, false}, {"xcd_blocks", 0, false}, {"stats_bins", 1, false}, {"conv_direct_rows", 32, false}, {"stem_bf16", 1, false}, {"fork_every", 2, false}, {"fuse_bn_bwd", 1, false}, {"bn_inline_rows", 64, false}, {"head_stage", 1, false}, {"conv_s2_pt2", 1, false}, {"dgrad_stuff_in_loader", 1, false}, {"wgrad_ring", 1, false}, {"conv_ring", 1, false}, {"bn_bwd_fused", 0, false}, {"conv_ring_max_wgs", 1024, false}, {"conv_stream", 1, false}, {"wgrad_xcd", 1, false}, {"side_low_priority", 0, false}, {"conv_stream_min_tiles", 2, false}, {"conv_stream_stagger", 0, false}, {"wgrad_pair_join", 0, false}, {"bn_fused_blocks", 0, false}, {"bn_fused_dbg", 0, false}, {"nl_fwd", 1, false}, {"bwd_bins", 0, false}, {"nl_ring", 1, false}, {"nl_max_c", 64, false}, {"fuse_slab_sum", 0, false}, {"conv_ring_xc", 0, false}, {"fuse_adamw_prepare", 1, false}, {"adamw_max_blocks", 0, false}, {"stem_group", 1, false}};
+Opt g_opts[] = {
+    // kernel families (each non-default value is exercised by a named test: tests/test_hip_baseline_sizes.py
+    // test_every_kernel_choice_option_gives_the_same_training_step, tests/test_hip_ops.py, tests/test_hip_unet.py)
+    {"side_stream", 1, false}, {"conv_direct", 1, false}, {"conv_nw8", 1, false}, {"conv_ring", 1, false}, {"conv_stream", 1, false},
+    {"wgrad_ring", 1, false}, {"wgrad_xcd", 1, false}, {"stats_bins", 1, false}, {"fuse_bn_bwd", 1, false}, {"nl_fwd", 1, false},
+    {"stem_bf16", 1, false},
+    // launch-size thresholds and split sizes (tuned on the batch-32 step / the 512^3 prediction; tools/ab_option.py)
+    {"conv_min_wgs", 512, false}, {"conv_nw8_min_wgs", 128, false}, {"conv_direct_min_px", 262144, false}, {"conv_direct_rows", 32, false},
+    {"conv_direct_rows_big", 128, false}, {"conv_ring_max_wgs", 1024, false}, {"conv_stream_min_tiles", 2, false},
+    {"wgrad_target", 96, false}, {"wgrad_target_plain", 256, false}, {"wgrad_slab_mb", 16, false}, {"fork_every", 2, false},
+    {"bn_inline_rows", 64, false}, {"nl_max_c", 64, false}};
 }
 int vs_option(const char* name) {
     for (auto& o : g_opts) {

@@ -72,8 +72,6 @@ extern "C" int vs_bn_fold_bias(const float* scale, const float* bias, float* shi
 int launch_adamw_prepare_all(int dtype, const vs_adamw_args& a, const float* grads, void* ws, int n, const long* w_off, const long* wc_off,
                              const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad, const int* cg,
                              const int* update, hipStream_t s);
-int launch_group_reduce_adamw(const vs_adamw_args& a, float* grads, const void* ws, int nred, const long* slab_off, const long* dw_off,
-                              const long* n, const int* nparts, int nrng, const long* roff, const long* rlen, hipStream_t s);
 int launch_weight_prepare_all(int dtype, const float* params, void* ws, int n, const long* w_off, const long* wc_off,
                               const long* wt_off, const int* cout, const int* taps, const int* cin, const int* cout_pad,
                               const int* cg, hipStream_t s);
@@ -158,10 +156,7 @@ struct Unit {
     bool frozen_candidate = false;  // "encoder" in name and "conv" in name (vol_seg_2d_trainer.py:102-108)
     size_t off_wc = 0, off_wt = 0, off_bn = 0;  // workspace offsets (bytes): weight copies, 4*C floats of BN constants
     size_t off_bins = 0;                         // stat_bins_rows(cout) rows of fixed-point statistics bins ([row][2][cout] 64-bit), training plans
-    size_t off_bbins = 0;                        // the same shape again for the BatchNorm-backward sums (ConvParams::bstats_bins); 0 = none
     size_t off_wc2 = 0, off_wt2 = 0;             // second set of weight copies (training workspaces): see vs_unet::wset
-    size_t off_slab = 0, slab_bytes = 0;         // this unit's OWN split-K slab region (plain dense U_CONV of training plans): with the fused
-                                                 // optimiser step the slabs stay here until the group's one update launch sums them
     std::vector<int> tens;                       // U_FPA: parameter tensor indices
     size_t off_fpa_pool = 0, off_fpa_arena = 0, off_fpa_plane = 0;   // U_FPA: pooled input, pyramid arena (fp32), attention plane (fp32)
     std::vector<int> members;                    // U_CONCAT: the activations whose channels `out` strings together, in order
@@ -216,7 +211,6 @@ struct vs_unet {
     std::vector<int> producer, first_consumer;   // per activation: unit that outputs it / lowest-index unit that reads it
     std::vector<int> bwd_stat_rows;              // per activation: partial rows left by the dgrad that completed its gradient
     std::vector<int> sole_consumer;              // per activation: the ONE unit that reads it (-1: none / several readers)
-    std::vector<char> bbins_dirty;               // per unit: its backward bins hold sums (the training forward's zero launch clears them all)
     // SyncBatchNorm under data parallelism (vs_unet_set_stats_hook): the statistics of every BatchNorm are summed over the ranks
     vs_stats_hook_fn stats_hook = nullptr; void* stats_user = nullptr; int stats_world = 1;
     size_t off_syncsc = 0;                       // 2 * cmax floats: the summed copies of a unit's (dbeta, dgamma) for the backward apply
@@ -232,17 +226,14 @@ struct vs_unet {
     size_t off_ys = 0;                 // scratch: the column form of a large-rate convolution's input gradient
     size_t off_ct = 0, off_ctdw = 0, ctdw_bytes = 0;   // transposed convolutions: un-shuffled output; dense 3x3 weight gradient
     int wset = 0;  // which set of weight copies the forward / backward read; the fused optimiser step fills the other and flips
-    std::vector<int> slab_parts;   // per unit: K splits its weight gradient left UNSUMMED in Unit::off_slab in the current backward
-                                   // (0: the gradient is complete in the flat buffer)
     std::vector<char> written;  // per activation: has its gradient buffer been written in the current backward pass
     // backward runs the weight-gradient kernels on an internal side stream, forked from / joined to the caller's stream
     static constexpr int kSide = 2;
     hipStream_t side[kSide] = {nullptr, nullptr};
-    std::vector<hipEvent_t> fork_events, pair_events;
+    std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event[kSide] = {nullptr, nullptr};
     ~vs_unet() {
         for (auto e : fork_events) (void)hipEventDestroy(e);
-        for (auto e : pair_events) (void)hipEventDestroy(e);
         for (int i = 0; i < kSide; ++i) {
             if (join_event[i]) (void)hipEventDestroy(join_event[i]);
             if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -1115,14 +1106,13 @@ size_t plan_workspace(vs_unet* net) {
         size_t total = 0;
         for (auto& u : net->units)
             if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64))
-                total += unit_bins_bytes(u.cout) + kTicketBytes + (u.kind == U_CONV ? unit_bins_bytes(u.cout) : 0);
+                total += unit_bins_bytes(u.cout) + kTicketBytes;
         net->bins_bytes = total;
         net->off_bins0 = take(total);
         size_t at = net->off_bins0;
         for (auto& u : net->units)
             if ((u.kind == U_CONV && u.bn_idx >= 0 && u.bias_idx < 0) || (u.kind == U_STEM && u.cout == 64)) {
                 u.off_bins = at; at += unit_bins_bytes(u.cout) + kTicketBytes;
-                if (u.kind == U_CONV) { u.off_bbins = at; at += unit_bins_bytes(u.cout); }
             }
     }
     // activations (a for all, z for conv/stem outputs)
@@ -1180,16 +1170,6 @@ size_t plan_workspace(vs_unet* net) {
     }
     net->wgws_bytes = wg;
     net->off_wgws = take(wg * vs_unet::kSide);  // one slab workspace per side stream
-    // ... and a region of its own for every plain dense convolution: with the optimiser step fused into backward the split-K slabs
-    // of a whole parameter group stay unsummed until the group's ONE update launch reads them (unet_backward_range: group_update)
-    for (auto& u : net->units) {
-        if (u.kind != U_CONV || u.cg || u.g2 || u.colr || u.w_idx < 0) continue;
-        WgradParams p{};
-        p.C0 = u.cin0; p.C1 = u.cin1; p.up0 = u.up0; p.N = (int)N; p.Hin = u.hin; p.Win = u.win;
-        p.Hout = u.hout; p.Wout = u.wout; p.stride = u.stride; p.pad = u.pad; p.KH = p.KW = u.k; p.Cout = u.cout; p.dil = u.dil;
-        u.slab_bytes = wgrad_workspace_bytes(net->dtype, p);
-        u.off_slab = take(u.slab_bytes);
-    }
     {
         const Unit& hd = net->units.back();
         net->off_headdw = take((size_t)16 * hd.k * hd.k * hd.cin0 * sizeof(float));
@@ -1555,7 +1535,7 @@ extern "C" int vs_unet_forward_to_volume(vs_unet_t* net, const float* params, fl
     const bool try_fused = mode == 0 || mode == 1;
     // slices along the volume's contiguous axis: the head stages its keys slice-major in the (otherwise unused) logits
     // buffer and a transposing pass merges them into the volume along that axis
-    const bool staged = mode == 1 && (m->ss == 1 || m->ss == -1) && m->sw != 1 && m->sw != -1 && n >= 8 && vs_option("head_stage");
+    const bool staged = mode == 1 && (m->ss == 1 || m->ss == -1) && m->sw != 1 && m->sw != -1 && n >= 8;
     if (staged) sc.stage = reinterpret_cast<uint32_t*>(lg);
     const int rc = unet_forward(net, params, bnstate, x, n, 0, lg, workspace, stream, try_fused ? &sc : nullptr);
     if (rc < 0) return rc;
@@ -1578,11 +1558,8 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     int carried_stat_rows = 0;     // partial statistic rows a plain convolution's epilogue left in bnws for the U_BN unit right behind it
     bool bn_folded_into_conv = false;   // evaluation: that U_BN's scale / shift / activation already ran in the convolution's epilogue
     net->nl_act.assign(net->acts.size(), 0);
-    if (training && dt == VS_BF16 && net->bins_bytes && vs_option("stats_bins") && vs_option("fuse_stats"))
-    {
+    if (training && dt == VS_BF16 && net->bins_bytes && vs_option("stats_bins"))
         if ((rc = launch_zero_u64((unsigned long long*)(c.ws + net->off_bins0), net->bins_bytes / sizeof(unsigned long long), c.s))) return rc;
-        net->bbins_dirty.assign(net->units.size(), 0);
-    }
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
         int fused_stat_rows = 0;
@@ -1592,7 +1569,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
         switch (u.kind) {
         case U_STEM: {
             ProfScope prof(PK_STEM, 2.0 * n * u.hout * u.wout * 64 * 49, 4.0 * n * net->h * net->w + act_bytes(c, u, 1), c.s);
-            if (training && u.cout == 64 && net->bins_bytes && vs_option("stats_bins") && vs_option("fuse_stats") && stem_fwd_bins_ok(dt)) {
+            if (training && u.cout == 64 && net->bins_bytes && vs_option("stats_bins") && stem_fwd_bins_ok(dt)) {
                 // batch statistics from the kernel's own accumulators (fixed-point bins, finalised inside the apply sweep)
                 if ((rc = launch_stem_fwd_bins(x, c.P(u.w_idx), c.z(u.out), n, net->h, net->w, (unsigned long long*)(c.ws + u.off_bins),
                                                stat_bins_rows(u.cout), c.s))) return rc;
@@ -1795,7 +1772,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             if (u.bn_idx < 0 && u.gn_idx < 0) {   // plain biased convolution (FPN's lateral 1x1s): no norm, no activation
                 p.out = c.a(u.out); p.shift = u.bias_idx >= 0 ? c.P(u.bias_idx) : nullptr;   // (EfficientNet's 1x1 convolutions: no bias either)
                 // its BatchNorm is the next unit (U_BN): the batch statistics come straight from the fp32 accumulators, as for the fused units
-                if (training && dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0 && unit_index + 1 < (int)net->units.size() &&
+                if (training && dt == VS_BF16 && u.bias_idx < 0 && unit_index + 1 < (int)net->units.size() &&
                     net->units[unit_index + 1].kind == U_BN && net->units[unit_index + 1].src0 == u.out) {
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     if (rows_needed > 0 && (size_t)rows_needed * 2 * u.cout * sizeof(float) <= net->bnws_bytes) {
@@ -1824,7 +1801,7 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
             if (training) {
                 p.out = c.z(u.out);
                 if (u.bias_idx >= 0) p.shift = c.P(u.bias_idx);   // smp's ConvBnRelu keeps the convolution's bias: z includes it
-                if (dt == VS_BF16 && vs_option("fuse_stats") && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
+                if (dt == VS_BF16 && u.bias_idx < 0) {  // batch statistics straight from the fp32 accumulators
                     const int rows_needed = conv_igemm_stat_rows(dt, p);
                     const bool bins_ok = u.bn_idx >= 0 && vs_option("stats_bins") && net->bins_bytes && conv_igemm_bins_ok(dt, p);
                     const bool nl = bins_ok && nl_consumer(c, unit_index) >= 0;
@@ -1984,24 +1961,15 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     AdamwRanges r{};
     long w_off[64], wc_off[64], wt_off[64];
     int cout[64], taps[64], cin[64], cpad[64], cgs[64], upd[64], nl = 0;
-    long red_slab[48], red_dw[48], red_n[48];
-    int red_parts[48], nred = 0;
     int rc;
-    // Per range of units: ONE launch sums the split-K slabs side_wgrad left unsummed AND steps the small tensors (BatchNorm affine
-    // parameters, biases, the stem, depthwise / attention tensors), ONE launch steps the convolution weights inside the derivation of
-    // their copies.  `fuse_adamw_prepare` 0: the two-launch form it replaces (ranged AdamW over everything, then the plain copies)
-    const bool fused_copy = vs_option("fuse_adamw_prepare") != 0;
+    // Per range of units: ONE launch steps the small tensors (BatchNorm affine parameters, biases, the stem, depthwise / attention
+    // tensors: ranges of the flat buffers), ONE launch steps the convolution weights INSIDE the derivation of their copies for the next
+    // forward (round 4: the AdamW launch over the group's convolution slices and the copy launch were two; 0.025 ms per step)
     auto flush = [&]() -> int {
         int rc2;
-        if (fused_copy) {
-            if ((r.n || nred) && (rc2 = launch_group_reduce_adamw(opt, const_cast<float*>(grads), c.ws, nred, red_slab, red_dw, red_n, red_parts, r.n,
-                                                                   r.off, r.len, s))) return rc2;
-            if (nl && (rc2 = launch_adamw_prepare_all(dt, opt, grads, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, upd, s))) return rc2;
-        } else {
-            if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
-            if (nl && (rc2 = launch_weight_prepare_all(dt, opt.params, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, s))) return rc2;
-        }
-        r.n = 0; nl = 0; nred = 0;
+        if (r.n && (rc2 = launch_adamw_ranges(opt, grads, r, s))) return rc2;
+        if (nl && (rc2 = launch_adamw_prepare_all(dt, opt, grads, c.ws, nl, w_off, wc_off, wt_off, cout, taps, cin, cpad, cgs, upd, s))) return rc2;
+        r.n = 0; nl = 0;
         return VS_OK;
     };
     auto push = [&](int idx) {
@@ -2014,11 +1982,11 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
     for (int k = lo; k < hi; ++k) {
         const Unit& v = net->units[k];
         if (v.w_idx < 0 && v.bn_idx < 0) continue;
-        if (r.n > 64 || nl == 64 || nred == 48) { if ((rc = flush())) return rc; }
+        if (r.n > 150 || nl == 64) { if ((rc = flush())) return rc; }
         if (v.kind == U_SE) { push(v.w_idx); push(v.w_idx + 1); push(v.w_idx + 2); push(v.w_idx + 3); continue; }
         if (v.kind == U_FPA) { for (int t : v.tens) push(t); continue; }
         const bool conv_w = v.kind == U_CONV || v.kind == U_HEAD;          // its weight is updated by the fused copy launch below
-        if (v.w_idx >= 0 && !(conv_w && fused_copy) && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
+        if (v.w_idx >= 0 && !conv_w && !(v.frozen_candidate && !need_encoder_wgrad)) push(v.w_idx);
         const bool aux_on = !(v.aux_frozen && !need_encoder_wgrad);      // (ResNeSt: BatchNorms / biases named conv2.bn0, conv2.fc1, conv1.1 ..)
         if (v.bn_idx >= 0 && aux_on) { push(v.bn_idx); push(v.bn_idx + 1); }
         if (v.gn_idx >= 0) { push(v.gn_idx); push(v.gn_idx + 1); }
@@ -2030,13 +1998,6 @@ static int update_units(const Ctx& c, int lo, int hi, bool need_encoder_wgrad, c
             cout[nl] = v.cout; taps[nl] = v.colr ? 1 : v.k * v.k; cin[nl] = v.colr ? 9 * v.cin0 : v.cin0 + v.cin1; cpad[nl] = v.kind == U_HEAD ? 16 : v.cout;
             cgs[nl] = v.g2 ? 255 : v.cg;
             upd[nl] = !(v.frozen_candidate && !need_encoder_wgrad);
-            if (upd[nl] && k < (int)net->slab_parts.size() && net->slab_parts[k] > 1) {      // its K splits are still unsummed
-                VS_REQUIRE(fused_copy, "update_units: unit %d left its slabs unsummed but the group launch is off", k);
-                red_slab[nred] = (long)v.off_slab; red_dw[nred] = c.t(v.w_idx).offset;
-                red_n[nred] = (long)v.cout * taps[nl] * cin[nl]; red_parts[nred] = net->slab_parts[k];
-                ++nred;
-                net->slab_parts[k] = 0;
-            }
             ++nl;
         }
     }
@@ -2074,12 +2035,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     if (use_side) {
         for (int i = 0; i < vs_unet::kSide; ++i) {
             if (net->side[i]) continue;
-            // the weight gradients are off the critical path: with `side_low_priority` their stream gets the lowest priority the
-            // device offers, so that the dispatcher prefers the caller's chain whenever both have workgroups ready
-            int prio_lo = 0, prio_hi = 0;
-            VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-            if (vs_option("side_low_priority")) VS_CHECK_HIP(hipStreamCreateWithPriority(&net->side[i], hipStreamNonBlocking, prio_lo));
-            else VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+            // (a lowest-priority side stream was measured: 4.843 vs 4.853 ms per step - no preference of the dispatcher to speak of)
+            VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
             VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
         }
         while (net->fork_events.size() < net->units.size()) {
@@ -2109,8 +2066,8 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     auto group_update = [&](int ui) -> int {
         if (net->group_first.empty()) {   // unit index -> does an optimiser group start here
             static const char* const kCuts[] = {"decoder.", "encoder.layer4.0.", "encoder.layer3.0.", "encoder.layer2.0.", "encoder.layer1.0."};
-            const int ncuts = vs_option("stem_group") ? 5 : 4;     // stem_group: the stem is a group of its own - layer1's update then runs
-            net->group_first.assign(net->units.size(), 0);        // under the max-pool / stem BatchNorm backward instead of behind the stem's gradient
+            const int ncuts = 5;                                  // (the stem is a group of its own: layer1's update then runs under the max-pool /
+            net->group_first.assign(net->units.size(), 0);        // stem BatchNorm backward instead of behind the stem's gradient - 0.03 ms per step)
             net->group_first[0] = 1;
             std::string prev;
             for (size_t k = 0; k < net->units.size(); ++k) {
@@ -2129,22 +2086,6 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     // Weight-gradient work of one unit, queued on the side stream (after a fork event that covers its dz).
     struct SideItem { int ui; const void* dzp; int dz_c; };
     std::vector<SideItem> pending;
-    // pair_join: the caller's stream waits for every unit's weight gradient before it goes on (the data gradient and the
-    // weight gradient of a unit - both MFMA-bound, both reading dz - run side by side; the latency-bound BatchNorm sweeps
-    // between them run alone).  The optimiser work stays behind the join.
-    const bool pair_join = use_side && vs_option("wgrad_pair_join") == 1;
-    const bool pair_sched = use_side && vs_option("wgrad_pair_join") == 2;
-    int last_pair = -1;
-    bool defer_group_update = pair_join || pair_sched;
-    const bool defer_slabs = opt != nullptr && do_side && vs_option("fuse_slab_sum") != 0 && vs_option("fuse_adamw_prepare") != 0;
-    if (net->slab_parts.size() != net->units.size()) net->slab_parts.assign(net->units.size(), 0);
-    if (pair_join || pair_sched) {
-        while (net->pair_events.size() < net->units.size()) {
-            hipEvent_t e;
-            VS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            net->pair_events.push_back(e);
-        }
-    }
     auto side_wgrad = [&](const SideItem& it) -> int {
         const int ui = it.ui;
         const Unit& u = net->units[ui];
@@ -2160,7 +2101,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, 64 * 49 * sizeof(float), ws_stream));
             }
-            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
+            return opt ? group_update(ui) : VS_OK;
         }
         if (u.kind == U_DWCONV2) {
             ProfScope prof(PK_CONV_WGRAD, want_w ? 2.0 * n * u.hout * u.wout * u.cout * u.k * u.k : 0, 0, ws_stream);
@@ -2170,13 +2111,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             } else {
                 VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0, (size_t)u.cout * u.k * u.k * sizeof(float), ws_stream));
             }
-            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
+            return opt ? group_update(ui) : VS_OK;
         }
         if (u.kind == U_DWCONV) {
             ProfScope prof(PK_CONV_WGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, ws_stream);
             if ((rc = vs_dwconv3x3_wgrad(dt, c.a(u.src0), dzp, grads + c.t(u.w_idx).offset, n, u.hin, u.win, u.cout, u.dil, wgws, net->wgws_bytes,
                                          (void*)ws_stream))) return rc;
-            return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
+            return opt ? group_update(ui) : VS_OK;
         }
         if (want_w) {
             ProfScope prof(PK_CONV_WGRAD, conv_flops(c, u), 0, ws_stream);
@@ -2200,24 +2141,17 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * u.k * u.k * u.cin0 * sizeof(float),
                                             hipMemcpyDeviceToDevice, ws_stream));
             } else {
+                // (the split-K slabs are summed right behind the kernel, out of the ONE slab buffer every layer reuses: it stays in the
+                // L2s / Infinity Cache.  Round 4 measured the alternatives: slabs kept per layer and summed once per optimiser group
+                // (+0.02 ms per step: 0.7 GB of slabs then go to HBM and back) or inside the optimiser launch (+0.33 ms))
                 p.dw = grads + c.t(u.w_idx).offset;
-                // fused optimiser step: the K splits stay unsummed in the unit's own slab region; the group's update launch sums
-                // them in launch_slab_reduce's order (no reduction launch, no write + re-read of the gradient in between)
-                int nsplit = 0;
-                const size_t nel = (size_t)dz_c * p.KH * p.KW * (p.C0 + p.C1);
-                if (defer_slabs && u.kind == U_CONV && u.slab_bytes && wgrad_workspace_bytes(dt, p) <= u.slab_bytes &&
-                    slab_reduce_groups((const float*)(c.ws + u.off_slab), p.dw, nel, 2) > 0) {
-                    p.partials = (float*)(c.ws + u.off_slab); p.partial_bytes = u.slab_bytes;
-                    p.defer_reduce = 1; p.nsplit_out = &nsplit;
-                }
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-                net->slab_parts[ui] = (p.defer_reduce && nsplit > 1) ? nsplit : 0;
             }
         } else {
             VS_CHECK_HIP(hipMemsetAsync(grads + c.t(u.w_idx).offset, 0,
                                         (size_t)u.cout * u.k * u.k * (u.cg ? u.cg : (u.cin0 + u.cin1) / (u.g2 ? 2 : 1)) * sizeof(float), ws_stream));
         }
-        return (opt && !defer_group_update) ? group_update(ui) : VS_OK;
+        return opt ? group_update(ui) : VS_OK;
     };
     const int fork_every = std::max(1, vs_option("fork_every"));
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
@@ -2484,13 +2418,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             }
             BnSync sy{net->stats_hook, net->stats_user, net->stats_world, (float*)(c.ws + net->off_syncsc)};
             const BnSync* sync = net->stats_hook ? &sy : nullptr;
-            if (net->bwd_stat_rows[u.out] < 0) {    // ... in fixed-point bins
-                ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
-                if ((rc = launch_bn_bwd_from_bins(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
-                                                  grads + c.t(u.bn_idx).offset, grads + c.t(u.bn_idx + 1).offset, c.rows(u), u.cout,
-                                                  (const unsigned long long*)(c.ws + u.off_bbins), -net->bwd_stat_rows[u.out], c.s))) return rc;
-                net->bwd_stat_rows[u.out] = 0;
-            } else if (net->bwd_stat_rows[u.out] > 0) {
+            if (net->bwd_stat_rows[u.out] > 0) {
                 // the dgrad that completed da(u.out) left the masked gradient and the reduction's partial rows: one sweep
                 ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, 3 + (dres ? 1 : 0)), c.s);
                 if ((rc = launch_bn_bwd_from_partials(dt, c.da(u.out), c.z(u.out), c.bnc(u, 2), c.bnc(u, 3), c.P(u.bn_idx), c.dz(u.out), dres,
@@ -2499,7 +2427,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 net->bwd_stat_rows[u.out] = 0;
             } else {
             // two sweeps: (dy, y, x) reduce, then (dy, y, x) -> dx (+ dres)
-            const bool recompute_mask = vs_option("recompute_mask") && u.relu && u.res < 0;  // mask from x: two tensor reads fewer
+            const bool recompute_mask = u.relu && u.res < 0;  // mask from x: two tensor reads fewer
             ProfScope prof(PK_BN_BWD, 0, act_bytes(c, u, ((u.relu && !recompute_mask) ? 6 : 4) + 1 + (dres ? 1 : 0)), c.s);
             if ((rc = bn_bwd_dispatch(dt, c.da(u.out), recompute_mask ? nullptr : c.a(u.out), c.z(u.out), c.bnc(u, 2),
                                       c.bnc(u, 3), c.P(u.bn_idx), c.P(u.bn_idx + 1), u.relu, c.dz(u.out), dres,
@@ -2523,12 +2451,9 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // weight-gradient work of up to `fork_every` consecutive units ----
         pending.push_back(SideItem{ui, dzp, dz_c});
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
-        // wgrad_sched: the weight gradient of a unit never runs beside a data gradient (both MFMA-bound) - it is released
-        // BEHIND this unit's data gradient and the caller's stream waits for it in front of the NEXT data gradient, so it
-        // shares the chip with the (memory-bound) BatchNorm sweeps of the next unit only
-        const bool sched = pair_sched && role == ROLE_BOTH;
-        if (sched && do_main && last_pair >= 0) { VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->pair_events[last_pair], 0)); last_pair = -1; }
-        if (!sched && flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
+        // (joining the side stream after every unit, or releasing a weight gradient only behind its unit's data gradient, were both
+        // measured slower - 6.0 ms per step - and are not kept)
+        if (flush && do_main && (rc = fork_mark(ui))) return rc;   // dz of every pending unit is complete at this point of the caller's stream
         if (u.colr && do_main) {   // data gradient of the 1x1 form = the input gradient's column form; its adjoint scatter onto the map
             ConvParams p{};
             p.src0 = dzp; p.C0 = u.cout; p.N = n; p.Hin = p.Hout = u.hin; p.Win = p.Wout = u.win; p.stride = 1; p.pad = 0; p.KH = p.KW = 1;
@@ -2554,7 +2479,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
         ConvParams p{};
         const void* dsrc = dzp;
-        const bool stuff_in_loader = u.stride == 2 && vs_option("dgrad_stuff_in_loader") && !(u.hin & 1) && !(u.win & 1);
+        const bool stuff_in_loader = u.stride == 2 && !(u.hin & 1) && !(u.win & 1);
         if (u.stride == 2 && !stuff_in_loader) {
             void* zs = c.ws + net->off_zs;
             ProfScope prof(PK_POOL_MISC, 0, (double)n * u.hin * u.win * dz_c * net->esz * 1.25, c.s);
@@ -2605,23 +2530,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 net->units[pu].bn_idx >= 0 && !(p.Cout & 3) && conv_igemm_variant(dt, p) % 10 != 4) {
                 const Unit& q = net->units[pu];
                 const int rows_needed = conv_igemm_stat_rows(dt, p);
-                // many tiles: the sums go into a few rows of fixed-point bins that the apply sweep adds up itself - no finalize launch
-                const bool bins = dt == VS_BF16 && !net->stats_hook && vs_option("bwd_bins") && vs_option("stats_bins") && vs_option("fuse_stats") && q.off_bbins &&
-                                  q.cout <= 512 && rows_needed > vs_option("bn_inline_rows") && net->bbins_dirty.size() == net->units.size();
-                if (bins) {
-                    unsigned long long* bb = (unsigned long long*)(c.ws + q.off_bbins);
-                    if (net->bbins_dirty[pu] && (rc = launch_zero_u64(bb, unit_bins_bytes(q.cout) / sizeof(unsigned long long), c.s))) return rc;
-                    net->bbins_dirty[pu] = 1;
-                    const bool recompute = vs_option("recompute_mask") && q.relu && q.res < 0;
-                    p.bz = c.z(q.out);
-                    p.by = (q.relu && !recompute) ? c.a(q.out) : nullptr;
-                    p.bmean = c.bnc(q, 2); p.binvstd = c.bnc(q, 3);
-                    p.bgamma = c.P(q.bn_idx); p.bbeta = c.P(q.bn_idx + 1);
-                    p.bstats_bins = bb; p.bstats_nb = stat_bins_rows(q.cout);
-                    p.brelu = q.relu;
-                    net->bwd_stat_rows[pa] = -p.bstats_nb;
-                } else if ((size_t)rows_needed * 2 * q.cout * sizeof(float) <= net->bnws_bytes) {
-                    const bool recompute = vs_option("recompute_mask") && q.relu && q.res < 0;
+                // (fixed-point bins for these sums - no finalize launch - were measured in round 3: -0.013 ms per step, and they are not
+                // scale-equivariant (gradients of 2 g != 2 x gradients of g bit for bit): not kept)
+                if ((size_t)rows_needed * 2 * q.cout * sizeof(float) <= net->bnws_bytes) {
+                    const bool recompute = q.relu && q.res < 0;
                     p.bz = c.z(q.out);
                     p.by = (q.relu && !recompute) ? c.a(q.out) : nullptr;
                     p.bmean = c.bnc(q, 2); p.binvstd = c.bnc(q, 3);
@@ -2638,26 +2550,11 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
             written[u.src0] = 1;
         }
         }
-        if (sched && flush && do_main && (rc = fork_mark(ui))) return rc;   // behind the data gradient
         if (flush) {
             if (do_side) {
                 if ((rc = fork_wait(ui))) return rc;
                 for (const SideItem& it : pending)
                     if ((rc = side_wgrad(it))) return rc;
-                if (sched) {
-                    VS_CHECK_HIP(hipEventRecord(net->pair_events[ui], ws_stream));
-                    last_pair = ui;
-                    if (opt)
-                        for (const SideItem& it : pending)
-                            if ((rc = group_update(it.ui))) return rc;
-                }
-                if (pair_join) {
-                    VS_CHECK_HIP(hipEventRecord(net->pair_events[ui], ws_stream));
-                    VS_CHECK_HIP(hipStreamWaitEvent(c.s, net->pair_events[ui], 0));
-                    if (opt)
-                        for (const SideItem& it : pending)
-                            if ((rc = group_update(it.ui))) return rc;
-                }
             }
             pending.clear();
             prof_set_tag(ui);
@@ -2759,7 +2656,7 @@ extern "C" int vs_unet_nl_plan(vs_unet_t* net, int n, int* flags, int cap) {
         const Unit& u = net->units[i];
         if (i < cap) flags[i] = 0;
         if (u.kind != U_CONV || net->dtype != VS_BF16 || u.bn_idx < 0 || u.gn_idx >= 0 || u.bias_idx >= 0) continue;
-        if (!vs_option("fuse_stats") || !vs_option("stats_bins") || !net->bins_bytes) continue;
+        if (!vs_option("stats_bins") || !net->bins_bytes) continue;
         ConvParams p = conv_params(c, u);
         if (!conv_igemm_bins_ok(net->dtype, p) || nl_consumer(c, i) < 0) continue;
         act[u.out] = 1;

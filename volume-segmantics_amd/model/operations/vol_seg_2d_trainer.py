@@ -195,9 +195,12 @@ class VolSeg2dTrainer:
         if self._aug_rng is None:     # draws of the device-side augmentation: one stream per rank
             self._aug_rng = np.random.default_rng([int(getattr(self.settings, "augment_seed", 0)), self.rank])
         inputs, targets = utils.prepare_training_batch(batch, self._device(), self.label_no, augment_rng=self._aug_rng)
-        fuse = getattr(self.model, "can_fuse_step", None)
+        # `step_mode: graph` replays the whole step (zero_grad .. optimizer.step) as recorded hipGraphs - same kernels, same order, same
+        # bits, 0.4 ms of host time per step instead of ~1.8; the default enqueues it call by call, which every box of rounds 3 and 4
+        # ran 2 - 4 % faster (4.65 vs 4.82 ms; the replay's range boundaries cost more than a host that keeps up) - for a slow or busy
+        # host the replay is the one to pick (bench.py times both and keeps the faster)
+        fuse = getattr(self.model, "can_fuse_step", None) if getattr(self.settings, "step_mode", "eager") == "graph" else None
         if fuse is not None and isinstance(self.loss_criterion, HipDiceLoss) and fuse(self.optimizer, inputs, targets):
-            # the whole step (zero_grad .. optimizer.step) as one replayed hipGraph - same kernels, same order, same bits
             loss = self.model.fused_train_step(inputs, targets, self.optimizer, eps=self.loss_criterion.epsilon)
             lr_scheduler.step()
             return loss
