@@ -62,6 +62,15 @@ int vs_conv2d_fwd(const vs_conv_desc* d, const void* src0, const void* src1, con
  * reference counterpart: a test / tooling query (tests assert which path a parity case exercised). */
 int vs_conv2d_variant(const vs_conv_desc* d);
 
+/* Two chained evaluation-mode layers in ONE launch: y = act2(conv(act1(conv(up?(src0), w1) * scale1 + shift1), w2) * scale2 + shift2), both
+ * 3x3 / stride 1 / padding 1, d1->cout == d2->c0 <= 16, d2->cout <= 16, 16-bit storage - smp's last decoder block at full resolution
+ * (DecoderBlock.conv1 / conv2 with BatchNorm folded, inside model(batch) at vol_seg_2d_predictor.py:44).  The tensor between the two
+ * layers is never written; every output bit equals two vs_conv2d_fwd launches.  vs_conv2d_pair_ok: whether the descriptors qualify
+ * (1 / 0; the network plan asks the same question before it pairs two units). */
+int vs_conv2d_pair_ok(const vs_conv_desc* d1, const vs_conv_desc* d2);
+int vs_conv2d_pair_fwd(const vs_conv_desc* d1, const vs_conv_desc* d2, const void* src0, const void* w1, const float* scale1, const float* shift1,
+                       const void* w2, const float* scale2, const float* shift2, void* y, void* stream);
+
 /* The TRAINING forms of the same convolution launch - what the network plan (vs_unet_forward / vs_unet_backward) asks of it around a
  * train-mode BatchNorm2d; exposed as one operator so that every kernel the batch-32 step selects (LDS-DMA ring tiles of 64 / 32
  * couts, pairs of 8 x 8 images) can be held against torch with its training epilogue, at the launch sizes that select it.

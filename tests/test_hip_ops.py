@@ -103,6 +103,45 @@ def test_conv_direct_kernel(code, force_direct_kernel):
         _conv_case(code, 1, 48, 32, 24, 16, 3, 1, 1, seed=15)                  # channel tail inside the chunk
 
 
+@pytest.mark.parametrize("code", [1, 2])
+@pytest.mark.parametrize("case", [(2, 64, 96, 32, 1, 16, 16, 1), (3, 40, 44, 16, 0, 16, 16, 1), (1, 34, 30, 32, 1, 16, 12, 2), (2, 32, 32, 24, 0, 8, 16, 0),
+                                  (1, 70, 16, 32, 1, 16, 16, 1)])
+def test_direct_pair_equals_two_launches_bit_for_bit(code, case, force_direct_kernel):
+    """conv_direct_pair_kernel - smp's last decoder block (Conv2dReLU(up(x)) -> Conv2dReLU, BatchNorm folded) as ONE evaluation-mode
+    launch whose intermediate tensor never exists - against the two strip-kernel launches it replaces: EVERY output bit equal (same
+    products, same order, the tensor in between rounded to the storage type on its way through LDS), and against torch CPU within
+    the bf16 / fp16 tolerance.  Strip widths that do not divide the image (14-column strips), heights that do not divide the row
+    chunks (force_direct_kernel: 6 rows), with and without the x2 upsampling of the source, 8 - 16 channels in between, ReLU /
+    swish / no activation."""
+    L = lib()
+    n, h, w, c0, up, cmid, cout, relu = case
+    g = torch.Generator().manual_seed(71 + h)
+    x0 = rounded(torch.randn(n, c0, h >> up, w >> up, generator=g), code)
+    w1 = rounded(torch.randn(cmid, c0, 3, 3, generator=g) / (c0 * 9) ** 0.5, code)
+    w2 = rounded(torch.randn(cout, cmid, 3, 3, generator=g) / (cmid * 9) ** 0.5, code)
+    s1, b1 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.2
+    s2, b2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    act = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[relu]
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up else x0
+    mid = rounded(act(F.conv2d(xin, w1, padding=1) * s1[None, :, None, None] + b1[None, :, None, None]), code)
+    ref = act(F.conv2d(mid, w2, padding=1) * s2[None, :, None, None] + b2[None, :, None, None])
+    d1 = conv_desc(L, code, n, h, w, c0, cmid, 3, 1, 1, up0=up, relu=relu)
+    d2 = conv_desc(L, code, n, h, w, cmid, cout, 3, 1, 1, relu=relu)
+    assert L.lib.vs_conv2d_pair_ok(d1, d2) == 1 and L.lib.vs_conv2d_variant(d1) % 10 == 4 and L.lib.vs_conv2d_variant(d2) % 10 == 4
+    x0d, w1d, w2d = to_nhwc(x0, code), w_krsc(w1, code), w_krsc(w2, code)
+    s1d, b1d, s2d, b2d = s1.to(DEV), b1.to(DEV), s2.to(DEV), b2.to(DEV)
+    midd = torch.full((n, h, w, cmid), float("nan"), device=DEV, dtype=tdtype(code))
+    two = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    one = torch.full((n, h, w, cout), float("nan"), device=DEV, dtype=tdtype(code))
+    L.check(L.lib.vs_conv2d_fwd(d1, L.ptr(x0d), None, L.ptr(w1d), L.ptr(s1d), L.ptr(b1d), None, L.ptr(midd), None, None))
+    L.check(L.lib.vs_conv2d_fwd(d2, L.ptr(midd), None, L.ptr(w2d), L.ptr(s2d), L.ptr(b2d), None, L.ptr(two), None, None))
+    L.check(L.lib.vs_conv2d_pair_fwd(d1, d2, L.ptr(x0d), L.ptr(w1d), L.ptr(s1d), L.ptr(b1d), L.ptr(w2d), L.ptr(s2d), L.ptr(b2d), L.ptr(one), None))
+    sync()
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)), (one.float() - two.float()).abs().max()
+    assert torch.allclose(from_nhwc(one), ref, **tol(code, ref.abs().max().item())), (from_nhwc(one) - ref).abs().max()
+
+
 @pytest.mark.parametrize("code", CODES)
 @pytest.mark.parametrize("cout", [16, 8])
 def test_conv_direct_kernel_pooled_data_gradient(code, cout, force_direct_kernel):

@@ -75,6 +75,8 @@ _SIGS = {
     "vs_conv2d_train_variant": (I, [C.POINTER(ConvDesc), C.POINTER(ConvTrain)]),
     "vs_conv2d_stat_rows": (I, [C.POINTER(ConvDesc), C.POINTER(ConvTrain)]),
     "vs_stat_scale": (C.c_double, [I]),
+    "vs_conv2d_pair_ok": (I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
+    "vs_conv2d_pair_fwd": (I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),

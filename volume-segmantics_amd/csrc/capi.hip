@@ -117,6 +117,29 @@ extern "C" int vs_conv2d_stat_rows(const vs_conv_desc* d, const vs_conv_train* t
 }
 extern "C" double vs_stat_scale(int which) { return which == 0 ? kStatScale1 : kStatScale2; }
 
+static int pair_params(const vs_conv_desc* d1, const vs_conv_desc* d2, ConvParams& p, ConvParams& q) {
+    int rc = desc_to_params(d1, p);
+    if (rc) return rc;
+    if ((rc = desc_to_params(d2, q))) return rc;
+    VS_REQUIRE(d1->dtype == d2->dtype && d1->c1 == 0 && d2->c1 == 0 && d1->split_c == 0 && d2->split_c == 0, "conv_pair: plain single-source layers of one dtype");
+    return VS_OK;
+}
+extern "C" int vs_conv2d_pair_ok(const vs_conv_desc* d1, const vs_conv_desc* d2) {
+    ConvParams p, q;
+    if (pair_params(d1, d2, p, q)) return 0;
+    fake_pointers(d1, p); fake_pointers(d2, q);
+    return conv_pair_ok(d1->dtype, p, q) ? 1 : 0;
+}
+extern "C" int vs_conv2d_pair_fwd(const vs_conv_desc* d1, const vs_conv_desc* d2, const void* src0, const void* w1, const float* scale1,
+                                  const float* shift1, const void* w2, const float* scale2, const float* shift2, void* y, void* stream) {
+    ConvParams p, q;
+    int rc = pair_params(d1, d2, p, q);
+    if (rc) return rc;
+    p.src0 = src0; p.w = w1; p.scale = scale1; p.shift = shift1;
+    q.src0 = (const void*)16; q.w = w2; q.scale = scale2; q.shift = shift2; q.out = y;      // (q's source is the tensor that is never written)
+    return launch_conv_pair(d1->dtype, p, q, (hipStream_t)stream);
+}
+
 static int desc_to_wgrad(const vs_conv_desc* d, WgradParams& p) {
     VS_REQUIRE(d, "conv: null descriptor");
     p = WgradParams{};

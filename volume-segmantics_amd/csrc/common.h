@@ -263,6 +263,9 @@ bool conv_head_scatter_ok(int dtype, const ConvParams& p);
 bool conv_igemm_bins_ok(int dtype, const ConvParams& p);     // whether p's kernel honours ConvParams::stats_bins   // whether launch_conv_igemm can honour p.scatter for this layer
 bool conv_igemm_nl_ok(int dtype, const ConvParams& p);       // whether launch_conv_igemm can honour p.nl_* (normalise src0 on load)
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
+// two chained evaluation-mode shallow layers (q reads p's output and nothing else does) as one launch: the tensor between them never exists
+bool conv_pair_ok(int dtype, const ConvParams& p, const ConvParams& q);
+int launch_conv_pair(int dtype, const ConvParams& p, const ConvParams& q, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
 int conv_igemm_stat_rows(int dtype, const ConvParams& p);   // number of partial rows stats_partial receives
 int conv_igemm_variant(int dtype, const ConvParams& p);      // BN*1000 + PT*100 + taps*10 + code of the chosen instantiation

@@ -535,6 +535,177 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
     }
 }
 
+// ---- two chained shallow layers in ONE launch (evaluation mode) ---------------------------------------------------------------
+// smp's last decoder block at full resolution - Conv2dReLU(up(x), 32 -> 16) then Conv2dReLU(16 -> 16), BatchNorm folded into
+// scale / shift (decoders/unet/decoder.py: DecoderBlock.conv1 / conv2, run by model(batch) at vol_seg_2d_predictor.py:44) - moves
+// 1.6 + 2.1 GB per 128 x 512^2 batch as two strip-kernel launches, all but 0.5 + 1.1 GB of it the 16-channel tensor between them.
+// Here a wave rolls BOTH layers down its strip: every row of the first layer's output goes - affine, ReLU, rounded to the storage
+// type exactly as the first launch would have stored it - into a 16-pixel LDS row of the wave's own, from which the second layer
+// reads its three column shifts as MFMA B fragments; the intermediate tensor never exists.  Strips are 14 output columns wide: lane
+// lr of the 16-lane rows holds column w0 - 1 + lr of the FIRST layer (the one-pixel halo the second layer's 3 x 3 window needs), the
+// second layer's lanes 0 and 15 compute nothing that is stored.  Rows / columns of the first layer's output outside the image are
+// written as zeros - they are the second layer's zero padding.  Per output value the products and their order (kh-major taps,
+// K = 32 MFMA k-steps over the same channel -> k mapping) are those of conv_direct_kernel / conv_igemm_kernel: bit-identical results
+// (tests/test_hip_ops.py::test_direct_pair_equals_two_launches_bit_for_bit).  16-bit storage types only.  Measured: 1 034 us against 2 x 562 us
+// per 128 x 512^2 batch, 0.8 % of a 512^3 prediction - the strip walk is bound by its MFMA + LDS-fragment issue (18 MFMAs and 22 LDS
+// operations per 16-pixel row and wave), not by the 2.1 GB of HBM traffic the fusion removes.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void conv_direct_pair_kernel(ConvParams p, ConvParams q, DirectGeom g) {
+    constexpr int EPS = CT<T>::EPS, NTAPS = 9, BN = 16, kD = 4;
+    constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
+    constexpr int kOob = (int)0x80000000;
+    constexpr int kRowB = 18 * 32;                                   // one first-layer row of a wave: 16 pixels + a zero pixel each side, 16 channels
+    __shared__ __attribute__((aligned(16))) char wl1[NTAPS * BN * kPS + 64];
+    __shared__ __attribute__((aligned(16))) char wl2[NTAPS * BN * kPS + 64];
+    __shared__ __attribute__((aligned(16))) char ybuf[4 * kRowB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int Cin = p.C0, Cmid = p.Cout;
+    {   // both weight slabs: once per workgroup (conv_direct_kernel's staging, rows = taps x 16 couts, 16-byte channel segments)
+        const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(p.w, p.Cout * NTAPS * Cin * (int)sizeof(T));
+        const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(q.w, q.Cout * NTAPS * Cmid * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) {
+            const int item = tid + i * 256;
+            const int row = item >> 2, seg = item & 3;
+            const int tap = row / BN, nr = row % BN;
+            const bool ok1 = item < WTOTAL && nr < p.Cout && seg * EPS < Cin, ok2 = item < WTOTAL && nr < q.Cout && seg * EPS < Cmid;
+            const uint4 v1 = bload(rw1, ok1 ? ((nr * NTAPS + tap) * Cin + seg * EPS) * (int)sizeof(T) : -1, 0);
+            const uint4 v2 = bload(rw2, ok2 ? ((nr * NTAPS + tap) * Cmid + seg * EPS) * (int)sizeof(T) : -1, 0);
+            const int dst = item < WTOTAL ? swz(row, row, seg) : NTAPS * BN * kPS;
+            *reinterpret_cast<uint4*>(wl1 + dst) = v1;
+            *reinterpret_cast<uint4*>(wl2 + dst) = v2;
+        }
+        char* yb = ybuf + wave * kRowB;                              // the halo pixels of this wave's row stay zero for good
+        if (lane < 4) *reinterpret_cast<uint4*>(yb + (lane & 1) * 16 + (lane >> 1) * 17 * 32) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int gw = blockIdx.x * 4 + wave;                            // this wave's strip
+    if (gw >= g.nwaves) return;
+    const int qq = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
+    const int ws = gw - qq * g.strips_w;
+    const int n = g.chunks_h == 1 ? qq : (int)__umulhi((unsigned)qq, g.ch_magic);
+    const int hc = qq - n * g.chunks_h;
+    const int w0 = ws * 14 - 1, h0 = hc * g.RH, h1 = min(q.Hout, h0 + g.RH);      // lane lr: column w0 + lr of BOTH layers' outputs
+    const int H0 = p.Hin >> p.up0, W0 = p.Win >> p.up0;
+    const int rowbytes = W0 * p.C0 * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const T*)p.src0 + (size_t)n * H0 * W0 * p.C0, H0 * rowbytes);
+    int coff[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int col = w0 + lr + kw - 1;
+        coff[kw] = (col >= 0 && col < p.Win && lq * EPS < Cin) ? ((col >> p.up0) * p.C0 + lq * EPS) * (int)sizeof(T) : -1;
+    }
+    const int wbase_l = swz(lr, lr, lq);
+    auto load_row = [&](int hi, uint4 (&x)[3]) {
+        const bool ok = hi >= 0 && hi < p.Hin;
+        const int soff = ok ? (hi >> p.up0) * rowbytes : 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) x[kw] = bload(rx, ok ? coff[kw] : -1, soff);
+    };
+    // the second layer's output: one descriptor per image, lane offset inside a row (lanes 0 / 15 and columns past the image: never stored)
+    const int wo = w0 + lr;
+    const bool inw = lr >= 1 && lr <= 14 && wo < q.Wout;
+    const bool col1 = wo >= 0 && wo < p.Wout;                        // this lane's first-layer column lies inside the image
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((T*)q.out + (size_t)n * q.Hout * q.Wout * q.Cout, q.Hout * q.Wout * q.Cout * (int)sizeof(T));
+    const int orow = q.Wout * q.Cout * (int)sizeof(T);
+    const int ooff = (inw && lq * 4 < q.Cout) ? (wo * q.Cout + lq * 4) * (int)sizeof(T) : kOob;
+    float4 sc1 = make_float4(1.f, 1.f, 1.f, 1.f), sh1 = make_float4(0.f, 0.f, 0.f, 0.f), sc2 = sc1, sh2 = sh1;
+    {
+        float a[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = lq * 4 + r;
+            if (c < p.Cout) { if (p.scale) a[r] = p.scale[c]; if (p.shift) b[r] = p.shift[c]; }
+            if (c < q.Cout) { if (q.scale) c2[r] = q.scale[c]; if (q.shift) d2[r] = q.shift[c]; }
+        }
+        sc1 = make_float4(a[0], a[1], a[2], a[3]); sh1 = make_float4(b[0], b[1], b[2], b[3]);
+        sc2 = make_float4(c2[0], c2[1], c2[2], c2[3]); sh2 = make_float4(d2[0], d2[1], d2[2], d2[3]);
+    }
+    const bool affine1 = p.scale || p.shift, affine2 = q.scale || q.shift;
+    auto act = [](float (&v)[4], int relu) {
+        if (relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        else if (relu == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+        }
+    };
+    char* yb = ybuf + wave * kRowB;
+    char* ywr = yb + (lr + 1) * 32 + lq * 8;                         // where this lane's 4 couts of pixel lr go
+    const char* yrd = yb + lr * 32 + lq * 16;                        // B fragment of column shift kw: + kw * 32 (lq < 2; else zeros)
+
+    // (both layers' weight fragments in registers for the whole strip - 194 VGPRs, two workgroups per CU - were measured: 0.3345 vs 0.3251 s
+    // per 8-direction 512^3 prediction with the fragments re-read from LDS every row at four workgroups per CU: not kept)
+    // x row hi completes first-layer row r1 = hi - 1, which completes second-layer row r2 = r1 - 1: three accumulators roll per layer
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
+    uint4 ring[kD][3];
+    const int hfirst = h0 - 2, hlast = h1 + 1;                       // x rows this strip needs (rows outside the image load as zeros)
+#pragma unroll
+    for (int u = 0; u < kD; ++u) load_row(hfirst + u, ring[u]);
+    for (int base = hfirst; base <= hlast; base += kD) {
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const int hi = base + u;
+            if (hi > hlast) break;
+            int wb = wbase_l;
+            asm volatile("" : "+v"(wb));   // keep the weight fragments in LDS (see conv_direct_kernel)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const uint4 w0f = *reinterpret_cast<const uint4*>(wl1 + ((0 * 3 + kw) * BN) * kPS + wb);
+                const uint4 w1f = *reinterpret_cast<const uint4*>(wl1 + ((1 * 3 + kw) * BN) * kPS + wb);
+                const uint4 w2f = *reinterpret_cast<const uint4*>(wl1 + ((2 * 3 + kw) * BN) * kPS + wb);
+                mma16<T>(a2, w0f, ring[u][kw]);
+                mma16<T>(a1, w1f, ring[u][kw]);
+                mma16<T>(a0, w2f, ring[u][kw]);
+            }
+            load_row(hi + kD, ring[u]);
+            // ---- first-layer row r1 is complete: epilogue, then into the wave's LDS row (zeros outside the image) ----
+            const int r1 = hi - 1;
+            {
+                float v[4] = {a0[0], a0[1], a0[2], a0[3]};
+                if (affine1) { v[0] = v[0] * sc1.x + sh1.x; v[1] = v[1] * sc1.y + sh1.y; v[2] = v[2] * sc1.z + sh1.z; v[3] = v[3] * sc1.w + sh1.w; }
+                act(v, p.relu);
+                const bool in1 = col1 && r1 >= 0 && r1 < p.Hout && lq * 4 < Cmid;
+                uint2 pk;
+                pk.x = in1 ? pack2<T>(v[0], v[1]) : 0u;
+                pk.y = in1 ? pack2<T>(v[2], v[3]) : 0u;
+                *reinterpret_cast<uint2*>(ywr) = pk;
+            }
+            a0 = a1; a1 = a2; a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the row is in LDS (one wave: its LDS operations execute in order)
+            __builtin_amdgcn_wave_barrier();
+            // ---- second layer: first-layer row r1 feeds rows r1 + 1 (kh 0), r1 (kh 1), r1 - 1 (kh 2) ----
+            int wb2 = wbase_l;
+            asm volatile("" : "+v"(wb2));
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                uint4 yf = make_uint4(0u, 0u, 0u, 0u);
+                if (lq < 2) yf = *reinterpret_cast<const uint4*>(yrd + kw * 32);
+                const uint4 w0f = *reinterpret_cast<const uint4*>(wl2 + ((0 * 3 + kw) * BN) * kPS + wb2);
+                const uint4 w1f = *reinterpret_cast<const uint4*>(wl2 + ((1 * 3 + kw) * BN) * kPS + wb2);
+                const uint4 w2f = *reinterpret_cast<const uint4*>(wl2 + ((2 * 3 + kw) * BN) * kPS + wb2);
+                mma16<T>(b2, w0f, yf);
+                mma16<T>(b1, w1f, yf);
+                mma16<T>(b0, w2f, yf);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the next row overwrites the LDS row
+            __builtin_amdgcn_wave_barrier();
+            const int r2 = r1 - 1;                                   // this second-layer row is complete now
+            {
+                float v[4] = {b0[0], b0[1], b0[2], b0[3]};
+                if (affine2) { v[0] = v[0] * sc2.x + sh2.x; v[1] = v[1] * sc2.y + sh2.y; v[2] = v[2] * sc2.z + sh2.z; v[3] = v[3] * sc2.w + sh2.w; }
+                act(v, q.relu);
+                const int off = (r2 >= h0 && r2 < h1) ? ooff : kOob;
+                uint2 pk;
+                pk.x = pack2<T>(v[0], v[1]);
+                pk.y = pack2<T>(v[2], v[3]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, off, r2 * orow, 0);
+            }
+            b0 = b1; b1 = b2; b2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // ---- segmentation head: <= 4 classes ---------------------------------------------------------------------------------
 // Same strip walk as conv_direct_kernel, but with <= 4 output channels a 16-row MFMA tile would be 3/4 empty and the
 // per-pixel epilogue (softmax / arg-max in prediction) would run on lanes that hold nothing: the kernel is VALU-bound.
@@ -723,6 +894,19 @@ int launch_direct(const ConvParams& p, int out_nchw, hipStream_t s) {
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
+}
+
+// the pair kernel's geometry: strips of 14 columns
+static DirectGeom pair_geom(const ConvParams& q) {
+    DirectGeom g{};
+    g.strips_w = cdiv(q.Wout, 14);
+    const bool big = (long)q.N * q.Hout * q.Wout >= (4L << 20) * 4;
+    g.RH = std::max(2, vs_option(big ? "conv_direct_rows_big" : "conv_direct_rows") & ~1);
+    g.chunks_h = cdiv(q.Hout, g.RH);
+    g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
+    g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
+    g.nwaves = q.N * g.strips_w * g.chunks_h;
+    return g;
 }
 
 template <typename T, int BN, int PT, int NTAPS, int STRIDE, int NW = 4, int DIL = 1, bool NLOAD = false>
@@ -989,4 +1173,27 @@ int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s) {
     }
     vs_set_error("conv_igemm: bad dtype %d", dtype);
     return VS_ERR_INVALID;
+}
+
+// Whether two chained evaluation-mode layers - p's output (NHWC, storage type) read by q and by nothing else - can run as ONE launch of
+// conv_direct_pair_kernel: both are strip-kernel layers on their own (direct_ok), 16-bit storage, at most 16 channels between them.
+bool conv_pair_ok(int dtype, const ConvParams& p, const ConvParams& q) {
+    if ((dtype != VS_BF16 && dtype != VS_F16) || !vs_option("conv_pair")) return false;
+    if (!direct_ok(dtype, p) || !direct_ok(dtype, q)) return false;
+    if (p.pool0 || q.pool0 || p.scatter || q.scatter || p.out_f32 || q.out_f32 || p.stats_partial || p.stats_bins || q.stats_partial || q.stats_bins ||
+        q.up0 || q.C1 || p.Cout > 16 || q.Cout > 16 || (p.Cout & 7) || (q.Cout & 3)) return false;
+    return q.C0 == p.Cout && q.N == p.N && q.Hin == p.Hout && q.Win == p.Wout && q.Hout == p.Hout && q.Wout == p.Wout;
+}
+
+int launch_conv_pair(int dtype, const ConvParams& p, const ConvParams& q, hipStream_t s) {
+    VS_REQUIRE(conv_pair_ok(dtype, p, q), "conv_pair: the two layers cannot share a launch (ask conv_pair_ok first)");
+    VS_REQUIRE(p.src0 && p.w && q.w && q.out, "conv_pair: null pointer");
+    VS_REQUIRE((double)p.Hin * p.Win * p.C0 * 2.0 < 2.0e9 && (double)q.Hout * q.Wout * q.Cout * 2.0 < 2.0e9, "conv_pair: tensor too large");
+    const DirectGeom g = pair_geom(q);
+    VS_REQUIRE((long)g.nwaves * 16 < (1L << 32), "conv_pair: grid too large");
+    const dim3 grid(cdiv(g.nwaves, 4));
+    if (dtype == VS_BF16) hipLaunchKernelGGL((conv_direct_pair_kernel<bf16_t>), grid, dim3(256), 0, s, p, q, g);
+    else hipLaunchKernelGGL((conv_direct_pair_kernel<f16_t>), grid, dim3(256), 0, s, p, q, g);
+    VS_LAUNCH_CHECK();
+    return VS_OK;
 }

@@ -18,6 +18,7 @@ enum ProfKind {
 bool prof_on();
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
+void prof_add_flops(double flops);   // more algorithmic work for the record that is open (a launch that turned out to cover two layers)
 void prof_set_tag(int tag);  // attached to subsequent records (unit index)
 void prof_set_variant(int v);  // kernel instantiation code of the next records (0 = n/a)
 int vs_option(const char* name);

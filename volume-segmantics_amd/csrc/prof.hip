@@ -32,6 +32,7 @@ void prof_begin(int kind, double flops, double bytes, hipStream_t s) {
     g_recs.push_back(r);
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+void prof_add_flops(double flops) { if (g_on && !g_recs.empty()) g_recs.back().flops += flops; }
 
 void prof_set_tag(int tag) { g_tag = tag; }
 void prof_set_variant(int v) { g_variant = v; }
@@ -79,7 +80,7 @@ Opt g_opts[] = {
     // test_every_kernel_choice_option_gives_the_same_training_step, tests/test_hip_ops.py, tests/test_hip_unet.py)
     {"side_stream", 1, false}, {"conv_direct", 1, false}, {"conv_nw8", 1, false}, {"conv_ring", 1, false}, {"conv_stream", 1, false},
     {"wgrad_ring", 1, false}, {"wgrad_xcd", 1, false}, {"stats_bins", 1, false}, {"fuse_bn_bwd", 1, false}, {"nl_fwd", 1, false},
-    {"stem_bf16", 1, false},
+    {"stem_bf16", 1, false}, {"conv_pair", 1, false},
     // launch-size thresholds and split sizes (tuned on the batch-32 step / the 512^3 prediction; tools/ab_option.py)
     {"conv_min_wgs", 512, false}, {"conv_nw8_min_wgs", 128, false}, {"conv_direct_min_px", 262144, false}, {"conv_direct_rows", 32, false},
     {"conv_direct_rows_big", 128, false}, {"conv_ring_max_wgs", 1024, false}, {"conv_stream_min_tiles", 2, false},

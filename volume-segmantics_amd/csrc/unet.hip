@@ -1560,8 +1560,10 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
     net->nl_act.assign(net->acts.size(), 0);
     if (training && dt == VS_BF16 && net->bins_bytes && vs_option("stats_bins"))
         if ((rc = launch_zero_u64((unsigned long long*)(c.ws + net->off_bins0), net->bins_bytes / sizeof(unsigned long long), c.s))) return rc;
+    int skip_units = 0;            // evaluation: units that already ran inside the previous unit's launch (conv_pair)
     for (auto& u : net->units) {
         prof_set_tag(++unit_index);
+        if (skip_units) { --skip_units; continue; }
         int fused_stat_rows = 0;
         bool fused_bins = false;
         float* rm = u.bn_idx >= 0 ? bnstate + c.t(u.bn_idx + 2).offset : nullptr;
@@ -1822,6 +1824,27 @@ static int unet_forward(vs_unet_t* net, const float* params, float* bnstate, con
                 p.scale = c.bnc(u, 0); p.shift = c.bnc(u, 1);
                 p.residual = u.res >= 0 ? c.a(u.res) : nullptr;
                 p.relu = u.relu;
+                // evaluation: this layer and the next one - its only reader, a plain conv + BN + ReLU - as ONE launch when both are
+                // strip-kernel layers (smp's last decoder block at full resolution): the tensor between them is never written
+                ensure_graph_maps(net);
+                const int vi = unit_index + 1;
+                if (vi < (int)net->units.size() && net->sole_consumer[u.out] == vi && u.res < 0 && u.bias_idx < 0 && u.bn_idx >= 0) {
+                    const Unit& v = net->units[vi];
+                    if (v.kind == U_CONV && v.src0 == u.out && v.src1 < 0 && !v.up0 && v.res < 0 && v.bn_idx >= 0 && v.gn_idx < 0 && v.bias_idx < 0 &&
+                        !v.colr && !v.cg && !v.g2) {
+                        ConvParams q = conv_params(c, v);
+                        q.out = c.a(v.out); q.scale = c.bnc(v, 0); q.shift = c.bnc(v, 1); q.relu = v.relu;
+                        ConvParams p1 = p;
+                        p1.out = nullptr;
+                        p1.out_f32 = 0; q.out_f32 = 0;
+                        if (conv_pair_ok(dt, p1, q)) {
+                            if ((rc = launch_conv_pair(dt, p1, q, c.s))) return rc;
+                            prof_add_flops(conv_flops(c, v));
+                            skip_units = 1;
+                            break;
+                        }
+                    }
+                }
             }
             if ((rc = launch_conv_igemm(dt, p, c.s))) return rc;
             break;
