@@ -278,3 +278,44 @@ def test_ring_forward_normalising_its_input_on_load(case):
     assert torch.allclose(from_nhwc(out), ref, **tol(BF, ref.abs().max().item())), (from_nhwc(out) - ref).abs().max()
     assert torch.allclose(rmd.cpu().double(), 0.9 * rm.double() + 0.1 * mean, atol=1e-5)
     assert torch.allclose(rvd.cpu().double(), 0.9 * rv.double() + 0.1 * var * rows / (rows - 1), rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [pytest.param((32, 32, 128, 0, 0, 128), id="layer2-128to128@32"),
+                                  pytest.param((16, 16, 256, 0, 0, 256), id="layer3-256to256@16"),
+                                  pytest.param((16, 16, 512, 256, 1, 256), id="dec0.conv1-up512+256to256@16"),
+                                  pytest.param((8, 8, 512, 0, 0, 512), id="layer4-512to512@8-two-images-per-tile"),
+                                  pytest.param((64, 64, 64, 0, 0, 64), id="layer1-64to64@64")])
+def test_ring_weight_gradient_at_32_images(case):
+    """ring::conv_wgrad_ring_kernel - the weight gradients of the stride-1 3x3 layers in the batch-32 step (30 of its 46 weight-gradient
+    launches) - at 32 images against autograd (loss.backward(), vol_seg_2d_trainer.py:429); the same launch twice gives the same bits
+    (slabs summed in a fixed order), and the register-staged kernel (`wgrad_ring` 0) agrees to fp32 summation order."""
+    L = lib()
+    h, w, c0, c1, up0, cout = case
+    g = torch.Generator().manual_seed(53)
+    x0, x1, xin, wt = _inputs(g, h, w, c0, c1, up0, cout)
+    wt = wt.requires_grad_()
+    y = F.conv2d(xin, wt, padding=1)
+    dy = rounded(torch.randn(y.shape, generator=g), BF)
+    y.backward(dy)
+    ref = wt.grad.permute(0, 2, 3, 1)
+    d = conv_desc(L, BF, N, h, w, c0, cout, 3, 1, 1, c1=c1, up0=up0)
+    x0d, x1d, dyd = to_nhwc(x0, BF), (to_nhwc(x1, BF) if c1 else None), to_nhwc(dy, BF)
+    outs = []
+    old = L.lib.vs_get_option(b"wgrad_ring")
+    try:
+        for ring in (1, 1, 0):
+            L.set_option("wgrad_ring", ring)
+            ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+            dw = torch.full((cout, 3, 3, c0 + c1), float("nan"), device=DEV)
+            L.check(L.lib.vs_conv2d_wgrad(d, _ptr(x0d), _ptr(x1d), _ptr(dyd), _ptr(dw), _ptr(ws), ws_bytes, None))
+            sync()
+            outs.append(dw)
+    finally:
+        L.set_option("wgrad_ring", old)
+    base = outs[0]
+    scale = ref.abs().max().item()
+    assert torch.isfinite(base).all()
+    assert torch.allclose(base.cpu(), ref, rtol=1e-3, atol=1e-3 * scale), (base.cpu() - ref).abs().max()
+    assert torch.equal(outs[1], base)
+    assert torch.allclose(outs[2], base, rtol=1e-5, atol=1e-5 * scale), (outs[2] - base).abs().max()
