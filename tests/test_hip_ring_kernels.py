@@ -319,3 +319,39 @@ def test_ring_weight_gradient_at_32_images(case):
     assert torch.allclose(base.cpu(), ref, rtol=1e-3, atol=1e-3 * scale), (base.cpu() - ref).abs().max()
     assert torch.equal(outs[1], base)
     assert torch.allclose(outs[2], base, rtol=1e-5, atol=1e-5 * scale), (outs[2] - base).abs().max()
+
+
+@pytest.mark.parametrize("case", [pytest.param((3, 128, 128, 0), id="3x128x128"), pytest.param((2, 24, 256, 0), id="2x24x256-ragged-row-ranges"),
+                                  pytest.param((1, 6, 512, 0), id="1x6x512"), pytest.param((32, 256, 256, 0), id="32x256x256-the-step's-launch"),
+                                  pytest.param((3, 128, 128, 1), id="up-3x128x128"), pytest.param((2, 28, 256, 1), id="up-2x28x256-ragged-row-ranges"),
+                                  pytest.param((1, 4, 512, 1), id="up-1x4x512"), pytest.param((32, 256, 256, 1), id="up-32x256x256-the-step's-launch")])
+def test_row_streaming_weight_gradient_of_the_full_resolution_layers(case):
+    """rows::conv_wgrad_rows16_kernel / conv_wgrad_rows_up32_kernel - the weight gradients of the 16-cout 3x3 layers at full
+    resolution (the last decoder block's two convolutions, the first behind the nearest upsampling of its 32-channel input, and the
+    segmentation head in the batch-32 step) - against autograd (loss.backward(), vol_seg_2d_trainer.py:429): row ranges that cross
+    image boundaries, heights that are no power of two, every row width the kernels are built for; the same launch twice gives the
+    same bits."""
+    L = lib()
+    n, h, w, up = case
+    cin = 32 if up else 16
+    g = torch.Generator().manual_seed(59)
+    x = rounded(torch.randn(n, cin, h >> up, w >> up, generator=g), BF)
+    wt = rounded(torch.randn(16, cin, 3, 3, generator=g) / 12.0, BF).requires_grad_()
+    dy = rounded(torch.randn(n, 16, h, w, generator=g), BF)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    F.conv2d(xin, wt, padding=1).backward(dy)
+    ref = wt.grad.permute(0, 2, 3, 1)
+    d = conv_desc(L, BF, n, h, w, cin, 16, 3, 1, 1, up0=up)
+    xd, dyd = to_nhwc(x, BF), to_nhwc(dy, BF)
+    outs = []
+    for _ in range(2):
+        ws_bytes = L.lib.vs_conv2d_wgrad_workspace(d)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        dw = torch.full((16, 3, 3, cin), float("nan"), device=DEV)
+        L.check(L.lib.vs_conv2d_wgrad(d, _ptr(xd), None, _ptr(dyd), _ptr(dw), _ptr(ws), ws_bytes, None))
+        sync()
+        outs.append(dw)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.allclose(outs[0].cpu(), ref, rtol=1e-3, atol=1e-3 * scale), (outs[0].cpu() - ref).abs().max()
+    assert torch.equal(outs[0], outs[1])

@@ -1,5 +1,5 @@
-"""A/B of several option settings on the eager training step, interleaved in one process: python ab2.py "a=1,b=2" "a=0" ..."""
-import sys, time
+"""A/B of several option settings on the eager training step, interleaved in one process: python tools/ab_multi.py "a=1,b=2" "a=0" "env:VS_X=0" ..."""
+import os, sys, time
 import pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 import bench
@@ -14,7 +14,9 @@ t = torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).to(dev, torch.uint8)
 crit = HipDiceLoss()
 def setopts(spec):
     for kv in spec.split(","):
-        k, v = kv.split("="); _lib.set_option(k, int(v))
+        k, v = kv.split("=")
+        if k.startswith("env:"): os.environ[k[4:]] = v      # (switches the library reads from the environment at every launch)
+        else: _lib.set_option(k, int(v))
 arms = {}
 for spec in arms_spec:
     setopts(spec)

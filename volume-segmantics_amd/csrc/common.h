@@ -309,7 +309,10 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
+    int cout_live;                        // 0 = all; else only the first cout_live gradient channels are real (the head's classes in its
+                                          // 16-channel gradient) and, IF conv_wgrad_honours_cout_live says so, dw is [cout_live][KH*KW][Cin]
 };
+bool conv_wgrad_honours_cout_live(int dtype, const WgradParams& p);
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 // dw[i] = sum_k partials[k*n + i], fixed summation order

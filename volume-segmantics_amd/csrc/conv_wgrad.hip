@@ -17,6 +17,7 @@
 #include "common.h"
 #include "prof.h"
 #include "conv_wgrad_ring.h"
+#include "conv_wgrad_rows.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ struct WGeom {
     int fast;                                        // bf16 fast path (conv_wgrad_bf16_kernel) applies
     int ring;                                        // 1 / 2: conv_wgrad_ring_kernel on 16 x 8 tiles / on pairs of 8 x 8 images
     int xmode, ppx;                                  // workgroup -> (pair, split) assignment (ring::wg_assign), bf16 kernels
+    int rows, rows_per;                              // 1: conv_wgrad_rows16_kernel (full-resolution 16 -> 16 layers), output rows per workgroup
     unsigned long long* probe;                       // phase timestamps (tools/convlab); null in normal operation
 };
 
@@ -499,6 +501,20 @@ int geom(const WgradParams& p, WGeom& g, int& WO) {
     g.fast = sizeof(T) == 2 && p.Cout % 8 == 0 && g.total_tiles < 65536 &&
              (double)p.N * p.Hin * p.Win * std::max(p.C0, p.C1) * 2.0 < 2.0e9 && (double)p.N * p.Hout * p.Wout * p.Cout * 2.0 < 2.0e9;
     g.ring = 0;
+    g.rows = 0; g.rows_per = 0;
+    // full-resolution 16-cout layers: the row-streaming kernels, one slab per workgroup (conv_wgrad_rows.h): 16 plain input channels
+    // (rows = 1) or 32 at half resolution behind the loader's nearest upsampling (rows = 2).  256 workgroups x 3 rows in flight:
+    // measured on the batch-32 step's launches against 128 / 512 / 768 / 1024 workgroups and 1 - 4 rows (profiles/r4_wgrad_rows_sweep.txt)
+    if (g.fast && vs_option("wgrad_ring") && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && p.C1 == 0 && p.Cout == 16 && p.pad == 1 &&
+        ((p.C0 == 16 && !p.up0) || (p.C0 == 32 && p.up0 == 1 && p.Hout % 2 == 0)) &&
+        (p.Wout == 128 || p.Wout == 256 || p.Wout == 512) && p.Hout >= 2 && (double)p.N * p.Hout * p.Wout * 32.0 < 2.0e9) {
+        g.rows = p.up0 ? 2 : 1;
+        const int R = p.N * p.Hout / g.rows;               // steps: output rows / source rows
+        g.rows_per = std::max(2, cdiv(R, 256));
+        g.nsplit = cdiv(R, g.rows_per);
+        WO = 1; g.ctiles = 1; g.dys = 0;
+        return VS_OK;
+    }
     if (g.fast && vs_option("wgrad_ring") && p.KH == 3 && p.stride == 1 && dil == 1 && !p.cg && (p.C0 % 32) == 0 && (p.C1 % 32) == 0) {
         if (PT == 2) g.ring = 1;
         else if (p.Hout == 8 && p.Wout == 8 && p.N % 2 == 0 && p.Cout >= 64) {   // 8 x 8 maps: two images per 128-pixel tile
@@ -583,6 +599,25 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
     return launch_slab_reduce(p.partials, p.dw, (size_t)p.Cout * NTAPS * (p.cg ? 32 : p.C0 + p.C1), g.nsplit, s);
 }
 
+// the row-streaming kernel of the full-resolution 16 -> 16 layers (conv_wgrad_rows.h)
+template <int WQ>
+int launch_rows_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
+    constexpr int PF = 3;                                   // rows in flight per workgroup
+    static bool attr_set[2] = {false, false};
+    const int up = g.rows == 2;
+    auto kern = up ? rows::conv_wgrad_rows_up32_kernel<WQ, PF> : rows::conv_wgrad_rows16_kernel<WQ, PF>;
+    const size_t lds = up ? rows::up_lds_bytes(128 * WQ) : rows::lds_bytes(128 * WQ);
+    if (!attr_set[up]) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[up] = true;
+    }
+    const int live = !up && p.cout_live > 0 && p.cout_live < 16 ? p.cout_live : 16;
+    rows::RGeom gr{p.N * p.Hout, g.rows_per, g.nsplit, p.Hout, p.Wout, live};
+    hipLaunchKernelGGL(kern, dim3(g.nsplit), dim3(256), lds, s, p, gr);
+    VS_LAUNCH_CHECK();
+    return launch_slab_reduce(p.partials, p.dw, (size_t)live * 9 * p.C0, g.nsplit, s);
+}
+
 // the ring-staged, pipelined kernel (conv_wgrad_ring.h): stride-1 3x3 layers on 128-pixel tiles
 template <int MO, int TWS, int IMGS>
 int launch_ring_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
@@ -649,6 +684,7 @@ int dispatch(const WgradParams& p, hipStream_t s) {
         return VS_OK;
     }
     if constexpr (sizeof(T) == 2) {
+        if (g.rows) return p.Wout == 128 ? launch_rows_wgrad<1>(p, g, s) : (p.Wout == 256 ? launch_rows_wgrad<2>(p, g, s) : launch_rows_wgrad<4>(p, g, s));
         if (g.fast) {
             if (p.dil == 2) {   // the dilated 3x3 layers (>= 32 channels): 64-pixel and 128-pixel tiles
                 if (WO == 4) return g.PT == 2 ? launch_fast<4, 9, 1, 2, 2>(p, g, s) : launch_fast<4, 9, 1, 1, 2>(p, g, s);
@@ -727,6 +763,11 @@ int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, h
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
+}
+
+bool conv_wgrad_honours_cout_live(int dtype, const WgradParams& p) {
+    WGeom g; int WO;
+    return dtype == VS_BF16 && geom<bf16_t>(p, g, WO) == VS_OK && g.rows == 1;
 }
 
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p) {

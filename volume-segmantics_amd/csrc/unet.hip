@@ -2159,10 +2159,17 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
                 if ((rc = launch_two_group_wgrad_extract(p.dw, grads + c.t(u.w_idx).offset, u.cout, u.k * u.k, u.cin0, ws_stream))) return rc;
             } else if (u.kind == U_HEAD) {
-                p.dw = (float*)(c.ws + net->off_headdw);
-                if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
-                VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * u.k * u.k * u.cin0 * sizeof(float),
-                                            hipMemcpyDeviceToDevice, ws_stream));
+                p.cout_live = net->classes;
+                if (conv_wgrad_honours_cout_live(dt, p)) {   // the row-streaming kernel leaves [classes][9][16] slabs: summed straight into the gradient
+                    p.dw = grads + c.t(u.w_idx).offset;
+                    if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                } else {
+                    p.cout_live = 0;
+                    p.dw = (float*)(c.ws + net->off_headdw);
+                    if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
+                    VS_CHECK_HIP(hipMemcpyAsync(grads + c.t(u.w_idx).offset, p.dw, (size_t)net->classes * u.k * u.k * u.cin0 * sizeof(float),
+                                                hipMemcpyDeviceToDevice, ws_stream));
+                }
             } else {
                 // (the split-K slabs are summed right behind the kernel, out of the ONE slab buffer every layer reuses: it stays in the
                 // L2s / Infinity Cache.  Round 4 measured the alternatives: slabs kept per layer and summed once per optimiser group
