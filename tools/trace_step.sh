@@ -19,3 +19,4 @@ with open(sys.argv[2], "w") as o:
     for r in win:
         o.write(f"{(r[2] - a) / 1e3:9.1f} {(r[3] - r[2]) / 1e3:7.1f} s{r[1]} {short(r[0])}\n")
 PY
+python tools/wg_time_step.py "$f" > gpurun_out/${tag}_wg_time.txt 2>&1
