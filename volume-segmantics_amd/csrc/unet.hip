@@ -2184,6 +2184,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         return opt ? group_update(ui) : VS_OK;
     };
     const int fork_every = std::max(1, vs_option("fork_every"));
+    const bool stem_on_caller = use_side && opt && role == ROLE_BOTH;
     for (int ui = unit_hi - 1; ui >= unit_lo; --ui) {
         const Unit& u = net->units[ui];
         prof_set_tag(ui);
@@ -2583,8 +2584,23 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         if (flush) {
             if (do_side) {
                 if ((rc = fork_wait(ui))) return rc;
-                for (const SideItem& it : pending)
+                for (const SideItem& it : pending) {
+                    // The stem is the last unit of the backward pass: behind its BatchNorm backward the caller's stream has nothing left
+                    // to do but wait for the side stream, which still owes layer1's last weight gradients and their update.  With the fused
+                    // optimiser step the stem's weight gradient and update (a group of its own) therefore run on the CALLER's stream, beside
+                    // that tail instead of behind it (second slab workspace; profiles/r4_ab_side_stream_experiments.log).
+                    if (stem_on_caller && net->units[it.ui].kind == U_STEM) {
+                        hipStream_t keep_s = ws_stream;
+                        float* keep_w = wgws;
+                        ws_stream = c.s;
+                        wgws = (float*)(c.ws + net->off_wgws + net->wgws_bytes);
+                        rc = side_wgrad(it);
+                        ws_stream = keep_s; wgws = keep_w;
+                        if (rc) return rc;
+                        continue;
+                    }
                     if ((rc = side_wgrad(it))) return rc;
+                }
             }
             pending.clear();
             prof_set_tag(ui);
