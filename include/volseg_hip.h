@@ -309,6 +309,13 @@ int vs_unet_backward_adamw(vs_unet_t* net, const float* x, const float* dlogits,
  * next forward reads (call it once, after every range of the network has been refreshed). */
 int vs_unet_prepare_range(vs_unet_t* net, const float* params, void* workspace, void* stream, int unit_lo, int unit_hi);
 int vs_unet_flip_weight_set(vs_unet_t* net);
+/* The weight-gradient work of vs_unet_backward* runs on library-owned side streams (one pair per device for every plan of the
+ * process).  HIP multiplexes streams onto a few hardware queues; two streams on one queue run in order.  The library therefore
+ * checks, the first time the streams serve a caller's stream, that a kernel on each really runs beside the other (two 100 us spin
+ * kernels, timed) and replaces a stream that does not.  This entry repeats that measurement for `stream`: *overlaps = 1 when the
+ * plan's weight-gradient stream and `stream` executed concurrently.  (No reference counterpart: torch's autograd engine runs on
+ * the caller's stream only.) */
+int vs_unet_side_stream_overlaps(vs_unet_t* net, void* stream, int* overlaps);
 int vs_unet_weight_set(const vs_unet_t* net);   /* 0 / 1: the weight set the next forward reads */
 
 /* ------------------------------------------------------------------------------------------

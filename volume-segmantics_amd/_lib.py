@@ -194,6 +194,7 @@ _SIGS = {
     "vs_unet_adamw_range": (I, [P, I, P, P, P, C.POINTER(AdamwArgs), I, I]),
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),
+    "vs_unet_side_stream_overlaps": (I, [P, P, C.POINTER(I)]),
     "vs_unet_weight_set": (I, [P]),
     "vs_capture_begin": (P, []),
     "vs_capture_end": (I, [C.POINTER(P)]),

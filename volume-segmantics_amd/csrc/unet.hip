@@ -234,12 +234,83 @@ struct vs_unet {
     hipEvent_t join_event[kSide] = {nullptr, nullptr};
     ~vs_unet() {
         for (auto e : fork_events) (void)hipEventDestroy(e);
-        for (int i = 0; i < kSide; ++i) {
-            if (join_event[i]) (void)hipEventDestroy(join_event[i]);
-            if (side[i]) (void)hipStreamDestroy(side[i]);
-        }
+        for (int i = 0; i < kSide; ++i)
+            if (join_event[i]) (void)hipEventDestroy(join_event[i]);   // (the side streams belong to the process-wide pool below)
     }
 };
+
+// ---- the side streams: one pair per device for every plan of the process, checked against the caller's stream -------------------
+// HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default).  A side stream that shares its queue with
+// the caller's stream runs its kernels IN ORDER with the caller's: the weight gradients no longer overlap the backward pass and the
+// batch-32 step takes 5.3 instead of 4.4 ms - measured for every second model a process creates when each plan made its own streams
+// (tools/placement_probe.py, profiles/r4_side_stream_hw_queues.txt).  So the streams are made once, and the first time they serve a
+// given caller's stream a 2 x 100 us timing probe (one spin kernel on each stream, started together) tells whether the two really run
+// beside one another; a stream that does not is parked (kept, so that the runtime's assignment moves on) and another one is tried.
+__global__ void side_probe_spin(unsigned long long ticks) {   // ticks of the 100 MHz wall clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+struct SidePool {
+    hipStream_t s[vs_unet::kSide] = {nullptr, nullptr};
+    hipStream_t checked_for = nullptr;
+    bool checked = false;
+    std::vector<hipStream_t> parked;
+};
+static SidePool& side_pool() {
+    static SidePool pools[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return pools[dev & 63];
+}
+// true: a kernel on `a` and a kernel on `b` ran at the same time
+static int streams_overlap(hipStream_t a, hipStream_t b, bool* yes) {
+    hipEvent_t e0, e1, eb;
+    VS_CHECK_HIP(hipEventCreate(&e0));
+    VS_CHECK_HIP(hipEventCreate(&e1));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    VS_CHECK_HIP(hipStreamSynchronize(a));
+    VS_CHECK_HIP(hipStreamSynchronize(b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {       // (the first pass also pays the kernel's load)
+        VS_CHECK_HIP(hipEventRecord(e0, a));
+        hipLaunchKernelGGL(side_probe_spin, dim3(1), dim3(64), 0, a, 10000ull);
+        hipLaunchKernelGGL(side_probe_spin, dim3(1), dim3(64), 0, b, 10000ull);
+        VS_CHECK_HIP(hipEventRecord(eb, b));
+        VS_CHECK_HIP(hipStreamWaitEvent(a, eb, 0));
+        VS_CHECK_HIP(hipEventRecord(e1, a));
+        VS_CHECK_HIP(hipStreamSynchronize(a));
+        float ms = 0.f;
+        VS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+    *yes = best < 0.160f;                     // two 100 us kernels: ~0.11 ms beside one another, ~0.21 ms one after the other
+    return VS_OK;
+}
+static int acquire_side_streams(vs_unet* net, hipStream_t caller) {
+    SidePool& pool = side_pool();
+    for (int i = 0; i < vs_unet::kSide; ++i)
+        if (!pool.s[i]) VS_CHECK_HIP(hipStreamCreateWithFlags(&pool.s[i], hipStreamNonBlocking));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(caller, &cap);
+    if (cap == hipStreamCaptureStatusNone && !(pool.checked && pool.checked_for == caller)) {
+        for (int i = 0; i < vs_unet::kSide; ++i) {
+            for (int attempt = 0; attempt < 8; ++attempt) {
+                bool ok = false;
+                const int rc = streams_overlap(caller, pool.s[i], &ok);
+                if (rc) return rc;
+                if (ok && i == 1) { const int rc2 = streams_overlap(pool.s[0], pool.s[1], &ok); if (rc2) return rc2; }
+                if (ok) break;
+                pool.parked.push_back(pool.s[i]);
+                VS_CHECK_HIP(hipStreamCreateWithFlags(&pool.s[i], hipStreamNonBlocking));
+            }
+        }
+        pool.checked = true;
+        pool.checked_for = caller;
+    }
+    for (int i = 0; i < vs_unet::kSide; ++i) net->side[i] = pool.s[i];
+    return VS_OK;
+}
 
 namespace {
 
@@ -1023,7 +1094,8 @@ int build(vs_unet* net) {
 size_t plan_workspace(vs_unet* net) {
     const size_t N = (size_t)net->max_batch, esz = net->esz;
     size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t skew = getenv("VS_WS_SKEW") ? (size_t)atol(getenv("VS_WS_SKEW")) : 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes + skew, 256); return o; };
     // weight copies + BN constants
     size_t ct = 0;
     for (auto& u : net->units) {
@@ -1503,6 +1575,16 @@ extern "C" int vs_unet_drop_connect_masks(const vs_unet_t* net, int64_t* offsets
     }
     return k;
 }
+extern "C" int vs_unet_side_stream_overlaps(vs_unet_t* net, void* stream, int* overlaps) {
+    VS_REQUIRE(net && overlaps, "unet_side_stream_overlaps: null pointer");
+    int rc = acquire_side_streams(net, (hipStream_t)stream);
+    if (rc) return rc;
+    bool yes = false;
+    if ((rc = streams_overlap((hipStream_t)stream, net->side[0], &yes))) return rc;
+    *overlaps = yes ? 1 : 0;
+    return VS_OK;
+}
+
 extern "C" int vs_unet_flip_weight_set(vs_unet_t* net) {
     VS_REQUIRE(net, "unet_flip_weight_set: null pointer");
     net->wset ^= 1;
@@ -2056,12 +2138,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
     bool side_used[vs_unet::kSide] = {false, false};   // side streams this call forked onto (only those are joined: under
                                                        // stream capture a stream that never joined the capture must not be waited on)
     if (use_side) {
-        for (int i = 0; i < vs_unet::kSide; ++i) {
-            if (net->side[i]) continue;
-            // (a lowest-priority side stream was measured: 4.843 vs 4.853 ms per step - no preference of the dispatcher to speak of)
-            VS_CHECK_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
-            VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
-        }
+        // (a lowest-priority side stream was measured: 4.843 vs 4.853 ms per step - no preference of the dispatcher to speak of)
+        if ((rc = acquire_side_streams(net, c.s))) return rc;
+        for (int i = 0; i < vs_unet::kSide; ++i)
+            if (!net->join_event[i]) VS_CHECK_HIP(hipEventCreateWithFlags(&net->join_event[i], hipEventDisableTiming));
         while (net->fork_events.size() < net->units.size()) {
             hipEvent_t e;
             VS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
