@@ -105,6 +105,16 @@ double vs_stat_scale(int which);   /* fixed-point scale of the bins: 0 = sum, 1 
 /* dw[cout][kh*kw][cin] (fp32) = sum_pixels dy (x) x.  torch: conv weight gradient of loss.backward()
  * (vol_seg_2d_trainer.py:429).  workspace >= vs_conv2d_wgrad_workspace(d). */
 size_t vs_conv2d_wgrad_workspace(const vs_conv_desc* d);
+/* The segmentation head's backward straight from dLoss / dlogits as autograd hands it over - fp32 NCHW planes of `classes` channels, no
+ * 16-channel NHWC copy in between (replaces the head's share of loss.backward(), volume_segmantics/model/operations/vol_seg_2d_trainer.py:429).
+ * vs_head_dgrad_planes: dx, the gradient of the head's 16-bit NHWC input [n][h][w][c] (c <= 16, a multiple of 4), from w = the forward's weight
+ * copy [classes][9][c] in `dtype` (VS_BF16 / VS_F16); the (tap, class) pairs are the MFMA's K index.  VS_ERR_UNSUPPORTED unless 9 * classes <= 64.
+ * vs_head_wgrad_planes: dw fp32 [classes][9][16] for a 16-channel bf16 input x; workspace from vs_head_wgrad_planes_workspace (0 = unsupported:
+ * more than 7 classes, row widths other than 128 / 256 / 512 - the caller then converts and uses vs_conv2d_wgrad). */
+int vs_head_dgrad_planes(int dtype, const float* dlogits, const void* w, void* dx, int n, int classes, int h, int wd, int c, void* stream);
+size_t vs_head_wgrad_planes_workspace(int dtype, int n, int classes, int h, int wd);
+int vs_head_wgrad_planes(int dtype, const void* x, const float* dlogits, float* dw, void* workspace, size_t workspace_bytes, int n, int classes,
+                         int h, int wd, void* stream);
 int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const void* src1, const void* dy,
                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -355,3 +355,37 @@ def test_row_streaming_weight_gradient_of_the_full_resolution_layers(case):
     assert torch.isfinite(outs[0]).all()
     assert torch.allclose(outs[0].cpu(), ref, rtol=1e-3, atol=1e-3 * scale), (outs[0].cpu() - ref).abs().max()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [pytest.param((3, 2, 40, 128), id="3x2cls-40x128"), pytest.param((2, 4, 30, 256), id="2x4cls-30x256-two-k-steps"),
+                                  pytest.param((1, 7, 6, 512), id="1x7cls-6x512"), pytest.param((32, 2, 256, 256), id="32x2cls-256x256-the-step's-launch")])
+def test_head_backward_from_the_loss_gradient_planes(case):
+    """head_dgrad_planes_kernel and the planes form of rows::conv_wgrad_rows16_kernel: the segmentation head's data and weight gradients
+    read dLoss / dlogits as autograd hands it over (fp32 NCHW planes) - no 16-channel NHWC copy in between.  Against autograd of
+    F.conv2d (loss.backward(), vol_seg_2d_trainer.py:429) with the gradient rounded to bf16 as the copy would have rounded it; 2 / 4 / 7
+    classes (one and two K = 32 MFMA steps), ragged heights, every row width; the same launches twice give the same bits."""
+    L = lib()
+    n, k, h, w = case
+    g = torch.Generator().manual_seed(67)
+    x = rounded(torch.randn(n, 16, h, w, generator=g), BF).requires_grad_()
+    wt = rounded(torch.randn(k, 16, 3, 3, generator=g) / 12.0, BF).requires_grad_()
+    dl = torch.randn(n, k, h, w, generator=g) * 0.1
+    F.conv2d(x, wt, padding=1).backward(rounded(dl, BF))
+    ref_dx, ref_dw = x.grad, wt.grad.permute(0, 2, 3, 1)
+    xd, wd, dld = to_nhwc(x.detach(), BF), w_krsc(wt.detach(), BF), dl.to(DEV).contiguous()
+    ws_bytes = L.lib.vs_head_wgrad_planes_workspace(BF, n, k, h, w)
+    assert ws_bytes > 0
+    outs = []
+    for _ in range(2):
+        dx = torch.full((n, h, w, 16), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dw = torch.full((k, 3, 3, 16), float("nan"), device=DEV)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        L.check(L.lib.vs_head_dgrad_planes(BF, _ptr(dld), _ptr(wd), _ptr(dx), n, k, h, w, 16, None))
+        L.check(L.lib.vs_head_wgrad_planes(BF, _ptr(xd), _ptr(dld), _ptr(dw), _ptr(ws), ws_bytes, n, k, h, w, None))
+        sync()
+        outs.append((dx, dw))
+    dx, dw = outs[0]
+    assert torch.isfinite(dx.float()).all() and torch.isfinite(dw).all()
+    assert torch.allclose(from_nhwc(dx), ref_dx, **tol(BF, ref_dx.abs().max().item())), (from_nhwc(dx) - ref_dx).abs().max()
+    assert torch.allclose(dw.cpu(), ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item()), (dw.cpu() - ref_dw).abs().max()
+    assert torch.equal(outs[1][0], dx) and torch.equal(outs[1][1], dw)

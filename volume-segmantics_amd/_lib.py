@@ -79,6 +79,9 @@ _SIGS = {
     "vs_conv2d_pair_fwd": (I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     "vs_conv2d_wgrad_workspace": (SZ, [C.POINTER(ConvDesc)]),
     "vs_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, P, P, P, P, SZ, P]),
+    "vs_head_dgrad_planes": (I, [I, P, P, P, I, I, I, I, I, P]),
+    "vs_head_wgrad_planes_workspace": (SZ, [I, I, I, I, I]),
+    "vs_head_wgrad_planes": (I, [I, P, P, P, P, SZ, I, I, I, I, P]),
     "vs_weights_prepare": (I, [I, P, P, P, I, I, I, P]),
     "vs_weights_prepare_grouped": (I, [I, P, P, P, I, I, I, P]),
     "vs_depth_to_space2": (I, [I, P, P, I, I, I, I, P, P, P, I, P]),

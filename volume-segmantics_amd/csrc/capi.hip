@@ -175,6 +175,35 @@ extern "C" int vs_conv2d_wgrad(const vs_conv_desc* d, const void* src0, const vo
     return launch_conv_wgrad(d->dtype, p, (hipStream_t)stream);
 }
 
+/* The segmentation head's backward straight from dLoss / dlogits as autograd hands it over (fp32 NCHW planes of `classes` channels, no
+ * 16-channel NHWC copy in between).  vs_head_dgrad_planes: the gradient of the head's 16-bit NHWC input ([n][h][w][c], c <= 16) from the
+ * forward's weight copy w ([classes][9][c]); returns VS_ERR_UNSUPPORTED outside 9 * classes <= 64.  vs_head_wgrad_planes: the weight gradient
+ * dw fp32 [classes][9][16] of a 16-channel input x; VS_ERR_UNSUPPORTED where the row-streaming kernel does not apply (classes > 7, widths other
+ * than 128 / 256 / 512).  Both are what vs_unet_backward* runs for the head where they apply. */
+extern "C" int vs_head_dgrad_planes(int dtype, const float* dlogits, const void* w, void* dx, int n, int classes, int h, int wd, int c, void* stream) {
+    VS_REQUIRE(dlogits && w && dx, "head_dgrad_planes: null pointer");
+    if (!head_dgrad_planes_ok(dtype, classes, h, wd, c)) { vs_set_error("head_dgrad_planes: unsupported shape"); return VS_ERR_UNSUPPORTED; }
+    return launch_head_dgrad_planes(dtype, dlogits, w, dx, n, classes, h, wd, c, (hipStream_t)stream);
+}
+static WgradParams head_wgrad_params(int n, int classes, int h, int wd) {
+    WgradParams p{};
+    p.C0 = 16; p.N = n; p.Hin = p.Hout = h; p.Win = p.Wout = wd; p.stride = 1; p.pad = 1; p.KH = p.KW = 3; p.Cout = 16;
+    p.cout_live = classes; p.dy_planes = classes;
+    return p;
+}
+extern "C" size_t vs_head_wgrad_planes_workspace(int dtype, int n, int classes, int h, int wd) {
+    const WgradParams p = head_wgrad_params(n, classes, h, wd);
+    return conv_wgrad_takes_planes(dtype, p) ? wgrad_workspace_bytes(dtype, p) : 0;
+}
+extern "C" int vs_head_wgrad_planes(int dtype, const void* x, const float* dlogits, float* dw, void* workspace, size_t workspace_bytes, int n, int classes,
+                                    int h, int wd, void* stream) {
+    VS_REQUIRE(x && dlogits && dw, "head_wgrad_planes: null pointer");
+    WgradParams p = head_wgrad_params(n, classes, h, wd);
+    if (!conv_wgrad_takes_planes(dtype, p)) { vs_set_error("head_wgrad_planes: unsupported shape"); return VS_ERR_UNSUPPORTED; }
+    p.src0 = x; p.dy = dlogits; p.dw = dw; p.partials = (float*)workspace; p.partial_bytes = workspace_bytes;
+    return launch_conv_wgrad(dtype, p, (hipStream_t)stream);
+}
+
 int launch_weight_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, int cout_pad, hipStream_t s);
 /* fp32 [cout][taps][cin] -> dtype copy (wc, may be null) and flipped/transposed dgrad copy [cin][taps][cout] (wt) */
 extern "C" int vs_weights_prepare(int dtype, const float* w, void* wc, void* wt, int cout, int taps, int cin, void* stream) {

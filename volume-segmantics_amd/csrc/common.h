@@ -264,6 +264,9 @@ bool conv_igemm_bins_ok(int dtype, const ConvParams& p);     // whether p's kern
 bool conv_igemm_nl_ok(int dtype, const ConvParams& p);       // whether launch_conv_igemm can honour p.nl_* (normalise src0 on load)
 int launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t s);
 // two chained evaluation-mode shallow layers (q reads p's output and nothing else does) as one launch: the tensor between them never exists
+// the segmentation head's data gradient from dLoss / dlogits as fp32 NCHW planes (w: the forward's [classes][9][C] copy; out: [N][H][W][C])
+bool head_dgrad_planes_ok(int dtype, int classes, int H, int W, int C);
+int launch_head_dgrad_planes(int dtype, const float* dl, const void* w, void* out, int N, int classes, int H, int W, int C, hipStream_t s);
 bool conv_pair_ok(int dtype, const ConvParams& p, const ConvParams& q);
 int launch_conv_pair(int dtype, const ConvParams& p, const ConvParams& q, hipStream_t s);
 bool conv_igemm_can_pool(const ConvParams& p);      // whether pool0 is supported for this geometry
@@ -309,10 +312,13 @@ struct WgradParams {
     int dil;                              // 0 / 1 = none; 2 = the forward convolution was dilated by 2 (stride 1, 3x3)
     int cg;                               // 0 = dense; else channels per group of a grouped convolution (4 / 8 / 16 / 32, C0 == Cout):
                                           // dw is [Cout][KH*KW][cg]
+    int dy_planes;                        // 0: dy is [N][Hout][Wout][Cout]; else dy is fp32 NCHW planes of dy_planes (= cout_live) channels -
+                                          // only where conv_wgrad_takes_planes says so (the segmentation head on the row-streaming kernel)
     int cout_live;                        // 0 = all; else only the first cout_live gradient channels are real (the head's classes in its
                                           // 16-channel gradient) and, IF conv_wgrad_honours_cout_live says so, dw is [cout_live][KH*KW][Cin]
 };
 bool conv_wgrad_honours_cout_live(int dtype, const WgradParams& p);
+bool conv_wgrad_takes_planes(int dtype, const WgradParams& p);   // (ask with dy_planes = the class count)
 size_t wgrad_workspace_bytes(int dtype, const WgradParams& p);
 int launch_conv_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 // dw[i] = sum_k partials[k*n + i], fixed summation order

@@ -535,6 +535,88 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
     }
 }
 
+// ---- the segmentation head's data gradient, straight from the loss gradient's planes ------------------------------------------
+// da[y][x][ci] = sum over (window row r, column s, class k) of W[k][r][s][ci] * dl[k][y + 1 - r][x + 1 - s] with dl = dLoss / dlogits as
+// autograd hands it over: fp32 NCHW planes of a FEW classes.  The strip kernel above wants it as a 16-channel NHWC tensor - a
+// conversion launch (67 MB written, 14 of its 16 channels zero at two classes) on the critical path between the forward and the
+// backward pass, then nine K = 32 MFMAs per 16 pixels that multiply mostly zeros.  Here the (tap, class) pairs ARE the K index:
+// kk = 9 * k' .. with tap = kk / classes, class = kk % classes, 9 * classes <= 64 -> one or two MFMAs per 16 pixels, the B fragment
+// gathered by each lane from the planes (8 scalar loads, L1 / L2 hits: every element is wanted by nine pixels), rounded to the
+// storage type exactly as the conversion would have rounded it.  A wave owns a 16-column strip of RH rows, no LDS, no barriers.
+// (Reference: the head's share of loss.backward(), vol_seg_2d_trainer.py:429.)
+template <typename T, int NK>
+__global__ __launch_bounds__(256, 4) void head_dgrad_planes_kernel(const float* __restrict__ dl, const T* __restrict__ w, T* __restrict__ out, int N, int classes,
+                                                                  int H, int W, int C, DirectGeom g) {
+    constexpr int kOob = (int)0x80000000;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= g.nwaves) return;
+    const int q = g.strips_w == 1 ? gw : (int)__umulhi((unsigned)gw, g.sw_magic);
+    const int ws = gw - q * g.strips_w;
+    const int n = g.chunks_h == 1 ? q : (int)__umulhi((unsigned)q, g.ch_magic);
+    const int hc = q - n * g.chunks_h;
+    const int x = ws * 16 + lr, h0 = hc * g.RH, h1 = min(H, h0 + g.RH);
+    const int KK = 9 * classes;
+    // A fragments: A[m = ci = lr][kk = 32 qq + 8 lq + j] = W[class][tap][ci] (w: [classes][9][C], the forward's copy)
+    uint4 af[NK];
+    int poff[NK][8];          // per K slot: offset of its plane element relative to (class plane 0, row y, column x); kOob = no such slot / column outside
+    int prow[NK][8];          // its window row r (the row bound check varies with y)
+#pragma unroll
+    for (int qq = 0; qq < NK; ++qq) {
+        unsigned short a8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 32 * qq + 8 * lq + j;
+            const bool live = kk < KK;
+            const int t = live ? kk / classes : 0, k = live ? kk - t * classes : 0;
+            const int r = t / 3, sft = t - 3 * r;
+            a8[j] = (live && lr < C) ? __builtin_bit_cast(unsigned short, w[((size_t)k * 9 + t) * C + lr]) : (unsigned short)0;
+            const int xx = x + 1 - sft;
+            poff[qq][j] = (live && xx >= 0 && xx < W) ? k * H * W + (1 - r) * W + xx : kOob;
+            prow[qq][j] = r;
+        }
+        af[qq] = make_uint4((unsigned)a8[0] | ((unsigned)a8[1] << 16), (unsigned)a8[2] | ((unsigned)a8[3] << 16),
+                            (unsigned)a8[4] | ((unsigned)a8[5] << 16), (unsigned)a8[6] | ((unsigned)a8[7] << 16));
+    }
+    const float* dn = dl + (size_t)n * classes * H * W;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)n * H * W * C, H * W * C * (int)sizeof(T));
+    const int ooff = (x < W && lq * 4 < C) ? (x * C + lq * 4) * (int)sizeof(T) : kOob;
+    auto gather = [&](int y, float (&v)[NK][8]) {
+        bool rok[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int yy = y + 1 - r; rok[r] = yy >= 0 && yy < H && y < h1; }
+#pragma unroll
+        for (int qq = 0; qq < NK; ++qq)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = poff[qq][j] != kOob && rok[prow[qq][j]];
+                v[qq][j] = ok ? dn[(size_t)y * W + poff[qq][j]] : 0.f;
+            }
+    };
+    float cur[NK][8], nxt[NK][8];
+    gather(h0, cur);
+    for (int y = h0; y < h1; ++y) {
+        gather(y + 1, nxt);                                  // in flight while this row's MFMAs and store run
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qq = 0; qq < NK; ++qq) {
+            uint4 b;
+            b.x = pack2<T>(cur[qq][0], cur[qq][1]); b.y = pack2<T>(cur[qq][2], cur[qq][3]);
+            b.z = pack2<T>(cur[qq][4], cur[qq][5]); b.w = pack2<T>(cur[qq][6], cur[qq][7]);
+            mma16<T>(acc, af[qq], b);
+        }
+        uint2 pk;
+        pk.x = pack2<T>(acc[0], acc[1]);
+        pk.y = pack2<T>(acc[2], acc[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, pk), ro, ooff, y * W * C * (int)sizeof(T), 0);
+#pragma unroll
+        for (int qq = 0; qq < NK; ++qq)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[qq][j] = nxt[qq][j];
+    }
+}
+
 // ---- two chained shallow layers in ONE launch (evaluation mode) ---------------------------------------------------------------
 // smp's last decoder block at full resolution - Conv2dReLU(up(x), 32 -> 16) then Conv2dReLU(16 -> 16), BatchNorm folded into
 // scale / shift (decoders/unet/decoder.py: DecoderBlock.conv1 / conv2, run by model(batch) at vol_seg_2d_predictor.py:44) - moves
@@ -1121,6 +1203,33 @@ int dispatch(const ConvParams& p, int out_nchw, hipStream_t s) {
 }
 
 }  // namespace
+
+bool head_dgrad_planes_ok(int dtype, int classes, int H, int W, int C) {
+    return (dtype == VS_BF16 || dtype == VS_F16) && classes >= 1 && 9 * classes <= 64 && C >= 4 && C <= 16 && !(C & 3) &&
+           (double)classes * H * W < 2.0e9 && (double)H * W * C * 2.0 < 2.0e9;
+}
+int launch_head_dgrad_planes(int dtype, const float* dl, const void* w, void* out, int N, int classes, int H, int W, int C, hipStream_t s) {
+    VS_REQUIRE(head_dgrad_planes_ok(dtype, classes, H, W, C), "head_dgrad_planes: unsupported shape (classes %d, %d x %d x %d)", classes, H, W, C);
+    DirectGeom g{};
+    g.strips_w = cdiv(W, 16);
+    g.RH = std::max(2, vs_option("conv_direct_rows") & ~1);
+    g.chunks_h = cdiv(H, g.RH);
+    g.sw_magic = 0xffffffffu / (unsigned)g.strips_w + 1u;
+    g.ch_magic = 0xffffffffu / (unsigned)g.chunks_h + 1u;
+    g.nwaves = N * g.strips_w * g.chunks_h;
+    const dim3 grid(cdiv(g.nwaves, 4));
+    const bool two = 9 * classes > 32;
+    if (dtype == VS_BF16) {
+        if (two) hipLaunchKernelGGL((head_dgrad_planes_kernel<bf16_t, 2>), grid, dim3(256), 0, s, dl, (const bf16_t*)w, (bf16_t*)out, N, classes, H, W, C, g);
+        else hipLaunchKernelGGL((head_dgrad_planes_kernel<bf16_t, 1>), grid, dim3(256), 0, s, dl, (const bf16_t*)w, (bf16_t*)out, N, classes, H, W, C, g);
+    } else {
+        if (two) hipLaunchKernelGGL((head_dgrad_planes_kernel<f16_t, 2>), grid, dim3(256), 0, s, dl, (const f16_t*)w, (f16_t*)out, N, classes, H, W, C, g);
+        else hipLaunchKernelGGL((head_dgrad_planes_kernel<f16_t, 1>), grid, dim3(256), 0, s, dl, (const f16_t*)w, (f16_t*)out, N, classes, H, W, C, g);
+    }
+    VS_LAUNCH_CHECK();
+    return VS_OK;
+}
+
 
 bool conv_igemm_can_pool(const ConvParams& p) {
     return pick_cfg(p).PT >= 2 && p.Wout >= 16 && !(p.Hout & 1) && !(p.Wout & 1);   // (the ring kernel's 16 x 16 tiles: the same condition)

@@ -603,13 +603,15 @@ int launch_fast(const WgradParams& p, const WGeom& g, hipStream_t s) {
 template <int WQ>
 int launch_rows_wgrad(const WgradParams& p, const WGeom& g, hipStream_t s) {
     constexpr int PF = 3;                                   // rows in flight per workgroup
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[3] = {false, false, false};
     const int up = g.rows == 2;
-    auto kern = up ? rows::conv_wgrad_rows_up32_kernel<WQ, PF> : rows::conv_wgrad_rows16_kernel<WQ, PF>;
+    const bool planes = !up && p.dy_planes > 0;
+    VS_REQUIRE(!p.dy_planes || (planes && p.dy_planes <= 7 && p.cout_live == p.dy_planes), "conv_wgrad: gradient planes are taken by the 16-channel row kernel only (<= 7 of them)");
+    auto kern = up ? rows::conv_wgrad_rows_up32_kernel<WQ, PF> : (planes ? rows::conv_wgrad_rows16_kernel<WQ, PF, true> : rows::conv_wgrad_rows16_kernel<WQ, PF, false>);
     const size_t lds = up ? rows::up_lds_bytes(128 * WQ) : rows::lds_bytes(128 * WQ);
-    if (!attr_set[up]) {
+    if (!attr_set[planes ? 2 : up]) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[up] = true;
+        attr_set[planes ? 2 : up] = true;
     }
     const int live = !up && p.cout_live > 0 && p.cout_live < 16 ? p.cout_live : 16;
     rows::RGeom gr{p.N * p.Hout, g.rows_per, g.nsplit, p.Hout, p.Wout, live};
@@ -683,6 +685,7 @@ int dispatch(const WgradParams& p, hipStream_t s) {
         VS_LAUNCH_CHECK();
         return VS_OK;
     }
+    VS_REQUIRE(!p.dy_planes || (sizeof(T) == 2 && g.rows == 1), "conv_wgrad: this launch cannot read gradient planes (ask conv_wgrad_takes_planes)");
     if constexpr (sizeof(T) == 2) {
         if (g.rows) return p.Wout == 128 ? launch_rows_wgrad<1>(p, g, s) : (p.Wout == 256 ? launch_rows_wgrad<2>(p, g, s) : launch_rows_wgrad<4>(p, g, s));
         if (g.fast) {
@@ -763,6 +766,11 @@ int launch_slab_reduce(const float* partials, float* dw, size_t n, int nparts, h
     }
     VS_LAUNCH_CHECK();
     return VS_OK;
+}
+
+bool conv_wgrad_takes_planes(int dtype, const WgradParams& p) {
+    WGeom g; int WO;
+    return dtype == VS_BF16 && p.dy_planes >= 1 && p.dy_planes <= 7 && geom<bf16_t>(p, g, WO) == VS_OK && g.rows == 1;
 }
 
 bool conv_wgrad_honours_cout_live(int dtype, const WgradParams& p) {

@@ -40,9 +40,14 @@ __host__ __device__ constexpr size_t lds_bytes(int W) {
 }
 
 // W = 128 * WQ pixels per row: wave w takes the k-steps w, w + 4, .. (WQ of them)
-template <int WQ, int PF>
+// PLANES: the gradient operand is NOT a 16-channel NHWC tensor but fp32 NCHW planes of g.cout_live (<= 7) channels - dLoss / dlogits as
+// autograd hands it to the segmentation head: the even threads gather their pixels' values from the planes (the loads stay in flight like the
+// NHWC pieces) and round them to bf16 on the way into the LDS row, the odd threads write the zero halves.  No conversion launch, 17 instead of
+// 67 MB read.
+template <int WQ, int PF, bool PLANES = false>
 __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, RGeom g) {
     constexpr int W = 128 * WQ, ROWB = row_bytes(W), DZB = W * 32;
+    constexpr int kMaxPlanes = 7;
     constexpr int SEGS = W * 2 / 256;                       // 16-byte pieces of one row per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xring = smem;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, R
     if (g0 >= g1) return;                                   // (uniform: whole workgroups only)
     const int total_bytes = g.rows_total * W * 32;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.src0, total_bytes);
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy, total_bytes);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy, PLANES ? 0 : total_bytes);
 
     // zero halo pixels (positions 0 and W + 1) of the four ring rows: the staging below never writes them
     if (tid < kRing * 4) {
@@ -89,6 +94,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, R
 #pragma unroll
         for (int i = 0; i < SEGS; ++i) *reinterpret_cast<uint4*>(row + ddst[i]) = v[i];
     };
+    // PLANES: piece i of a thread is the channel half tid & 1 of pixel (i * 256 + tid) >> 1: even threads own the live halves
+    const float* planes = reinterpret_cast<const float*>(p.dy);
+    const int ncls = g.cout_live;
+    auto load_dp = [&](int grow, float (&v)[SEGS][kMaxPlanes]) {
+        const bool ok = grow < g1 && !(tid & 1);
+        const int n = grow / g.H, y = grow - n * g.H;
+        const float* base = planes + ((size_t)n * ncls * g.H + y) * W;
+#pragma unroll
+        for (int i = 0; i < SEGS; ++i)
+#pragma unroll
+            for (int k = 0; k < kMaxPlanes; ++k) v[i][k] = (ok && k < ncls) ? base[(size_t)k * g.H * W + ((i * 256 + tid) >> 1)] : 0.f;
+    };
+    auto put_dp = [&](int grow, const float (&v)[SEGS][kMaxPlanes]) {
+        char* row = dzb + (grow & 1) * DZB;
+#pragma unroll
+        for (int i = 0; i < SEGS; ++i) {
+            uint4 o;
+            o.x = pack2<bf16_t>(v[i][0], v[i][1]); o.y = pack2<bf16_t>(v[i][2], v[i][3]);
+            o.z = pack2<bf16_t>(v[i][4], v[i][5]); o.w = pack2<bf16_t>(v[i][6], 0.f);
+            *reinterpret_cast<uint4*>(row + ddst[i]) = (tid & 1) ? make_uint4(0u, 0u, 0u, 0u) : o;
+        }
+    };
 
     // fragment addresses of k-step `wave`: pixel 32 * wave + 8 lq + (lr >> 2) + 4 h, 8 bytes at channel 4 (lr & 3)
     int da[2], xa[2][3];
@@ -105,6 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, R
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 xs[PF][SEGS], ds[PF][SEGS];                       // rows in flight: PF steps ahead of the MFMAs
+    float dp[PLANES ? PF : 1][SEGS][kMaxPlanes];
     load_x(g0 - 1, xs[0]);
     load_x(g0, ds[0]);
     put_x(g0 - 1, xs[0]);
@@ -112,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, R
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         load_x(g0 + 1 + j, xs[j]);
-        load_d(g0 + j, ds[j]);
+        if constexpr (PLANES) load_dp(g0 + j, dp[j]); else load_d(g0 + j, ds[j]);
     }
     int y = g0 % g.H;
     for (int gbase = g0; gbase < g1; gbase += PF) {
@@ -121,10 +149,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows16_kernel(WgradParams p, R
             const int grow = gbase + j;
             if (grow >= g1) break;                          // (uniform)
             put_x(grow + 1, xs[j]);
-            put_d(grow, ds[j]);
+            if constexpr (PLANES) put_dp(grow, dp[j]); else put_d(grow, ds[j]);
             __syncthreads();
             load_x(grow + 1 + PF, xs[j]);                   // in flight while this and the next PF - 1 rows' MFMAs run
-            load_d(grow + PF, ds[j]);
+            if constexpr (PLANES) load_dp(grow + PF, dp[j]); else load_d(grow + PF, ds[j]);
             const char* drow = dzb + (grow & 1) * DZB;
 #pragma unroll
             for (int q = 0; q < WQ; ++q) {

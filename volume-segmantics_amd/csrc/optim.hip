@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256) void dlogits_to_nhwc16_kernel(const float* __r
         float v[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) { v[c] = c < k ? d[((size_t)b * k + c) * hw + px] : 0.f; sum[c] += v[c]; }
-        st8(o + (size_t)i * 16, v);
-        st8(o + (size_t)i * 16 + 8, v + 8);
+        if (o) {                                           // (null: the bias gradient only)
+            st8(o + (size_t)i * 16, v);
+            st8(o + (size_t)i * 16 + 8, v + 8);
+        }
     }
     if (!partial) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -203,7 +203,7 @@ struct vs_unet {
     size_t esz;
     // workspace regions (bytes)
     size_t off_bins0 = 0, bins_bytes = 0;        // all units' statistics bins, contiguous: zeroed by ONE launch per training forward
-    size_t off_bnws = 0, bnws_bytes = 0, off_wgws = 0, wgws_bytes = 0, off_headdw = 0, off_dyh = 0, off_dup = 0,
+    size_t off_bnws = 0, bnws_bytes = 0, off_wgws = 0, wgws_bytes = 0, off_headdw = 0, off_headpart = 0, off_dyh = 0, off_dup = 0,
            off_zs = 0, off_idx = 0;
     size_t ws_eval = 0, ws_train = 0, off_logits = 0, off_bncnt = 0;
     int last_n = 0;
@@ -1245,6 +1245,7 @@ size_t plan_workspace(vs_unet* net) {
     {
         const Unit& hd = net->units.back();
         net->off_headdw = take((size_t)16 * hd.k * hd.k * hd.cin0 * sizeof(float));
+        net->off_headpart = take((size_t)1024 * 16 * sizeof(float));   // bias-gradient partials of the head's conversion sweep when it runs on the side stream
     }
     net->off_dyh = take(N * net->h * net->w * 16 * esz);
     size_t dup = 0, zs = 0;
@@ -2187,6 +2188,9 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         return update_units(c, ui, hi, need_encoder_wgrad != 0, grads, *opt, ws_stream);
     };
     // Weight-gradient work of one unit, queued on the side stream (after a fork event that covers its dz).
+    bool head_planes = false;                 // the head's data gradient reads dlogits' planes (head_dgrad_planes_kernel)
+    const float* head_dl = dlogits;
+    const bool head_planes_on = vs_option("conv_direct") != 0;    // (the strip-kernel family's switch)
     struct SideItem { int ui; const void* dzp; int dz_c; };
     std::vector<SideItem> pending;
     auto side_wgrad = [&](const SideItem& it) -> int {
@@ -2240,6 +2244,13 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 if ((rc = launch_two_group_wgrad_extract(p.dw, grads + c.t(u.w_idx).offset, u.cout, u.k * u.k, u.cin0, ws_stream))) return rc;
             } else if (u.kind == U_HEAD) {
                 p.cout_live = net->classes;
+                if (head_planes) {    // the bias gradient, and - unless the weight-gradient kernel reads the planes itself - its 16-channel operand: off the caller's stream
+                    p.dy_planes = net->classes;
+                    const bool direct = conv_wgrad_takes_planes(dt, p);
+                    if (direct) p.dy = head_dl; else p.dy_planes = 0;
+                    if ((rc = launch_dlogits_to_nhwc16(dt, head_dl, direct ? nullptr : c.ws + net->off_dyh, n, net->classes, (int64_t)u.hout * u.wout,
+                                                       grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_headpart), ws_stream))) return rc;
+                }
                 if (conv_wgrad_honours_cout_live(dt, p)) {   // the row-streaming kernel leaves [classes][9][16] slabs: summed straight into the gradient
                     p.dw = grads + c.t(u.w_idx).offset;
                     if ((rc = launch_conv_wgrad(dt, p, ws_stream))) return rc;
@@ -2486,15 +2497,22 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         int dz_c;
         if (u.kind == U_HEAD) {
             void* dyh = c.ws + net->off_dyh;
+            // The data gradient reads dLoss / dlogits straight from its planes where head_dgrad_planes_kernel applies; the 16-channel NHWC
+            // form (+ the bias gradient of the same sweep) is then only the weight gradient's operand and is made on ITS stream.
+            head_planes = head_planes_on && u.k == 3 && u.stride == 1 && u.pad == 1 && u.dil <= 1 && !u.cg && u.cin1 == 0 && !u.up0 &&
+                          net->first_consumer[u.src0] == ui && head_dgrad_planes_ok(dt, net->classes, u.hout, u.wout, u.cin0);
+            head_dl = dlogits;
             if (do_main) {
             ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
-            const float* dl = dlogits;
             if (net->head_up > 1) {   // back through the head's bilinear upsampling first
                 float* ds = (float*)(c.ws + net->off_dlsmall);
                 if ((rc = vs_bilinear_up_planes_bwd(dlogits, ds, n * net->classes, u.hout, u.wout, net->head_up, stream))) return rc;
-                dl = ds;
             }
-            if ((rc = launch_dlogits_to_nhwc16(dt, dl, dyh, n, net->classes, (int64_t)u.hout * u.wout, grads + c.t(u.bias_idx).offset,
+            }
+            if (net->head_up > 1) head_dl = (const float*)(c.ws + net->off_dlsmall);
+            if (do_main && !head_planes) {
+            ProfScope prof(PK_HEAD, 0, (double)n * net->h * net->w * (net->classes * 8 + 16 * net->esz), c.s);
+            if ((rc = launch_dlogits_to_nhwc16(dt, head_dl, dyh, n, net->classes, (int64_t)u.hout * u.wout, grads + c.t(u.bias_idx).offset,
                                                (float*)(c.ws + net->off_bnws), c.s))) return rc;   // + bias gradient, same sweep
             }
             dzp = dyh; dz_c = 16;
@@ -2585,6 +2603,10 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         } else if (u.kind == U_DWCONV && do_main) {   // data gradient of a depthwise convolution: the same sweep, taps reversed
             ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * u.cout * 9, 0, c.s);
             if ((rc = vs_dwconv3x3(dt, dzp, c.P(u.w_idx), c.da(u.src0), n, u.hin, u.win, u.cout, u.dil, 1 | (written[u.src0] ? 2 : 0), stream))) return rc;
+            written[u.src0] = 1;
+        } else if (u.kind == U_HEAD && head_planes && do_main) {
+            ProfScope prof(PK_CONV_DGRAD, 2.0 * n * u.hout * u.wout * net->classes * u.k * u.k * u.cin0, 0, c.s);
+            if ((rc = launch_head_dgrad_planes(dt, head_dl, c.ws + Ctx::wc_off(u, net->wset), c.da(u.src0), n, net->classes, u.hout, u.wout, u.cin0, c.s))) return rc;
             written[u.src0] = 1;
         } else if (u.kind != U_STEM && do_main) {
         // ---- data gradient (queued before the side-stream work so the caller's stream is fed first) ----
