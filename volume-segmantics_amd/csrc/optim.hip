@@ -234,6 +234,28 @@ __global__ __launch_bounds__(256) void dlogits_to_nhwc16_kernel(const float* __r
     if (threadIdx.x < k) partial[(size_t)blockIdx.x * k + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// per-class sum of fp32 NCHW planes d (n, k, hw) without the NHWC copy: block (b, s, c) sums segment s of plane (b, c), 16 bytes per lane;
+// partial[(b * S + s) * k + c], finished by bias_grad_final in block order
+constexpr int kPlaneSegs = 4;
+__global__ __launch_bounds__(256) void planes_sum_kernel(const float* __restrict__ d, int k, int64_t hw, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int c = blockIdx.x % k, bs = blockIdx.x / k, s = bs % kPlaneSegs, b = bs / kPlaneSegs;
+    const float* p = d + ((size_t)b * k + c) * hw;
+    const int64_t per = ((hw + kPlaneSegs - 1) / kPlaneSegs + 3) & ~(int64_t)3, i0 = s * per, i1 = i0 + per < hw ? i0 + per : hw;
+    float sum = 0.f;
+    if ((((uintptr_t)p) & 15) == 0) {
+        int64_t i = i0 + threadIdx.x * 4;
+        for (; i + 3 < i1; i += 1024) { const float4 v = *reinterpret_cast<const float4*>(p + i); sum += (v.x + v.y) + (v.z + v.w); }
+        for (; i < i1; ++i) sum += p[i];                       // (a ragged tail: at most 3 elements of one thread)
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) sum += p[i];
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)bs * k + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // per-class sum of dlogits: stage 2 = one wave per class over the sweep's block partials (fixed order)
 __global__ __launch_bounds__(64) void bias_grad_final(const float* __restrict__ partial, float* __restrict__ db, int nblk, int k) {
     const int c = blockIdx.x;
@@ -400,6 +422,14 @@ constexpr int kHeadBlocks = 1024;
 int launch_dlogits_to_nhwc16(int dtype, const float* d, void* o, int n, int k, int64_t hw, float* db, float* partial, hipStream_t s) {
     VS_REQUIRE(k >= 1 && k <= 16, "segmentation head: classes must be <= 16 (got %d)", k);
     VS_REQUIRE(!db || partial, "segmentation head: the bias gradient needs a partial buffer");
+    if (!o) {   // the bias gradient only (the head's backward reads the planes itself)
+        VS_REQUIRE(db && (size_t)n * kPlaneSegs <= (size_t)kHeadBlocks, "segmentation head: bias-only sweep needs db and at most %d images", kHeadBlocks / kPlaneSegs);
+        hipLaunchKernelGGL(planes_sum_kernel, dim3(n * kPlaneSegs * k), dim3(256), 0, s, d, k, hw, partial);
+        VS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bias_grad_final, dim3(k), dim3(64), 0, s, partial, db, n * kPlaneSegs, k);
+        VS_LAUNCH_CHECK();
+        return VS_OK;
+    }
     const int blocks = db ? kHeadBlocks : grid_for((int64_t)n * hw);
     VS_FOR_T(dtype, hipLaunchKernelGGL(dlogits_to_nhwc16_kernel<T>, dim3(blocks), dim3(256), 0, s, d, (T*)o, n, k, hw, db ? partial : nullptr));
     VS_LAUNCH_CHECK();

@@ -2246,7 +2246,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
                 p.cout_live = net->classes;
                 if (head_planes) {    // the bias gradient, and - unless the weight-gradient kernel reads the planes itself - its 16-channel operand: off the caller's stream
                     p.dy_planes = net->classes;
-                    const bool direct = conv_wgrad_takes_planes(dt, p);
+                    const bool direct = conv_wgrad_takes_planes(dt, p) && n <= 256;   // (the bias-only sweep's partial buffer: 4 segments x 256 images)
                     if (direct) p.dy = head_dl; else p.dy_planes = 0;
                     if ((rc = launch_dlogits_to_nhwc16(dt, head_dl, direct ? nullptr : c.ws + net->off_dyh, n, net->classes, (int64_t)u.hout * u.wout,
                                                        grads + c.t(u.bias_idx).offset, (float*)(c.ws + net->off_headpart), ws_stream))) return rc;
@@ -2579,6 +2579,7 @@ static int unet_backward_range(vs_unet_t* net, const float* params, const float*
         // ---- fork policy: one event (a barrier packet on the caller's stream, ~7 us of command-processor time) covers the
         // weight-gradient work of up to `fork_every` consecutive units ----
         pending.push_back(SideItem{ui, dzp, dz_c});
+        // (releasing the head's weight gradient at once - its operands exist before the backward pass starts - was measured: 4.512 vs 4.477 ms, not kept)
         const bool flush = (int)pending.size() >= fork_every || ui == unit_lo || u.kind == U_STEM;
         // (joining the side stream after every unit, or releasing a weight gradient only behind its unit's data gradient, were both
         // measured slower - 6.0 ms per step - and are not kept)

@@ -79,7 +79,7 @@ class _FusedDiceFn(torch.autograd.Function):
         dx = torch.empty_like(logits)
         # (global Dice: every rank holds d loss / d its own logits; the gradient all-reduce AVERAGES the ranks' parameter gradients,
         # the global loss wants their SUM)
-        g = (grad_out * float(world)).contiguous().float()
+        g = (grad_out if world == 1 else grad_out * float(world)).contiguous().float()    # (one rank: no multiply launch)
         _lib.check(_lib.lib.vs_dice_loss_bwd(_lib.ptr(logits), _lib.ptr(targets), int(is_f32), _lib.ptr(g), n, k, hw, eps,
                                             _lib.ptr(ws), _lib.ptr(dx), _lib.stream_ptr()))
         return dx, None, None, None
