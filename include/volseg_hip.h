@@ -326,6 +326,9 @@ int vs_unet_flip_weight_set(vs_unet_t* net);
  * plan's weight-gradient stream and `stream` executed concurrently.  (No reference counterpart: torch's autograd engine runs on
  * the caller's stream only.) */
 int vs_unet_side_stream_overlaps(vs_unet_t* net, void* stream, int* overlaps);
+/* The library's side stream `index` (0 / 1) itself, verified against `stream` as above - for a host that replays recorded shares of the
+ * step (vs_unet_backward_adamw_part, role 2) or runs its own side work and wants a stream known to overlap the caller's. */
+int vs_unet_side_stream(vs_unet_t* net, void* stream, int index, void** side);
 int vs_unet_weight_set(const vs_unet_t* net);   /* 0 / 1: the weight set the next forward reads */
 
 /* ------------------------------------------------------------------------------------------

@@ -198,6 +198,7 @@ _SIGS = {
     "vs_unet_prepare_range": (I, [P, P, P, P, I, I]),
     "vs_unet_flip_weight_set": (I, [P]),
     "vs_unet_side_stream_overlaps": (I, [P, P, C.POINTER(I)]),
+    "vs_unet_side_stream": (I, [P, P, I, C.POINTER(P)]),
     "vs_unet_weight_set": (I, [P]),
     "vs_capture_begin": (P, []),
     "vs_capture_end": (I, [C.POINTER(P)]),

@@ -1576,6 +1576,14 @@ extern "C" int vs_unet_drop_connect_masks(const vs_unet_t* net, int64_t* offsets
     }
     return k;
 }
+extern "C" int vs_unet_side_stream(vs_unet_t* net, void* stream, int index, void** side) {
+    VS_REQUIRE(net && side && index >= 0 && index < vs_unet::kSide, "unet_side_stream: bad arguments");
+    const int rc = acquire_side_streams(net, (hipStream_t)stream);
+    if (rc) return rc;
+    *side = (void*)net->side[index];
+    return VS_OK;
+}
+
 extern "C" int vs_unet_side_stream_overlaps(vs_unet_t* net, void* stream, int* overlaps) {
     VS_REQUIRE(net && overlaps, "unet_side_stream_overlaps: null pointer");
     int rc = acquire_side_streams(net, (hipStream_t)stream);

@@ -584,7 +584,7 @@ class VolSegUnet(nn.Module):
                     prog.append(("join", torch.cuda.Event()))
                 st["graphs"][wset] = prog
             if self._step_side is None:
-                self._step_side = torch.cuda.Stream(device=self.device)
+                self._step_side = self._library_side_stream(hd, 0)
             cur = torch.cuda.current_stream()
             for op, obj in prog:
                 if op == "main":
@@ -597,7 +597,7 @@ class VolSegUnet(nn.Module):
                 elif op == "reduce":
                     import torch.distributed as dist
                     if self._dp_side is None:
-                        self._dp_side = torch.cuda.Stream(device=self.device)
+                        self._dp_side = self._library_side_stream(hd, 1)
                     a, b = obj
                     from . import dist as vdist
                     comm = vdist.vs_comm(self.device)
@@ -631,6 +631,14 @@ class VolSegUnet(nn.Module):
             self._attach_grads(accumulate=False)    # param.grad = views of the flat gradient buffer the step writes
             st["grads_attached"] = True
         return st["loss"].clone() if clone_loss else st["loss"]
+
+    def _library_side_stream(self, handle, index: int):
+        """The library's own side stream `index`, checked to sit on another hardware queue than the current stream (HIP multiplexes streams
+        onto four queues by default; a torch.cuda.Stream() made here lands on the caller's queue for every second model of a process and
+        then runs IN ORDER with it - csrc/unet.hip: acquire_side_streams)."""
+        out = _lib.C.c_void_p()
+        check(lib.vs_unet_side_stream(handle, _lib.stream_ptr(), index, _lib.C.byref(out)))
+        return torch.cuda.ExternalStream(out.value, device=self.device)
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -667,7 +675,7 @@ class VolSegUnet(nn.Module):
         handles = []
         main = torch.cuda.current_stream()
         if self._dp_side is None:
-            self._dp_side = torch.cuda.Stream(device=self.device)
+            self._dp_side = self._library_side_stream(plan["handle"], 1)
         side = self._dp_side
         comm = vdist.vs_comm(self.device)     # VOLSEG_COMM=rccl: the C ABI's communicator, stream-ordered on the side stream
         low = None
