@@ -348,7 +348,7 @@ struct DirectGeom {
 // the input ring are counted ones and kD rows stay in flight per wave.
 template <typename T, int BN, int MODE>
 __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, DirectGeom g) {
-    constexpr int EPS = CT<T>::EPS, NJ = BN / 16, NTAPS = 9, kD = (BN == 32 && MODE == 1) ? 2 : 4;   // input rows in flight
+    constexpr int EPS = CT<T>::EPS, NJ = BN / 16, NTAPS = 9, kD = (BN == 32 && MODE == 1) ? 2 : ((BN == 16 && MODE == 0) ? 2 : 4);   // input rows in flight
     constexpr int WTOTAL = NTAPS * BN * 4, WITEMS = (WTOTAL + 255) / 256;
     constexpr int kOob = (int)0x80000000;
     __shared__ __attribute__((aligned(16))) char wl[NTAPS * BN * kPS + 64];
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 4) void conv_direct_kernel(ConvParams p, Direc
             const int hi = base + u;
             if (hi > h1) break;
             int wb = wbase_l;
-            asm volatile("" : "+v"(wb));   // keep the weight fragments in LDS, not in 36 / 72 hoisted registers
+            if (NJ > 1 || MODE != 0) asm volatile("" : "+v"(wb));   // keep the weight fragments in LDS, not in 72 hoisted registers (16 couts: 36 registers, hoisted)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
