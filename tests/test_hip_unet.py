@@ -170,6 +170,12 @@ def test_backward_self_consistency_at_the_headline_batch32_256():
     _backward_self_consistency("bf16", 32, 256, torch.float32)
 
 
+def test_backward_self_consistency_at_512_wide_rows():
+    """The same per-layer recomputation at 512 x 512 (batch 2, bf16): the full-resolution layers' row-streaming weight gradients and the
+    head's backward from the loss gradient's planes run their 512-pixel-row forms (four 128-pixel k-step groups per row) inside the network."""
+    _backward_self_consistency("bf16", 2, 512, torch.float32)
+
+
 def _backward_self_consistency(precision, B, hw, cpu_dtype):
     import ctypes as C
     import torch.nn.functional as F
